@@ -1,0 +1,73 @@
+"""Hot-path configuration: the reference's flat argparse namespace, same flag names.
+
+Only the flags the ranking-loss training step reads are kept (reference
+``main.py:26-137``; the model reads them at ``models/item_transformer.py:27-44,72-83``
+and ``models/ps_model.py:20-35``).  Defaults are the reference's defaults; the
+README's TEM command (``README.md:13-25``) overrides ``inter_layers=1``,
+``lr=0.0005``, ``batch_size=384``, ``uprev_review_limit=20``.
+"""
+from argparse import Namespace
+
+# reference main.py:26-137 defaults (hot-path flags only)
+_DEFAULTS = dict(
+    seed=666,
+    train_from='',
+    model_name='item_transformer',     # main.py:29 (default there is review_transformer)
+    sep_prod_emb=False,                # main.py:31
+    pretrain_emb_dir='',               # main.py:33
+    pretrain_up_emb_dir='',            # main.py:34
+    use_dot_prod=True,                 # main.py:45
+    sim_func='product',                # main.py:47
+    use_pos_emb=True,                  # main.py:48
+    use_seg_emb=True,
+    use_item_pos=False,                # main.py:52
+    use_item_emb=False,
+    use_user_emb=False,
+    dropout=0.1,                       # main.py:60
+    optim='adam',                      # main.py:62
+    lr=0.002,                          # main.py:63
+    beta1=0.9,
+    beta2=0.999,
+    decay_method='adam',               # main.py:66
+    warmup_steps=8000,
+    max_grad_norm=5.0,                 # main.py:68
+    pos_weight=False,                  # main.py:76
+    l2_lambda=0.0,                     # main.py:78
+    batch_size=32,
+    valid_batch_size=24,
+    candi_batch_size=500,
+    query_encoder_name='fs',           # main.py:97
+    review_encoder_name='pvc',
+    embedding_size=128,                # main.py:101
+    ff_size=512,                       # main.py:102
+    heads=8,                           # main.py:103
+    inter_layers=2,                    # main.py:104 (README uses 1)
+    review_word_limit=100,
+    uprev_review_limit=20,             # main.py:107
+    iprev_review_limit=30,
+    pv_window_size=1,                  # main.py:113
+    corrupt_rate=0.9,
+    train_review_only=True,
+    train_pv_epoch=0,
+    neg_per_pos=5,                     # main.py:125
+    device='cuda',
+)
+
+
+def default_args(**overrides):
+    """Namespace with the reference's flag names/defaults; ``overrides`` replace them."""
+    unknown = set(overrides) - set(_DEFAULTS)
+    if unknown:
+        raise KeyError("unknown ProdSearch flags: %s" % sorted(unknown))
+    d = dict(_DEFAULTS)
+    d.update(overrides)
+    return Namespace(**d)
+
+
+def readme_tem_args(**overrides):
+    """The README's TEM training command (README.md:13-25) + the metric's 20 negatives."""
+    base = dict(model_name='item_transformer', decay_method='adam', lr=0.0005,
+                batch_size=384, uprev_review_limit=20, embedding_size=128,
+                inter_layers=1, ff_size=512, heads=8, neg_per_pos=20)
+    base.update(overrides)
+    return default_args(**base)

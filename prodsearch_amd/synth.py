@@ -1,0 +1,166 @@
+"""Synthetic "Amazon-5core-shaped" inputs for the TEM hot path.
+
+The reference ships no data (its ``data/`` directory is code only), so shapes and
+distributions are this build's choice, fixed here so tests, fixtures and the
+bench all draw the same batches:
+
+* query length ~U{2..6}, padded to Q with ``vocab_size-1``;
+* history length ``min(L, Geometric(0.15))`` with >=5 % zero-history users, padded
+  with ``product_size`` (reference pads: ``data/item_pv_dataloader.py:135-139``);
+* history/target item ids Zipf(1.05) over a fixed permutation, negatives uniform
+  over ``[0, P)`` (reference: ``prod_dists = ones(P)``, ``item_transformer.py:33``);
+* word ids from ``word_dists`` = ``(freq/sum)^0.75`` renormalised with Zipf(1.0)
+  freq and pad weight 0 (reference: ``data/data_util.py:155-162``).
+
+Everything is numpy ``PCG64`` seeded; nothing here touches the GPU.
+"""
+import hashlib
+import numpy as np
+import torch
+
+from .batch import ItemPVBatch
+
+
+def rng_for(seed):
+    return np.random.Generator(np.random.PCG64(int(seed)))
+
+
+def make_word_dists(vocab_size, seed=7):
+    """float64 [V] negative-word distribution; last entry (pad) has weight 0."""
+    rng = rng_for(seed)
+    n = vocab_size - 1
+    freq = 1.0 / np.arange(1, n + 1, dtype=np.float64)
+    freq = freq[rng.permutation(n)]
+    wf = freq / freq.sum()
+    wf = np.power(wf, 0.75)
+    wf = wf / wf.sum()
+    return np.concatenate([wf, [0.0]])
+
+
+def _zipf_ids(rng, n_ids, size, a=1.05, perm_seed=11):
+    w = 1.0 / np.power(np.arange(1, n_ids + 1, dtype=np.float64), a)
+    w /= w.sum()
+    perm = rng_for(perm_seed).permutation(n_ids)
+    return perm[rng.choice(n_ids, size=size, p=w)]
+
+
+def make_tem_batch(seed, B, product_size, vocab_size, Q=8, L=20, W=1, C=0,
+                   word_dists=None, zero_hist_frac=0.05, full_history=False):
+    """One TEM batch (``ItemPVBatch``), CPU int64 tensors."""
+    rng = rng_for(seed)
+    P, V = product_size, vocab_size
+    if word_dists is None:
+        word_dists = make_word_dists(V)
+    # queries
+    qlen = rng.integers(2, min(6, Q) + 1, size=B)
+    qw = np.full((B, Q), V - 1, dtype=np.int64)
+    words = rng.choice(V, size=(B, Q), p=word_dists)
+    for b in range(B):
+        qw[b, :qlen[b]] = words[b, :qlen[b]]
+    # history
+    if full_history:
+        hlen = np.full(B, L, dtype=np.int64)
+    else:
+        hlen = np.minimum(L, rng.geometric(0.15, size=B))
+        hlen[rng.random(B) < zero_hist_frac] = 0
+    ui = np.full((B, L), P, dtype=np.int64)
+    items = _zipf_ids(rng, P, (B, L))
+    for b in range(B):
+        ui[b, :hlen[b]] = items[b, :hlen[b]]
+    target = _zipf_ids(rng, P, B)
+    # positive item words (pv window); a few pads when W > 1
+    pw = rng.choice(V, size=(B, W), p=word_dists).astype(np.int64)
+    if W > 1:
+        pw[rng.random((B, W)) < 0.15] = V - 1
+        pw[:, 0] = np.where(pw[:, 0] == V - 1, 0, pw[:, 0])
+    candi = []
+    if C > 0:
+        candi = rng.integers(0, P, size=(B, C)).astype(np.int64)
+        candi[:, 0] = target            # target among candidates (as validation does)
+        candi[-1, C - max(1, C // 8):] = P   # ragged tail padded with P (item_pv_dataloader.py:44)
+    return ItemPVBatch(qw, target.astype(np.int64), ui, pw,
+                       query_idxs=list(range(B)), user_idxs=list(range(B)),
+                       candi_prod_idxs=candi)
+
+
+def sample_negatives(seed, B, K, W, product_size, word_dists):
+    """Host-side stand-in for the two ``torch.multinomial`` draws of one forward
+    (items first, ``item_transformer.py:447``; words second, ``:268``)."""
+    rng = rng_for(seed)
+    neg_items = rng.integers(0, product_size, size=(B, K)).astype(np.int64)
+    neg_words = rng.choice(len(word_dists), size=(B, W * K), p=word_dists).astype(np.int64)
+    return torch.from_numpy(neg_items), torch.from_numpy(neg_words)
+
+
+def tem_param_shapes(args, vocab_size, product_size):
+    """state_dict name -> shape of the reference's ItemTransformerRanker
+    (item_transformer.py:46-84, transformer.py:59-69, neural.py:20-26,86-96)."""
+    d, F = args.embedding_size, args.ff_size
+    P1, V = product_size + 1, vocab_size
+    shapes = {
+        'product_bias': (P1,),
+        'word_bias': (V,),
+        'product_emb.weight': (P1, d),
+    }
+    if args.sep_prod_emb:
+        shapes['hist_product_emb.weight'] = (P1, d)
+    shapes['word_embeddings.weight'] = (V, d)
+    if args.model_name == 'item_transformer':
+        te = 'transformer_encoder.'
+        for i in range(args.inter_layers):
+            p = te + 'transformer_inter.%d.' % i
+            for lin in ('linear_keys', 'linear_values', 'linear_query', 'final_linear'):
+                shapes[p + 'self_attn.%s.weight' % lin] = (d, d)
+                shapes[p + 'self_attn.%s.bias' % lin] = (d,)
+            shapes[p + 'feed_forward.w_1.weight'] = (F, d)
+            shapes[p + 'feed_forward.w_1.bias'] = (F,)
+            shapes[p + 'feed_forward.w_2.weight'] = (d, F)
+            shapes[p + 'feed_forward.w_2.bias'] = (d,)
+            shapes[p + 'feed_forward.layer_norm.weight'] = (d,)
+            shapes[p + 'feed_forward.layer_norm.bias'] = (d,)
+            shapes[p + 'layer_norm.weight'] = (d,)
+            shapes[p + 'layer_norm.bias'] = (d,)
+        shapes[te + 'layer_norm.weight'] = (d,)
+        shapes[te + 'layer_norm.bias'] = (d,)
+        shapes[te + 'wo.weight'] = (1, d)
+        shapes[te + 'wo.bias'] = (1,)
+    else:
+        p = 'attention_encoder.'
+        for lin in ('linear_keys', 'linear_values', 'linear_query', 'final_linear'):
+            shapes[p + '%s.weight' % lin] = (d, d)
+            shapes[p + '%s.bias' % lin] = (d,)
+    if args.query_encoder_name == 'fs':
+        shapes['query_encoder.f_W.weight'] = (d, d)
+        shapes['query_encoder.f_W.bias'] = (d,)
+    shapes['seg_embeddings.weight'] = (4, d)
+    return shapes
+
+
+def make_state_dict(shapes, seed, pad_rows=None):
+    """Deterministic fp32 weights for parity tests: N(0, s) with s chosen per
+    tensor so activations stay O(1) (tables 0.5, matrices 1/sqrt(fan_in),
+    LayerNorm gains 1 + 0.1 N, biases 0.05 N).  ``pad_rows`` = {name: row} rows
+    zeroed (the reference's ``padding_idx`` rows of product_emb)."""
+    rng = rng_for(seed)
+    sd = {}
+    for name, shp in shapes.items():
+        x = rng.standard_normal(shp).astype(np.float32)
+        if name.endswith('layer_norm.weight'):
+            x = 1.0 + 0.1 * x
+        elif len(shp) == 1:
+            x = 0.05 * x
+        elif 'emb' in name:
+            x = 0.5 * x
+        else:
+            x = x / np.sqrt(shp[-1])
+        sd[name] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    for name, row in (pad_rows or {}).items():
+        if name in sd:
+            sd[name][row] = 0.0
+    return sd
+
+
+def checksum(t):
+    """sha256 of the raw little-endian bytes of a tensor/array (fixture pinning)."""
+    a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures ``tests/golden/*.npz`` from the REFERENCE itself.
+
+Runs only in the build container (needs ``/root/reference``); the fixtures it
+writes are data (inputs + the reference's outputs) and are what travels.  The
+reference is imported unmodified; the harness adds exactly two hooks, both on
+torch, none on reference code:
+
+1. ``Tensor.masked_fill`` accepts the uint8 masks the reference builds
+   (legacy torch semantics: non-zero = True) — torch >= 2 rejects them at
+   ``models/neural.py:214``;
+2. ``torch.multinomial`` returns pre-drawn negatives (items first,
+   ``item_transformer.py:447``; words second, ``:268``) so that index inputs are
+   fixture data instead of an unreproducible RNG stream.
+
+Read-only taps record intermediates: the output of ``query_encoder``, of the
+first ``transformer_encoder.encode`` call, and the logits handed to
+``binary_cross_entropy_with_logits``.
+
+Usage:  python tests/golden/make_golden.py [case ...]
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference')
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from prodsearch_amd import synth
+from prodsearch_amd.config import default_args
+
+torch.set_num_threads(4)
+
+# ---------------------------------------------------------------- harness hooks
+_orig_mf = torch.Tensor.masked_fill
+_orig_mf_ = torch.Tensor.masked_fill_
+
+
+def _mf(self, mask, value):
+    return _orig_mf(self, mask.bool() if mask.dtype == torch.uint8 else mask, value)
+
+
+def _mf_(self, mask, value):
+    return _orig_mf_(self, mask.bool() if mask.dtype == torch.uint8 else mask, value)
+
+
+torch.Tensor.masked_fill = _mf
+torch.Tensor.masked_fill_ = _mf_
+
+_draw_queue = []
+_orig_multinomial = torch.multinomial
+
+
+def _multinomial(dist, n, replacement=False, **kw):
+    assert _draw_queue, "unexpected torch.multinomial call"
+    out = _draw_queue.pop(0)
+    assert out.numel() == n, (out.shape, n)
+    return out.reshape(-1).clone()
+
+
+torch.multinomial = _multinomial
+
+_bce_tap = []
+_orig_bce = F.binary_cross_entropy_with_logits
+
+
+def _bce(inp, target, *a, **kw):
+    _bce_tap.append(inp.detach().clone())
+    return _orig_bce(inp, target, *a, **kw)
+
+
+F.binary_cross_entropy_with_logits = _bce
+torch.nn.functional.binary_cross_entropy_with_logits = _bce
+
+from models.item_transformer import ItemTransformerRanker   # noqa: E402  (reference)
+from models.ps_model import build_optim                       # noqa: E402  (reference)
+from data.batch_data import ItemPVBatch as RefBatch           # noqa: E402  (reference)
+
+
+# ------------------------------------------------------------------------ cases
+CASES = {
+    # BASELINE.json configs[0]: "HEM (PV only, no transformer)", 1k items / 5k vocab, d=32, bs=64.
+    # The repo has no HEM class; QEM is its query-only scorer + PV loss.
+    'qem_c1': dict(args=dict(model_name='QEM', embedding_size=32, heads=8, ff_size=64,
+                             inter_layers=1, neg_per_pos=5, dropout=0.0, lr=0.002),
+                   P=1000, V=5001, B=64, Q=6, L=20, W=1, C=50, steps=3),
+    'tem_c1': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=8, ff_size=64,
+                             inter_layers=1, neg_per_pos=5, dropout=0.0, lr=0.002),
+                   P=1000, V=5001, B=64, Q=6, L=20, W=1, C=50, steps=3),
+    # cut-down BASELINE configs[1]: d=128, 1 layer, 8 heads, ff 512, uprev 20, 20 neg
+    'tem_c2s': dict(args=dict(model_name='item_transformer', embedding_size=128, heads=8, ff_size=512,
+                              inter_layers=1, neg_per_pos=20, dropout=0.0, lr=0.0005),
+                    P=500, V=800, B=32, Q=8, L=20, W=1, C=40, steps=3),
+    # main.py default depth (2 layers): exercises the i != 0 pre-LayerNorm branch
+    'tem_l2': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=4, ff_size=64,
+                             inter_layers=2, neg_per_pos=5, dropout=0.0, lr=0.002),
+                   P=300, V=400, B=16, Q=6, L=12, W=1, C=20, steps=2),
+    # every optional branch of the dot-product path at once
+    'tem_opts': dict(args=dict(model_name='item_transformer', embedding_size=64, heads=8, ff_size=128,
+                               inter_layers=1, neg_per_pos=7, dropout=0.0, lr=0.002,
+                               sim_func='bias_product', pos_weight=True, sep_prod_emb=True,
+                               use_item_pos=True, pv_window_size=3, decay_method='noam',
+                               warmup_steps=10, l2_lambda=0.01),
+                     P=300, V=400, B=24, Q=5, L=7, W=3, C=30, steps=3),
+    'tem_avg_nopos': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=2, ff_size=96,
+                                    inter_layers=1, neg_per_pos=4, dropout=0.0, lr=0.002,
+                                    query_encoder_name='avg', use_pos_emb=False),
+                          P=200, V=300, B=8, Q=4, L=5, W=1, C=10, steps=1),
+}
+
+
+def pack_rows(out, key, t, base=None):
+    """2-D tensors with many rows are stored as (rows that differ from ``base`` /
+    are non-zero, their values) + full-tensor float64 sum and sum of squares."""
+    a = t.detach().cpu().numpy().copy()      # copy: optim.step() clips p.grad in place later
+    if a.ndim == 2 and a.shape[0] > 256:
+        ref = np.zeros_like(a) if base is None else base.detach().cpu().numpy()
+        rows = np.nonzero((a != ref).any(axis=1))[0].astype(np.int64)
+        out[key + '__rows'] = rows
+        out[key + '__vals'] = a[rows]
+        out[key + '__shape'] = np.asarray(a.shape, dtype=np.int64)
+        out[key + '__sums'] = np.asarray([a.astype(np.float64).sum(), (a.astype(np.float64) ** 2).sum()])
+    else:
+        out[key] = a
+
+
+def run_case(name, spec):
+    args = default_args(**spec['args'])
+    args.device = 'cpu'
+    P_, V_, B, Q, L, W, C = (spec[k] for k in ('P', 'V', 'B', 'Q', 'L', 'W', 'C'))
+    K = args.neg_per_pos
+    wd = synth.make_word_dists(V_, seed=101)
+    torch.manual_seed(0)
+    model = ItemTransformerRanker(args, 'cpu', V_, P_, None, word_dists=wd)
+    ref_sd = model.state_dict()
+    shapes = synth.tem_param_shapes(args, V_, P_)
+    # boundary check: our shape table IS the reference's state_dict (minus the pe buffer)
+    ref_shapes = {k: tuple(v.shape) for k, v in ref_sd.items() if not k.endswith('pos_emb.pe')}
+    assert ref_shapes == shapes, (set(ref_shapes) ^ set(shapes))
+    assert list(ref_shapes) == list(shapes), "state_dict key order differs"
+    wseed = 1000 + sum(map(ord, name))
+    pad_rows = {'product_emb.weight': P_, 'hist_product_emb.weight': P_}
+    sd = synth.make_state_dict(shapes, wseed, pad_rows)
+    model.load_state_dict(sd, strict=False)
+    optim = build_optim(args, model, None)
+
+    bt = synth.make_tem_batch(2000 + wseed, B, P_, V_, Q=Q, L=L, W=W, C=C, word_dists=wd)
+    rb = RefBatch(bt.query_word_idxs, bt.target_prod_idxs, bt.u_item_idxs, bt.pos_iword_idxs,
+                  bt.query_idxs, bt.user_idxs, bt.candi_prod_idxs, to_tensor=False)
+    out = {}
+    meta = dict(case=name, args=spec['args'], P=P_, V=V_, B=B, Q=Q, L=L, W=W, C=C, K=K,
+                steps=spec['steps'], weight_seed=wseed, word_dists_seed=101,
+                weight_checksum={k: synth.checksum(v) for k, v in sd.items()},
+                torch=torch.__version__, numpy=np.__version__)
+    for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs', 'candi_prod_idxs'):
+        out['in_' + k] = getattr(bt, k).numpy()
+    out['in_word_dists'] = wd
+
+    taps = {}
+    def q_tap(m, i, o):            # must return None: a returned value would REPLACE the output
+        taps.setdefault('query_emb', o.detach().clone())
+    hq = model.query_encoder.register_forward_hook(q_tap)
+    if args.model_name == 'item_transformer':
+        enc_orig = model.transformer_encoder.encode
+
+        def enc_tap(*a, **kw):
+            o = enc_orig(*a, **kw)
+            taps.setdefault('enc_full', o.detach().clone())
+            return o
+        model.transformer_encoder.encode = enc_tap
+
+    # eval on the INITIAL weights: model.test (trainer.py:190,201) + ranklist/metrics (trainer.py:136,171-187)
+    model.eval()
+    with torch.no_grad():
+        scores = model.test(rb)
+    s = scores.numpy()
+    out['test_scores'] = s
+    order = s.argsort(axis=-1)[:, ::-1]
+    out['test_ranklist'] = order.astype(np.int64)
+    cand, tgt = bt.candi_prod_idxs.numpy(), bt.target_prod_idxs.numpy()
+    mrr = prec = 0.0
+    for i in range(B):
+        hit = np.where(cand[i][order[i]] == tgt[i])[0]
+        if len(hit):
+            mrr += 1.0 / (hit[0] + 1)
+            prec += float(hit[0] == 0)
+    out['test_mrr'] = np.float64(mrr / B)
+    out['test_p1'] = np.float64(prec / B)
+    taps.clear()
+    del _bce_tap[:]
+    model.train()
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    for step in range(spec['steps']):
+        ni, nw = synth.sample_negatives(3000 + wseed + step, B, K, W, P_, wd)
+        out['in_neg_item_idxs_%d' % step] = ni.numpy()
+        out['in_neg_word_idxs_%d' % step] = nw.numpy()
+        _draw_queue[:] = [ni, nw]
+        del _bce_tap[:]
+        model.clear_loss()
+        loss = model(rb, train_pv=False)                 # trainer.py:74
+        assert not _draw_queue
+        model.zero_grad()                                 # trainer.py:76
+        loss.backward()                                   # trainer.py:77
+        out['loss_%d' % step] = np.float32(loss.item())
+        out['ps_loss_%d' % step] = np.float32(model.ps_loss)
+        out['item_loss_%d' % step] = np.float32(model.item_loss)
+        if step == 0:
+            out['query_emb'] = taps['query_emb'].numpy()
+            if 'enc_full' in taps:
+                out['enc_full'] = taps['enc_full'].numpy()     # [B,S,d] final-LN output of the pos encode
+            out['prod_scores'] = _bce_tap[0].numpy()           # [B,1+K]
+            out['word_scores'] = _bce_tap[1].numpy()           # [B,W,1+K]
+            none_grads = []
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    none_grads.append(n)
+                else:
+                    pack_rows(out, 'grad_' + n, p.grad)
+            meta['none_grads'] = none_grads
+        optim.step()                                      # trainer.py:78 (clips p.grad in place)
+        out['lr_%d' % step] = np.float64(optim.learning_rate)
+        if step in (0, spec['steps'] - 1):
+            for n, p in model.named_parameters():
+                pack_rows(out, 'param%d_%s' % (step, n), p.data, base=init[n])
+    hq.remove()
+
+    out['meta'] = np.asarray(json.dumps(meta))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-14s loss0=%.6f  ->  %s (%.1f KB)' % (name, out['loss_0'], path, os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or list(CASES)
+    for c in todo:
+        run_case(c, CASES[c])

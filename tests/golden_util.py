@@ -1,0 +1,69 @@
+"""Load a golden fixture (tests/golden/*.npz, written by make_golden.py from the
+reference) into the objects the oracle / the product take."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from prodsearch_amd import synth
+from prodsearch_amd.batch import ItemPVBatch
+from prodsearch_amd.config import default_args
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz'))
+TEM_CASES = [c for c in CASES if c.startswith('tem_')]
+
+
+class Golden(object):
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False)
+        self.meta = json.loads(str(self.z['meta']))
+        m = self.meta
+        self.args = default_args(**m['args'])
+        self.args.device = 'cpu'
+        self.P, self.V, self.B, self.K, self.W = m['P'], m['V'], m['B'], m['K'], m['W']
+        self.steps = m['steps']
+        self.word_dists = self.z['in_word_dists']
+
+    def params(self):
+        """Regenerate the deterministic weights and check them against the pinned checksums."""
+        shapes = synth.tem_param_shapes(self.args, self.V, self.P)
+        pad_rows = {'product_emb.weight': self.P, 'hist_product_emb.weight': self.P}
+        sd = synth.make_state_dict(shapes, self.meta['weight_seed'], pad_rows)
+        for k, v in sd.items():
+            assert synth.checksum(v) == self.meta['weight_checksum'][k], "weight generator drifted: " + k
+        return sd
+
+    def batch(self):
+        t = lambda k: torch.from_numpy(self.z['in_' + k])
+        return ItemPVBatch(t('query_word_idxs'), t('target_prod_idxs'), t('u_item_idxs'),
+                           t('pos_iword_idxs'), list(range(self.B)), list(range(self.B)),
+                           t('candi_prod_idxs'), to_tensor=False)
+
+    def negs(self, step):
+        return (torch.from_numpy(self.z['in_neg_item_idxs_%d' % step]),
+                torch.from_numpy(self.z['in_neg_word_idxs_%d' % step]))
+
+    def has(self, key):
+        return key in self.z.files or (key + '__rows') in self.z.files
+
+    def tensor(self, key, base=None):
+        """Unpack a tensor stored either whole or as (rows, vals) over ``base``/zeros."""
+        if key in self.z.files:
+            return torch.from_numpy(self.z[key])
+        rows = self.z[key + '__rows']
+        shape = tuple(self.z[key + '__shape'])
+        full = torch.zeros(shape) if base is None else base.clone()
+        full[torch.from_numpy(rows)] = torch.from_numpy(self.z[key + '__vals'])
+        sums = self.z[key + '__sums']
+        f64 = full.double()
+        assert abs(float(f64.sum()) - sums[0]) <= 1e-6 * max(1.0, abs(sums[0]))
+        assert abs(float((f64 ** 2).sum()) - sums[1]) <= 1e-6 * max(1.0, abs(sums[1]))
+        return full
+
+
+def rel_err(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
