@@ -1,0 +1,192 @@
+/*
+ * prodsearch_hip.h — C ABI of libprodsearch_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the ProdSearch ranking-loss training step.  The
+ * reference (kepingbi/ProdSearch) is pure Python/PyTorch and has NO FFI of its
+ * own; each entry point below names the reference interface it replaces
+ * (file:line relative to the reference repo).  A maintainer binds them with the
+ * ctypes stub shown in INTEGRATION.md (prodsearch_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - indices are int64 (the reference's torch.int64 batches, data/batch_data.py:17-22),
+ *     parameters/activations are fp32, row-major, nn.Linear weights are [out, in];
+ *   - every call is asynchronous on `stream` (a hipStream_t), allocates nothing,
+ *     synchronises nothing, and may be captured into a hipGraph;
+ *   - return value: 0 = ok, otherwise an error code; ps_last_error() gives text;
+ *   - no CPU fallback exists: without a gfx950 device every compute call fails.
+ */
+#ifndef PRODSEARCH_HIP_H
+#define PRODSEARCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_MAX_LAYERS 8
+#define PS_OK 0
+#define PS_ERR_ARG 1      /* bad descriptor / unsupported shape */
+#define PS_ERR_HIP 2      /* a HIP runtime call failed          */
+
+typedef void* ps_stream_t; /* hipStream_t */
+
+enum { PS_MODEL_TEM = 0, PS_MODEL_QEM = 1 };
+enum { PS_QENC_FS = 0, PS_QENC_AVG = 1 };
+
+/* Shape/flag descriptor of one step.  Field <- reference flag (main.py:26-137). */
+typedef struct PsTemDesc {
+  int32_t B;             /* batch rows                         (--batch_size)            */
+  int32_t K;             /* negatives per positive             (--neg_per_pos)           */
+  int32_t L;             /* padded history length              (<= --uprev_review_limit) */
+  int32_t Q;             /* padded query length                                          */
+  int32_t W;             /* PV window                          (--pv_window_size)        */
+  int32_t C;             /* candidates per row, eval only      (--candi_batch_size)      */
+  int32_t d;             /* --embedding_size                                             */
+  int32_t H;             /* --heads                                                      */
+  int32_t F;             /* --ff_size                                                    */
+  int32_t n_layers;      /* --inter_layers                                               */
+  int64_t product_size;  /* P; pad index = P, tables have P+1 rows (item_transformer.py:34,46) */
+  int64_t vocab_size;    /* V; pad index = V-1                    (item_transformer.py:35)     */
+  int32_t model;         /* PS_MODEL_TEM: forward_dotproduct; PS_MODEL_QEM: forward_attn/QEM */
+  int32_t query_encoder; /* PS_QENC_FS / PS_QENC_AVG          (--query_encoder_name)     */
+  int32_t use_pos_emb;   /* --use_pos_emb                                                */
+  int32_t use_item_pos;  /* --use_item_pos : output position -1 instead of 0             */
+  int32_t bias_product;  /* --sim_func bias_product                                      */
+  int32_t pos_weight;    /* --pos_weight : weight K on the positive's loss term          */
+  int32_t sep_prod_emb;  /* --sep_prod_emb : history rows come from hist_product_emb     */
+  int32_t training;      /* nn.Module.training; dropout is drawn only if set and dropout>0 */
+  float   dropout;       /* --dropout                                                    */
+  uint64_t seed;         /* Philox key of the dropout / sampling streams                 */
+  uint64_t step;         /* Philox counter word: distinct per training step              */
+} PsTemDesc;
+
+/* One transformer layer's tensors (state_dict keys under
+ * transformer_encoder.transformer_inter.{i}. — transformer.py:37-45, neural.py:20-26,86-96). */
+typedef struct PsLayerTensors {
+  float *wk, *bk;        /* self_attn.linear_keys   [d,d],[d] */
+  float *wv, *bv;        /* self_attn.linear_values           */
+  float *wq, *bq;        /* self_attn.linear_query            */
+  float *wo, *bo;        /* self_attn.final_linear            */
+  float *w1, *b1;        /* feed_forward.w_1 [F,d],[F]        */
+  float *w2, *b2;        /* feed_forward.w_2 [d,F],[d]        */
+  float *ff_ln_g, *ff_ln_b; /* feed_forward.layer_norm        */
+  float *ln_g, *ln_b;    /* layer_norm (pre-LN, used only when i != 0: transformer.py:48-51) */
+} PsLayerTensors;
+
+/* A full set of model tensors.  The same struct describes parameters, their
+ * gradients, and Adam moments (pointers may be NULL where the reference has no
+ * gradient: product_bias unless bias_product, layer-0 ln, hist table unless sep). */
+typedef struct PsTemTensors {
+  float *product_emb;       /* product_emb.weight      [P+1, d] (item_transformer.py:46) */
+  float *hist_product_emb;  /* hist_product_emb.weight [P+1, d] (:48) or NULL            */
+  float *word_emb;          /* word_embeddings.weight  [V, d]   (:70)                    */
+  float *product_bias;      /* product_bias            [P+1]    (:56)                    */
+  float *word_bias;         /* word_bias               [V]      (:57)                    */
+  float *fs_w, *fs_b;       /* query_encoder.f_W       [d,d],[d] (text_encoder.py:24)    */
+  float *pe;                /* transformer_encoder.pos_emb.pe [5000, d] buffer (transformer.py:10-19) */
+  float *final_ln_g, *final_ln_b; /* transformer_encoder.layer_norm (transformer.py:68)  */
+  PsLayerTensors layer[PS_MAX_LAYERS];
+} PsTemTensors;
+
+/* The reference's ItemPVBatch (data/batch_data.py:3-37) + the two multinomial draws. */
+typedef struct PsTemBatch {
+  const int64_t *query_word_idxs;   /* [B,Q]   pad V-1 */
+  const int64_t *target_prod_idxs;  /* [B]             */
+  const int64_t *u_item_idxs;       /* [B,L]   pad P   */
+  const int64_t *pos_iword_idxs;    /* [B,W]   pad V-1 */
+  const int64_t *neg_item_idxs;     /* [B,K]   draw 1: torch.multinomial(prod_dists) item_transformer.py:447 */
+  const int64_t *neg_word_idxs;     /* [B,W*K] draw 2: torch.multinomial(word_dists) item_transformer.py:268 */
+  const int64_t *candi_prod_idxs;   /* [B,C]   eval only, pad P (item_pv_dataloader.py:44) */
+} PsTemBatch;
+
+/* Float offsets (in units of sizeof(float)) of the intermediates inside the
+ * workspace; exported so the parity tests can compare every stage to the oracle.
+ * Only the LAST layer's buffers are listed (n_layers == 1 covers everything). */
+typedef struct PsTemWsLayout {
+  int64_t total_floats;
+  int32_t R;             /* encoder replicas per batch row: K+1 if dropout is drawn, else 1 */
+  int32_t S;             /* L+1 */
+  int64_t qmean, query_emb, x;                 /* [B,d],[B,d],[B,S,d]                 */
+  int64_t kp, vp, qp, attn, ctx;               /* last layer: [n_in*S,d] x2, [n_in,d].. */
+  int64_t y1, ln1, a1, h1, y2, enc;            /* last layer replica rows              */
+  int64_t item_scores, word_scores, loss_parts;/* [B,1+K],[B,W,1+K],[B,2]             */
+  int64_t denc, dx;                            /* backward: [B*R,d], [B,S,d]           */
+} PsTemWsLayout;
+
+const char* ps_version(void);
+const char* ps_last_error(void);
+
+/* Workspace the caller allocates once per shape (bytes) and its layout. */
+int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);
+
+/* loss = model(batch)                      -- ItemTransformerRanker.forward
+ *   (models/item_transformer.py:352-359 -> forward_dotproduct :440-520, or forward_attn/QEM :361-438)
+ * loss3[0..2] = {ps_loss + item_loss, ps_loss, item_loss} (device floats). */
+int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                   float* workspace, float* loss3, ps_stream_t stream);
+
+/* loss.backward()                          -- trainer.py:77 (autograd of the above).
+ * ACCUMULATES loss_scale * dloss/dparam into `grads` (dense, like the reference's
+ * nn.Embedding(sparse=False)); the caller zeroes grads (model.zero_grad(), trainer.py:76). */
+int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                    float* workspace, const PsTemTensors* grads, float loss_scale,
+                    const float* loss_scale_dev /* optional device scalar multiplied in (autograd's grad_output) */,
+                    ps_stream_t stream);
+
+/* scores = model.test(batch) [B,C]         -- test_dotproduct (item_transformer.py:111-146)
+ *                                             / test_attn QEM (:148-160,189-195) */
+int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                 float* workspace, float* scores, ps_stream_t stream);
+
+/* The two torch.multinomial draws of one forward (item_transformer.py:447, :268):
+ * uniform items over [0,P) and alias-table words ~ word_dists.  alias tables are
+ * built on the host by ps_build_alias_host. */
+int ps_sample_negatives(const PsTemDesc* desc, const float* alias_prob, const int32_t* alias_idx,
+                        int64_t* neg_item_idxs, int64_t* neg_word_idxs, ps_stream_t stream);
+int ps_build_alias_host(const double* dist_host, int64_t n, float* prob_host, int32_t* alias_host);
+
+/* optim.step()                             -- Optimizer.step (models/optimizers.py:205-243):
+ * clip_grad_norm_(max_grad_norm) over all listed grads, then dense Adam(eps) with
+ * bias correction, optional L2 (weight_decay) and noam schedule.  The tensor
+ * table lives on the device (ps_adam_plan_bytes / ps_adam_plan_write_host).
+ * state[0] (device, int64) holds the step count and is incremented by the call;
+ * (float*)(state+2) is scratch for n_chunks partial sums. */
+typedef struct PsAdamHyper {
+  float lr;            /* --lr (original_lr when noam)                 */
+  float beta1, beta2;  /* --beta1 --beta2                              */
+  float eps;           /* 1e-9 (optimizers.py:186-187)                 */
+  float weight_decay;  /* --l2_lambda                                  */
+  float max_grad_norm; /* --max_grad_norm, 0 = no clip                 */
+  int32_t noam;        /* --decay_method noam                          */
+  int32_t warmup_steps;/* --warmup_steps                               */
+  float grad_scale;    /* multiplies every grad first (1/world for DP) */
+} PsAdamHyper;
+
+int64_t ps_adam_plan_bytes(int32_t n_tensors, const int64_t* numel_host);
+int ps_adam_plan_write_host(int32_t n_tensors, float* const* p, float* const* g, float* const* m,
+                            float* const* v, const int64_t* numel_host, void* plan_host);
+int32_t ps_adam_plan_chunks_host(const void* plan_host);     /* grid size; state needs 2 int64 + n_chunks floats */
+int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper,
+                       int64_t* state_dev, float* gnorm_out_dev /* [2]: norm, lr; may be NULL */,
+                       ps_stream_t stream);
+
+/* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
+int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);
+
+/* Host evaluation of the dropout stream (tests pin oracle/philox.py to it): multiplier
+ * (0 or 1/(1-p)) of element (row, col) of dropout site `site` at desc->seed/step/dropout. */
+float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint32_t row, uint32_t col);
+
+/* Unit-test hook of the fp32 MFMA GEMM: C[M,N] = alpha * op(A) op(B) (+bias) (+C if accumulate).
+ * ta: A stored [K,M];  tb==0: B stored [N,K] (nn.Linear), tb==1: B stored [K,N]. */
+int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int ldb, int tb,
+                float* Cm, int ldc, int M, int N, int K, const float* bias, float alpha,
+                int accumulate, ps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRODSEARCH_HIP_H */

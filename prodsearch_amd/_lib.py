@@ -1,0 +1,121 @@
+"""ctypes binding of libprodsearch_hip.so (the C ABI in include/prodsearch_hip.h).
+
+This is the reference-side stub INTEGRATION.md shows: plain pointers and sizes,
+no torch types cross the boundary.  There is NO CPU fallback: if the library is
+missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+PS_MAX_LAYERS = 8
+PS_MODEL_TEM, PS_MODEL_QEM = 0, 1
+PS_QENC_FS, PS_QENC_AVG = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+
+
+class PsTemDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('B', 'K', 'L', 'Q', 'W', 'C', 'd', 'H', 'F', 'n_layers')] + \
+               [('product_size', C.c_int64), ('vocab_size', C.c_int64)] + \
+               [(n, C.c_int32) for n in ('model', 'query_encoder', 'use_pos_emb', 'use_item_pos',
+                                         'bias_product', 'pos_weight', 'sep_prod_emb', 'training')] + \
+               [('dropout', C.c_float), ('seed', C.c_uint64), ('step', C.c_uint64)]
+
+
+LAYER_FIELDS = ('wk', 'bk', 'wv', 'bv', 'wq', 'bq', 'wo', 'bo', 'w1', 'b1', 'w2', 'b2',
+                'ff_ln_g', 'ff_ln_b', 'ln_g', 'ln_b')
+TOP_FIELDS = ('product_emb', 'hist_product_emb', 'word_emb', 'product_bias', 'word_bias',
+              'fs_w', 'fs_b', 'pe', 'final_ln_g', 'final_ln_b')
+
+
+class PsLayerTensors(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LAYER_FIELDS]
+
+
+class PsTemTensors(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TOP_FIELDS] + [('layer', PsLayerTensors * PS_MAX_LAYERS)]
+
+
+class PsTemBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs',
+                                          'pos_iword_idxs', 'neg_item_idxs', 'neg_word_idxs',
+                                          'candi_prod_idxs')]
+
+
+class PsTemWsLayout(C.Structure):
+    _fields_ = [('total_floats', C.c_int64), ('R', C.c_int32), ('S', C.c_int32)] + \
+               [(n, C.c_int64) for n in ('qmean', 'query_emb', 'x', 'kp', 'vp', 'qp', 'attn', 'ctx',
+                                         'y1', 'ln1', 'a1', 'h1', 'y2', 'enc',
+                                         'item_scores', 'word_scores', 'loss_parts', 'denc', 'dx')]
+
+
+class PsAdamHyper(C.Structure):
+    _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+                ('weight_decay', C.c_float), ('max_grad_norm', C.c_float), ('noam', C.c_int32),
+                ('warmup_steps', C.c_int32), ('grad_scale', C.c_float)]
+
+
+# every symbol include/prodsearch_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    'ps_version': (C.c_char_p, []),
+    'ps_last_error': (C.c_char_p, []),
+    'ps_tem_workspace_layout': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemWsLayout)]),
+    'ps_tem_forward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_tem_backward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
+                                  C.c_void_p, C.POINTER(PsTemTensors), C.c_float, C.c_void_p, C.c_void_p]),
+    'ps_tem_score': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_sample_negatives': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    'ps_build_alias_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'ps_adam_plan_bytes': (C.c_int64, [C.c_int32, C.c_void_p]),
+    'ps_adam_plan_write_host': (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    'ps_adam_plan_chunks_host': (C.c_int32, [C.c_void_p]),
+    'ps_clip_adam_dense': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsAdamHyper), C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
+    'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
+                              C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the in-tree library (never builds implicitly on a GPU box: the .so travels)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libprodsearch_hip.so not found at %s: run `python -m prodsearch_amd.build` "
+                           "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ps_last_error().decode('utf-8', 'replace')
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,189 @@
+// common.h — device helpers shared by the gfx950 kernels of libprodsearch_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/prodsearch_hip.h"
+
+#define PS_WAVE 64
+
+// ----------------------------------------------------------------- error plumbing
+void ps_set_error(const char* fmt, ...);
+#define PS_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      ps_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return PS_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+#define PS_REQUIRE(cond, ...)                                                     \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      ps_set_error(__VA_ARGS__);                                                  \
+      return PS_ERR_ARG;                                                          \
+    }                                                                             \
+  } while (0)
+#define PS_LAUNCH_CHECK() PS_CHECK_HIP(hipGetLastError())
+
+static inline int ps_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------- Philox4x32-10
+// Counter-based RNG (Salmon et al., SC'11), the generator torch/curand use; 10 rounds.
+// Dropout element (row, col) of site s at step t:  ctr = (col, row>>2, s, t), word = row&3,
+// keep iff word >= thr(p).  The oracle restates the same function (oracle/philox.py).
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+  return o;
+}
+
+struct DropSpec {      // one dropout site
+  uint32_t thr;        // keep iff u32 >= thr ; thr = floor(p * 2^32); 0 => disabled
+  float scale;         // 1/(1-p)
+  uint32_t site, step, k0, k1;
+};
+
+__host__ inline DropSpec make_drop(const PsTemDesc& d, uint32_t site) {
+  DropSpec s;
+  bool on = d.training && d.dropout > 0.f;
+  double p = on ? (double)d.dropout : 0.0;
+  s.thr = on ? (uint32_t)(p * 4294967296.0) : 0u;
+  s.scale = on ? (float)(1.0 / (1.0 - p)) : 1.f;
+  s.site = site; s.step = (uint32_t)d.step;
+  s.k0 = (uint32_t)(d.seed & 0xffffffffu); s.k1 = (uint32_t)(d.seed >> 32);
+  return s;
+}
+
+__device__ inline float drop_word(const DropSpec& s, uint32_t word) {
+  return word >= s.thr ? s.scale : 0.f;
+}
+// multiplier (0 or 1/(1-p)) of element (row, col)
+__device__ inline float drop_mult(const DropSpec& s, uint32_t row, uint32_t col) {
+  if (s.thr == 0u) return 1.f;
+  Philox4 r = philox4x32_10(col, row >> 2, s.site, s.step, s.k0, s.k1);
+  uint32_t sel = row & 3u;
+  uint32_t wv = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+  return drop_word(s, wv);
+}
+
+// site ids
+#define PS_SITE_FS 0u
+#define PS_SITE_ATTN(l) (1u + 8u * (uint32_t)(l) + 0u)
+#define PS_SITE_CTX(l)  (1u + 8u * (uint32_t)(l) + 1u)
+#define PS_SITE_FF1(l)  (1u + 8u * (uint32_t)(l) + 2u)
+#define PS_SITE_FF2(l)  (1u + 8u * (uint32_t)(l) + 3u)
+#define PS_SITE_SAMPLE_ITEM 0x40000000u
+#define PS_SITE_SAMPLE_WORD 0x40000001u
+
+// ------------------------------------------------------------------ wave helpers
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over groups of `width` consecutive lanes (width power of two <= 64)
+__device__ inline float group_sum(float v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ inline float gelu_tanh_f(float x) {     // models/neural.py:7-8
+  const float c = 0.7978845608028654f;             // sqrt(2/pi)
+  float u = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ inline float gelu_tanh_grad(float x) {
+  const float c = 0.7978845608028654f;
+  float x2 = x * x;
+  float u = c * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  float du = c * (1.f + 3.f * 0.044715f * x2);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+__device__ inline float softplus_f(float x) {      // log(1+exp(x)), stable
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ inline float sigmoid_f(float x) {
+  if (x >= 0.f) { float e = expf(-x); return 1.f / (1.f + e); }
+  float e = expf(x);
+  return e / (1.f + e);
+}
+
+// ------------------------------------------------------------------- GEMM launcher
+enum { RES_NONE = 0, RES_DIRECT = 1, RES_GATHER = 2, RES_FANIN = 3 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_GELU_BWD = 3, ACT_TANH_BWD = 4 };
+
+struct ResMap {           // row map between replica rows and layer-input rows
+  int mode;               // RES_*
+  const float* ptr;       // residual source
+  int ld;                 // row stride of ptr (floats)
+  int Sq, fan, S, qpos;   // GATHER: out row m=(n_out,i) -> src row (n_out/fan)*S + (Sq==S ? i : qpos)
+                          // FANIN : out row m=(n_in,pos) -> sum_j src row ((n_in*fan+j)*Sq + i), only q rows
+};
+
+__device__ inline float res_value(const ResMap& R, int row, int col) {
+  if (R.mode == RES_DIRECT) return R.ptr[(size_t)row * R.ld + col];
+  if (R.mode == RES_GATHER) {
+    int nout = row / R.Sq, i = row - nout * R.Sq;
+    int src = (nout / R.fan) * R.S + (R.Sq == R.S ? i : R.qpos);
+    return R.ptr[(size_t)src * R.ld + col];
+  }
+  if (R.mode == RES_FANIN) {
+    int nin = row / R.S, pos = row - nin * R.S;
+    int i;
+    if (R.Sq == R.S) i = pos;
+    else if (pos == R.qpos) i = 0;
+    else return 0.f;
+    float s = 0.f;
+    for (int j = 0; j < R.fan; ++j) s += R.ptr[(size_t)((nin * R.fan + j) * R.Sq + i) * R.ld + col];
+    return s;
+  }
+  return 0.f;
+}
+
+struct GemmProblem {
+  const float* A; int lda; int ta;      // ta: A stored [K][M] (reduction index is the slow one)
+  const float* Bseg[3]; int kseg;       // up to 3 B segments of kseg reduction rows each (nseg = ceil(K/kseg))
+  int ldb; int tb;                      // tb==0: B[n][k] (nn.Linear), tb==1: B[k][n]
+  float* C; int ldc;
+  int M, N, K;
+  const float* bias;                    // [N] or null
+  float alpha;                          // applied after bias:  v = (acc + bias) * alpha
+  int act;                              // ACT_*
+  const float* act_aux;                 // ACT_*_BWD: pre-activation / activation, same shape+ld as C
+  float* aux_out;                       // if set: pre-activation (acc+bias)*alpha stored here (ld = ldc)
+  DropSpec drop;                        // dropout applied after act
+  ResMap res;                           // residual added after dropout
+  float* out2; int ld2; const float* add2;  // if set: out2[row*ld2+col] = v + add2[col] (second copy of the result)
+  float* colsum;                        // if set: atomicAdd column sums of the final value into colsum[n]
+  int accumulate;                       // 0: C = v ; 1: C += v (plain) ; 2: atomicAdd(C, v) (split reduction)
+  int ksplit;                           // number of reduction splits (grid.z multiplier), >=1
+};
+
+struct GemmGroup {
+  GemmProblem p[3];
+  int n;
+};
+
+int ps_launch_gemm(const GemmGroup& g, hipStream_t stream);

@@ -1,0 +1,97 @@
+// rowwise.h — launchers of the row-parallel (HBM/latency-bound) kernels.
+#pragma once
+#include "common.h"
+
+struct EmbedArgs {
+  int B, Q, L, S, d;
+  int64_t P, V;
+  int tem;                       // 1: build the [B,S,d] sequence; 0 (QEM): query only
+  int fs;                        // 1: FS encoder (row 0 of x is written by the FS GEMM), 0: AVG
+  int use_pos;
+  const int64_t* qw; const int64_t* ui;
+  const float* word_emb; const float* hist_tab; const float* pe;
+  DropSpec drop_fs;
+  float* qmean_d;                // [B,d] mean after FS dropout
+  float* query_emb;              // [B,d] written here only for AVG
+  float* x;                      // [B,S,d]
+};
+int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);
+
+struct LnFwdArgs {
+  const float* x; int ldx; float* y; int ldy; float* stats;  // stats [rows,2] = mean, rstd
+  const float* g; const float* b; int rows, d; float eps;
+};
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st);
+
+struct LnBwdArgs {
+  const float* dy; int lddy;     // grad wrt LN output
+  const float* x; int ldx;       // LN input
+  const float* stats; const float* g;
+  int rows, d;
+  ResMap res;                    // added to dx after the LN backward
+  float* dx; int lddx;
+  float* out2;                   // optional: dx * dropout(site) (ld = d)
+  DropSpec drop2;
+  float* colsum;                 // optional: += column sums of (out2 if out2 else dx)
+  float* dgamma; float* dbeta;   // += (atomics)
+};
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st);
+
+struct AttnArgs {
+  int n_in, fan, H, S, Sq, d, dh, qpos;
+  int seq_div;                   // batch row = n_in_index / seq_div
+  int L; int64_t P; const int64_t* ui;   // key-padding mask source (u_item_idxs != P)
+  const float* kp; const float* vp; const float* qp;   // [n_in*S,d] x2, [n_in*Sq,d] (q pre-scaled)
+  float* attn;                   // [n_in,H,Sq,S] softmax (pre-dropout)
+  float* ctx;                    // [n_in*fan*Sq, d]
+  DropSpec drop;
+  // backward only
+  const float* dctx;             // [n_in*fan*Sq, d]
+  float* dq; int lddq;           // grad wrt the un-scaled query linear output
+  float* dkv; int lddkv;         // dK at col 0.., dV at col d..
+  float* dbq; float* dbk; float* dbv;   // += (atomics)
+  float qscale;                  // 1/sqrt(dh)
+};
+int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
+int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
+
+struct ScoreArgs {
+  int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)
+  int64_t P, V;
+  int bias_product, pos_weight;
+  const int64_t* target; const int64_t* neg_items; const int64_t* pos_words; const int64_t* neg_words;
+  const int64_t* candi;
+  const float* product_emb; const float* word_emb; const float* product_bias; const float* word_bias;
+  const float* enc;              // [B*R, d]
+  float* item_scores;            // [B,1+K]   (eval: [B,C])
+  float* word_scores;            // [B,W,1+K]
+  float* loss_parts;             // [B,2]
+  float* loss3;                  // {total, ps, item}
+  // backward
+  float scale;                   // loss_scale
+  const float* scale_dev;        // optional device scalar multiplied into scale
+  float* denc;                   // [B*R,d]
+  float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
+};
+int launch_score_fwd(const ScoreArgs& a, hipStream_t st);     // gather + dot ("gather+score kernel")
+int launch_loss(const ScoreArgs& a, hipStream_t st);
+int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
+
+struct EmbedBwdArgs {
+  int B, Q, L, S, d;
+  int64_t P, V;
+  int tem;
+  const int64_t* qw; const int64_t* ui;
+  const float* dx;               // [B,S,d] (tem)
+  const float* dqmean_d;         // [B,d] grad wrt the post-dropout query mean
+  DropSpec drop_fs;
+  float* g_hist_tab; float* g_word_emb;
+};
+int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
+
+// dqpre = dqe * (1 - qe^2), dfb += colsum(dqpre)
+int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
+                    hipStream_t st);
+
+int launch_sample(const PsTemDesc& d, const float* alias_prob, const int32_t* alias_idx, int64_t* neg_items,
+                  int64_t* neg_words, hipStream_t st);

@@ -1,0 +1,716 @@
+// rowwise.hip — the row-parallel kernels of the TEM step (gfx950): embedding
+// gathers + paragraph-vector mean-pool, LayerNorm fwd/bwd, the tiny per-(sequence,
+// head) attention, the gather+score kernel with its loss, their backward
+// scatter-adds, and negative sampling.  All are HBM/L2-latency bound integer +
+// fp32 work: rows are read with 16-byte lanes (coalesced 128 B..1 KiB per row),
+// reductions are wavefront shuffles, nothing here is reshaped into a GEMM.
+#include "rowwise.h"
+
+static inline int lpr_for(int d) {   // lanes per row for float4 lanes: pow2 >= d/4, <= 64
+  int n = d / 4, l = 1;
+  while (l < n && l < 64) l <<= 1;
+  return l;
+}
+
+__device__ inline int64_t clamp_idx(int64_t i, int64_t hi) { return i < 0 ? hi : (i > hi ? hi : i); }
+
+// =============================================================== embed forward
+// Reference: word_embeddings(query_word_idxs) + get_vector_mean (item_transformer.py:449-450,
+// text_encoder.py:6-16) + FS dropout (text_encoder.py:34-35); history gather, mask and
+// positional add (item_transformer.py:452,466-471, transformer.py:77-81).
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
+  extern __shared__ float red[];   // [rpp][d]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int d = a.d, nchunk = d >> 2;
+  const int rpp = 256 / nchunk;
+  const int rg = tid / nchunk, c = tid - rg * nchunk;
+  const bool active = rg < rpp;
+  const int64_t wpad = a.V - 1;
+  int cnt = 0;
+  for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != wpad);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    for (int q = rg; q < a.Q; q += rpp) {
+      int64_t idx = a.qw[(size_t)b * a.Q + q];
+      if (idx != wpad && idx >= 0 && idx < a.V) {
+        float4 v = *reinterpret_cast<const float4*>(a.word_emb + (size_t)idx * d + 4 * c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    *reinterpret_cast<float4*>(red + (size_t)rg * d + 4 * c) = acc;
+  }
+  __syncthreads();
+  if (tid < nchunk) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rpp; ++r) {
+      float4 v = *reinterpret_cast<const float4*>(red + (size_t)r * d + 4 * c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    float m[4] = {s.x * inv, s.y * inv, s.z * inv, s.w * inv};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] *= drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)(4 * c + e));
+    float4 md = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(a.qmean_d + (size_t)b * d + 4 * c) = md;
+    if (!a.fs) {
+      *reinterpret_cast<float4*>(a.query_emb + (size_t)b * d + 4 * c) = md;
+      if (a.tem) {
+        float4 o = md;
+        if (a.use_pos) {
+          float4 p = *reinterpret_cast<const float4*>(a.pe + 4 * c);
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        *reinterpret_cast<float4*>(a.x + (size_t)b * a.S * d + 4 * c) = o;
+      }
+    }
+  }
+  if (a.tem && active) {
+    for (int l = rg; l < a.L; l += rpp) {
+      int64_t idx = a.ui[(size_t)b * a.L + l];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx != a.P && idx >= 0 && idx < a.P)
+        v = *reinterpret_cast<const float4*>(a.hist_tab + (size_t)idx * d + 4 * c);
+      if (a.use_pos) {
+        float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)(1 + l) * d + 4 * c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      *reinterpret_cast<float4*>(a.x + ((size_t)b * a.S + 1 + l) * d + 4 * c) = v;
+    }
+  }
+}
+
+int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d % 4 == 0 && a.d <= 1024, "embed: d=%d unsupported", a.d);
+  int rpp = 256 / (a.d / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B), dim3(256), (size_t)rpp * a.d * sizeof(float), st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ================================================================== LayerNorm
+// nn.LayerNorm(d, eps=1e-6): transformer.py:44,68,86 ; neural.py:25.  One wave per row.
+#define LN_MAXI 8   // d <= 512
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const float invd = 1.f / (float)a.d;
+  for (int row = wave; row < a.rows; row += nw) {
+    float v[LN_MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      int col = lane + 64 * i;
+      v[i] = col < a.d ? a.x[(size_t)row * a.ldx + col] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) * invd;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      int col = lane + 64 * i;
+      float t = col < a.d ? v[i] - mean : 0.f;
+      q += t * t;
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * invd + a.eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      int col = lane + 64 * i;
+      if (col < a.d) a.y[(size_t)row * a.ldy + col] = (v[i] - mean) * rstd * a.g[col] + a.b[col];
+    }
+    if (lane == 0) { a.stats[2 * (size_t)row] = mean; a.stats[2 * (size_t)row + 1] = rstd; }
+  }
+}
+
+int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d <= 64 * LN_MAXI, "layernorm: d=%d > %d", a.d, 64 * LN_MAXI);
+  int blocks = ps_cdiv(a.rows, 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+  __shared__ float sh[3][4][64 * LN_MAXI];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const float invd = 1.f / (float)a.d;
+  float ag[LN_MAXI], ab[LN_MAXI], ac[LN_MAXI];
+#pragma unroll
+  for (int i = 0; i < LN_MAXI; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
+  for (int row = wave; row < a.rows; row += nw) {
+    const float mean = a.stats[2 * (size_t)row], rstd = a.stats[2 * (size_t)row + 1];
+    float xh[LN_MAXI], dxh[LN_MAXI], dyv[LN_MAXI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      int col = lane + 64 * i;
+      if (col < a.d) {
+        float x = a.x[(size_t)row * a.ldx + col];
+        dyv[i] = a.dy[(size_t)row * a.lddy + col];
+        xh[i] = (x - mean) * rstd;
+        dxh[i] = dyv[i] * a.g[col];
+      } else { xh[i] = 0.f; dxh[i] = 0.f; dyv[i] = 0.f; }
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+    }
+    s1 = wave_sum(s1) * invd;
+    s2 = wave_sum(s2) * invd;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      int col = lane + 64 * i;
+      if (col < a.d) {
+        float dx = rstd * (dxh[i] - s1 - xh[i] * s2);
+        if (a.res.mode != RES_NONE) dx += res_value(a.res, row, col);
+        a.dx[(size_t)row * a.lddx + col] = dx;
+        float v2 = dx;
+        if (a.out2) {
+          v2 = dx * drop_mult(a.drop2, (uint32_t)row, (uint32_t)col);
+          a.out2[(size_t)row * a.d + col] = v2;
+        }
+        ag[i] += dyv[i] * xh[i];
+        ab[i] += dyv[i];
+        ac[i] += v2;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXI; ++i) {
+    sh[0][wv][lane + 64 * i] = ag[i];
+    sh[1][wv][lane + 64 * i] = ab[i];
+    sh[2][wv][lane + 64 * i] = ac[i];
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < a.d; col += 256) {
+    float g = sh[0][0][col] + sh[0][1][col] + sh[0][2][col] + sh[0][3][col];
+    float b = sh[1][0][col] + sh[1][1][col] + sh[1][2][col] + sh[1][3][col];
+    float c = sh[2][0][col] + sh[2][1][col] + sh[2][2][col] + sh[2][3][col];
+    if (a.dgamma) atomicAdd(&a.dgamma[col], g);
+    if (a.dbeta) atomicAdd(&a.dbeta[col], b);
+    if (a.colsum) atomicAdd(&a.colsum[col], c);
+  }
+}
+
+int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d <= 64 * LN_MAXI, "layernorm bwd: d=%d > %d", a.d, 64 * LN_MAXI);
+  int blocks = ps_cdiv(a.rows, 4);
+  if (blocks > 512) blocks = 512;      // rows are grid-strided; bounds the gamma/beta atomics
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ================================================================== attention
+// MultiHeadedAttention.forward live branch (neural.py:142-145, 206-231) per (sequence, head):
+// scores = Qs.K^T, masked_fill(key pad, -1e18), softmax, dropout, attn.V.  S <= 64 keys and
+// dh <= 64, so one wave owns one (sequence, head) with everything in LDS.
+struct AttnLds {
+  float *Ks, *Vs, *Qs, *Ps, *Pd, *valid;
+};
+__device__ inline AttnLds attn_carve(float* base, int S, int Sq, int dh) {
+  AttnLds l;
+  l.Ks = base; base += S * dh;
+  l.Vs = base; base += S * dh;
+  l.Qs = base; base += Sq * dh;
+  l.Ps = base; base += Sq * (S + 1);
+  l.Pd = base; base += Sq * (S + 1);
+  l.valid = base;
+  return l;
+}
+static inline size_t attn_fwd_lds(int S, int Sq, int dh) {
+  return sizeof(float) * ((size_t)2 * S * dh + Sq * dh + 2 * Sq * (S + 1) + S);
+}
+
+__device__ inline void attn_load_common(const AttnArgs& a, const AttnLds& l, int b, int h, int tid) {
+  const int S = a.S, Sq = a.Sq, dh = a.dh, d = a.d;
+  for (int i = tid; i < S * dh; i += 64) {
+    int s = i / dh, c = i - s * dh;
+    size_t off = ((size_t)b * S + s) * d + h * dh + c;
+    l.Ks[i] = a.kp[off];
+    l.Vs[i] = a.vp[off];
+  }
+  for (int i = tid; i < Sq * dh; i += 64) {
+    int q = i / dh, c = i - q * dh;
+    l.Qs[i] = a.qp[((size_t)b * Sq + q) * d + h * dh + c];
+  }
+  const int brow = b / a.seq_div;
+  for (int s = tid; s < S; s += 64)
+    l.valid[s] = (s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ float lds[];
+  const int S = a.S, Sq = a.Sq, dh = a.dh, d = a.d, tid = threadIdx.x;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  AttnLds l = attn_carve(lds, S, Sq, dh);
+  attn_load_common(a, l, b, h, tid);
+  __syncthreads();
+  for (int idx = tid; idx < Sq * S; idx += 64) {
+    int i = idx / S, s = idx - i * S;
+    float acc = 0.f;
+    for (int c = 0; c < dh; ++c) acc += l.Qs[i * dh + c] * l.Ks[s * dh + c];
+    l.Ps[i * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;
+  }
+  __syncthreads();
+  for (int i = tid; i < Sq; i += 64) {
+    float* p = l.Ps + i * (S + 1);
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, p[s]);
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) { float e = expf(p[s] - m); p[s] = e; sum += e; }
+    float inv = 1.f / sum;
+    for (int s = 0; s < S; ++s) p[s] *= inv;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < Sq * S; idx += 64) {
+    int i = idx / S, s = idx - i * S;
+    a.attn[((size_t)(b * a.H + h) * Sq + i) * S + s] = l.Ps[i * (S + 1) + s];
+  }
+  for (int j = 0; j < a.fan; ++j) {
+    const int nout = b * a.fan + j;
+    const float* P = l.Ps;
+    if (a.drop.thr != 0u) {
+      __syncthreads();
+      for (int idx = tid; idx < Sq * S; idx += 64) {
+        int i = idx / S, s = idx - i * S;
+        uint32_t row = (uint32_t)((nout * a.H + h) * Sq + i);
+        l.Pd[i * (S + 1) + s] = l.Ps[i * (S + 1) + s] * drop_mult(a.drop, row, (uint32_t)s);
+      }
+      __syncthreads();
+      P = l.Pd;
+    }
+    for (int idx = tid; idx < Sq * dh; idx += 64) {
+      int i = idx / dh, c = idx - i * dh;
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += P[i * (S + 1) + s] * l.Vs[s * dh + c];
+      a.ctx[((size_t)nout * Sq + i) * d + h * dh + c] = acc;
+    }
+  }
+}
+
+int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  size_t lds = attn_fwd_lds(a.S, a.Sq, a.dh);
+  PS_REQUIRE(a.S <= 64 && lds <= 64 * 1024, "attention: S=%d dh=%d needs %zu B LDS", a.S, a.dh, lds);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.n_in * a.H), dim3(64), lds, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+static inline size_t attn_bwd_lds(int S, int Sq, int dh) {
+  return attn_fwd_lds(S, Sq, dh) + sizeof(float) * ((size_t)Sq * (S + 1) + 2 * S * dh + 2 * Sq * dh);
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
+  extern __shared__ float lds[];
+  const int S = a.S, Sq = a.Sq, dh = a.dh, d = a.d, tid = threadIdx.x;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  AttnLds l = attn_carve(lds, S, Sq, dh);
+  float* dP = l.valid + S;              // [Sq][S+1]
+  float* dVs = dP + Sq * (S + 1);       // [S][dh]
+  float* dKs = dVs + S * dh;            // [S][dh]
+  float* dC = dKs + S * dh;             // [Sq][dh]
+  float* dQs = dC + Sq * dh;            // [Sq][dh]
+  attn_load_common(a, l, b, h, tid);
+  for (int idx = tid; idx < Sq * S; idx += 64) {
+    int i = idx / S, s = idx - i * S;
+    l.Ps[i * (S + 1) + s] = a.attn[((size_t)(b * a.H + h) * Sq + i) * S + s];
+    dP[i * (S + 1) + s] = 0.f;
+  }
+  for (int i = tid; i < S * dh; i += 64) dVs[i] = 0.f;
+  __syncthreads();
+  for (int j = 0; j < a.fan; ++j) {
+    const int nout = b * a.fan + j;
+    for (int idx = tid; idx < Sq * dh; idx += 64) {
+      int i = idx / dh, c = idx - i * dh;
+      dC[idx] = a.dctx[((size_t)nout * Sq + i) * d + h * dh + c];
+    }
+    for (int idx = tid; idx < Sq * S; idx += 64) {
+      int i = idx / S, s = idx - i * S;
+      uint32_t row = (uint32_t)((nout * a.H + h) * Sq + i);
+      l.Pd[i * (S + 1) + s] = drop_mult(a.drop, row, (uint32_t)s);   // multiplier only
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * dh; idx += 64) {          // dV[s][c] += sum_i P*m*dC
+      int s = idx / dh, c = idx - s * dh;
+      float acc = 0.f;
+      for (int i = 0; i < Sq; ++i) acc += l.Ps[i * (S + 1) + s] * l.Pd[i * (S + 1) + s] * dC[i * dh + c];
+      dVs[idx] += acc;
+    }
+    for (int idx = tid; idx < Sq * S; idx += 64) {          // dP[i][s] += m * dC[i].V[s]
+      int i = idx / S, s = idx - i * S;
+      float acc = 0.f;
+      for (int c = 0; c < dh; ++c) acc += dC[i * dh + c] * l.Vs[s * dh + c];
+      dP[i * (S + 1) + s] += l.Pd[i * (S + 1) + s] * acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < Sq; i += 64) {                      // softmax backward
+    float* p = l.Ps + i * (S + 1);
+    float* g = dP + i * (S + 1);
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += p[s] * g[s];
+    for (int s = 0; s < S; ++s) g[s] = p[s] * (g[s] - t);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < Sq * dh; idx += 64) {           // dQ (un-scaled linear output)
+    int i = idx / dh, c = idx - i * dh;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += dP[i * (S + 1) + s] * l.Ks[s * dh + c];
+    acc *= a.qscale;
+    dQs[idx] = acc;
+    a.dq[((size_t)b * Sq + i) * a.lddq + h * dh + c] = acc;
+  }
+  for (int idx = tid; idx < S * dh; idx += 64) {            // dK, dV
+    int s = idx / dh, c = idx - s * dh;
+    float acc = 0.f;
+    for (int i = 0; i < Sq; ++i) acc += dP[i * (S + 1) + s] * l.Qs[i * dh + c];
+    dKs[idx] = acc;
+    size_t off = ((size_t)b * S + s) * a.lddkv + h * dh + c;
+    a.dkv[off] = acc;
+    a.dkv[off + d] = dVs[idx];
+  }
+  __syncthreads();
+  for (int c = tid; c < dh; c += 64) {                      // bias grads
+    float sq = 0.f, sk = 0.f, sv = 0.f;
+    for (int i = 0; i < Sq; ++i) sq += dQs[i * dh + c];
+    for (int s = 0; s < S; ++s) { sk += dKs[s * dh + c]; sv += dVs[s * dh + c]; }
+    atomicAdd(&a.dbq[h * dh + c], sq);
+    atomicAdd(&a.dbk[h * dh + c], sk);
+    atomicAdd(&a.dbv[h * dh + c], sv);
+  }
+}
+
+int launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
+  size_t lds = attn_bwd_lds(a.S, a.Sq, a.dh);
+  PS_REQUIRE(a.S <= 64 && lds <= 64 * 1024, "attention bwd: S=%d dh=%d needs %zu B LDS", a.S, a.dh, lds);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.n_in * a.H), dim3(64), lds, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ========================================================== gather + score kernel
+// The embedding-gather+score kernel of the metric: one task = one table row
+// (target / negative item, or positive / negative word) dotted with its vector
+// (the encoder output of its replica, or the target item's row):
+//   pos/neg scores  item_transformer.py:464-465,485,493-499
+//   item_to_words   item_transformer.py:262-275
+// A row group of LPR lanes (16 B per lane) owns 4 tasks at a time: 4 index loads, then
+// 4 row + 4 vector loads in flight, then shuffle reductions.
+struct Task {
+  const float* row; const float* vec; float bias; float* out;
+};
+__device__ inline Task score_task(const ScoreArgs& a, int t) {
+  Task k;
+  const int K1 = a.K + 1;
+  if (a.C > 0) {                                   // eval: candidates
+    int b = t / a.C;
+    int64_t idx = clamp_idx(a.candi[t], a.P);
+    k.row = a.product_emb + (size_t)idx * a.d;
+    k.vec = a.enc + (size_t)b * a.R * a.d;
+    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
+    k.out = a.item_scores + t;
+    return k;
+  }
+  const int nitem = a.B * K1;
+  if (t < nitem) {
+    int b = t / K1, j = t - b * K1;
+    int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+    k.row = a.product_emb + (size_t)idx * a.d;
+    k.vec = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * a.d;
+    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
+    k.out = a.item_scores + t;
+  } else {
+    int u = t - nitem;
+    int b = u / (a.W * K1), r = u - b * (a.W * K1);
+    int w = r / K1, j = r - w * K1;
+    int64_t idx = clamp_idx(j == 0 ? a.pos_words[(size_t)b * a.W + w]
+                                   : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+    int64_t tb = clamp_idx(a.target[b], a.P);
+    k.row = a.word_emb + (size_t)idx * a.d;
+    k.vec = a.product_emb + (size_t)tb * a.d;
+    k.bias = a.word_bias[idx];
+    k.out = a.word_scores + u;
+  }
+  return k;
+}
+
+#define SCORE_U 4
+__global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int ntask, int lpr) {
+  const int tid = threadIdx.x;
+  const int gpb = 256 / lpr;                       // row groups per block
+  const int grp = blockIdx.x * gpb + tid / lpr;
+  const int c = tid % lpr;
+  const int nch = a.d >> 2;
+  const int t0 = grp * SCORE_U;
+  Task tk[SCORE_U];
+  float4 r[SCORE_U], v[SCORE_U];
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u) {
+    int t = t0 + u;
+    if (t < ntask) tk[u] = score_task(a, t);
+    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; }
+  }
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u) {
+    r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[u] = r[u];
+    if (tk[u].row && c < nch) {
+      r[u] = *reinterpret_cast<const float4*>(tk[u].row + 4 * c);
+      v[u] = *reinterpret_cast<const float4*>(tk[u].vec + 4 * c);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u) {
+    float s = r[u].x * v[u].x + r[u].y * v[u].y + r[u].z * v[u].z + r[u].w * v[u].w;
+    if (tk[u].row)
+      for (int cc = c + lpr; cc < nch; cc += lpr) {          // d > 256 only
+        float4 rr = *reinterpret_cast<const float4*>(tk[u].row + 4 * cc);
+        float4 vv = *reinterpret_cast<const float4*>(tk[u].vec + 4 * cc);
+        s += rr.x * vv.x + rr.y * vv.y + rr.z * vv.z + rr.w * vv.w;
+      }
+    s = group_sum(s, lpr);
+    if (c == 0 && tk[u].out) *tk[u].out = s + tk[u].bias;
+  }
+}
+
+int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
+  int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
+  int lpr = lpr_for(a.d);
+  int groups = ps_cdiv(ntask, SCORE_U);
+  int blocks = ps_cdiv(groups, 256 / lpr);
+  hipLaunchKernelGGL(score_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// Loss (item_transformer.py:500-514 weighted BCE-with-logits; :277-282 PV loss): one block,
+// fixed-order tree reduction => bitwise reproducible.
+__global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
+  __shared__ float sps[256], sil[256];
+  const int tid = threadIdx.x, K1 = a.K + 1;
+  const float wpos = a.pos_weight ? (float)a.K : 1.f;
+  float aps = 0.f, ail = 0.f;
+  for (int b = tid; b < a.B; b += 256) {
+    const float* s = a.item_scores + (size_t)b * K1;
+    float ps = wpos * softplus_f(-s[0]);
+    for (int k = 1; k < K1; ++k) ps += softplus_f(s[k]);
+    float il = 0.f;
+    int cnt = 0;
+    for (int w = 0; w < a.W; ++w) {
+      bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
+      cnt += valid;
+      if (valid) {
+        const float* ws = a.word_scores + ((size_t)b * a.W + w) * K1;
+        float l = softplus_f(-ws[0]);
+        for (int k = 1; k < K1; ++k) l += softplus_f(ws[k]);
+        il += l;
+      }
+    }
+    il /= (float)(cnt > 0 ? cnt : 1);
+    a.loss_parts[2 * b] = ps;
+    a.loss_parts[2 * b + 1] = il;
+    aps += ps; ail += il;
+  }
+  sps[tid] = aps; sil[tid] = ail;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sps[tid] += sps[tid + o]; sil[tid] += sil[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float ps = sps[0] / (float)a.B, il = sil[0] / (float)a.B;
+    a.loss3[0] = ps + il; a.loss3[1] = ps; a.loss3[2] = il;
+  }
+}
+
+int launch_loss(const ScoreArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// Backward of score + loss: per batch row, half-wave (32 lanes, 128-B segments) per task so
+// that every fp32 atomic wave-instruction covers two contiguous 128-B row segments.
+#define BW_MAXE 16   // d <= 512
+__global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
+  extern __shared__ float red[];                 // [8][d]
+  const int b = blockIdx.x, tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
+  const int d = a.d, epl = d >> 5, K1 = a.K + 1;
+  const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+  const float wpos = a.pos_weight ? (float)a.K : 1.f;
+  const int64_t tb = clamp_idx(a.target[b], a.P);
+  float acc[BW_MAXE];
+#pragma unroll
+  for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
+  // ---- item tasks
+  for (int j = rg; j < K1; j += 8) {
+    int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+    float s = a.item_scores[(size_t)b * K1 + j];
+    float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
+    const float* encr = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * d;
+    const float* row = a.product_emb + (size_t)idx * d;
+    float* grow = a.g_product_emb + (size_t)idx * d;
+#pragma unroll
+    for (int k = 0; k < BW_MAXE; ++k) {
+      if (k < epl) {
+        int e = c + 32 * k;
+        float rv = row[e], ev = encr[e];
+        if (idx != a.P) atomicAdd(&grow[e], ds * ev);
+        if (a.R > 1) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv;
+        else acc[k] += ds * rv;
+      }
+    }
+    if (a.bias_product && c == 0) atomicAdd(&a.g_product_bias[idx], ds);
+  }
+  if (a.R == 1) {
+#pragma unroll
+    for (int k = 0; k < BW_MAXE; ++k)
+      if (k < epl) red[rg * d + c + 32 * k] = acc[k];
+    __syncthreads();
+    for (int e = tid; e < d; e += 256) {
+      float s = 0.f;
+      for (int r = 0; r < 8; ++r) s += red[r * d + e];
+      a.denc[(size_t)b * d + e] = s;
+    }
+    __syncthreads();
+  }
+  // ---- word tasks
+#pragma unroll
+  for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
+  int cnt = 0;
+  for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
+  const float cf = invB / (float)(cnt > 0 ? cnt : 1);
+  const float* prow = a.product_emb + (size_t)tb * d;
+  for (int t = rg; t < a.W * K1; t += 8) {
+    int w = t / K1, j = t - w * K1;
+    int64_t pw = a.pos_words[(size_t)b * a.W + w];
+    if (pw == a.V - 1) continue;                                  // masked window slot (get_vector_mean)
+    int64_t idx = clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+    float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
+    float ds = (j == 0 ? sigmoid_f(s) - 1.f : sigmoid_f(s)) * cf;
+    const float* wrow = a.word_emb + (size_t)idx * d;
+    float* grow = a.g_word_emb + (size_t)idx * d;
+#pragma unroll
+    for (int k = 0; k < BW_MAXE; ++k) {
+      if (k < epl) {
+        int e = c + 32 * k;
+        if (idx != a.V - 1) atomicAdd(&grow[e], ds * prow[e]);
+        acc[k] += ds * wrow[e];
+      }
+    }
+    if (c == 0) atomicAdd(&a.g_word_bias[idx], ds);
+  }
+#pragma unroll
+  for (int k = 0; k < BW_MAXE; ++k)
+    if (k < epl) red[rg * d + c + 32 * k] = acc[k];
+  __syncthreads();
+  if (tb != a.P)
+    for (int e = tid; e < d; e += 256) {
+      float s = 0.f;
+      for (int r = 0; r < 8; ++r) s += red[r * d + e];
+      atomicAdd(&a.g_product_emb[(size_t)tb * d + e], s);
+    }
+}
+
+int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d % 32 == 0 && a.d <= 32 * BW_MAXE, "score bwd: d=%d unsupported", a.d);
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B), dim3(256), (size_t)8 * a.d * sizeof(float), st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ========================================================== embedding scatter-add
+// Backward of the history gather (item_transformer.py:466-469) and of the query mean
+// (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask) {
+  const int tid = threadIdx.x, c = tid & 31;
+  const int t = blockIdx.x * 8 + (tid >> 5);
+  if (t >= ntask) return;
+  const int d = a.d, epl = d >> 5;
+  const int nitem = a.tem ? a.B * a.L : 0;
+  if (t < nitem) {
+    int b = t / a.L, l = t - b * a.L;
+    int64_t idx = a.ui[t];
+    if (idx == a.P || idx < 0 || idx > a.P) return;
+    const float* src = a.dx + ((size_t)b * a.S + 1 + l) * d;
+    float* dst = a.g_hist_tab + (size_t)idx * d;
+    for (int k = 0; k < epl; ++k) atomicAdd(&dst[c + 32 * k], src[c + 32 * k]);
+  } else {
+    int u = t - nitem;
+    int b = u / a.Q;
+    int64_t idx = a.qw[u];
+    if (idx == a.V - 1 || idx < 0 || idx >= a.V) return;
+    int cnt = 0;
+    for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    const float* src = a.dqmean_d + (size_t)b * d;
+    float* dst = a.g_word_emb + (size_t)idx * d;
+    for (int k = 0; k < epl; ++k) {
+      int e = c + 32 * k;
+      atomicAdd(&dst[e], src[e] * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)e) * inv);
+    }
+  }
+}
+
+int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.d % 32 == 0, "embed scatter: d %% 32");
+  int ntask = (a.tem ? a.B * a.L : 0) + a.B * a.Q;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ps_cdiv(ntask, 8)), dim3(256), 0, st, a, ntask);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// dqpre = dqe * (1 - qe^2)  (tanh backward of FSEncoder, text_encoder.py:39), dfb += colsum
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dqe, int lddqe, const float* qe, float* dqpre,
+                                                       float* dfb, int rows, int d) {
+  const int r0 = blockIdx.x * 32;
+  for (int col = threadIdx.x; col < d; col += 256) {
+    float s = 0.f;
+    for (int r = r0; r < min(rows, r0 + 32); ++r) {
+      float y = qe[(size_t)r * d + col];
+      float v = dqe[(size_t)r * lddqe + col] * (1.f - y * y);
+      dqpre[(size_t)r * d + col] = v;
+      s += v;
+    }
+    atomicAdd(&dfb[col], s);
+  }
+}
+
+int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ps_cdiv(rows, 32)), dim3(256), 0, st, dqe, lddqe, qe, dqpre, dfb, rows, d);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ============================================================ negative sampling
+// Stand-in for the two torch.multinomial draws (item_transformer.py:447 uniform items over
+// [0,P), :268 words ~ word_dists via a Vose alias table); Philox streams keyed by (seed, step).
+__global__ __launch_bounds__(256) void sample_kernel(int nitem, int nword, int64_t P, int64_t V, uint32_t step,
+                                                     uint32_t k0, uint32_t k1, const float* prob,
+                                                     const int32_t* alias, int64_t* neg_items, int64_t* neg_words) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nitem) {
+    Philox4 r = philox4x32_10((uint32_t)t, 0u, PS_SITE_SAMPLE_ITEM, step, k0, k1);
+    neg_items[t] = (int64_t)(((uint64_t)r.x * (uint64_t)P) >> 32);
+  } else if (t < nitem + nword) {
+    int u = t - nitem;
+    Philox4 r = philox4x32_10((uint32_t)u, 0u, PS_SITE_SAMPLE_WORD, step, k0, k1);
+    int64_t i = (int64_t)(((uint64_t)r.x * (uint64_t)V) >> 32);
+    float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+    neg_words[u] = f < prob[i] ? i : (int64_t)alias[i];
+  }
+}
+
+int launch_sample(const PsTemDesc& d, const float* alias_prob, const int32_t* alias_idx, int64_t* neg_items,
+                  int64_t* neg_words, hipStream_t st) {
+  int nitem = d.B * d.K, nword = d.B * d.W * d.K;
+  hipLaunchKernelGGL(sample_kernel, dim3(ps_cdiv(nitem + nword, 256)), dim3(256), 0, st, nitem, nword,
+                     d.product_size, d.vocab_size, (uint32_t)d.step, (uint32_t)(d.seed & 0xffffffffu),
+                     (uint32_t)(d.seed >> 32), alias_prob, alias_idx, neg_items, neg_words);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

@@ -1,0 +1,561 @@
+// tem.hip — host orchestration + C ABI of the TEM / QEM ranking-loss step (gfx950).
+//
+// Forward  = ItemTransformerRanker.forward_dotproduct (item_transformer.py:440-520)
+//            / forward_attn with model_name == 'QEM' (:361-438)
+// Backward = autograd of the same (trainer.py:77)
+// Score    = test_dotproduct (:111-146) / test_attn QEM (:148-195)
+//
+// Structure of the encoder ("replicas"): the reference encodes the SAME (query, history)
+// sequence K+1 times (once for the positive, K expanded copies for the negatives).  The copies
+// only differ through dropout, which first acts on the softmax output of layer 0, so:
+//   * K/V/Q projections and softmax of layer 0 run once per batch row          (n_in  = B)
+//   * everything after the first dropout runs per replica                       (n_out = B*R)
+//     with R = K+1 when dropout is drawn (training && dropout > 0) and R = 1 otherwise,
+//     where all replicas are bit-identical and one is computed;
+//   * the LAST layer only produces the one output position that is consumed
+//     (x[:, 0] or x[:, -1], item_transformer.py:482-492), so its query/attention/FFN rows
+//     are n_out x 1 instead of n_out x S.
+#include "rowwise.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[512] = "";
+void ps_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ps_last_error(void) { return g_err; }
+extern "C" const char* ps_version(void) { return "prodsearch_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+// ------------------------------------------------------------- workspace layout
+struct LayerWs {
+  int n_in, fan, n_out, Sq, M2;
+  int64_t xn, pre_stats, kp, vp, qp, attn, ctx, y1, ff_stats, ln1, a1, h1, y2;
+};
+struct Ws {
+  int R, S, Mf, qpos;
+  int64_t qmean, query_emb, x;
+  LayerWs layer[PS_MAX_LAYERS];
+  int64_t fin_stats, enc;
+  int64_t item_scores, word_scores, loss_parts;
+  int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
+  int64_t total;
+};
+
+static int check_desc(const PsTemDesc& D) {
+  PS_REQUIRE(D.B > 0 && D.K >= 0 && D.Q > 0 && D.W >= 0 && D.d > 0, "desc: bad sizes B=%d K=%d Q=%d W=%d d=%d",
+             D.B, D.K, D.Q, D.W, D.d);
+  PS_REQUIRE(D.d % 32 == 0 && D.d <= 512, "desc: embedding_size %d must be a multiple of 32 and <= 512", D.d);
+  PS_REQUIRE(D.model == PS_MODEL_TEM || D.model == PS_MODEL_QEM, "desc: model %d", D.model);
+  if (D.model == PS_MODEL_TEM) {
+    PS_REQUIRE(D.L >= 0 && D.L + 1 <= 64, "desc: history length %d (S <= 64)", D.L);
+    PS_REQUIRE(D.n_layers >= 0 && D.n_layers <= PS_MAX_LAYERS, "desc: inter_layers %d", D.n_layers);
+    if (D.n_layers > 0) {
+      PS_REQUIRE(D.H > 0 && D.d % D.H == 0 && D.d / D.H <= 64, "desc: heads %d for d %d", D.H, D.d);
+      PS_REQUIRE(D.F > 0 && D.F % 4 == 0, "desc: ff_size %d", D.F);
+    }
+  }
+  PS_REQUIRE(D.dropout >= 0.f && D.dropout < 1.f, "desc: dropout %f", D.dropout);
+  PS_REQUIRE(D.product_size > 0 && D.vocab_size > 1, "desc: table sizes");
+  return PS_OK;
+}
+
+static inline int64_t take(int64_t& cur, int64_t n) {
+  int64_t o = cur;
+  cur += (n + 3) & ~(int64_t)3;     // keep every buffer 16-byte aligned
+  return o;
+}
+
+static int make_ws(const PsTemDesc& D, Ws& w) {
+  int rc = check_desc(D);
+  if (rc) return rc;
+  memset(&w, 0, sizeof(w));
+  const bool tem = D.model == PS_MODEL_TEM;
+  const bool drop = D.training && D.dropout > 0.f;
+  const int B = D.B, d = D.d, S = tem ? D.L + 1 : 1, NL = tem ? D.n_layers : 0;
+  w.S = S;
+  w.R = (tem && drop && NL > 0 && D.C == 0) ? D.K + 1 : 1;
+  w.qpos = D.use_item_pos ? S - 1 : 0;
+  int64_t cur = 0;
+  w.qmean = take(cur, (int64_t)B * d);
+  w.query_emb = take(cur, (int64_t)B * d);
+  w.x = tem ? take(cur, (int64_t)B * S * d) : 0;
+  int64_t maxM2 = 0, maxNS = 0;
+  for (int i = 0; i < NL; ++i) {
+    LayerWs& l = w.layer[i];
+    l.n_in = i == 0 ? B : B * w.R;
+    l.n_out = B * w.R;
+    l.fan = l.n_out / l.n_in;
+    l.Sq = i == NL - 1 ? 1 : S;
+    l.M2 = l.n_out * l.Sq;
+    const int64_t ns = (int64_t)l.n_in * S;
+    l.xn = i == 0 ? w.x : take(cur, ns * d);
+    l.pre_stats = i == 0 ? 0 : take(cur, ns * 2);
+    l.kp = take(cur, ns * d);
+    l.vp = take(cur, ns * d);
+    l.qp = take(cur, (int64_t)l.n_in * l.Sq * d);
+    l.attn = take(cur, (int64_t)l.n_in * D.H * l.Sq * S);
+    l.ctx = take(cur, (int64_t)l.M2 * d);
+    l.y1 = take(cur, (int64_t)l.M2 * d);
+    l.ff_stats = take(cur, (int64_t)l.M2 * 2);
+    l.ln1 = take(cur, (int64_t)l.M2 * d);
+    l.a1 = take(cur, (int64_t)l.M2 * D.F);
+    l.h1 = take(cur, (int64_t)l.M2 * D.F);
+    l.y2 = take(cur, (int64_t)l.M2 * d);
+    maxM2 = l.M2 > maxM2 ? l.M2 : maxM2;
+    maxNS = ns > maxNS ? ns : maxNS;
+  }
+  w.Mf = B * w.R;
+  w.fin_stats = take(cur, (int64_t)w.Mf * 2);
+  w.enc = tem ? take(cur, (int64_t)w.Mf * d) : w.query_emb;
+  const int C = D.C > 0 ? D.C : D.K + 1;
+  w.item_scores = take(cur, (int64_t)B * C);
+  w.word_scores = take(cur, (int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1));
+  w.loss_parts = take(cur, (int64_t)B * 2);
+  // backward scratch (sized for the widest layer)
+  w.denc = take(cur, (int64_t)w.Mf * d);
+  if (tem) {
+    const int64_t F = NL > 0 ? D.F : 0;
+    w.dy2 = take(cur, (maxM2 > w.Mf ? maxM2 : w.Mf) * d);
+    w.do2 = take(cur, maxM2 * d);
+    w.da1 = take(cur, maxM2 * F);
+    w.dln1 = take(cur, maxM2 * d);
+    w.dy1 = take(cur, maxM2 * d);
+    w.do_ = take(cur, maxM2 * d);
+    w.dctx = take(cur, maxM2 * d);
+    w.dq = take(cur, maxNS * d);
+    w.dkv = take(cur, maxNS * 3 * d);
+    w.dxn = take(cur, maxNS * d);
+    w.dx = take(cur, (int64_t)B * S * d);
+  }
+  w.dqpre = take(cur, (int64_t)B * d);
+  w.dqmean = take(cur, (int64_t)B * d);
+  w.total = cur;
+  return PS_OK;
+}
+
+extern "C" int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out) {
+  PS_REQUIRE(desc && out, "workspace_layout: null argument");
+  Ws w;
+  int rc = make_ws(*desc, w);
+  if (rc) return rc;
+  memset(out, 0, sizeof(*out));
+  out->total_floats = w.total;
+  out->R = w.R; out->S = w.S;
+  out->qmean = w.qmean; out->query_emb = w.query_emb; out->x = w.x;
+  const int NL = desc->model == PS_MODEL_TEM ? desc->n_layers : 0;
+  if (NL > 0) {
+    const LayerWs& l = w.layer[NL - 1];
+    out->kp = l.kp; out->vp = l.vp; out->qp = l.qp; out->attn = l.attn; out->ctx = l.ctx;
+    out->y1 = l.y1; out->ln1 = l.ln1; out->a1 = l.a1; out->h1 = l.h1; out->y2 = l.y2;
+  }
+  out->enc = w.enc;
+  out->item_scores = w.item_scores; out->word_scores = w.word_scores; out->loss_parts = w.loss_parts;
+  out->denc = w.denc; out->dx = w.dx;
+  return PS_OK;
+}
+
+// ----------------------------------------------------------------- GEMM helpers
+static GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M,
+                      int N, int K) {
+  GemmProblem p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.ta = ta;
+  p.Bseg[0] = Bm; p.kseg = K; p.ldb = ldb; p.tb = tb;
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.alpha = 1.f; p.ksplit = 1;
+  return p;
+}
+static int run1(const GemmProblem& p, hipStream_t st) {
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = 1; g.p[0] = p;
+  return ps_launch_gemm(g, st);
+}
+// weight gradient  dW[N_out, K_in] += dY[rows, N_out]^T . X[rows, K_in]   (atomic, split over rows)
+static GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in,
+                            int rows) {
+  GemmProblem p = gp(dY, lddy, 1, X, ldx, 1, dW, k_in, n_out, k_in, rows);
+  p.accumulate = 2;
+  return p;
+}
+static int pick_ksplit(int tiles, int rows) {
+  int want = 256 / (tiles > 0 ? tiles : 1);
+  int cap = rows / 128;
+  int ks = want < cap ? want : cap;
+  return ks < 1 ? 1 : ks;
+}
+static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int tiles = 0, rows = 0;
+  for (int i = 0; i < n; ++i) {
+    tiles += ps_cdiv(ps[i].M, 64) * ps_cdiv(ps[i].N, 64);
+    rows = ps[i].K > rows ? ps[i].K : rows;
+  }
+  int ks = pick_ksplit(tiles, rows);
+  for (int i = 0; i < n; ++i) { g.p[i] = ps[i]; g.p[i].ksplit = ks; }
+  return ps_launch_gemm(g, st);
+}
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+// -------------------------------------------------------------- encoder forward
+static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
+                          hipStream_t st) {
+  const bool tem = D.model == PS_MODEL_TEM;
+  const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0;
+  const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
+  PS_REQUIRE(P.word_emb && P.product_emb && hist, "forward: null embedding table");
+  EmbedArgs e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size;
+  e.tem = tem; e.fs = D.query_encoder == PS_QENC_FS; e.use_pos = D.use_pos_emb;
+  e.qw = Bt.query_word_idxs; e.ui = Bt.u_item_idxs;
+  e.word_emb = P.word_emb; e.hist_tab = hist; e.pe = P.pe;
+  e.drop_fs = make_drop(D, PS_SITE_FS);
+  e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
+  PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
+  PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
+  TRY(launch_embed_fwd(e, st));
+  if (e.fs) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
+    PS_REQUIRE(P.fs_w && P.fs_b, "forward: null FS encoder weights");
+    GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
+    p.bias = P.fs_b; p.act = ACT_TANH;
+    if (tem) { p.out2 = ws + w.x; p.ld2 = S * d; p.add2 = D.use_pos_emb ? P.pe : nullptr; }
+    TRY(run1(p, st));
+  }
+  if (!tem) return PS_OK;
+
+  const float qscale = 1.f / sqrtf((float)(d / (D.H > 0 ? D.H : 1)));
+  for (int i = 0; i < NL; ++i) {
+    const LayerWs& l = w.layer[i];
+    const PsLayerTensors& Lp = P.layer[i];
+    PS_REQUIRE(Lp.wk && Lp.wv && Lp.wq && Lp.wo && Lp.w1 && Lp.w2 && Lp.bk && Lp.bv && Lp.bq && Lp.bo && Lp.b1 &&
+               Lp.b2 && Lp.ff_ln_g && Lp.ff_ln_b, "forward: layer %d has null tensors", i);
+    const float* xin = i == 0 ? ws + w.x : ws + w.layer[i - 1].y2;
+    const int ns = l.n_in * S;
+    if (i != 0) {   // pre-LayerNorm only when iter != 0 (transformer.py:48-51)
+      PS_REQUIRE(Lp.ln_g && Lp.ln_b, "forward: layer %d null pre-LN", i);
+      LnFwdArgs a = {xin, d, ws + l.xn, d, ws + l.pre_stats, Lp.ln_g, Lp.ln_b, ns, d, 1e-6f};
+      TRY(launch_ln_fwd(a, st));
+    }
+    const float* xn = ws + l.xn;
+    {   // K, V, Q projections (neural.py:192-197), Q pre-divided by sqrt(dh) (:206)
+      GemmGroup g;
+      memset(&g, 0, sizeof(g));
+      g.n = 3;
+      g.p[0] = gp(xn, d, 0, Lp.wk, d, 0, ws + l.kp, d, ns, d, d); g.p[0].bias = Lp.bk;
+      g.p[1] = gp(xn, d, 0, Lp.wv, d, 0, ws + l.vp, d, ns, d, d); g.p[1].bias = Lp.bv;
+      if (l.Sq == S) g.p[2] = gp(xn, d, 0, Lp.wq, d, 0, ws + l.qp, d, ns, d, d);
+      else g.p[2] = gp(xn + (size_t)w.qpos * d, S * d, 0, Lp.wq, d, 0, ws + l.qp, d, l.n_in, d, d);
+      g.p[2].bias = Lp.bq; g.p[2].alpha = qscale;
+      TRY(ps_launch_gemm(g, st));
+    }
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
+    a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = Bt.u_item_idxs;
+    a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
+    a.drop = make_drop(D, PS_SITE_ATTN(i));
+    TRY(launch_attn_fwd(a, st));
+    {   // final_linear + dropout + residual (neural.py:228-231, transformer.py:56)
+      GemmProblem p = gp(ws + l.ctx, d, 0, Lp.wo, d, 0, ws + l.y1, d, l.M2, d, d);
+      p.bias = Lp.bo; p.drop = make_drop(D, PS_SITE_CTX(i));
+      p.res.mode = RES_GATHER; p.res.ptr = xin; p.res.ld = d; p.res.Sq = l.Sq; p.res.fan = l.fan; p.res.S = S;
+      p.res.qpos = w.qpos;
+      TRY(run1(p, st));
+    }
+    {   // PositionwiseFeedForward (neural.py:30-33)
+      LnFwdArgs n = {ws + l.y1, d, ws + l.ln1, d, ws + l.ff_stats, Lp.ff_ln_g, Lp.ff_ln_b, l.M2, d, 1e-6f};
+      TRY(launch_ln_fwd(n, st));
+      GemmProblem p1 = gp(ws + l.ln1, d, 0, Lp.w1, d, 0, ws + l.h1, D.F, l.M2, D.F, d);
+      p1.bias = Lp.b1; p1.aux_out = ws + l.a1; p1.act = ACT_GELU; p1.drop = make_drop(D, PS_SITE_FF1(i));
+      TRY(run1(p1, st));
+      GemmProblem p2 = gp(ws + l.h1, D.F, 0, Lp.w2, D.F, 0, ws + l.y2, d, l.M2, d, D.F);
+      p2.bias = Lp.b2; p2.drop = make_drop(D, PS_SITE_FF2(i));
+      p2.res.mode = RES_DIRECT; p2.res.ptr = ws + l.y1; p2.res.ld = d;
+      TRY(run1(p2, st));
+    }
+  }
+  // final LayerNorm (transformer.py:86) on the consumed position only
+  PS_REQUIRE(P.final_ln_g && P.final_ln_b, "forward: null final LayerNorm");
+  LnFwdArgs f;
+  if (NL > 0) {
+    const LayerWs& l = w.layer[NL - 1];
+    f = LnFwdArgs{ws + l.y2, d, ws + w.enc, d, ws + w.fin_stats, P.final_ln_g, P.final_ln_b, w.Mf, d, 1e-6f};
+  } else {
+    f = LnFwdArgs{ws + w.x + (size_t)w.qpos * d, S * d, ws + w.enc, d, ws + w.fin_stats, P.final_ln_g,
+                  P.final_ln_b, B, d, 1e-6f};
+  }
+  TRY(launch_ln_fwd(f, st));
+  return PS_OK;
+}
+
+static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
+                       ScoreArgs& s) {
+  memset(&s, 0, sizeof(s));
+  s.B = D.B; s.K = D.K; s.W = D.W; s.C = 0; s.R = w.R; s.d = D.d;
+  s.P = D.product_size; s.V = D.vocab_size;
+  s.bias_product = D.bias_product; s.pos_weight = D.pos_weight;
+  s.target = Bt.target_prod_idxs; s.neg_items = Bt.neg_item_idxs; s.pos_words = Bt.pos_iword_idxs;
+  s.neg_words = Bt.neg_word_idxs; s.candi = Bt.candi_prod_idxs;
+  s.product_emb = P.product_emb; s.word_emb = P.word_emb; s.product_bias = P.product_bias; s.word_bias = P.word_bias;
+  s.enc = ws + w.enc;
+  s.item_scores = ws + w.item_scores; s.word_scores = ws + w.word_scores; s.loss_parts = ws + w.loss_parts;
+}
+
+extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                              float* workspace, float* loss3, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace && loss3, "forward: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  PS_REQUIRE(batch->target_prod_idxs && batch->neg_item_idxs && (D.W == 0 || (batch->pos_iword_idxs &&
+             batch->neg_word_idxs)), "forward: null batch tensors");
+  PS_REQUIRE(params->word_bias && (!D.bias_product || params->product_bias), "forward: null bias tensors");
+  TRY(encode_forward(D, *params, *batch, workspace, w, st));
+  ScoreArgs s;
+  fill_score(D, *params, *batch, workspace, w, s);
+  s.loss3 = loss3;
+  TRY(launch_score_fwd(s, st));
+  TRY(launch_loss(s, st));
+  return PS_OK;
+}
+
+extern "C" int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                            float* workspace, float* scores, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace && scores, "score: null argument");
+  PsTemDesc D = *desc;
+  PS_REQUIRE(D.C > 0 && batch->candi_prod_idxs, "score: needs C > 0 candidates");
+  D.training = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  TRY(encode_forward(D, *params, *batch, workspace, w, st));
+  ScoreArgs s;
+  fill_score(D, *params, *batch, workspace, w, s);
+  s.C = D.C; s.item_scores = scores;
+  TRY(launch_score_fwd(s, st));
+  return PS_OK;
+}
+
+// --------------------------------------------------------------------- backward
+extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                               float* ws, const PsTemTensors* grads, float loss_scale, const float* loss_scale_dev,
+                               ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && ws && grads, "backward: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  const PsTemTensors& P = *params;
+  const PsTemTensors& G = *grads;
+  const bool tem = D.model == PS_MODEL_TEM;
+  const bool drop = D.training && D.dropout > 0.f;
+  const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0, F = D.F;
+  const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
+  float* ghist = D.sep_prod_emb ? G.hist_product_emb : G.product_emb;
+  PS_REQUIRE(G.product_emb && G.word_emb && G.word_bias && ghist && hist, "backward: null table gradient");
+  PS_REQUIRE(!D.bias_product || G.product_bias, "backward: null product_bias gradient");
+
+  // 1. loss + score backward: d enc, table-row scatter-adds
+  ScoreArgs s;
+  fill_score(D, P, *batch, ws, w, s);
+  s.scale = loss_scale; s.scale_dev = loss_scale_dev; s.denc = ws + w.denc;
+  s.g_product_emb = G.product_emb; s.g_word_emb = G.word_emb; s.g_product_bias = G.product_bias;
+  s.g_word_bias = G.word_bias;
+  TRY(launch_score_bwd(s, st));
+
+  const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
+  int lddqe = d;
+  if (tem) {
+    PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
+    // 2. final LayerNorm backward
+    LnBwdArgs f;
+    memset(&f, 0, sizeof(f));
+    f.dy = ws + w.denc; f.lddy = d; f.stats = ws + w.fin_stats; f.g = P.final_ln_g; f.d = d;
+    f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
+    if (NL > 0) {
+      const LayerWs& l = w.layer[NL - 1];
+      f.x = ws + l.y2; f.ldx = d; f.rows = w.Mf; f.dx = ws + w.dy2; f.lddx = d;
+      f.colsum = G.layer[NL - 1].b2;
+      if (drop) { f.out2 = ws + w.do2; f.drop2 = make_drop(D, PS_SITE_FF2(NL - 1)); }
+      TRY(launch_ln_bwd(f, st));
+    } else {
+      PS_CHECK_HIP(hipMemsetAsync(ws + w.dx, 0, sizeof(float) * (size_t)B * S * d, st));
+      f.x = ws + w.x + (size_t)w.qpos * d; f.ldx = S * d; f.rows = B;
+      f.dx = ws + w.dx + (size_t)w.qpos * d; f.lddx = S * d;
+      TRY(launch_ln_bwd(f, st));
+    }
+    // 3. layers, last to first
+    for (int i = NL - 1; i >= 0; --i) {
+      const LayerWs& l = w.layer[i];
+      const PsLayerTensors& Lp = P.layer[i];
+      const PsLayerTensors& Lg = G.layer[i];
+      PS_REQUIRE(Lg.wk && Lg.wv && Lg.wq && Lg.wo && Lg.w1 && Lg.w2 && Lg.bk && Lg.bv && Lg.bq && Lg.bo && Lg.b1 &&
+                 Lg.b2 && Lg.ff_ln_g && Lg.ff_ln_b, "backward: layer %d has null gradients", i);
+      const float* xin = i == 0 ? ws + w.x : ws + w.layer[i - 1].y2;
+      const float* xn = ws + l.xn;
+      const int ns = l.n_in * S, M2 = l.M2;
+      const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
+      // FFN backward
+      {
+        GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
+        p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
+        TRY(run1(p, st));
+        GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};    // dW2 += do2^T . h1
+        TRY(run_wgrads(wg, 1, st));
+        GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
+        TRY(run1(q, st));
+        GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
+        TRY(run_wgrads(wg1, 1, st));
+        LnBwdArgs n;
+        memset(&n, 0, sizeof(n));
+        n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
+        n.rows = M2; n.d = d;
+        n.res.mode = RES_DIRECT; n.res.ptr = ws + w.dy2; n.res.ld = d;            // residual  output + x
+        n.dx = ws + w.dy1; n.lddx = d;
+        if (drop) { n.out2 = ws + w.do_; n.drop2 = make_drop(D, PS_SITE_CTX(i)); }
+        n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
+        TRY(launch_ln_bwd(n, st));
+      }
+      const float* dout = drop ? ws + w.do_ : ws + w.dy1;
+      // attention backward
+      {
+        GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
+        TRY(run1(p, st));
+        GemmProblem wg[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
+        TRY(run_wgrads(wg, 1, st));
+        AttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
+        a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = batch->u_item_idxs;
+        a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn;
+        a.drop = make_drop(D, PS_SITE_ATTN(i));
+        a.dctx = ws + w.dctx;
+        const bool qall = l.Sq == S;
+        a.lddkv = qall ? 3 * d : 2 * d;
+        a.dkv = ws + w.dkv;
+        a.dq = qall ? ws + w.dkv + 2 * d : ws + w.dq;
+        a.lddq = qall ? 3 * d : d;
+        a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
+        a.qscale = 1.f / sqrtf((float)(d / D.H));
+        TRY(launch_attn_bwd(a, st));
+        // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
+        float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
+        GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);
+        x.kseg = d; x.Bseg[1] = Lp.wv; x.Bseg[2] = Lp.wq;
+        if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
+          x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
+          x.res.S = S; x.res.qpos = w.qpos;
+        }
+        TRY(run1(x, st));
+        if (!qall) {
+          GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
+          xq.accumulate = 1;
+          TRY(run1(xq, st));
+        }
+        GemmProblem wg3[3];
+        wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
+        wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
+        if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
+        else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
+        TRY(run_wgrads(wg3, 3, st));
+      }
+      if (i != 0) {   // pre-LayerNorm backward -> grad wrt the previous layer's output
+        PS_REQUIRE(Lg.ln_g && Lg.ln_b, "backward: layer %d null pre-LN gradient", i);
+        LnBwdArgs n;
+        memset(&n, 0, sizeof(n));
+        n.dy = ws + w.dxn; n.lddy = d; n.x = xin; n.ldx = d; n.stats = ws + l.pre_stats; n.g = Lp.ln_g;
+        n.rows = ns; n.d = d;
+        n.res.mode = RES_FANIN; n.res.ptr = ws + w.dy1; n.res.ld = d; n.res.Sq = l.Sq; n.res.fan = l.fan;
+        n.res.S = S; n.res.qpos = w.qpos;
+        n.dx = ws + w.dy2; n.lddx = d;
+        if (drop) { n.out2 = ws + w.do2; n.drop2 = make_drop(D, PS_SITE_FF2(i - 1)); }
+        n.colsum = G.layer[i - 1].b2; n.dgamma = Lg.ln_g; n.dbeta = Lg.ln_b;
+        TRY(launch_ln_bwd(n, st));
+      }
+    }
+    dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
+    lddqe = S * d;
+  }
+
+  // 4. query encoder backward + scatter to the word / history rows
+  EmbedBwdArgs e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size; e.tem = tem;
+  e.qw = batch->query_word_idxs; e.ui = batch->u_item_idxs; e.dx = ws + w.dx;
+  e.drop_fs = make_drop(D, PS_SITE_FS);
+  e.g_hist_tab = ghist; e.g_word_emb = G.word_emb;
+  if (D.query_encoder == PS_QENC_FS) {
+    PS_REQUIRE(G.fs_w && G.fs_b, "backward: null FS encoder gradient");
+    TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
+    GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
+    TRY(run1(p, st));
+    GemmProblem wg[1] = {gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B)};
+    TRY(run_wgrads(wg, 1, st));
+    e.dqmean_d = ws + w.dqmean;
+  } else {
+    // AVG encoder: query_emb == post-dropout mean; copy rows to a dense [B,d] buffer
+    PS_CHECK_HIP(hipMemcpy2DAsync(ws + w.dqmean, sizeof(float) * d, dqe, sizeof(float) * lddqe, sizeof(float) * d, B,
+                                  hipMemcpyDeviceToDevice, st));
+    e.dqmean_d = ws + w.dqmean;
+  }
+  TRY(launch_embed_scatter(e, st));
+  return PS_OK;
+}
+
+extern "C" float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint32_t row, uint32_t col) {
+  PsTemDesc D = *desc;
+  D.training = 1;
+  DropSpec s = make_drop(D, site);
+  if (s.thr == 0u) return 1.f;
+  Philox4 r = philox4x32_10(col, row >> 2, s.site, s.step, s.k0, s.k1);
+  uint32_t sel = row & 3u;
+  uint32_t wv = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
+  return wv >= s.thr ? s.scale : 0.f;
+}
+
+// ------------------------------------------------------------ sampling / alias
+extern "C" int ps_sample_negatives(const PsTemDesc* desc, const float* alias_prob, const int32_t* alias_idx,
+                                   int64_t* neg_item_idxs, int64_t* neg_word_idxs, ps_stream_t stream) {
+  PS_REQUIRE(desc && alias_prob && alias_idx && neg_item_idxs && neg_word_idxs, "sample: null argument");
+  return launch_sample(*desc, alias_prob, alias_idx, neg_item_idxs, neg_word_idxs, (hipStream_t)stream);
+}
+
+// Vose's alias method over `n` outcomes with (unnormalised) weights dist[].
+extern "C" int ps_build_alias_host(const double* dist, int64_t n, float* prob, int32_t* alias) {
+  PS_REQUIRE(dist && prob && alias && n > 0 && n < (1ll << 31), "alias: bad argument");
+  double sum = 0;
+  for (int64_t i = 0; i < n; ++i) { PS_REQUIRE(dist[i] >= 0, "alias: negative weight"); sum += dist[i]; }
+  PS_REQUIRE(sum > 0, "alias: zero total weight");
+  double* q = new double[n];
+  int32_t* small = new int32_t[n];
+  int32_t* large = new int32_t[n];
+  int64_t ns = 0, nl = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    q[i] = dist[i] / sum * (double)n;
+    alias[i] = (int32_t)i;
+    if (q[i] < 1.0) small[ns++] = (int32_t)i; else large[nl++] = (int32_t)i;
+  }
+  while (ns > 0 && nl > 0) {
+    int32_t s = small[--ns], l = large[--nl];
+    prob[s] = (float)q[s];
+    alias[s] = l;
+    q[l] = (q[l] + q[s]) - 1.0;
+    if (q[l] < 1.0) small[ns++] = l; else large[nl++] = l;
+  }
+  while (nl > 0) prob[large[--nl]] = 1.f;
+  while (ns > 0) prob[small[--ns]] = 1.f;
+  delete[] q; delete[] small; delete[] large;
+  return PS_OK;
+}

@@ -1,0 +1,473 @@
+"""ItemTransformerRanker — drop-in boundary of the TEM / QEM ranking-loss step.
+
+Mirrors the reference's ``nn.Module`` contract (``models/item_transformer.py:22-100,
+352-359``; call sites ``main.py:148-149``, ``trainer.py:74-79,190,201``):
+
+    model = ItemTransformerRanker(args, device, vocab_size, product_size, vocab_words, word_dists)
+    loss = model(batch, train_pv)      # 0-dim fp32 tensor with a grad_fn
+    model.zero_grad(); loss.backward(); optim.step(); loss.item()
+    scores = model.test(batch)         # [B, candi_k]
+
+Same parameter names / shapes / ``state_dict`` keys, so reference checkpoints load
+(``load_cp``).  The torch modules below are PARAMETER HOLDERS only: no torch math
+runs on the hot path.  ``forward`` / ``backward`` / ``test`` are one C-ABI call
+each into ``libprodsearch_hip.so`` (hand-written gfx950 kernels); PyTorch owns
+the memory and lends raw pointers for the duration of the call.  There is no
+CPU fallback — on a CPU tensor the model raises.
+
+Supported: ``model_name`` in {item_transformer (with use_dot_prod), QEM}.  The other
+scoring heads of the reference (forward_trans, ZAM/AEM, forward_seq) are outside
+the hot path and raise NotImplementedError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+# ------------------------------------------------------------ parameter holders
+class _Holder(nn.Module):
+    def forward(self, *a, **k):     # pragma: no cover - never on the hot path
+        raise RuntimeError("parameter holder: the hot path runs in libprodsearch_hip.so")
+
+
+class _PositionalEncoding(_Holder):
+    """``PositionalEncoding`` buffer (transformer.py:10-19): pe [1, 5000, d]."""
+    def __init__(self, dim, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, dim)
+        position = torch.arange(0, max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float) * -(math.log(10000.0) / dim))
+        pe[:, 0::2] = torch.sin(position.float() * div_term)
+        pe[:, 1::2] = torch.cos(position.float() * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+
+class _MultiHeadedAttention(_Holder):
+    """neural.py:86-96 parameter names."""
+    def __init__(self, d):
+        super().__init__()
+        self.linear_keys = nn.Linear(d, d)
+        self.linear_values = nn.Linear(d, d)
+        self.linear_query = nn.Linear(d, d)
+        self.final_linear = nn.Linear(d, d)
+
+
+class _PositionwiseFeedForward(_Holder):
+    """neural.py:20-26 parameter names."""
+    def __init__(self, d, ff):
+        super().__init__()
+        self.w_1 = nn.Linear(d, ff)
+        self.w_2 = nn.Linear(ff, d)
+        self.layer_norm = nn.LayerNorm(d, eps=1e-6)
+
+
+class _TransformerEncoderLayer(_Holder):
+    """transformer.py:37-45."""
+    def __init__(self, d, ff):
+        super().__init__()
+        self.self_attn = _MultiHeadedAttention(d)
+        self.feed_forward = _PositionwiseFeedForward(d, ff)
+        self.layer_norm = nn.LayerNorm(d, eps=1e-6)
+
+
+class _TransformerEncoder(_Holder):
+    """transformer.py:59-69."""
+    def __init__(self, d, ff, n_layers):
+        super().__init__()
+        self.pos_emb = _PositionalEncoding(d)
+        self.transformer_inter = nn.ModuleList([_TransformerEncoderLayer(d, ff) for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d, eps=1e-6)
+        self.wo = nn.Linear(d, 1, bias=True)
+
+
+class _FSEncoder(_Holder):
+    """text_encoder.py:19-26."""
+    def __init__(self, d):
+        super().__init__()
+        self.f_W = nn.Linear(d, d)
+
+
+def _init_like_reference(module):
+    """``initialize_parameters`` (transformer.py:100-118, text_encoder.py:42-60): >=2-D
+    'weight' Xavier-normal, 'bias' 0, everything else (1-D LayerNorm gains!) N(0,1)."""
+    for name, p in module.named_parameters():
+        if 'weight' in name and p.dim() > 1:
+            nn.init.xavier_normal_(p)
+        elif 'bias' in name:
+            nn.init.constant_(p, 0)
+        else:
+            nn.init.normal_(p)
+
+
+# -------------------------------------------------------------------- autograd
+class _RankLossFn(torch.autograd.Function):
+    """One node: forward launched the HIP forward; backward launches the HIP backward,
+    which writes the dense ``.grad`` of every reachable parameter directly."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, plan, loss3):
+        ctx.model, ctx.plan = model, plan
+        return loss3[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._run_backward(ctx.plan, grad_out)
+        return None, None, None, None
+
+
+class _Plan(object):
+    """Per-shape cached call state: descriptor, batch struct, workspace."""
+    __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep')
+
+
+# ------------------------------------------------------------------------ model
+class ItemTransformerRanker(nn.Module):
+    def __init__(self, args, device, vocab_size, product_size, vocab_words, word_dists=None):
+        super(ItemTransformerRanker, self).__init__()
+        if args.model_name not in ('item_transformer', 'QEM'):
+            raise NotImplementedError("model_name %r is outside the hot path (item_transformer/QEM only)"
+                                      % args.model_name)
+        if args.model_name == 'item_transformer' and not args.use_dot_prod:
+            raise NotImplementedError("forward_trans (use_dot_prod=False) is outside the hot path")
+        if getattr(args, 'pretrain_emb_dir', '') or getattr(args, 'pretrain_up_emb_dir', ''):
+            raise NotImplementedError("pretrained-embedding text loaders are out of scope; load a state_dict")
+        self.args = args
+        self.device = device
+        self.train_review_only = args.train_review_only
+        self.embedding_size = args.embedding_size
+        self.vocab_words = vocab_words
+        self.vocab_size = vocab_size
+        self.product_size = product_size
+        self.word_dists = None
+        if word_dists is not None:
+            self.word_dists = torch.as_tensor(word_dists, dtype=torch.float64)
+        self.prod_pad_idx = product_size
+        self.word_pad_idx = vocab_size - 1
+        self.seg_pad_idx = 3
+        self.emb_dropout = args.dropout
+        d = self.embedding_size
+
+        # same registration order as the reference => same state_dict key order
+        self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
+        if args.sep_prod_emb:
+            self.hist_product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
+        self.product_bias = nn.Parameter(torch.zeros(product_size + 1), requires_grad=True)
+        self.word_bias = nn.Parameter(torch.zeros(vocab_size), requires_grad=True)
+        self.word_embeddings = nn.Embedding(vocab_size, d, padding_idx=self.word_pad_idx)
+        if args.model_name == 'item_transformer':
+            self.transformer_encoder = _TransformerEncoder(d, args.ff_size, args.inter_layers)
+        else:
+            self.attention_encoder = _MultiHeadedAttention(d)
+        if args.query_encoder_name == 'fs':
+            self.query_encoder = _FSEncoder(d)
+        else:
+            self.query_encoder = _Holder()
+        self.seg_embeddings = nn.Embedding(4, d, padding_idx=self.seg_pad_idx)
+        self.initialize_parameters()
+        self.to(device)
+
+        self._plans = {}
+        self._params_struct = None
+        self._grads_struct = None
+        self._grad_flat = None
+        self._grad_views = None
+        self._loss_acc = None
+        self._alias = None
+        self._fwd_step = 0
+        self._seed = int(getattr(args, 'seed', 666))
+
+    # ---------------------------------------------------------------- reference API
+    def initialize_parameters(self, logger=None):
+        """item_transformer.py:576-586."""
+        nn.init.normal_(self.word_embeddings.weight)
+        nn.init.normal_(self.seg_embeddings.weight)
+        if self.args.query_encoder_name == 'fs':
+            _init_like_reference(self.query_encoder)
+        if self.args.model_name == 'item_transformer':
+            _init_like_reference(self.transformer_encoder)
+
+    def clear_loss(self):
+        if self._loss_acc is not None:
+            self._loss_acc.zero_()
+
+    @property
+    def ps_loss(self):
+        """Accumulated on the device; reading it is the only host sync (the reference
+        syncs twice per step with .item(), item_transformer.py:516-517)."""
+        return 0.0 if self._loss_acc is None else float(self._loss_acc[0])
+
+    @property
+    def item_loss(self):
+        return 0.0 if self._loss_acc is None else float(self._loss_acc[1])
+
+    def load_cp(self, pt, strict=True):
+        self.load_state_dict(pt['model'], strict=strict)
+
+    def forward(self, batch_data, train_pv=False, neg_item_idxs=None, neg_word_idxs=None):
+        plan, loss3 = self._run_forward(batch_data, neg_item_idxs, neg_word_idxs)
+        if not torch.is_grad_enabled():
+            return loss3[0]
+        return _RankLossFn.apply(self._anchor(), self, plan, loss3)
+
+    def test(self, batch_data):
+        return self._run_score(batch_data)
+
+    # -------------------------------------------------------------------- plumbing
+    def _dev(self):
+        p = self.word_embeddings.weight
+        if not p.is_cuda:
+            raise RuntimeError("ItemTransformerRanker needs its parameters on a gfx950 device "
+                               "(no CPU fallback): model.to('cuda')")
+        return p.device
+
+    def _anchor(self):
+        a = getattr(self, '_anchor_t', None)
+        if a is None or a.device != self._dev():
+            a = torch.zeros((), device=self._dev(), requires_grad=True)
+            self._anchor_t = a
+        return a
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        # storage may have moved: drop cached pointers
+        self._plans = {}
+        self._params_struct = None
+        self._grads_struct = None
+        self._grad_flat = None
+        self._grad_views = None
+        self._loss_acc = None
+        self._alias = None
+        return r
+
+    def _named_hot_params(self):
+        """(C-ABI field path, parameter) of every tensor the kernels read."""
+        a = self.args
+        out = [(('product_emb',), self.product_emb.weight),
+               (('word_emb',), self.word_embeddings.weight),
+               (('product_bias',), self.product_bias),
+               (('word_bias',), self.word_bias)]
+        if a.sep_prod_emb:
+            out.append((('hist_product_emb',), self.hist_product_emb.weight))
+        if a.query_encoder_name == 'fs':
+            out += [(('fs_w',), self.query_encoder.f_W.weight), (('fs_b',), self.query_encoder.f_W.bias)]
+        if a.model_name == 'item_transformer':
+            te = self.transformer_encoder
+            out += [(('final_ln_g',), te.layer_norm.weight), (('final_ln_b',), te.layer_norm.bias)]
+            for i, l in enumerate(te.transformer_inter):
+                sa, ff = l.self_attn, l.feed_forward
+                out += [(('layer', i, 'wk'), sa.linear_keys.weight), (('layer', i, 'bk'), sa.linear_keys.bias),
+                        (('layer', i, 'wv'), sa.linear_values.weight), (('layer', i, 'bv'), sa.linear_values.bias),
+                        (('layer', i, 'wq'), sa.linear_query.weight), (('layer', i, 'bq'), sa.linear_query.bias),
+                        (('layer', i, 'wo'), sa.final_linear.weight), (('layer', i, 'bo'), sa.final_linear.bias),
+                        (('layer', i, 'w1'), ff.w_1.weight), (('layer', i, 'b1'), ff.w_1.bias),
+                        (('layer', i, 'w2'), ff.w_2.weight), (('layer', i, 'b2'), ff.w_2.bias),
+                        (('layer', i, 'ff_ln_g'), ff.layer_norm.weight), (('layer', i, 'ff_ln_b'), ff.layer_norm.bias),
+                        (('layer', i, 'ln_g'), l.layer_norm.weight), (('layer', i, 'ln_b'), l.layer_norm.bias)]
+        return out
+
+    def _has_grad(self, path):
+        """Parameters the reference's autograd reaches in this configuration (others keep
+        grad None exactly like the reference: product_bias unless bias_product, layer-0
+        pre-LN, seg_embeddings, wo)."""
+        if path == ('product_bias',):
+            return self.args.sim_func == 'bias_product'
+        if path[0] == 'layer' and path[2] in ('ln_g', 'ln_b'):
+            return path[1] != 0
+        return True
+
+    @staticmethod
+    def _set_field(struct, path, value):
+        if path[0] == 'layer':
+            setattr(struct.layer[path[1]], path[2], value)
+        else:
+            setattr(struct, path[0], value)
+
+    def _structs(self):
+        if self._params_struct is not None:
+            return self._params_struct, self._grads_struct
+        dev = self._dev()
+        hot = self._named_hot_params()
+        for _, p in hot:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("parameters must be contiguous fp32")
+        ps, gs = _lib.PsTemTensors(), _lib.PsTemTensors()
+        for path, p in hot:
+            self._set_field(ps, path, p.data_ptr())
+        if self.args.model_name == 'item_transformer':
+            ps.pe = self.transformer_encoder.pos_emb.pe.data_ptr()
+        # one flat gradient buffer: small tensors first, tables last; 16-byte aligned slices
+        graded = [(path, p) for path, p in hot if self._has_grad(path)]
+        graded.sort(key=lambda t: t[1].numel())
+        offs, cur = [], 0
+        for _, p in graded:
+            offs.append(cur)
+            cur += (p.numel() + 3) // 4 * 4
+        self._grad_flat = torch.zeros(cur, device=dev, dtype=torch.float32)
+        self._grad_views = []
+        for (path, p), o in zip(graded, offs):
+            v = self._grad_flat[o:o + p.numel()].view_as(p)
+            self._grad_views.append((p, v))
+            self._set_field(gs, path, v.data_ptr())
+        self._n_small = sum((p.numel() + 3) // 4 * 4 for _, p in graded if p.numel() < (1 << 20))
+        self._params_struct, self._grads_struct = ps, gs
+        self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)
+        return ps, gs
+
+    def _check_idx(self, t, name, shape_tail=None):
+        if not torch.is_tensor(t) or t.dtype != torch.int64 or not t.is_cuda:
+            raise RuntimeError("batch.%s must be an int64 tensor on the model's device" % name)
+        return t if t.is_contiguous() else t.contiguous()
+
+    def _plan_for(self, batch, eval_mode):
+        a = self.args
+        qw = self._check_idx(batch.query_word_idxs, 'query_word_idxs')
+        ui = self._check_idx(batch.u_item_idxs, 'u_item_idxs')
+        B, Q = qw.shape
+        L = ui.shape[1]
+        C = 0
+        if eval_mode:
+            C = batch.candi_prod_idxs.shape[1]
+            W = max(1, getattr(a, 'pv_window_size', 1))
+        else:
+            W = batch.pos_iword_idxs.shape[1]
+        training = bool(self.training) and not eval_mode
+        key = (B, Q, L, W, C, training)
+        plan = self._plans.get(key)
+        if plan is None:
+            lib = _lib.load()
+            plan = _Plan()
+            plan.key = key
+            d = _lib.PsTemDesc()
+            d.B, d.K, d.L, d.Q, d.W, d.C = B, a.neg_per_pos, L, Q, W, C
+            d.d, d.H, d.F = a.embedding_size, a.heads, a.ff_size
+            d.n_layers = a.inter_layers if a.model_name == 'item_transformer' else 0
+            d.product_size, d.vocab_size = self.product_size, self.vocab_size
+            d.model = _lib.PS_MODEL_TEM if a.model_name == 'item_transformer' else _lib.PS_MODEL_QEM
+            d.query_encoder = _lib.PS_QENC_FS if a.query_encoder_name == 'fs' else _lib.PS_QENC_AVG
+            d.use_pos_emb, d.use_item_pos = int(a.use_pos_emb), int(a.use_item_pos)
+            d.bias_product = int(a.sim_func == 'bias_product')
+            d.pos_weight, d.sep_prod_emb = int(a.pos_weight), int(a.sep_prod_emb)
+            d.training, d.dropout = int(training), float(a.dropout)
+            d.seed, d.step = self._seed, 0
+            lay = _lib.PsTemWsLayout()
+            _lib.check(lib.ps_tem_workspace_layout(d, lay), 'ps_tem_workspace_layout')
+            plan.desc, plan.layout = d, lay
+            plan.ws = torch.empty(lay.total_floats, device=self._dev(), dtype=torch.float32)
+            plan.batch = _lib.PsTemBatch()
+            plan.neg_items = plan.neg_words = None
+            plan.keep = None
+            self._plans[key] = plan
+        return plan
+
+    def _fill_batch(self, plan, batch, eval_mode, neg_items=None, neg_words=None):
+        b = plan.batch
+        qw = self._check_idx(batch.query_word_idxs, 'query_word_idxs')
+        ui = self._check_idx(batch.u_item_idxs, 'u_item_idxs')
+        keep = [qw, ui]
+        b.query_word_idxs, b.u_item_idxs = qw.data_ptr(), ui.data_ptr()
+        if eval_mode:
+            ca = self._check_idx(batch.candi_prod_idxs, 'candi_prod_idxs')
+            b.candi_prod_idxs = ca.data_ptr()
+            keep.append(ca)
+        else:
+            tg = self._check_idx(batch.target_prod_idxs, 'target_prod_idxs')
+            pw = self._check_idx(batch.pos_iword_idxs, 'pos_iword_idxs')
+            b.target_prod_idxs, b.pos_iword_idxs = tg.data_ptr(), pw.data_ptr()
+            ni = self._check_idx(neg_items, 'neg_item_idxs')
+            nw = self._check_idx(neg_words, 'neg_word_idxs')
+            d = plan.desc
+            if ni.numel() != d.B * d.K or nw.numel() != d.B * d.W * d.K:
+                raise RuntimeError("negative sample shapes: want [%d,%d] and [%d,%d]" % (d.B, d.K, d.B, d.W * d.K))
+            b.neg_item_idxs, b.neg_word_idxs = ni.data_ptr(), nw.data_ptr()
+            keep += [tg, pw, ni, nw]
+        plan.keep = keep       # keep the index tensors alive until backward has run
+
+    def _stream(self):
+        return torch.cuda.current_stream(self._dev()).cuda_stream
+
+    def _alias_tables(self):
+        if self._alias is None:
+            if self.word_dists is None:
+                raise RuntimeError("word_dists is required to sample negative words "
+                                   "(or pass neg_word_idxs= explicitly)")
+            lib = _lib.load()
+            wd = self.word_dists.contiguous()
+            n = wd.numel()
+            prob = torch.empty(n, dtype=torch.float32)
+            alias = torch.empty(n, dtype=torch.int32)
+            _lib.check(lib.ps_build_alias_host(wd.data_ptr(), n, prob.data_ptr(), alias.data_ptr()),
+                       'ps_build_alias_host')
+            self._alias = (prob.to(self._dev()), alias.to(self._dev()))
+        return self._alias
+
+    def sample_negatives(self, plan):
+        """The two ``torch.multinomial`` draws (item_transformer.py:447, :268) on the device."""
+        lib = _lib.load()
+        d = plan.desc
+        if plan.neg_items is None:
+            plan.neg_items = torch.empty(d.B, d.K, device=self._dev(), dtype=torch.int64)
+            plan.neg_words = torch.empty(d.B, d.W * d.K, device=self._dev(), dtype=torch.int64)
+        prob, alias = self._alias_tables()
+        _lib.check(lib.ps_sample_negatives(d, prob.data_ptr(), alias.data_ptr(), plan.neg_items.data_ptr(),
+                                           plan.neg_words.data_ptr(), self._stream()), 'ps_sample_negatives')
+        return plan.neg_items, plan.neg_words
+
+    def _run_forward(self, batch, neg_items=None, neg_words=None):
+        lib = _lib.load()
+        ps, _ = self._structs()
+        plan = self._plan_for(batch, eval_mode=False)
+        self._fwd_step += 1
+        plan.desc.step = self._fwd_step
+        if neg_items is None or neg_words is None:
+            neg_items, neg_words = self.sample_negatives(plan)
+        self._fill_batch(plan, batch, False, neg_items, neg_words)
+        loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
+        _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
+                                      self._stream()), 'ps_tem_forward')
+        self._loss_acc.add_(loss3[1:3])
+        return plan, loss3
+
+    def _assign_grads(self):
+        """Give every reachable parameter its dense ``.grad`` view; returns True if the flat
+        buffer must be zeroed first (i.e. zero_grad() ran, trainer.py:76)."""
+        fresh = self._grad_views[0][0].grad is None
+        for p, v in self._grad_views:
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("a foreign .grad tensor is attached to a hot-path parameter; "
+                                   "call model.zero_grad() before backward")
+        return fresh
+
+    def _run_backward(self, plan, grad_out):
+        lib = _lib.load()
+        ps, gs = self._structs()
+        st = self._stream()
+        if self._assign_grads():
+            _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(), st), 'ps_zero_floats')
+        go = grad_out.contiguous().float()
+        _lib.check(lib.ps_tem_backward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), gs, 1.0,
+                                       go.data_ptr(), st), 'ps_tem_backward')
+
+    def _run_score(self, batch):
+        lib = _lib.load()
+        ps, _ = self._structs()
+        plan = self._plan_for(batch, eval_mode=True)
+        self._fill_batch(plan, batch, True)
+        d = plan.desc
+        scores = torch.empty(d.B, d.C, device=self._dev(), dtype=torch.float32)
+        _lib.check(lib.ps_tem_score(d, ps, plan.batch, plan.ws.data_ptr(), scores.data_ptr(), self._stream()),
+                   'ps_tem_score')
+        return scores
+
+    # --------------------------------------------------------------- test support
+    def workspace_view(self, plan, name, shape):
+        """View of one intermediate inside the workspace (parity tests compare every stage)."""
+        off = getattr(plan.layout, name)
+        n = 1
+        for s in shape:
+            n *= s
+        return plan.ws[off:off + n].view(*shape)

@@ -1,0 +1,161 @@
+"""Optimizer — the reference's controller class over the fused HIP clip + Adam.
+
+Mirrors ``models/optimizers.py:111-243`` (``Optimizer(method, learning_rate,
+max_grad_norm, beta1, beta2, decay_method, warmup_steps, weight_decay)``,
+``set_parameters(named_params)``, ``step()``, ``learning_rate``, ``_step``) and
+``build_optim`` (``models/ps_model.py:20-51``) for ``method == 'adam'``, the only
+method the hot path uses (``main.py:62``).  ``step()`` is two kernel launches
+(global-norm partials, then clip + Adam over every tensor) through
+``ps_clip_adam_dense``; dense semantics identical to ``torch.optim.Adam(eps=1e-9)``
+after ``clip_grad_norm_`` — parameters without a gradient are skipped, as there.
+"""
+import torch
+
+from . import _lib
+
+
+class Optimizer(object):
+    def __init__(self, method, learning_rate, max_grad_norm,
+                 lr_decay=1, start_decay_steps=None, decay_steps=None,
+                 beta1=0.9, beta2=0.999, adagrad_accum=0.0,
+                 decay_method=None, warmup_steps=4000, weight_decay=0.):
+        if method != 'adam':
+            raise NotImplementedError("only method='adam' is on the hot path (main.py:62)")
+        self.last_ppl = None
+        self.learning_rate = learning_rate
+        self.original_lr = learning_rate
+        self.max_grad_norm = max_grad_norm
+        self.method = method
+        self.lr_decay = lr_decay
+        self.start_decay_steps = start_decay_steps
+        self.decay_steps = decay_steps
+        self.start_decay = False
+        self._step = 0
+        self.betas = [beta1, beta2]
+        self.decay_method = decay_method
+        self.warmup_steps = warmup_steps
+        self.weight_decay = weight_decay
+        self.eps = 1e-9                      # optimizers.py:186-187
+        self.grad_scale = 1.0                # 1/world_size under data parallelism
+        self.params = []
+        self._plan = None
+
+    def set_parameters(self, params):
+        """``set_parameters`` (optimizers.py:165-187): every parameter that requires grad."""
+        self.params = [p for _, p in params if p.requires_grad]
+        self._names = [k for k, p in params if p.requires_grad]
+        self._plan = None
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self):
+        lib = _lib.load()
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            raise RuntimeError("Optimizer.step(): no parameter has a gradient")
+        dev = live[0].device
+        if not live[0].is_cuda:
+            raise RuntimeError("Optimizer.step() needs parameters on a gfx950 device (no CPU fallback)")
+        n = len(live)
+        numel = torch.tensor([p.numel() for p in live], dtype=torch.int64)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in live]
+        total = sum(sizes)
+        old = getattr(self, '_state_tensors', None)
+        self._m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        ms, vs, o = [], [], 0
+        for p, s in zip(live, sizes):
+            ms.append(self._m_flat[o:o + p.numel()].view_as(p))
+            vs.append(self._v_flat[o:o + p.numel()].view_as(p))
+            o += s
+        if old is not None:          # keep moments of parameters that were already being updated
+            for p, m, v in zip(live, ms, vs):
+                if id(p) in old:
+                    m.copy_(old[id(p)][0]); v.copy_(old[id(p)][1])
+        self._state_tensors = {id(p): (m, v) for p, m, v in zip(live, ms, vs)}
+        addr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64)
+        pa, ga, ma, va = addr(live), addr([p.grad for p in live]), addr(ms), addr(vs)
+        nbytes = lib.ps_adam_plan_bytes(n, numel.data_ptr())
+        host = torch.zeros(nbytes, dtype=torch.uint8)
+        _lib.check(lib.ps_adam_plan_write_host(n, pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(),
+                                               numel.data_ptr(), host.data_ptr()), 'ps_adam_plan_write_host')
+        n_chunks = lib.ps_adam_plan_chunks_host(host.data_ptr())
+        plan = dict(dev=host.to(dev), n_chunks=n_chunks, live=live,
+                    sig=tuple((p.data_ptr(), p.grad.data_ptr()) for p in live),
+                    state=torch.zeros(2 + (n_chunks + 1) // 2, device=dev, dtype=torch.int64),
+                    gnorm=torch.zeros(2, device=dev, dtype=torch.float32))
+        plan['state'][0] = self._step
+        self._plan = plan
+        return plan
+
+    def _plan_ok(self):
+        pl = self._plan
+        if pl is None:
+            return False
+        live = [p for p in self.params if p.grad is not None]
+        if len(live) != len(pl['live']):
+            return False
+        return all(a is b and (a.data_ptr(), a.grad.data_ptr()) == s for a, b, s in zip(live, pl['live'], pl['sig']))
+
+    # ------------------------------------------------------------------ step
+    def step(self):
+        """``Optimizer.step`` (optimizers.py:205-243)."""
+        lib = _lib.load()
+        plan = self._plan if self._plan_ok() else self._build_plan()
+        self._step += 1
+        if self.decay_method == "noam":      # host mirror of the in-kernel schedule (optimizers.py:214-219)
+            self.learning_rate = self.original_lr * min(self._step ** (-0.5),
+                                                        self._step * self.warmup_steps ** (-1.5))
+        hp = _lib.PsAdamHyper()
+        hp.lr = self.original_lr if self.decay_method == "noam" else self.learning_rate
+        hp.beta1, hp.beta2, hp.eps = self.betas[0], self.betas[1], self.eps
+        hp.weight_decay = self.weight_decay
+        hp.max_grad_norm = self.max_grad_norm if self.max_grad_norm else 0.0
+        hp.noam = int(self.decay_method == "noam")
+        hp.warmup_steps = self.warmup_steps
+        hp.grad_scale = self.grad_scale
+        dev = plan['live'][0].device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.ps_clip_adam_dense(plan['dev'].data_ptr(), plan['n_chunks'], hp, plan['state'].data_ptr(),
+                                          plan['gnorm'].data_ptr(), st), 'ps_clip_adam_dense')
+
+    @property
+    def last_grad_norm(self):
+        """Pre-clip global gradient norm of the last step (host sync when read)."""
+        return float(self._plan['gnorm'][0]) if self._plan else None
+
+    # ------------------------------------------------------------ checkpointing
+    def state_dict(self):
+        """Adam state in ``torch.optim.Adam.state_dict()`` form (exp_avg / exp_avg_sq / step per
+        parameter index) so a reference checkpoint's ``optim.optimizer.state_dict()`` maps 1:1."""
+        state = {}
+        st = getattr(self, '_state_tensors', {})
+        for i, p in enumerate(self.params):
+            if id(p) in st:
+                m, v = st[id(p)]
+                state[i] = {'step': torch.tensor(float(self._step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+        return {'state': state, 'param_groups': [{'lr': self.learning_rate, 'betas': tuple(self.betas),
+                                                  'eps': self.eps, 'weight_decay': self.weight_decay,
+                                                  'params': list(range(len(self.params)))}], '_step': self._step}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd.get('_step', 0))
+        loaded = {}
+        for i, s in sd['state'].items():
+            p = self.params[int(i)]
+            loaded[id(p)] = (s['exp_avg'].to(p.device), s['exp_avg_sq'].to(p.device))
+            self._step = max(self._step, int(float(s['step'])))
+        self._state_tensors = loaded
+        self._plan = None
+
+
+def build_optim(args, model, checkpoint):
+    """``build_optim`` (models/ps_model.py:20-51)."""
+    optim = Optimizer(args.optim, args.lr, args.max_grad_norm,
+                      beta1=args.beta1, beta2=args.beta2,
+                      decay_method=args.decay_method,
+                      warmup_steps=args.warmup_steps,
+                      weight_decay=args.l2_lambda)
+    optim.set_parameters(list(model.named_parameters()))
+    if getattr(args, 'train_from', '') != '' and checkpoint is not None:
+        optim.load_state_dict(checkpoint['optim'])
+    return optim

@@ -67,6 +67,47 @@ def _multinomial(dist, n, replacement=False, **kw):
 
 torch.multinomial = _multinomial
 
+# 3. (dropout cases only) torch.dropout / F.dropout multiply by the product's Philox masks
+#    (oracle/philox.py) instead of torch's RNG, identified by call order inside one forward:
+#    FS (text_encoder.py:34), then per encode call and layer: attn (neural.py:226), context
+#    (transformer.py:56), ff dropout_1, dropout_2 (neural.py:31-32).
+from oracle.philox import PhiloxDropout   # noqa: E402
+
+_drop = {'gen': None, 'n': 0, 'layers': 1}
+_orig_Fdropout = F.dropout
+_orig_tdropout = torch.dropout
+
+
+def _site_of_call(n, layers):
+    if n == 0:
+        return 'fs', 0
+    n -= 1
+    c, r = divmod(n, 4 * layers)
+    layer, k = divmod(r, 4)
+    return ('attn', 'ctx', 'ff1', 'ff2')[k], (c, layer)
+
+
+def _philox_dropout(x, p, train):
+    g = _drop['gen']
+    if g is None or not train or p == 0.0:
+        return x
+    kind, call = _site_of_call(_drop['n'], _drop['layers'])
+    _drop['n'] += 1
+    return g(x, kind, call)
+
+
+def _Fdropout(input, p=0.5, training=True, inplace=False):
+    return _philox_dropout(input, p, training)
+
+
+def _tdropout(input, p, train):
+    return _philox_dropout(input, p, train)
+
+
+F.dropout = _Fdropout
+torch.nn.functional.dropout = _Fdropout
+torch.dropout = _tdropout
+
 _bce_tap = []
 _orig_bce = F.binary_cross_entropy_with_logits
 
@@ -109,6 +150,16 @@ CASES = {
                                use_item_pos=True, pv_window_size=3, decay_method='noam',
                                warmup_steps=10, l2_lambda=0.01),
                      P=300, V=400, B=24, Q=5, L=7, W=3, C=30, steps=3),
+    # dropout DRAWN (reference default 0.1): the K+1 encoder replicas diverge; masks = product's Philox
+    'tem_c1_drop': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=8, ff_size=64,
+                                  inter_layers=1, neg_per_pos=5, dropout=0.1, lr=0.002, seed=666),
+                        P=1000, V=5001, B=24, Q=6, L=20, W=1, C=20, steps=2),
+    'tem_c2s_drop': dict(args=dict(model_name='item_transformer', embedding_size=128, heads=8, ff_size=512,
+                                   inter_layers=1, neg_per_pos=20, dropout=0.1, lr=0.0005, seed=666),
+                         P=300, V=400, B=8, Q=8, L=20, W=1, C=10, steps=1),
+    'tem_l2_drop': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=4, ff_size=64,
+                                  inter_layers=2, neg_per_pos=3, dropout=0.2, lr=0.002, seed=7),
+                        P=300, V=400, B=6, Q=6, L=9, W=1, C=10, steps=1),
     'tem_avg_nopos': dict(args=dict(model_name='item_transformer', embedding_size=32, heads=2, ff_size=96,
                                     inter_layers=1, neg_per_pos=4, dropout=0.0, lr=0.002,
                                     query_encoder_name='avg', use_pos_emb=False),
@@ -202,10 +253,18 @@ def run_case(name, spec):
         out['in_neg_item_idxs_%d' % step] = ni.numpy()
         out['in_neg_word_idxs_%d' % step] = nw.numpy()
         _draw_queue[:] = [ni, nw]
+        if args.dropout > 0:
+            S_ = L + 1
+            _drop['gen'] = PhiloxDropout(args.dropout, args.seed, step + 1, B, K, args.heads, S_,
+                                         args.inter_layers, (S_ - 1) if args.use_item_pos else 0)
+            _drop['n'], _drop['layers'] = 0, args.inter_layers
         del _bce_tap[:]
         model.clear_loss()
         loss = model(rb, train_pv=False)                 # trainer.py:74
         assert not _draw_queue
+        if args.dropout > 0:
+            assert _drop['n'] == 1 + 8 * args.inter_layers, _drop['n']
+            _drop['gen'] = None
         model.zero_grad()                                 # trainer.py:76
         loss.backward()                                   # trainer.py:77
         out['loss_%d' % step] = np.float32(loss.item())

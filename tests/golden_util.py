@@ -46,6 +46,14 @@ class Golden(object):
         return (torch.from_numpy(self.z['in_neg_item_idxs_%d' % step]),
                 torch.from_numpy(self.z['in_neg_word_idxs_%d' % step]))
 
+    def dropout(self, step):
+        """The Philox mask generator the reference ran with at training step ``step`` (0-based)."""
+        from oracle.philox import PhiloxDropout
+        a = self.args
+        S = self.z['in_u_item_idxs'].shape[1] + 1
+        return PhiloxDropout(a.dropout, a.seed, step + 1, self.B, self.K, a.heads, S, a.inter_layers,
+                             (S - 1) if a.use_item_pos else 0)
+
     def has(self, key):
         return key in self.z.files or (key + '__rows') in self.z.files
 

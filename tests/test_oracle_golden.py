@@ -17,6 +17,11 @@ def _fwd(g, P, step, replicate, keep=None):
     ni, nw = g.negs(step)
     fn = otem.qem_forward if g.args.model_name == 'QEM' else otem.tem_forward
     kw = {} if g.args.model_name == 'QEM' else dict(replicate=replicate)
+    if g.args.dropout > 0:
+        # dropout drawn: the reference ran with the product's Philox masks (make_golden.py hook 3);
+        # only the replicated structure is meaningful (the K+1 copies diverge)
+        kw['replicate'] = True
+        kw['drop'] = g.dropout(step)
     return fn(P, g.args, g.batch(), ni, nw, g.V, g.P, training=True, keep=keep, **kw)
 
 
@@ -26,6 +31,8 @@ def test_forward_loss_and_intermediates(case, replicate):
     g = Golden(case)
     if g.args.model_name == 'QEM' and replicate:
         pytest.skip('QEM has no replicated encoder')
+    if g.args.dropout > 0 and not replicate:
+        pytest.skip('dropout drawn: replicas differ, dedup structure does not apply')
     P = g.params()
     keep = {}
     with torch.no_grad():
