@@ -136,6 +136,12 @@ int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params, const PsT
                     const float* loss_scale_dev /* optional device scalar multiplied in (autograd's grad_output) */,
                     ps_stream_t stream);
 
+/* The embedding-gather+score kernel alone (the launch ps_tem_forward makes after the encoder):
+ * B*(1+K) item rows . encoder output + B*W*(1+K) word rows . target item row -> workspace scores.
+ * Exposed so bench.py / rocprofv3 can time exactly this launch. */
+int ps_gather_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                    float* workspace, ps_stream_t stream);
+
 /* scores = model.test(batch) [B,C]         -- test_dotproduct (item_transformer.py:111-146)
  *                                             / test_attn QEM (:148-160,189-195) */
 int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,

@@ -67,6 +67,8 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_tem_backward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                   C.c_void_p, C.POINTER(PsTemTensors), C.c_float, C.c_void_p, C.c_void_p]),
+    'ps_gather_score': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
+                                  C.c_void_p, C.c_void_p]),
     'ps_tem_score': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_sample_negatives': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.c_void_p, C.c_void_p,

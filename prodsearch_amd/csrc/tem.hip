@@ -330,6 +330,18 @@ extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params,
   return PS_OK;
 }
 
+extern "C" int ps_gather_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                               float* workspace, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace, "gather_score: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  ScoreArgs s;
+  fill_score(D, *params, *batch, workspace, w, s);
+  return launch_score_fwd(s, (hipStream_t)stream);
+}
+
 extern "C" int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
                             float* workspace, float* scores, ps_stream_t stream) {
   PS_REQUIRE(desc && params && batch && workspace && scores, "score: null argument");
