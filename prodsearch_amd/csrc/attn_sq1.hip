@@ -1,0 +1,197 @@
+// attn_sq1.hip — attention of the LAST encoder layer, where only ONE query position per
+// sequence is consumed (x[:, 0] or x[:, -1], item_transformer.py:482-492): one workgroup
+// (4 waves) per input sequence, all heads at once, K/V rows staged once in LDS and shared by
+// every dropout replica of that sequence (MultiHeadedAttention.forward, neural.py:206-231).
+//
+// Forward : scores[h][s] = q_h . K_s,h ; masked softmax ; per replica j: dropout(P) . V
+// Backward: per replica j: dV += (P*m_j)^T dctx_j ; dP += m_j * (dctx_j . V) ; then softmax
+//           backward, dq = dS . K / sqrt(dh), dK = dS^T q, bias gradients.
+// Everything is LDS-resident fp32 VALU work (S <= 64, a few KB per sequence); replicas are
+// processed in chunks of JC so that the Philox masks are generated once per element.
+#include "rowwise.h"
+
+#define JC 8
+
+struct Sq1Lds {
+  float *Ks, *Vs, *q, *P, *valid, *Pd, *dC, *dV, *dP;
+};
+
+__device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd) {
+  Sq1Lds l;
+  l.Ks = base; base += S * d;
+  l.Vs = base; base += S * d;
+  l.q = base; base += d;
+  l.P = base; base += H * (S + 1);
+  l.valid = base; base += (S + 3) & ~3;
+  l.Pd = base; base += JC * H * (S + 1);
+  l.dC = base; l.dV = base; l.dP = base;
+  if (bwd) {
+    l.dC = base; base += JC * d;
+    l.dV = base; base += S * d;
+    l.dP = base;
+  }
+  return l;
+}
+static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd) {
+  size_t n = (size_t)2 * S * d + d + H * (S + 1) + ((S + 3) & ~3) + (size_t)JC * H * (S + 1);
+  if (bwd) n += (size_t)JC * d + (size_t)S * d + H * (S + 1);
+  return n * sizeof(float);
+}
+
+__device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid) {
+  const int S = a.S, d = a.d, nv = S * d / 4;
+  const float4* k4 = reinterpret_cast<const float4*>(a.kp + (size_t)b * S * d);
+  const float4* v4 = reinterpret_cast<const float4*>(a.vp + (size_t)b * S * d);
+  float4* lk = reinterpret_cast<float4*>(l.Ks);
+  float4* lv = reinterpret_cast<float4*>(l.Vs);
+  for (int i = tid; i < nv; i += 256) { lk[i] = k4[i]; lv[i] = v4[i]; }
+  for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * d + i];
+  const int brow = b / a.seq_div;
+  for (int s = tid; s < S; s += 256)
+    l.valid[s] = (s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f;
+}
+
+// dropout multipliers (or P * multipliers) of replicas j0..j0+nj-1 into Pd[jj][h][s]
+__device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int j0, int nj, int tid, bool times_p) {
+  const int S = a.S, H = a.H, per = H * S;
+  for (int i = tid; i < nj * per; i += 256) {
+    const int jj = i / per, r = i - jj * per, h = r / S, s = r - h * S;
+    const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + h);        // Sq == 1: row = nout*H + h
+    float m = drop_mult(a.drop, row, (uint32_t)s);
+    if (times_p) m *= l.P[h * (S + 1) + s];
+    l.Pd[(jj * H + h) * (S + 1) + s] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
+  extern __shared__ float lds[];
+  const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  Sq1Lds l = sq1_carve(lds, S, d, H, false);
+  sq1_load(a, l, b, tid);
+  __syncthreads();
+  for (int i = tid; i < H * S; i += 256) {
+    const int h = i / S, s = i - h * S;
+    float acc = 0.f;
+    for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[s * d + h * dh + c];
+    l.P[h * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;               // masked_fill(mask, -1e18)
+  }
+  __syncthreads();
+  for (int h = tid; h < H; h += 256) {
+    float* p = l.P + h * (S + 1);
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, p[s]);
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) { float e = expf(p[s] - m); p[s] = e; sum += e; }
+    const float inv = 1.f / sum;
+    for (int s = 0; s < S; ++s) p[s] *= inv;
+  }
+  __syncthreads();
+  for (int i = tid; i < H * S; i += 256) {
+    const int h = i / S, s = i - h * S;
+    a.attn[((size_t)b * H + h) * S + s] = l.P[h * (S + 1) + s];
+  }
+  for (int j0 = 0; j0 < a.fan; j0 += JC) {
+    const int nj = min(JC, a.fan - j0);
+    __syncthreads();
+    sq1_masks(a, l, b, j0, nj, tid, true);
+    __syncthreads();
+    for (int i = tid; i < nj * d; i += 256) {
+      const int jj = i / d, c = i - jj * d, h = c / dh;
+      const float* pd = l.Pd + (jj * H + h) * (S + 1);
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * d + c];
+      a.ctx[((size_t)b * a.fan + j0 + jj) * d + c] = acc;
+    }
+  }
+}
+
+bool attn_sq1_fits(const AttnArgs& a) {
+  return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true) <= 64 * 1024;
+}
+
+int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
+  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, false);
+  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention(sq1): S=%d d=%d needs %zu B LDS",
+             a.S, a.d, lds);
+  hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
+  extern __shared__ float lds[];
+  const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  Sq1Lds l = sq1_carve(lds, S, d, H, true);
+  sq1_load(a, l, b, tid);
+  for (int i = tid; i < H * S; i += 256) {
+    const int h = i / S, s = i - h * S;
+    l.P[h * (S + 1) + s] = a.attn[((size_t)b * H + h) * S + s];
+    l.dP[h * (S + 1) + s] = 0.f;
+  }
+  for (int i = tid; i < S * d; i += 256) l.dV[i] = 0.f;
+  for (int j0 = 0; j0 < a.fan; j0 += JC) {
+    const int nj = min(JC, a.fan - j0);
+    __syncthreads();
+    sq1_masks(a, l, b, j0, nj, tid, false);
+    for (int i = tid; i < nj * d; i += 256) {
+      const int jj = i / d, c = i - jj * d;
+      l.dC[i] = a.dctx[((size_t)b * a.fan + j0 + jj) * d + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < S * d; i += 256) {                 // dV[s][c] += sum_j P*m_j * dctx_j[c]
+      const int s = i / d, c = i - s * d, h = c / dh;
+      const float p = l.P[h * (S + 1) + s];
+      float acc = 0.f;
+      for (int jj = 0; jj < nj; ++jj) acc += l.Pd[(jj * H + h) * (S + 1) + s] * l.dC[jj * d + c];
+      l.dV[i] += p * acc;
+    }
+    for (int i = tid; i < H * S; i += 256) {                 // dP[h][s] += sum_j m_j * (dctx_j,h . V_s,h)
+      const int h = i / S, s = i - h * S;
+      float acc = 0.f;
+      for (int jj = 0; jj < nj; ++jj) {
+        float dot = 0.f;
+        for (int c = 0; c < dh; ++c) dot += l.dC[jj * d + h * dh + c] * l.Vs[s * d + h * dh + c];
+        acc += l.Pd[(jj * H + h) * (S + 1) + s] * dot;
+      }
+      l.dP[h * (S + 1) + s] += acc;
+    }
+  }
+  __syncthreads();
+  for (int h = tid; h < H; h += 256) {                       // softmax backward
+    float* p = l.P + h * (S + 1);
+    float* g = l.dP + h * (S + 1);
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += p[s] * g[s];
+    for (int s = 0; s < S; ++s) g[s] = p[s] * (g[s] - t);
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += 256) {
+    const int h = c / dh;
+    const float* g = l.dP + h * (S + 1);
+    const float qc = l.q[c];
+    float dq = 0.f, sk = 0.f, sv = 0.f;
+    for (int s = 0; s < S; ++s) {
+      dq += g[s] * l.Ks[s * d + c];
+      const float dk = g[s] * qc;
+      const float dv = l.dV[s * d + c];
+      const size_t off = ((size_t)b * S + s) * a.lddkv + c;
+      a.dkv[off] = dk;
+      a.dkv[off + d] = dv;
+      sk += dk; sv += dv;
+    }
+    dq *= a.qscale;
+    a.dq[(size_t)b * a.lddq + c] = dq;
+    atomicAdd(&a.dbq[c], dq);
+    atomicAdd(&a.dbk[c], sk);
+    atomicAdd(&a.dbv[c], sv);
+  }
+}
+
+int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
+  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, true);
+  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention bwd(sq1): S=%d d=%d needs %zu B LDS",
+             a.S, a.d, lds);
+  hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

@@ -6,68 +6,91 @@
 // with v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate = a k-ordered fmaf chain,
 // so results are exact fp32 like the reference's mm), tiled for 64-wide waves:
 //
-//   workgroup = 4 waves, tile 64x64 (each wave one 32x32 accumulator = 16 VGPRs),
-//   BK = 32 reduction slab, both operands staged global -> registers -> LDS
-//   (double-buffered, one barrier per slab) in a [k][row+1] image so that every
-//   MFMA operand fetch is one conflict-free ds_read_b32 per lane.
+//   workgroup = 4 waves, tile 64x64 (each wave one 32x32 accumulator = 16 AGPRs);
+//   the reduction advances in 128-deep slabs: the hot path's K is d = 128 (or F = 512),
+//   so a whole projection is ONE global->register->LDS round trip followed by 64
+//   back-to-back MFMAs per wave; the next slab is prefetched into registers while the
+//   current one is multiplied; operands sit in LDS as [k][row+1] so every MFMA operand
+//   fetch is a conflict-free ds_read_b32 per lane, issued 16 steps ahead of its MFMA.
 //
 // One kernel serves forward (A[m][k] . W[n][k]), input-grad (dY[m][n] . W[n][k'])
-// and weight-grad (dY[m][n]^T . X[m][k'], split over the row reduction with
-// fp32 atomics) through (ta, tb) layouts; the epilogue fuses bias, scale,
-// GELU/tanh (or their derivatives), Philox dropout, residual (direct / gathered
-// from the layer input / fan-in summed over replicas), bias-grad column sums.
+// and weight-grad (dY[m][n]^T . X[m][k'], split over the row reduction with fp32
+// atomics) through (ta, tb) layouts.  Two epilogue instantiations keep the code in
+// the instruction cache: PLAIN (bias, scale, store / += / atomic) and FULL (adds
+// GELU/tanh or their derivatives, Philox dropout, residual direct / gathered from
+// the layer input / fan-in summed over replicas, bias-grad column sums, 2nd output),
+// whose body is a rolled loop over an LDS-staged tile so it exists once in the code.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BM 64
 #define BN 64
-#define BK 32
 #define LDT (BM + 1)
 
-template <int TRANS>  // TRANS==0: src[row][k] (k contiguous) ; TRANS==1: src[k][row] (row contiguous)
+// TRANS==0: src[row][k] (k contiguous): one instruction = 8 rows x 128 B
+// TRANS==1: src[k][row] (row contiguous): one instruction = 4 k-rows x 256 B
+struct SegTab {              // up to 3 reduction segments of kseg rows each (segment s serves k in [s*kseg, (s+1)*kseg))
+  const float* seg[3];
+  int kseg;
+  bool multi;
+};
+
+// BK = reduction depth of one slab (32 or 128); NLD = float4 loads per thread per operand per slab
+template <int TRANS, int BK>
 __device__ inline void tile_load(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int kend,
-                                 float4 (&reg)[2], int tid) {
+                                 float4 (&reg)[BK / 16], int tid, const SegTab* st = nullptr) {
+  constexpr int NLD = BK / 16;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int f = tid + 256 * u;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < NLD; ++u) {
+    int r, k;
     if (TRANS == 0) {
-      int i = f >> 3, kq = f & 7;
-      int r = row0 + i, k = k0 + kq * 4;
-      if (r < nrows && k < kend) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld + k);
+      r = row0 + (tid >> 3) + 32 * (u & 1);
+      k = k0 + 32 * (u >> 1) + 4 * (tid & 7);
     } else {
-      int kk = f >> 4, iq = f & 15;
-      int r = row0 + iq * 4, k = k0 + kk;
-      if (r < nrows && k < kend) v = *reinterpret_cast<const float4*>(src + (size_t)k * ld + r);
+      r = row0 + 4 * (tid & 15);
+      k = k0 + (tid >> 4) + 16 * u;
     }
-    reg[u] = v;
+    const bool ok = r < nrows && k < kend;
+    int kl = k, kl0 = k0;
+    if (st && st->multi) {                     // K-concatenated operand: pick the segment of this k
+      const int sg = ok ? k / st->kseg : k0 / st->kseg;
+      src = st->seg[sg];
+      kl = k - sg * st->kseg;
+      kl0 = k0 - sg * st->kseg;
+    }
+    const size_t off = TRANS == 0 ? (size_t)r * ld + kl : (size_t)kl * ld + r;
+    const size_t safe = TRANS == 0 ? (size_t)row0 * ld + kl0 : (size_t)kl0 * ld + row0;   // always in range
+    float4 v = *reinterpret_cast<const float4*>(src + (ok ? off : safe));   // unconditional load
+    reg[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
-template <int TRANS>
-__device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[2], int tid) {
+template <int TRANS, int BK>
+__device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16], int tid) {
+  constexpr int NLD = BK / 16;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int f = tid + 256 * u;
+  for (int u = 0; u < NLD; ++u) {
     if (TRANS == 0) {
-      int i = f >> 3, kq = f & 7;
-      T[kq * 4 + 0][i] = reg[u].x;
-      T[kq * 4 + 1][i] = reg[u].y;
-      T[kq * 4 + 2][i] = reg[u].z;
-      T[kq * 4 + 3][i] = reg[u].w;
+      const int i = (tid >> 3) + 32 * (u & 1), kk = 32 * (u >> 1) + 4 * (tid & 7);
+      T[kk + 0][i] = reg[u].x;
+      T[kk + 1][i] = reg[u].y;
+      T[kk + 2][i] = reg[u].z;
+      T[kk + 3][i] = reg[u].w;
     } else {
-      int kk = f >> 4, iq = f & 15;
-      T[kk][iq * 4 + 0] = reg[u].x;
-      T[kk][iq * 4 + 1] = reg[u].y;
-      T[kk][iq * 4 + 2] = reg[u].z;
-      T[kk][iq * 4 + 3] = reg[u].w;
+      const int kk = (tid >> 4) + 16 * u, i = 4 * (tid & 15);
+      T[kk][i + 0] = reg[u].x;
+      T[kk][i + 1] = reg[u].y;
+      T[kk][i + 2] = reg[u].z;
+      T[kk][i + 3] = reg[u].w;
     }
   }
 }
 
-template <int TA, int TB>
+template <int TA, int TB, int FULL, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
+  constexpr int NLD = BK / 16;
   __shared__ float As[2][BK][LDT];
   __shared__ float Bs[2][BK][LDT];
 
@@ -89,39 +112,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float4 ra[2], rb[2];
-  auto bptr = [&](int k) -> const float* {
-    int s = k / P.kseg;
-    const float* b = P.Bseg[s];
-    // segment-local k offset
-    return TB == 0 ? b - (size_t)s * P.kseg : b - (size_t)s * P.kseg * P.ldb;
-  };
+  float4 ra[NLD], rb[NLD];
+  const int ldb = P.ldb;
+  SegTab st;
+  st.seg[0] = P.Bseg[0]; st.seg[1] = P.Bseg[1]; st.seg[2] = P.Bseg[2];
+  st.kseg = P.kseg; st.multi = K > P.kseg;
 
-  tile_load<TA>(P.A, P.lda, m0, M, kbeg, kend, ra, tid);
-  tile_load<TB>(bptr(kbeg), P.ldb, n0, N, kbeg, kend, rb, tid);
-  tile_store<TA>(As[0], ra, tid);
-  tile_store<TB>(Bs[0], rb, tid);
+  tile_load<TA, BK>(P.A, P.lda, m0, M, kbeg, kend, ra, tid);
+  tile_load<TB, BK>(st.seg[0], ldb, n0, N, kbeg, kend, rb, tid, &st);
+  tile_store<TA, BK>(As[0], ra, tid);
+  tile_store<TB, BK>(Bs[0], rb, tid);
   __syncthreads();
 
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const int kn = k0 + BK;
     const bool more = kn < kend;
-    if (more) {
-      tile_load<TA>(P.A, P.lda, m0, M, kn, kend, ra, tid);
-      tile_load<TB>(bptr(kn), P.ldb, n0, N, kn, kend, rb, tid);
+    if (more) {                                    // prefetch the next slab while this one is multiplied
+      tile_load<TA, BK>(P.A, P.lda, m0, M, kn, kend, ra, tid);
+      tile_load<TB, BK>(st.seg[0], ldb, n0, N, kn, kend, rb, tid, &st);
     }
     const float* a_base = &As[buf][h][wm * 32 + l31];
     const float* b_base = &Bs[buf][h][wn * 32 + l31];
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      float a = a_base[2 * s * LDT];
-      float b = b_base[2 * s * LDT];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int q = 0; q < BK / 32; ++q) {
+      float av[16], bv[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        av[s] = a_base[(32 * q + 2 * s) * LDT];
+        bv[s] = b_base[(32 * q + 2 * s) * LDT];
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
     }
     if (more) {
-      tile_store<TA>(As[buf ^ 1], ra, tid);
-      tile_store<TB>(Bs[buf ^ 1], rb, tid);
+      tile_store<TA, BK>(As[buf ^ 1], ra, tid);
+      tile_store<TB, BK>(Bs[buf ^ 1], rb, tid);
     }
     __syncthreads();
     buf ^= 1;
@@ -131,40 +157,91 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int col = n0 + wn * 32 + l31;
   const bool col_ok = col < N;
   const float bias = (P.bias && col_ok && split == 0) ? P.bias[col] : 0.f;
-  float csum = 0.f;
+  const float alpha = P.alpha;
+  float* const C = P.C;
+  const int ldc = P.ldc, accumulate = P.accumulate;
+  if (!FULL) {
 #pragma unroll
-  for (int gq = 0; gq < 4; ++gq) {
-    const int rbase = m0 + wm * 32 + 8 * gq + 4 * h;     // rows rbase..rbase+3 <-> regs 4gq..4gq+3
-    Philox4 rnd;
-    if (P.drop.thr != 0u)
-      rnd = philox4x32_10((uint32_t)col, (uint32_t)rbase >> 2, P.drop.site, P.drop.step, P.drop.k0, P.drop.k1);
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (col_ok && row < M) {
+        const float v = (acc[r] + bias) * alpha;
+        const size_t off = (size_t)row * ldc + col;
+        if (accumulate == 0) C[off] = v;
+        else if (accumulate == 1) C[off] += v;
+        else atomicAdd(&C[off], v);
+      }
+    }
+    return;
+  }
+  // FULL: stage the 64x64 tile through LDS so that the (large) epilogue body exists ONCE in the
+  // instruction stream: thread t owns column t&63 and rows 4*((t>>6)+4i)+q  (i,q < 4); the four q-rows
+  // of one i share a Philox call (counter (col, row>>2), word row&3); stores are 256-B coalesced.
+  float (*Ct)[LDT] = reinterpret_cast<float (*)[LDT]>(&As[0][0][0]);   // 64x65 floats fit As for BK >= 32
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ct[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h][wn * 32 + l31] = acc[r];
+  __syncthreads();
+  const int ccol = tid & 63, gcol = n0 + ccol;
+  if (gcol >= N) return;
+  const float cbias = (P.bias && split == 0) ? P.bias[gcol] : 0.f;
+  const int act = P.act;
+  const DropSpec drop = P.drop;
+  const bool dropping = drop.thr != 0u, has_res = P.res.mode != RES_NONE;
+  const float add2 = (P.out2 && P.add2) ? P.add2[gcol] : 0.f;
+  float csum = 0.f;
+  // global operands of the epilogue (activation aux, residual) for row group i; fetched one group
+  // AHEAD of its use so the rolled loop does not serialise four global-latency round trips
+  const bool need_aux = act == ACT_GELU_BWD || act == ACT_TANH_BWD;
+  struct Pre { float aux[4], res[4]; };
+  auto preload = [&](int i, Pre& pr) {
+    const int rbase = m0 + 4 * ((tid >> 6) + 4 * i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rbase + q;
-      if (!(col_ok && row < M)) continue;
-      float v = (acc[4 * gq + q] + bias) * P.alpha;
-      const size_t off = (size_t)row * P.ldc + col;
-      if (P.aux_out) P.aux_out[off] = v;
-      if (P.act == ACT_GELU) v = gelu_tanh_f(v);
-      else if (P.act == ACT_TANH) v = tanhf(v);
-      else if (P.act == ACT_GELU_BWD) v *= gelu_tanh_grad(P.act_aux[off]);
-      else if (P.act == ACT_TANH_BWD) { float y = P.act_aux[off]; v *= (1.f - y * y); }
-      if (P.drop.thr != 0u) {
-        uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
-        v *= drop_word(P.drop, wv);
-      }
-      if (P.res.mode != RES_NONE) v += res_value(P.res, row, col);
-      csum += v;
-      if (P.out2) P.out2[(size_t)row * P.ld2 + col] = v + (P.add2 ? P.add2[col] : 0.f);
-      if (P.accumulate == 0) P.C[off] = v;
-      else if (P.accumulate == 1) P.C[off] += v;
-      else atomicAdd(&P.C[off], v);
+      const bool ok = i < 4 && row < M;
+      pr.aux[q] = (need_aux && ok) ? P.act_aux[(size_t)row * ldc + gcol] : 0.f;
+      pr.res[q] = (has_res && ok) ? res_value(P.res, row, gcol) : 0.f;
     }
+  };
+  Pre cur, nxt;
+  preload(0, cur);
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int lrow = 4 * ((tid >> 6) + 4 * i);
+    const int rbase = m0 + lrow;
+    if (rbase >= M) break;
+    preload(i + 1, nxt);
+    Philox4 rnd = {0u, 0u, 0u, 0u};
+    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop.step, drop.k0, drop.k1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + q;
+      if (row >= M) break;
+      float v = (Ct[lrow + q][ccol] + cbias) * alpha;
+      const size_t off = (size_t)row * ldc + gcol;
+      if (P.aux_out) P.aux_out[off] = v;
+      if (act == ACT_GELU) v = gelu_tanh_f(v);
+      else if (act == ACT_TANH) v = tanhf(v);
+      else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(cur.aux[q]);
+      else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
+      if (dropping) {
+        const uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
+        v *= drop_word(drop, wv);
+      }
+      v += cur.res[q];
+      csum += v;
+      if (P.out2) P.out2[(size_t)row * P.ld2 + gcol] = v + add2;
+      if (accumulate == 0) C[off] = v;
+      else if (accumulate == 1) C[off] += v;
+      else atomicAdd(&C[off], v);
+    }
+    cur = nxt;
   }
-  if (P.colsum) {
-    csum += __shfl_xor(csum, 32, 64);
-    if (h == 0 && col_ok) atomicAdd(&P.colsum[col], csum);
-  }
+  if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
+}
+
+static bool needs_full(const GemmProblem& p) {
+  return p.act != ACT_NONE || p.drop.thr != 0u || p.res.mode != RES_NONE || p.aux_out || p.out2 || p.colsum;
 }
 
 static int validate(const GemmProblem& p) {
@@ -177,17 +254,26 @@ static int validate(const GemmProblem& p) {
   else PS_REQUIRE(p.K % 4 == 0, "gemm: K %% 4 != 0 (%d)", p.K);
   int nseg = (p.K + p.kseg - 1) / p.kseg;
   PS_REQUIRE(p.kseg > 0 && nseg <= 3, "gemm: bad segments kseg=%d K=%d", p.kseg, p.K);
-  if (nseg > 1) PS_REQUIRE(p.kseg % BK == 0, "gemm: kseg %% %d != 0 (%d)", BK, p.kseg);
+  if (nseg > 1) PS_REQUIRE(p.kseg % 4 == 0, "gemm: kseg %% 4 != 0 (%d)", p.kseg);
   for (int s = 0; s < nseg; ++s)
     PS_REQUIRE(p.Bseg[s] && ((uintptr_t)p.Bseg[s] & 15) == 0, "gemm: B segment %d null/unaligned", s);
   PS_REQUIRE(p.ksplit >= 1, "gemm: ksplit");
-  if (p.ksplit > 1) PS_REQUIRE(p.accumulate == 2, "gemm: split reduction needs atomic accumulate");
+  if (p.ksplit > 1) PS_REQUIRE(p.accumulate == 2 && !needs_full(p), "gemm: split reduction needs a plain atomic epilogue");
   return PS_OK;
+}
+
+template <int FULL, int BK>
+static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGroup& g) {
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, FULL, BK>), grid, dim3(256), 0, stream, g);
+  else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, FULL, BK>), grid, dim3(256), 0, stream, g);
+  else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, FULL, BK>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0, FULL, BK>), grid, dim3(256), 0, stream, g);
 }
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
   PS_REQUIRE(g.n >= 1 && g.n <= 3, "gemm: group size %d", g.n);
   int maxM = 0, maxN = 0;
+  bool full = false;
   for (int i = 0; i < g.n; ++i) {
     int rc = validate(g.p[i]);
     if (rc) return rc;
@@ -195,14 +281,19 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
                "gemm: group members must share layout and ksplit");
     maxM = g.p[i].M > maxM ? g.p[i].M : maxM;
     maxN = g.p[i].N > maxN ? g.p[i].N : maxN;
+    full = full || needs_full(g.p[i]);
   }
   dim3 grid(ps_cdiv(maxN, BN), ps_cdiv(maxM, BM), g.n * g.p[0].ksplit);
   PS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
-  const int ta = g.p[0].ta, tb = g.p[0].tb;
-  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, dim3(256), 0, stream, g);
-  else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, dim3(256), 0, stream, g);
-  else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, stream, g);
-  else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 0>), grid, dim3(256), 0, stream, g);
+  static const int repeat = getenv("PS_DEBUG_REPEAT") ? atoi(getenv("PS_DEBUG_REPEAT")) : 1;   // timing experiments only
+  for (int r = 0; r < repeat; ++r) {
+    // few workgroups (latency-bound chain): one deep slab per round trip; many: shallow slabs, 4 wgs per CU
+    const bool deep = (size_t)grid.x * grid.y * grid.z <= 64;
+    if (full && deep) launch<1, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);
+    else if (full) launch<1, 32>(g.p[0].ta, g.p[0].tb, grid, stream, g);
+    else if (deep) launch<0, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);
+    else launch<0, 32>(g.p[0].ta, g.p[0].tb, grid, stream, g);
+  }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -54,6 +54,10 @@ struct AttnArgs {
 };
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
+// last-layer form (Sq == 1): one workgroup per sequence, all heads, replicas share K/V in LDS (attn_sq1.hip)
+int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st);
+int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
+bool attn_sq1_fits(const AttnArgs& a);
 
 struct ScoreArgs {
   int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)
@@ -66,6 +70,8 @@ struct ScoreArgs {
   float* item_scores;            // [B,1+K]   (eval: [B,C])
   float* word_scores;            // [B,W,1+K]
   float* loss_parts;             // [B,2]
+  float* item_terms;             // [B,1+K]   per-task loss terms (softplus), written by the gather+score kernel
+  float* word_terms;             // [B,W,1+K]
   float* loss3;                  // {total, ps, item}
   // backward
   float scale;                   // loss_scale

@@ -90,16 +90,17 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
 // ================================================================== LayerNorm
 // nn.LayerNorm(d, eps=1e-6): transformer.py:44,68,86 ; neural.py:25.  One wave per row.
 #define LN_MAXI 8   // d <= 512
+template <int DPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
   const float invd = 1.f / (float)a.d;
   for (int row = wave; row < a.rows; row += nw) {
-    float v[LN_MAXI];
+    float v[DPL];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       int col = lane + 64 * i;
       v[i] = col < a.d ? a.x[(size_t)row * a.ldx + col] : 0.f;
       s += v[i];
@@ -107,14 +108,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdArgs a) {
     const float mean = wave_sum(s) * invd;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       int col = lane + 64 * i;
       float t = col < a.d ? v[i] - mean : 0.f;
       q += t * t;
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) * invd + a.eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       int col = lane + 64 * i;
       if (col < a.d) a.y[(size_t)row * a.ldy + col] = (v[i] - mean) * rstd * a.g[col] + a.b[col];
     }
@@ -126,26 +127,35 @@ int launch_ln_fwd(const LnFwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d <= 64 * LN_MAXI, "layernorm: d=%d > %d", a.d, 64 * LN_MAXI);
   int blocks = ps_cdiv(a.rows, 4);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  const int dpl = ps_cdiv(a.d, 64);
+  if (dpl <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
+  else if (dpl <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+  else if (dpl <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ln_fwd_kernel<8>, dim3(blocks), dim3(256), 0, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
-  __shared__ float sh[3][4][64 * LN_MAXI];
+// Backward: 16 waves per workgroup so the gamma/beta/bias column sums are combined in LDS
+// before they reach the (contended) fp32 atomics: one atomic per column per workgroup.
+#define LNB_WAVES 16
+template <int DPL>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const LnBwdArgs a) {
+  extern __shared__ float sh[];      // [3][LNB_WAVES][64*DPL]
+  const int W = 64 * DPL;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
   const float invd = 1.f / (float)a.d;
-  float ag[LN_MAXI], ab[LN_MAXI], ac[LN_MAXI];
+  float ag[DPL], ab[DPL], ac[DPL];
 #pragma unroll
-  for (int i = 0; i < LN_MAXI; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
+  for (int i = 0; i < DPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; ac[i] = 0.f; }
   for (int row = wave; row < a.rows; row += nw) {
     const float mean = a.stats[2 * (size_t)row], rstd = a.stats[2 * (size_t)row + 1];
-    float xh[LN_MAXI], dxh[LN_MAXI], dyv[LN_MAXI];
+    float xh[DPL], dxh[DPL], dyv[DPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       int col = lane + 64 * i;
       if (col < a.d) {
         float x = a.x[(size_t)row * a.ldx + col];
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     s1 = wave_sum(s1) * invd;
     s2 = wave_sum(s2) * invd;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < DPL; ++i) {
       int col = lane + 64 * i;
       if (col < a.d) {
         float dx = rstd * (dxh[i] - s1 - xh[i] * s2);
@@ -177,27 +187,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXI; ++i) {
-    sh[0][wv][lane + 64 * i] = ag[i];
-    sh[1][wv][lane + 64 * i] = ab[i];
-    sh[2][wv][lane + 64 * i] = ac[i];
+  for (int i = 0; i < DPL; ++i) {
+    sh[(0 * LNB_WAVES + wv) * W + lane + 64 * i] = ag[i];
+    sh[(1 * LNB_WAVES + wv) * W + lane + 64 * i] = ab[i];
+    sh[(2 * LNB_WAVES + wv) * W + lane + 64 * i] = ac[i];
   }
   __syncthreads();
-  for (int col = threadIdx.x; col < a.d; col += 256) {
-    float g = sh[0][0][col] + sh[0][1][col] + sh[0][2][col] + sh[0][3][col];
-    float b = sh[1][0][col] + sh[1][1][col] + sh[1][2][col] + sh[1][3][col];
-    float c = sh[2][0][col] + sh[2][1][col] + sh[2][2][col] + sh[2][3][col];
-    if (a.dgamma) atomicAdd(&a.dgamma[col], g);
-    if (a.dbeta) atomicAdd(&a.dbeta[col], b);
-    if (a.colsum) atomicAdd(&a.colsum[col], c);
+  for (int t = threadIdx.x; t < 3 * a.d; t += blockDim.x) {
+    const int which = t / a.d, col = t - which * a.d;
+    float* dst = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.colsum);
+    if (!dst) continue;
+    float s = 0.f;
+    for (int w = 0; w < LNB_WAVES; ++w) s += sh[(which * LNB_WAVES + w) * W + col];
+    atomicAdd(&dst[col], s);
   }
 }
 
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d <= 64 * LN_MAXI, "layernorm bwd: d=%d > %d", a.d, 64 * LN_MAXI);
-  int blocks = ps_cdiv(a.rows, 4);
-  if (blocks > 512) blocks = 512;      // rows are grid-strided; bounds the gamma/beta atomics
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, st, a);
+  int blocks = ps_cdiv(a.rows, LNB_WAVES);
+  if (blocks > 256) blocks = 256;      // rows are grid-strided; bounds the gamma/beta atomics
+  const int dpl = ps_cdiv(a.d, 64);
+  const int dp = dpl <= 1 ? 1 : (dpl <= 2 ? 2 : (dpl <= 4 ? 4 : 8));
+  const size_t lds = sizeof(float) * 3 * LNB_WAVES * 64 * dp;
+  const dim3 blk(64 * LNB_WAVES);
+  if (dp == 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(blocks), blk, lds, st, a);
+  else if (dp == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(blocks), blk, lds, st, a);
+  else if (dp == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(blocks), blk, lds, st, a);
+  else hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(blocks), blk, lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -400,6 +417,7 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
 // 4 row + 4 vector loads in flight, then shuffle reductions.
 struct Task {
   const float* row; const float* vec; float bias; float* out;
+  float* term; float tw;     // loss term = |tw| * softplus(sign(tw) * score): tw < 0 for the positive
 };
 __device__ inline Task score_task(const ScoreArgs& a, int t) {
   Task k;
@@ -411,6 +429,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.vec = a.enc + (size_t)b * a.R * a.d;
     k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
     k.out = a.item_scores + t;
+    k.term = nullptr; k.tw = 0.f;
     return k;
   }
   const int nitem = a.B * K1;
@@ -421,6 +440,8 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.vec = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * a.d;
     k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
     k.out = a.item_scores + t;
+    k.term = a.item_terms + t;
+    k.tw = j == 0 ? -(a.pos_weight ? (float)a.K : 1.f) : 1.f;
   } else {
     int u = t - nitem;
     int b = u / (a.W * K1), r = u - b * (a.W * K1);
@@ -432,6 +453,8 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.vec = a.product_emb + (size_t)tb * a.d;
     k.bias = a.word_bias[idx];
     k.out = a.word_scores + u;
+    k.term = a.word_terms + u;
+    k.tw = j == 0 ? -1.f : 1.f;
   }
   return k;
 }
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
   for (int u = 0; u < SCORE_U; ++u) {
     int t = t0 + u;
     if (t < ntask) tk[u] = score_task(a, t);
-    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; }
+    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; }
   }
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
@@ -471,7 +494,12 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
         s += rr.x * vv.x + rr.y * vv.y + rr.z * vv.z + rr.w * vv.w;
       }
     s = group_sum(s, lpr);
-    if (c == 0 && tk[u].out) *tk[u].out = s + tk[u].bias;
+    if (c == 0 && tk[u].out) {
+      const float sc = s + tk[u].bias;
+      *tk[u].out = sc;
+      // BCE-with-logits term of this task (item_transformer.py:510-513, :280): target 1 -> softplus(-s)
+      if (tk[u].term) *tk[u].term = fabsf(tk[u].tw) * softplus_f(tk[u].tw < 0.f ? -sc : sc);
+    }
   }
 }
 
@@ -491,21 +519,20 @@ int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
   __shared__ float sps[256], sil[256];
   const int tid = threadIdx.x, K1 = a.K + 1;
-  const float wpos = a.pos_weight ? (float)a.K : 1.f;
   float aps = 0.f, ail = 0.f;
   for (int b = tid; b < a.B; b += 256) {
-    const float* s = a.item_scores + (size_t)b * K1;
-    float ps = wpos * softplus_f(-s[0]);
-    for (int k = 1; k < K1; ++k) ps += softplus_f(s[k]);
+    const float* s = a.item_terms + (size_t)b * K1;
+    float ps = 0.f;
+    for (int k = 0; k < K1; ++k) ps += s[k];
     float il = 0.f;
     int cnt = 0;
     for (int w = 0; w < a.W; ++w) {
       bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
       cnt += valid;
       if (valid) {
-        const float* ws = a.word_scores + ((size_t)b * a.W + w) * K1;
-        float l = softplus_f(-ws[0]);
-        for (int k = 1; k < K1; ++k) l += softplus_f(ws[k]);
+        const float* ws = a.word_terms + ((size_t)b * a.W + w) * K1;
+        float l = 0.f;
+        for (int k = 0; k < K1; ++k) l += ws[k];
         il += l;
       }
     }
@@ -535,8 +562,9 @@ int launch_loss(const ScoreArgs& a, hipStream_t st) {
 // Backward of score + loss: per batch row, half-wave (32 lanes, 128-B segments) per task so
 // that every fp32 atomic wave-instruction covers two contiguous 128-B row segments.
 #define BW_MAXE 16   // d <= 512
-__global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
-  extern __shared__ float red[];                 // [8][d]
+#define SB_RG 16     // half-wave row groups per workgroup
+__global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a) {
+  extern __shared__ float red[];                 // [SB_RG][d]
   const int b = blockIdx.x, tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
   const int d = a.d, epl = d >> 5, K1 = a.K + 1;
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
@@ -546,7 +574,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
 #pragma unroll
   for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
   // ---- item tasks
-  for (int j = rg; j < K1; j += 8) {
+  for (int j = rg; j < K1; j += SB_RG) {
     int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
     float s = a.item_scores[(size_t)b * K1 + j];
     float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
@@ -570,9 +598,9 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
     for (int k = 0; k < BW_MAXE; ++k)
       if (k < epl) red[rg * d + c + 32 * k] = acc[k];
     __syncthreads();
-    for (int e = tid; e < d; e += 256) {
+    for (int e = tid; e < d; e += 32 * SB_RG) {
       float s = 0.f;
-      for (int r = 0; r < 8; ++r) s += red[r * d + e];
+      for (int r = 0; r < SB_RG; ++r) s += red[r * d + e];
       a.denc[(size_t)b * d + e] = s;
     }
     __syncthreads();
@@ -584,7 +612,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
   for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
   const float cf = invB / (float)(cnt > 0 ? cnt : 1);
   const float* prow = a.product_emb + (size_t)tb * d;
-  for (int t = rg; t < a.W * K1; t += 8) {
+  for (int t = rg; t < a.W * K1; t += SB_RG) {
     int w = t / K1, j = t - w * K1;
     int64_t pw = a.pos_words[(size_t)b * a.W + w];
     if (pw == a.V - 1) continue;                                  // masked window slot (get_vector_mean)
@@ -608,16 +636,16 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const ScoreArgs a) {
     if (k < epl) red[rg * d + c + 32 * k] = acc[k];
   __syncthreads();
   if (tb != a.P)
-    for (int e = tid; e < d; e += 256) {
+    for (int e = tid; e < d; e += 32 * SB_RG) {
       float s = 0.f;
-      for (int r = 0; r < 8; ++r) s += red[r * d + e];
+      for (int r = 0; r < SB_RG; ++r) s += red[r * d + e];
       atomicAdd(&a.g_product_emb[(size_t)tb * d + e], s);
     }
 }
 
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0 && a.d <= 32 * BW_MAXE, "score bwd: d=%d unsupported", a.d);
-  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B), dim3(256), (size_t)8 * a.d * sizeof(float), st, a);
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

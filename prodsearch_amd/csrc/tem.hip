@@ -42,7 +42,7 @@ struct Ws {
   int64_t qmean, query_emb, x;
   LayerWs layer[PS_MAX_LAYERS];
   int64_t fin_stats, enc;
-  int64_t item_scores, word_scores, loss_parts;
+  int64_t item_scores, word_scores, loss_parts, item_terms, word_terms;
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
   int64_t total;
 };
@@ -117,6 +117,8 @@ static int make_ws(const PsTemDesc& D, Ws& w) {
   w.item_scores = take(cur, (int64_t)B * C);
   w.word_scores = take(cur, (int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1));
   w.loss_parts = take(cur, (int64_t)B * 2);
+  w.item_terms = take(cur, (int64_t)B * (D.K + 1));
+  w.word_terms = take(cur, (int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1));
   // backward scratch (sized for the widest layer)
   w.denc = take(cur, (int64_t)w.Mf * d);
   if (tem) {
@@ -184,9 +186,9 @@ static GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, 
   p.accumulate = 2;
   return p;
 }
-static int pick_ksplit(int tiles, int rows) {
-  int want = 256 / (tiles > 0 ? tiles : 1);
-  int cap = rows / 128;
+static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, at least one 128-row slab each
+  int want = 512 / (tiles > 0 ? tiles : 1);
+  int cap = (rows + 127) / 128;
   int ks = want < cap ? want : cap;
   return ks < 1 ? 1 : ks;
 }
@@ -263,7 +265,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
     a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = Bt.u_item_idxs;
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
-    TRY(launch_attn_fwd(a, st));
+    TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     {   // final_linear + dropout + residual (neural.py:228-231, transformer.py:56)
       GemmProblem p = gp(ws + l.ctx, d, 0, Lp.wo, d, 0, ws + l.y1, d, l.M2, d, d);
       p.bias = Lp.bo; p.drop = make_drop(D, PS_SITE_CTX(i));
@@ -308,6 +310,7 @@ static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBat
   s.product_emb = P.product_emb; s.word_emb = P.word_emb; s.product_bias = P.product_bias; s.word_bias = P.word_bias;
   s.enc = ws + w.enc;
   s.item_scores = ws + w.item_scores; s.word_scores = ws + w.word_scores; s.loss_parts = ws + w.loss_parts;
+  s.item_terms = ws + w.item_terms; s.word_terms = ws + w.word_terms;
 }
 
 extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
@@ -461,7 +464,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         a.lddq = qall ? 3 * d : d;
         a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
         a.qscale = 1.f / sqrtf((float)(d / D.H));
-        TRY(launch_attn_bwd(a, st));
+        TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
         // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
         float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
         GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);
