@@ -124,9 +124,11 @@ int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);
 
 /* loss = model(batch)                      -- ItemTransformerRanker.forward
  *   (models/item_transformer.py:352-359 -> forward_dotproduct :440-520, or forward_attn/QEM :361-438)
- * loss3[0..2] = {ps_loss + item_loss, ps_loss, item_loss} (device floats). */
+ * loss3[0..2] = {ps_loss + item_loss, ps_loss, item_loss} (device floats);
+ * loss_acc (optional, device float[2]) += {ps_loss, item_loss}: the running sums the reference keeps in
+ * model.ps_loss / model.item_loss with two .item() syncs per step (item_transformer.py:516-517). */
 int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
-                   float* workspace, float* loss3, ps_stream_t stream);
+                   float* workspace, float* loss3, float* loss_acc, ps_stream_t stream);
 
 /* loss.backward()                          -- trainer.py:77 (autograd of the above).
  * ACCUMULATES loss_scale * dloss/dparam into `grads` (dense, like the reference's

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   for (int i = tid; i < H * S; i += 256) {
     const int h = i / S, s = i - h * S;
     float acc = 0.f;
+#pragma unroll 8
     for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[s * d + h * dh + c];
     l.P[h * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;               // masked_fill(mask, -1e18)
   }
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
       const int jj = i / d, c = i - jj * d, h = c / dh;
       const float* pd = l.Pd + (jj * H + h) * (S + 1);
       float acc = 0.f;
+#pragma unroll 8
       for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * d + c];
       a.ctx[((size_t)b * a.fan + j0 + jj) * d + c] = acc;
     }
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
       const int s = i / d, c = i - s * d, h = c / dh;
       const float p = l.P[h * (S + 1) + s];
       float acc = 0.f;
+#pragma unroll 8
       for (int jj = 0; jj < nj; ++jj) acc += l.Pd[(jj * H + h) * (S + 1) + s] * l.dC[jj * d + c];
       l.dV[i] += p * acc;
     }
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
       float acc = 0.f;
       for (int jj = 0; jj < nj; ++jj) {
         float dot = 0.f;
+#pragma unroll 8
         for (int c = 0; c < dh; ++c) dot += l.dC[jj * d + h * dh + c] * l.Vs[s * d + h * dh + c];
         acc += l.Pd[(jj * H + h) * (S + 1) + s] * dot;
       }
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     const float* g = l.dP + h * (S + 1);
     const float qc = l.q[c];
     float dq = 0.f, sk = 0.f, sv = 0.f;
+#pragma unroll 4
     for (int s = 0; s < S; ++s) {
       dq += g[s] * l.Ks[s * d + c];
       const float dk = g[s] * qc;

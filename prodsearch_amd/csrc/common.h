@@ -108,26 +108,32 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// tanh via one v_exp_f32 + one v_rcp_f32: 1 - 2/(e^{2u}+1); saturates correctly at +-inf.
+// |error| <= ~2e-7 absolute, far inside the 1e-4 budget and ~8x fewer instructions than tanhf.
+__device__ inline float tanh_fast(float u) {
+  const float e = __expf(2.f * u);
+  return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
 __device__ inline float gelu_tanh_f(float x) {     // models/neural.py:7-8
   const float c = 0.7978845608028654f;             // sqrt(2/pi)
   float u = c * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.f + tanhf(u));
+  return 0.5f * x * (1.f + tanh_fast(u));
 }
 __device__ inline float gelu_tanh_grad(float x) {
   const float c = 0.7978845608028654f;
   float x2 = x * x;
   float u = c * (x + 0.044715f * x * x2);
-  float t = tanhf(u);
+  float t = tanh_fast(u);
   float du = c * (1.f + 3.f * 0.044715f * x2);
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
 }
 __device__ inline float softplus_f(float x) {      // log(1+exp(x)), stable
-  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+  return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
 }
 __device__ inline float sigmoid_f(float x) {
-  if (x >= 0.f) { float e = expf(-x); return 1.f / (1.f + e); }
-  float e = expf(x);
-  return e / (1.f + e);
+  const float e = __expf(-fabsf(x));
+  const float r = __frcp_rn(1.f + e);
+  return x >= 0.f ? r : e * r;
 }
 
 // ------------------------------------------------------------------- GEMM launcher

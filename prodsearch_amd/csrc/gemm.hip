@@ -98,7 +98,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int split = blockIdx.z - prob * g.p[0].ksplit;
   const GemmProblem& P = g.p[prob];
   const int M = P.M, N = P.N, K = P.K;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
+  // so give every XCD whole ROW tiles: all column tiles that re-read one A row-tile share an L2.
+  int tm = blockIdx.y, tn = blockIdx.x;
+  {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int L = blockIdx.y * nx + blockIdx.x;       // dispatch order (x fastest)
+    const int grp = L / (8 * nx), r = L - grp * 8 * nx;
+    const int rows_here = min(8, ny - grp * 8);
+    tm = grp * 8 + r % rows_here;
+    tn = r / rows_here;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int nslab = (K + BK - 1) / BK;
   const int per = (nslab + P.ksplit - 1) / P.ksplit;
   const int kbeg = split * per * BK;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       const size_t off = (size_t)row * ldc + gcol;
       if (P.aux_out) P.aux_out[off] = v;
       if (act == ACT_GELU) v = gelu_tanh_f(v);
-      else if (act == ACT_TANH) v = tanhf(v);
+      else if (act == ACT_TANH) v = tanh_fast(v);
       else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(cur.aux[q]);
       else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
       if (dropping) {

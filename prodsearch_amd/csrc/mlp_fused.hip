@@ -1,0 +1,263 @@
+// mlp_fused.hip — the per-replica tail of the last encoder layer as ONE kernel (gfx950, d = 128).
+//
+// After attention, every encoder replica row m (B*R of them, R = K+1 when dropout is drawn) runs
+//   y1  = dropout(ctx . Wo^T + bo) + x[b, qpos]                 (neural.py:228-231, transformer.py:56)
+//   ln1 = LayerNorm_ff(y1) ; a1 = ln1 . W1^T + b1 ; h1 = dropout(gelu(a1))
+//   y2  = dropout(h1 . W2^T + b2) + y1                           (neural.py:30-33)
+//   enc = LayerNorm_final(y2)                                    (transformer.py:86)
+// Unfused this is 3 GEMM + 2 LayerNorm launches whose 64x64 tiles each live for one short,
+// latency-bound round trip.  Here a workgroup (4 waves) owns 32 replica rows for the whole chain:
+// activations stay in LDS/registers, and the 0.6 MB of weights stream through a double-buffered
+// LDS slab ring (32-deep slabs of 128 output columns, prefetched global->registers while the
+// previous slab is multiplied), so the MFMA pipe sees 36 slabs x 16 v_mfma_f32_32x32x2_f32 per
+// wave back to back instead of 5 cold starts.  W1/W2 are walked in 128-unit chunks of the hidden
+// layer so h1 never exists as a whole tile: a1 chunk -> gelu/dropout -> LDS -> accumulate into y2.
+// Everything the backward needs (y1, ln1, a1, h1, y2, LN statistics) is still written once.
+#include "rowwise.h"
+#include <stdlib.h>
+
+bool ps_fusion_enabled() {
+  static const bool on = !(getenv("PS_NO_FUSE") && atoi(getenv("PS_NO_FUSE")) != 0);
+  return on;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Launder a value through an empty asm: stops LLVM from hoisting the (many) per-row store addresses of the
+// stage epilogues out of the slab loop, which would pin >100 VGPRs for the whole kernel.
+__device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+#define MD 128            // model width this kernel is specialised for
+#define MBM 32            // replica rows per workgroup
+#define MBK 32            // reduction depth of one weight slab
+#define XLD 33            // k-major activation tiles: [k][row + 1]
+#define WLD 129           // weight slabs: [k][col + 1]
+#define YLD 129           // row-major staging tile for the LayerNorms: [row][col + 1]
+
+struct MlpLds {
+  float Xs[MD * XLD];           // A operand of Wo / W1 products: ctx, then ln1      (k-major)
+  float Hs[MD * XLD];           // A operand of the W2 product: h1 chunk (k-major); aliased as Y staging
+  float Ws[2][MBK * WLD];       // weight slab ring
+};
+static_assert(MBM * YLD <= MD * XLD, "Y staging must fit the h1 tile");
+
+// global -> registers: slab of 128 output rows x 32 k from a [n][k] (k contiguous) matrix
+__device__ inline void slab_load(const float* __restrict__ W, int ldw, int n0, int k0, float4 (&r)[4], int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = (tid >> 3) + 32 * u, kq = tid & 7;
+    r[u] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + n) * ldw + k0 + 4 * kq);
+  }
+}
+__device__ inline void slab_store(float* Wsb, const float4 (&r)[4], int tid) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int n = (tid >> 3) + 32 * u, kk = 4 * (tid & 7);
+    Wsb[(kk + 0) * WLD + n] = r[u].x;
+    Wsb[(kk + 1) * WLD + n] = r[u].y;
+    Wsb[(kk + 2) * WLD + n] = r[u].z;
+    Wsb[(kk + 3) * WLD + n] = r[u].w;
+  }
+}
+
+// LayerNorm of the 32 x 128 tile staged row-major in Y: wave w normalises rows 8w..8w+7, two columns per lane.
+// Writes the normalised tile k-major into Xk (if given), row-major to `out` (global, ld = MD), stats to `stats`.
+__device__ inline void tile_layernorm(const float* Y, const float* __restrict__ g, const float* __restrict__ bta,
+                                      float* Xk, float* out, float* stats, int m0, int M, int wave, int lane) {
+  const float g0 = g[lane], g1 = g[lane + 64], b0 = bta[lane], b1 = bta[lane + 64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wave * 8 + i;
+    const float v0 = Y[row * YLD + lane], v1 = Y[row * YLD + lane + 64];
+    const float mean = wave_sum(v0 + v1) * (1.f / MD);
+    const float d0 = v0 - mean, d1 = v1 - mean;
+    const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / MD) + 1e-6f);
+    const float o0 = d0 * rstd * g0 + b0, o1 = d1 * rstd * g1 + b1;
+    if (Xk) { Xk[lane * XLD + row] = o0; Xk[(lane + 64) * XLD + row] = o1; }
+    const int m = m0 + row;
+    if (m < M) {
+      out[(size_t)m * MD + lane] = o0;
+      out[(size_t)m * MD + lane + 64] = o1;
+      if (lane == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const MlpFwdArgs a) {
+  extern __shared__ float lds_raw[];
+  MlpLds& L = *reinterpret_cast<MlpLds*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * MBM, M = a.M;
+  const int col = wave * 32 + l31;                 // this lane's output column in every 128-wide product
+  const int nchunk = a.F / 128;
+  const int NS = 4 + 8 * nchunk;                   // weight slabs: Wo(4), then per chunk W1c(4) + W2c(4)
+
+  auto slab_src = [&](int s, const float*& W, int& ldw, int& n0, int& k0) {
+    if (s < 4) { W = a.wo; ldw = MD; n0 = 0; k0 = 32 * s; return; }
+    const int t = s - 4, c = t >> 3, r = t & 7;
+    if (r < 4) { W = a.w1; ldw = MD; n0 = 128 * c; k0 = 32 * r; }
+    else { W = a.w2; ldw = a.F; n0 = 0; k0 = 128 * c + 32 * (r - 4); }
+  };
+
+  // ---- prologue: first weight slab, the ctx tile (k-major), the residual rows
+  float4 wr[4];
+  {
+    const float* W; int ldw, n0, k0;
+    slab_src(0, W, ldw, n0, k0);
+    slab_load(W, ldw, n0, k0, wr, tid);
+  }
+  {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = tid + 256 * u, row = f >> 5, kq = f & 31;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < M) v = *reinterpret_cast<const float4*>(a.ctx + (size_t)(m0 + row) * MD + 4 * kq);
+      L.Xs[(4 * kq + 0) * XLD + row] = v.x;
+      L.Xs[(4 * kq + 1) * XLD + row] = v.y;
+      L.Xs[(4 * kq + 2) * XLD + row] = v.z;
+      L.Xs[(4 * kq + 3) * XLD + row] = v.w;
+    }
+  }
+  float y1v[16];                                    // starts as the residual x[b, qpos][col] of this lane's 16 rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    y1v[r] = m < M ? a.xin[((size_t)(m / a.fan) * a.S + a.qpos) * MD + col] : 0.f;
+  }
+  slab_store(L.Ws[0], wr, tid);
+  __syncthreads();
+
+  f32x16 acc, acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
+  int buf = 0;
+
+  for (int s = 0; s < NS; ++s) {
+    if (s + 1 < NS && !(a.dbg & 1)) {
+      const float* W; int ldw, n0, k0;
+      slab_src(s + 1, W, ldw, n0, k0);
+      slab_load(W, ldw, n0, k0, wr, tid);
+    }
+    // which product is this slab part of?
+    const int t = s - 4, r8 = t & 7;
+    const bool is_w2 = s >= 4 && r8 >= 4;
+    const int ka = s < 4 ? 32 * s : (is_w2 ? 32 * (r8 - 4) : 32 * r8);     // k offset inside the A tile
+    const float* A = is_w2 ? L.Hs : L.Xs;
+    const float* ab = A + (ka + h) * XLD + l31;
+    const float* bb = L.Ws[buf] + h * WLD + col;
+    float av[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLD]; }
+    if (a.dbg & 2) {
+      acc[0] += av[0] * bv[0] + av[15] * bv[15];
+    } else if (is_w2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+    }
+
+    // ---- stage boundaries
+    if (s == 3) {
+      // y1 = dropout(ctx.Wo^T + bo) + residual ; LayerNorm_ff -> ln1 (k-major in Xs)
+      const float bias = a.bo[col];
+      float* Y = L.Hs;
+      const int mm0 = opaque(m0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int rb = mm0 + 8 * gq + 4 * h;
+        Philox4 rnd = {0u, 0u, 0u, 0u};
+        if (a.drop_ctx.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ctx.site, a.drop_ctx.step,
+                                               a.drop_ctx.k0, a.drop_ctx.k1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * gq + q;
+          float v = acc[r] + bias;
+          if (a.drop_ctx.thr) v *= drop_word(a.drop_ctx, q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w)));
+          v += y1v[r];
+          y1v[r] = v;
+          const int lrow = 8 * gq + 4 * h + q;
+          Y[lrow * YLD + col] = v;
+          if (rb + q < M) a.y1[(size_t)(rb + q) * MD + col] = v;
+          acc[r] = 0.f;
+        }
+      }
+      __syncthreads();                              // Y complete; every wave is done reading ctx from Xs
+      tile_layernorm(Y, a.g1, a.be1, L.Xs, a.ln1, a.st1, opaque(m0), M, wave, lane);
+      // the end-of-iteration barrier below publishes ln1 before the W1 slabs read it
+    } else if (s >= 4 && r8 == 3) {
+      // a1 chunk -> gelu -> dropout -> h1 chunk (k-major in Hs)
+      const int c = t >> 3, f = 128 * c + col;
+      const float bias = a.b1[f];
+      const int mm0 = opaque(m0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int rb = mm0 + 8 * gq + 4 * h;
+        Philox4 rnd = {0u, 0u, 0u, 0u};
+        if (a.drop_ff1.thr) rnd = philox4x32_10((uint32_t)f, (uint32_t)rb >> 2, a.drop_ff1.site, a.drop_ff1.step,
+                                               a.drop_ff1.k0, a.drop_ff1.k1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * gq + q;
+          const float pre = acc[r] + bias;
+          float hv = gelu_tanh_f(pre);
+          if (a.drop_ff1.thr) hv *= drop_word(a.drop_ff1, q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w)));
+          const int lrow = 8 * gq + 4 * h + q;
+          L.Hs[col * XLD + lrow] = hv;
+          if (rb + q < M) {
+            a.a1[(size_t)(rb + q) * a.F + f] = pre;
+            a.h1[(size_t)(rb + q) * a.F + f] = hv;
+          }
+          acc[r] = 0.f;
+        }
+      }
+    } else if (s == NS - 1) {
+      // y2 = dropout(h1.W2^T + b2) + y1 ; final LayerNorm -> enc
+      const float bias = a.b2[col];
+      float* Y = L.Hs;
+      __syncthreads();                              // every wave is done reading the last h1 chunk from Hs
+      const int mm0 = opaque(m0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int rb = mm0 + 8 * gq + 4 * h;
+        Philox4 rnd = {0u, 0u, 0u, 0u};
+        if (a.drop_ff2.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ff2.site, a.drop_ff2.step,
+                                               a.drop_ff2.k0, a.drop_ff2.k1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * gq + q;
+          float v = acc_o[r] + bias;
+          if (a.drop_ff2.thr) v *= drop_word(a.drop_ff2, q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w)));
+          v += y1v[r];
+          const int lrow = 8 * gq + 4 * h + q;
+          Y[lrow * YLD + col] = v;
+          if (rb + q < M) a.y2[(size_t)(rb + q) * MD + col] = v;
+        }
+      }
+      __syncthreads();
+      tile_layernorm(Y, a.gf, a.bef, nullptr, a.enc, a.stf, opaque(m0), M, wave, lane);
+    }
+
+    if (s + 1 < NS) slab_store(L.Ws[buf ^ 1], wr, tid);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.F % 128 == 0 && a.M > 0, "fused mlp: F=%d M=%d", a.F, a.M);
+  static bool attr_set = false;
+  const size_t lds = sizeof(MlpLds);
+  if (!attr_set) {
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_fused_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  static const int dbg = getenv("PS_MLP_DBG") ? atoi(getenv("PS_MLP_DBG")) : 0;
+  MlpFwdArgs b = a;
+  b.dbg = dbg;
+  hipLaunchKernelGGL(mlp_fwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, b);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

@@ -73,6 +73,7 @@ struct ScoreArgs {
   float* item_terms;             // [B,1+K]   per-task loss terms (softplus), written by the gather+score kernel
   float* word_terms;             // [B,W,1+K]
   float* loss3;                  // {total, ps, item}
+  float* loss_acc;               // optional running sums {ps, item} (item_transformer.py:516-517)
   // backward
   float scale;                   // loss_scale
   const float* scale_dev;        // optional device scalar multiplied into scale
@@ -101,3 +102,16 @@ int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, 
 
 int launch_sample(const PsTemDesc& d, const float* alias_prob, const int32_t* alias_idx, int64_t* neg_items,
                   int64_t* neg_words, hipStream_t st);
+
+// ---- fused per-replica tail of the last encoder layer (mlp_fused.hip; d == 128 only)
+struct MlpFwdArgs {
+  int M, F;                       // replica rows, hidden width (multiple of 128)
+  int fan, S, qpos;               // residual source row of replica m: (m / fan) * S + qpos of xin
+  const float* ctx; const float* xin;
+  const float *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *gf, *bef;
+  DropSpec drop_ctx, drop_ff1, drop_ff2;
+  float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
+  int dbg;                        // timing experiments only (PS_MLP_DBG): 1 = no slab loads, 2 = no MFMA, 4 = no stores
+};
+int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
+bool ps_fusion_enabled();

@@ -550,6 +550,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
   if (tid == 0) {
     float ps = sps[0] / (float)a.B, il = sil[0] / (float)a.B;
     a.loss3[0] = ps + il; a.loss3[1] = ps; a.loss3[2] = il;
+    if (a.loss_acc) { a.loss_acc[0] += ps; a.loss_acc[1] += il; }     // model.ps_loss / item_loss running sums
   }
 }
 
@@ -694,22 +695,25 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
 // dqpre = dqe * (1 - qe^2)  (tanh backward of FSEncoder, text_encoder.py:39), dfb += colsum
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dqe, int lddqe, const float* qe, float* dqpre,
                                                        float* dfb, int rows, int d) {
-  const int r0 = blockIdx.x * 32;
-  for (int col = threadIdx.x; col < d; col += 256) {
-    float s = 0.f;
-    for (int r = r0; r < min(rows, r0 + 32); ++r) {
-      float y = qe[(size_t)r * d + col];
-      float v = dqe[(size_t)r * lddqe + col] * (1.f - y * y);
-      dqpre[(size_t)r * d + col] = v;
-      s += v;
-    }
-    atomicAdd(&dfb[col], s);
+  extern __shared__ float csum[];                // [d]
+  const int r0 = blockIdx.x * 8, nr = min(8, rows - r0);
+  for (int c = threadIdx.x; c < d; c += 256) csum[c] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr * d; i += 256) {
+    const int r = r0 + i / d, col = i % d;
+    const float y = qe[(size_t)r * d + col];
+    const float v = dqe[(size_t)r * lddqe + col] * (1.f - y * y);
+    dqpre[(size_t)r * d + col] = v;
+    atomicAdd(&csum[col], v);                    // LDS atomic: 8 adders per column
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(&dfb[c], csum[c]);
 }
 
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
                     hipStream_t st) {
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ps_cdiv(rows, 32)), dim3(256), 0, st, dqe, lddqe, qe, dqpre, dfb, rows, d);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ps_cdiv(rows, 8)), dim3(256), (size_t)d * sizeof(float), st, dqe, lddqe,
+                     qe, dqpre, dfb, rows, d);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

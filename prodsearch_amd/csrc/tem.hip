@@ -235,6 +235,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   if (!tem) return PS_OK;
 
   const float qscale = 1.f / sqrtf((float)(d / (D.H > 0 ? D.H : 1)));
+  bool fused_final = false;
   for (int i = 0; i < NL; ++i) {
     const LayerWs& l = w.layer[i];
     const PsLayerTensors& Lp = P.layer[i];
@@ -266,6 +267,23 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
     TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
+    const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
+                      P.final_ln_g && P.final_ln_b;
+    if (fuse) {   // Wo + LN + W1 + GELU + W2 + final LN of the last layer in one kernel (mlp_fused.hip)
+      MlpFwdArgs m;
+      memset(&m, 0, sizeof(m));
+      m.M = l.M2; m.F = D.F; m.fan = l.fan; m.S = S; m.qpos = w.qpos;
+      m.ctx = ws + l.ctx; m.xin = xin;
+      m.wo = Lp.wo; m.bo = Lp.bo; m.g1 = Lp.ff_ln_g; m.be1 = Lp.ff_ln_b; m.w1 = Lp.w1; m.b1 = Lp.b1;
+      m.w2 = Lp.w2; m.b2 = Lp.b2; m.gf = P.final_ln_g; m.bef = P.final_ln_b;
+      m.drop_ctx = make_drop(D, PS_SITE_CTX(i)); m.drop_ff1 = make_drop(D, PS_SITE_FF1(i));
+      m.drop_ff2 = make_drop(D, PS_SITE_FF2(i));
+      m.y1 = ws + l.y1; m.ln1 = ws + l.ln1; m.st1 = ws + l.ff_stats; m.a1 = ws + l.a1; m.h1 = ws + l.h1;
+      m.y2 = ws + l.y2; m.stf = ws + w.fin_stats; m.enc = ws + w.enc;
+      TRY(launch_mlp_fwd_fused(m, st));
+      fused_final = true;
+      continue;
+    }
     {   // final_linear + dropout + residual (neural.py:228-231, transformer.py:56)
       GemmProblem p = gp(ws + l.ctx, d, 0, Lp.wo, d, 0, ws + l.y1, d, l.M2, d, d);
       p.bias = Lp.bo; p.drop = make_drop(D, PS_SITE_CTX(i));
@@ -285,6 +303,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
       TRY(run1(p2, st));
     }
   }
+  if (fused_final) return PS_OK;
   // final LayerNorm (transformer.py:86) on the consumed position only
   PS_REQUIRE(P.final_ln_g && P.final_ln_b, "forward: null final LayerNorm");
   LnFwdArgs f;
@@ -314,7 +333,7 @@ static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBat
 }
 
 extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
-                              float* workspace, float* loss3, ps_stream_t stream) {
+                              float* workspace, float* loss3, float* loss_acc, ps_stream_t stream) {
   PS_REQUIRE(desc && params && batch && workspace && loss3, "forward: null argument");
   PsTemDesc D = *desc;
   D.C = 0;
@@ -327,7 +346,7 @@ extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params,
   TRY(encode_forward(D, *params, *batch, workspace, w, st));
   ScoreArgs s;
   fill_score(D, *params, *batch, workspace, w, s);
-  s.loss3 = loss3;
+  s.loss3 = loss3; s.loss_acc = loss_acc;
   TRY(launch_score_fwd(s, st));
   TRY(launch_loss(s, st));
   return PS_OK;

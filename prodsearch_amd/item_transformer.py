@@ -426,8 +426,7 @@ class ItemTransformerRanker(nn.Module):
         self._fill_batch(plan, batch, False, neg_items, neg_words)
         loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
         _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
-                                      self._stream()), 'ps_tem_forward')
-        self._loss_acc.add_(loss3[1:3])
+                                      self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
         return plan, loss3
 
     def _assign_grads(self):
