@@ -1,0 +1,78 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the gradient exchange the GPU ranks use
+(prodsearch_amd/dist.py): flat-buffer all-reduce + 1/world scale hand-off, parameter broadcast,
+max-over-ranks timing, per-rank Philox keys."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from prodsearch_amd import dist as pdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeOptim(object):
+    grad_scale = 1.0
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r, l, w = pdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)
+    flat = torch.randn(1000)
+    mine = flat.clone()
+    opt = _FakeOptim()
+    ex = pdist.GradExchange(lambda: flat, opt)
+    ex()
+    # every rank must now hold the SAME summed buffer, and the optimizer the mean scale
+    gathered = [torch.zeros(1000) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered)
+    ok_sum = torch.allclose(flat, want, atol=1e-6) and opt.grad_scale == 1.0 / world
+    # replicas start identical after broadcast
+    lin = torch.nn.Linear(4, 3)
+    pdist.broadcast_parameters(lin, src=0)
+    ws = [torch.zeros_like(lin.weight) for _ in range(world)]
+    dist.all_gather(ws, lin.weight.data)
+    ok_bc = all(torch.equal(ws[0], x) for x in ws)
+    mx = pdist.max_over_ranks(float(rank + 1), torch.device('cpu'))
+    q.put((rank, bool(ok_sum), bool(ok_bc), mx, pdist.rank_seed(666, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(r[1] and r[2] for r in res)
+    assert all(r[3] == float(world) for r in res)          # max over ranks
+    assert res[0][4] != res[1][4]                           # per-rank Philox key
+    assert res[0][4] == 666                                 # rank 0 keeps the base seed
+
+
+def test_single_process_is_a_no_op():
+    flat = torch.ones(8)
+    opt = _FakeOptim()
+    ex = pdist.GradExchange(lambda: flat, opt)
+    assert ex() is None and opt.grad_scale == 1.0 and float(flat.sum()) == 8.0
+    assert pdist.max_over_ranks(3.5, torch.device('cpu')) == 3.5
