@@ -117,3 +117,35 @@ class PhiloxDropout(object):
         if self.p == 0.0:
             return x
         return x * torch.from_numpy(self.mult(tuple(x.shape), kind, call))
+
+
+# ----------------------------------------------------------------------------- RTM
+SITE_REV_PV, SITE_REV_POS, SITE_REV_NEG, SITE_TOK_POS, SITE_TOK_NEG = 0x200, 0x201, 0x202, 0x203, 0x204
+
+
+class RtmPhiloxDropout(PhiloxDropout):
+    """Masks of the RTM step (oracle.rtm): the encoder sites of the parent class (sequence
+    n = b*(1+K)+j, so ``R = K+1`` rows per batch row and no replica fan-out) plus the review
+    sites:  rev_pv / rev_pos [B*R,d] row = b*R+r;  rev_neg [B,K,R,d] row = (b*K+k)*R+r;
+    token dropout of the pvc encoder [N,WL] row = review row, col = word slot, p = corrupt_rate."""
+
+    def __init__(self, p, seed, step, B, K, H, S, n_layers, corrupt_rate=0.0):
+        super().__init__(p, seed, step, B, K, H, S, n_layers, 0)
+        self.corrupt_rate = float(corrupt_rate)
+
+    def mult(self, shape, kind, call):
+        if kind in ('rev_pv', 'rev_pos', 'rev_neg'):
+            site = {'rev_pv': SITE_REV_PV, 'rev_pos': SITE_REV_POS, 'rev_neg': SITE_REV_NEG}[kind]
+            width = shape[-1]
+            nrows = int(np.prod(shape[:-1]))
+            m = drop_mult(np.arange(nrows)[:, None], np.arange(width)[None, :], site, self.step, self.seed, self.p)
+            return m.reshape(shape)
+        return super().mult(shape, kind, call)
+
+    def tok(self, shape, which):
+        if self.corrupt_rate <= 0.0:
+            return None
+        site = SITE_TOK_POS if which == 'pos' else SITE_TOK_NEG
+        N, WL = shape
+        return torch.from_numpy(drop_mult(np.arange(N)[:, None], np.arange(WL)[None, :], site, self.step, self.seed,
+                                          self.corrupt_rate))

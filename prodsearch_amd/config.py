@@ -23,6 +23,10 @@ _DEFAULTS = dict(
     use_item_pos=False,                # main.py:52
     use_item_emb=False,
     use_user_emb=False,
+    fix_emb=False,                     # main.py:43
+    do_subsample_mask=False,           # main.py:72
+    do_seq_review_train=False,
+    fix_train_review=False,
     dropout=0.1,                       # main.py:60
     optim='adam',                      # main.py:62
     lr=0.002,                          # main.py:63

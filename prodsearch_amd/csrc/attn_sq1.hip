@@ -10,17 +10,20 @@
 // processed in chunks of JC so that the Philox masks are generated once per element.
 #include "rowwise.h"
 
-#define JC 8
+// replicas are processed JC at a time (all of them when the LDS budget allows: one global round trip)
+static inline int sq1_pick_jc(int S, int d, int H, int fan);
+#define KLD(d) ((d) + 1)     // K/V rows are padded by one float in LDS: threads that walk over keys s at a
+                             // fixed column would otherwise all hit one bank (row stride d = 0 mod 32)
 
 struct Sq1Lds {
   float *Ks, *Vs, *q, *P, *valid, *Pd, *dC, *dV, *dP;
 };
 
-__device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd) {
+__device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd, int JC) {
   Sq1Lds l;
-  l.Ks = base; base += S * d;
-  l.Vs = base; base += S * d;
-  l.q = base; base += d;
+  l.Ks = base; base += S * KLD(d);
+  l.Vs = base; base += S * KLD(d);
+  l.q = base; base += (d + 3) & ~3;
   l.P = base; base += H * (S + 1);
   l.valid = base; base += (S + 3) & ~3;
   l.Pd = base; base += JC * H * (S + 1);
@@ -32,8 +35,8 @@ __device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd) {
   }
   return l;
 }
-static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd) {
-  size_t n = (size_t)2 * S * d + d + H * (S + 1) + ((S + 3) & ~3) + (size_t)JC * H * (S + 1);
+static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd, int JC) {
+  size_t n = (size_t)2 * S * KLD(d) + ((d + 3) & ~3) + H * (S + 1) + ((S + 3) & ~3) + (size_t)JC * H * (S + 1);
   if (bwd) n += (size_t)JC * d + (size_t)S * d + H * (S + 1);
   return n * sizeof(float);
 }
@@ -42,9 +45,15 @@ __device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int t
   const int S = a.S, d = a.d, nv = S * d / 4;
   const float4* k4 = reinterpret_cast<const float4*>(a.kp + (size_t)b * S * d);
   const float4* v4 = reinterpret_cast<const float4*>(a.vp + (size_t)b * S * d);
-  float4* lk = reinterpret_cast<float4*>(l.Ks);
-  float4* lv = reinterpret_cast<float4*>(l.Vs);
-  for (int i = tid; i < nv; i += 256) { lk[i] = k4[i]; lv[i] = v4[i]; }
+  const int d4 = d >> 2;
+  for (int i = tid; i < nv; i += 256) {
+    const int sr = fdiv(i, a.fd4), c4 = (i - sr * d4) * 4;
+    const float4 kk = k4[i], vv = v4[i];
+    float* lk = l.Ks + sr * KLD(d) + c4;
+    float* lv = l.Vs + sr * KLD(d) + c4;
+    lk[0] = kk.x; lk[1] = kk.y; lk[2] = kk.z; lk[3] = kk.w;
+    lv[0] = vv.x; lv[1] = vv.y; lv[2] = vv.z; lv[3] = vv.w;
+  }
   for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * d + i];
   const int brow = b / a.seq_div;
   for (int s = tid; s < S; s += 256)
@@ -54,8 +63,33 @@ __device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int t
 // dropout multipliers (or P * multipliers) of replicas j0..j0+nj-1 into Pd[jj][h][s]
 __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int j0, int nj, int tid, bool times_p) {
   const int S = a.S, H = a.H, per = H * S;
+  if (a.drop.thr == 0u) {
+    for (int i = tid; i < nj * per; i += 256) {
+      const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
+      l.Pd[(jj * H + h) * (S + 1) + s] = times_p ? l.P[h * (S + 1) + s] : 1.f;
+    }
+    return;
+  }
+  if ((H & 3) == 0) {
+    // rows nout*H + 4g .. +3 share one Philox counter (col = s, row >> 2): one call serves 4 heads
+    const int HQ = H >> 2, perq = HQ * S;
+    for (int i = tid; i < nj * perq; i += 256) {
+      const int jj = fdiv(i, a.fHQS), r = i - jj * perq, g = fdiv(r, a.fS), s = r - g * S;
+      const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + 4 * g);
+      const Philox4 w = philox4x32_10((uint32_t)s, row >> 2, a.drop.site, a.drop.step, a.drop.k0, a.drop.k1);
+      const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = 4 * g + q;
+        float m = drop_word(a.drop, ws[q]);
+        if (times_p) m *= l.P[h * (S + 1) + s];
+        l.Pd[(jj * H + h) * (S + 1) + s] = m;
+      }
+    }
+    return;
+  }
   for (int i = tid; i < nj * per; i += 256) {
-    const int jj = i / per, r = i - jj * per, h = r / S, s = r - h * S;
+    const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
     const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + h);        // Sq == 1: row = nout*H + h
     float m = drop_mult(a.drop, row, (uint32_t)s);
     if (times_p) m *= l.P[h * (S + 1) + s];
@@ -66,14 +100,15 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
 __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
   const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
-  Sq1Lds l = sq1_carve(lds, S, d, H, false);
+  const int JC = a.jc;
+  Sq1Lds l = sq1_carve(lds, S, d, H, false, JC);
   sq1_load(a, l, b, tid);
   __syncthreads();
   for (int i = tid; i < H * S; i += 256) {
-    const int h = i / S, s = i - h * S;
+    const int h = fdiv(i, a.fS), s = i - h * S;
     float acc = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[s * d + h * dh + c];
+    for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[s * KLD(d) + h * dh + c];
     l.P[h * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;               // masked_fill(mask, -1e18)
   }
   __syncthreads();
@@ -88,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   }
   __syncthreads();
   for (int i = tid; i < H * S; i += 256) {
-    const int h = i / S, s = i - h * S;
+    const int h = fdiv(i, a.fS), s = i - h * S;
     a.attn[((size_t)b * H + h) * S + s] = l.P[h * (S + 1) + s];
   }
   for (int j0 = 0; j0 < a.fan; j0 += JC) {
@@ -97,25 +132,32 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
     sq1_masks(a, l, b, j0, nj, tid, true);
     __syncthreads();
     for (int i = tid; i < nj * d; i += 256) {
-      const int jj = i / d, c = i - jj * d, h = c / dh;
+      const int jj = fdiv(i, a.fd), c = i - jj * d, h = fdiv(c, a.fdh);
       const float* pd = l.Pd + (jj * H + h) * (S + 1);
       float acc = 0.f;
 #pragma unroll 8
-      for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * d + c];
+      for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * KLD(d) + c];
       a.ctx[((size_t)b * a.fan + j0 + jj) * d + c] = acc;
     }
   }
 }
 
+static inline int sq1_pick_jc(int S, int d, int H, int fan) {
+  int jc = fan < 24 ? fan : 24;
+  while (jc > 1 && sq1_lds_bytes(S, d, H, true, jc) > 64 * 1024) jc = (jc + 1) / 2;
+  return jc;
+}
 bool attn_sq1_fits(const AttnArgs& a) {
-  return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true) <= 64 * 1024;
+  return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true, 1) <= 64 * 1024;
 }
 
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
-  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, false);
+  AttnArgs b = a;
+  b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
+  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, false, b.jc);
   PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
-  hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -123,10 +165,11 @@ int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
   const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
-  Sq1Lds l = sq1_carve(lds, S, d, H, true);
+  const int JC = a.jc;
+  Sq1Lds l = sq1_carve(lds, S, d, H, true, JC);
   sq1_load(a, l, b, tid);
   for (int i = tid; i < H * S; i += 256) {
-    const int h = i / S, s = i - h * S;
+    const int h = fdiv(i, a.fS), s = i - h * S;
     l.P[h * (S + 1) + s] = a.attn[((size_t)b * H + h) * S + s];
     l.dP[h * (S + 1) + s] = 0.f;
   }
@@ -136,28 +179,27 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     __syncthreads();
     sq1_masks(a, l, b, j0, nj, tid, false);
     for (int i = tid; i < nj * d; i += 256) {
-      const int jj = i / d, c = i - jj * d;
+      const int jj = fdiv(i, a.fd), c = i - jj * d;
       l.dC[i] = a.dctx[((size_t)b * a.fan + j0 + jj) * d + c];
     }
     __syncthreads();
     for (int i = tid; i < S * d; i += 256) {                 // dV[s][c] += sum_j P*m_j * dctx_j[c]
-      const int s = i / d, c = i - s * d, h = c / dh;
+      const int s = fdiv(i, a.fd), c = i - s * d, h = fdiv(c, a.fdh);
       const float p = l.P[h * (S + 1) + s];
       float acc = 0.f;
 #pragma unroll 8
       for (int jj = 0; jj < nj; ++jj) acc += l.Pd[(jj * H + h) * (S + 1) + s] * l.dC[jj * d + c];
       l.dV[i] += p * acc;
     }
-    for (int i = tid; i < H * S; i += 256) {                 // dP[h][s] += sum_j m_j * (dctx_j,h . V_s,h)
-      const int h = i / S, s = i - h * S;
-      float acc = 0.f;
-      for (int jj = 0; jj < nj; ++jj) {
+    for (int i = tid; i < nj * H * S; i += 256) {            // dP[h][s] += m_j * (dctx_j,h . V_s,h), all (j,h,s) in parallel
+      const int jj = fdiv(i, a.fHS), r = i - jj * H * S, h = fdiv(r, a.fS), s = r - h * S;
+      const float m = l.Pd[(jj * H + h) * (S + 1) + s];
+      if (m != 0.f) {
         float dot = 0.f;
 #pragma unroll 8
-        for (int c = 0; c < dh; ++c) dot += l.dC[jj * d + h * dh + c] * l.Vs[s * d + h * dh + c];
-        acc += l.Pd[(jj * H + h) * (S + 1) + s] * dot;
+        for (int c = 0; c < dh; ++c) dot += l.dC[jj * d + h * dh + c] * l.Vs[s * KLD(d) + h * dh + c];
+        atomicAdd(&l.dP[h * (S + 1) + s], m * dot);         // LDS atomic, <= JC adders per element
       }
-      l.dP[h * (S + 1) + s] += acc;
     }
   }
   __syncthreads();
@@ -170,13 +212,13 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   }
   __syncthreads();
   for (int c = tid; c < d; c += 256) {
-    const int h = c / dh;
+    const int h = fdiv(c, a.fdh);
     const float* g = l.dP + h * (S + 1);
     const float qc = l.q[c];
     float dq = 0.f, sk = 0.f, sv = 0.f;
 #pragma unroll 4
     for (int s = 0; s < S; ++s) {
-      dq += g[s] * l.Ks[s * d + c];
+      dq += g[s] * l.Ks[s * KLD(d) + c];
       const float dk = g[s] * qc;
       const float dv = l.dV[s * d + c];
       const size_t off = ((size_t)b * S + s) * a.lddkv + c;
@@ -193,10 +235,12 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
 }
 
 int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
-  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, true);
+  AttnArgs b = a;
+  b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
+  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, true, b.jc);
   PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention bwd(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
-  hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -91,6 +91,20 @@ __device__ inline float drop_mult(const DropSpec& s, uint32_t row, uint32_t col)
 #define PS_SITE_SAMPLE_ITEM 0x40000000u
 #define PS_SITE_SAMPLE_WORD 0x40000001u
 
+// ------------------------------------------------------- division by a launch-invariant
+// A runtime integer division costs ~40 VALU instructions on gfx950 and the row-wise kernels do
+// several per element; q = mulhi(n, ceil(2^32/d)) is exact while n*d < 2^32 (all uses here).
+struct FDiv {
+  uint32_t d, m;
+};
+__host__ inline FDiv make_fdiv(int d) {
+  FDiv f;
+  f.d = (uint32_t)(d > 0 ? d : 1);
+  f.m = f.d == 1 ? 0u : (uint32_t)((0x100000000ull + f.d - 1) / f.d);
+  return f;
+}
+__device__ inline int fdiv(int n, const FDiv& f) { return f.d == 1 ? n : (int)__umulhi((uint32_t)n, f.m); }
+
 // ------------------------------------------------------------------ wave helpers
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -144,6 +158,7 @@ struct ResMap {           // row map between replica rows and layer-input rows
   int mode;               // RES_*
   const float* ptr;       // residual source
   int ld;                 // row stride of ptr (floats)
+  FDiv dSq, dfan, dS;     // fast dividers of Sq, fan, S (filled by res_finish)
   int Sq, fan, S, qpos;   // GATHER: out row m=(n_out,i) -> src row (n_out/fan)*S + (Sq==S ? i : qpos)
                           // FANIN : out row m=(n_in,pos) -> sum_j src row ((n_in*fan+j)*Sq + i), only q rows
 };
@@ -151,12 +166,12 @@ struct ResMap {           // row map between replica rows and layer-input rows
 __device__ inline float res_value(const ResMap& R, int row, int col) {
   if (R.mode == RES_DIRECT) return R.ptr[(size_t)row * R.ld + col];
   if (R.mode == RES_GATHER) {
-    int nout = row / R.Sq, i = row - nout * R.Sq;
-    int src = (nout / R.fan) * R.S + (R.Sq == R.S ? i : R.qpos);
+    int nout = fdiv(row, R.dSq), i = row - nout * R.Sq;
+    int src = fdiv(nout, R.dfan) * R.S + (R.Sq == R.S ? i : R.qpos);
     return R.ptr[(size_t)src * R.ld + col];
   }
   if (R.mode == RES_FANIN) {
-    int nin = row / R.S, pos = row - nin * R.S;
+    int nin = fdiv(row, R.dS), pos = row - nin * R.S;
     int i;
     if (R.Sq == R.S) i = pos;
     else if (pos == R.qpos) i = 0;
@@ -166,6 +181,10 @@ __device__ inline float res_value(const ResMap& R, int row, int col) {
     return s;
   }
   return 0.f;
+}
+
+__host__ inline void res_finish(ResMap& R) {   // call after Sq/fan/S are set
+  R.dSq = make_fdiv(R.Sq); R.dfan = make_fdiv(R.fan); R.dS = make_fdiv(R.S);
 }
 
 struct GemmProblem {

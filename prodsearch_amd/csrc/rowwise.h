@@ -39,6 +39,8 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 
 struct AttnArgs {
   int n_in, fan, H, S, Sq, d, dh, qpos;
+  FDiv fS, fd, fdh, fd4, fHS, fHQS;  // fast dividers (filled by attn_finish)
+  int jc;                        // replicas per LDS chunk (sq1 kernels; set by the launcher)
   int seq_div;                   // batch row = n_in_index / seq_div
   int L; int64_t P; const int64_t* ui;   // key-padding mask source (u_item_idxs != P)
   const float* kp; const float* vp; const float* qp;   // [n_in*S,d] x2, [n_in*Sq,d] (q pre-scaled)
@@ -52,6 +54,10 @@ struct AttnArgs {
   float* dbq; float* dbk; float* dbv;   // += (atomics)
   float qscale;                  // 1/sqrt(dh)
 };
+inline void attn_finish(AttnArgs& a) {
+  a.fS = make_fdiv(a.S); a.fd = make_fdiv(a.d); a.fdh = make_fdiv(a.dh); a.fd4 = make_fdiv(a.d / 4);
+  a.fHS = make_fdiv(a.H * a.S); a.fHQS = make_fdiv((a.H / 4 > 0 ? a.H / 4 : 1) * a.S);
+}
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
 // last-layer form (Sq == 1): one workgroup per sequence, all heads, replicas share K/V in LDS (attn_sq1.hip)
@@ -61,6 +67,7 @@ bool attn_sq1_fits(const AttnArgs& a);
 
 struct ScoreArgs {
   int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)
+  FDiv fK1, fWK1, fC;            // fast dividers of K+1, W*(K+1), C (filled by score_finish)
   int64_t P, V;
   int bias_product, pos_weight;
   const int64_t* target; const int64_t* neg_items; const int64_t* pos_words; const int64_t* neg_words;
@@ -80,6 +87,9 @@ struct ScoreArgs {
   float* denc;                   // [B*R,d]
   float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
 };
+inline void score_finish(ScoreArgs& a) {
+  a.fK1 = make_fdiv(a.K + 1); a.fWK1 = make_fdiv(a.W * (a.K + 1)); a.fC = make_fdiv(a.C > 0 ? a.C : 1);
+}
 int launch_score_fwd(const ScoreArgs& a, hipStream_t st);     // gather + dot ("gather+score kernel")
 int launch_loss(const ScoreArgs& a, hipStream_t st);
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st);

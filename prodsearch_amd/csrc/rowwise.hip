@@ -423,7 +423,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
   Task k;
   const int K1 = a.K + 1;
   if (a.C > 0) {                                   // eval: candidates
-    int b = t / a.C;
+    int b = fdiv(t, a.fC);
     int64_t idx = clamp_idx(a.candi[t], a.P);
     k.row = a.product_emb + (size_t)idx * a.d;
     k.vec = a.enc + (size_t)b * a.R * a.d;
@@ -434,7 +434,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
   }
   const int nitem = a.B * K1;
   if (t < nitem) {
-    int b = t / K1, j = t - b * K1;
+    int b = fdiv(t, a.fK1), j = t - b * K1;
     int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
     k.row = a.product_emb + (size_t)idx * a.d;
     k.vec = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * a.d;
@@ -444,8 +444,8 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.tw = j == 0 ? -(a.pos_weight ? (float)a.K : 1.f) : 1.f;
   } else {
     int u = t - nitem;
-    int b = u / (a.W * K1), r = u - b * (a.W * K1);
-    int w = r / K1, j = r - w * K1;
+    int b = fdiv(u, a.fWK1), r = u - b * (a.W * K1);
+    int w = fdiv(r, a.fK1), j = r - w * K1;
     int64_t idx = clamp_idx(j == 0 ? a.pos_words[(size_t)b * a.W + w]
                                    : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
     int64_t tb = clamp_idx(a.target[b], a.P);

@@ -207,6 +207,52 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
 }
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
+// ---- weight-gradient GEMMs run on a side stream: they are off the dX critical path (nothing in
+// the backward consumes dW), so they overlap the latency-bound main chain.  Fork = event recorded on
+// the main stream after the producer; join = the main stream waits for the side stream's last event.
+#include <stdlib.h>
+struct SideCtx {
+  hipStream_t stream;
+  hipEvent_t ev[8];
+  hipEvent_t join;
+  int next;
+  bool used;
+};
+static SideCtx* side_ctx() {
+  static SideCtx ctx;
+  static int state = 0;           // 0 = uninitialised, 1 = ready, -1 = disabled
+  if (state == 0) {
+    state = -1;
+    const char* e = getenv("PS_NO_SIDE");
+    if (!(e && atoi(e) != 0)) {
+      bool ok = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking) == hipSuccess;
+      for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ctx.ev[i], hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&ctx.join, hipEventDisableTiming) == hipSuccess;
+      ctx.next = 0; ctx.used = false;
+      if (ok) state = 1;
+    }
+  }
+  return state == 1 ? &ctx : nullptr;
+}
+static int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
+  SideCtx* c = side_ctx();
+  if (!c) return run_wgrads(ps, n, main_st);
+  hipEvent_t ev = c->ev[c->next];
+  c->next = (c->next + 1) & 7;
+  PS_CHECK_HIP(hipEventRecord(ev, main_st));
+  PS_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+  c->used = true;
+  return run_wgrads(ps, n, c->stream);
+}
+static int side_join(hipStream_t main_st) {
+  SideCtx* c = side_ctx();
+  if (!c || !c->used) return PS_OK;
+  PS_CHECK_HIP(hipEventRecord(c->join, c->stream));
+  PS_CHECK_HIP(hipStreamWaitEvent(main_st, c->join, 0));
+  c->used = false;
+  return PS_OK;
+}
+
 // -------------------------------------------------------------- encoder forward
 static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
                           hipStream_t st) {
@@ -266,6 +312,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
     a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = Bt.u_item_idxs;
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
+    attn_finish(a);
     TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
                       P.final_ln_g && P.final_ln_b;
@@ -288,7 +335,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
       GemmProblem p = gp(ws + l.ctx, d, 0, Lp.wo, d, 0, ws + l.y1, d, l.M2, d, d);
       p.bias = Lp.bo; p.drop = make_drop(D, PS_SITE_CTX(i));
       p.res.mode = RES_GATHER; p.res.ptr = xin; p.res.ld = d; p.res.Sq = l.Sq; p.res.fan = l.fan; p.res.S = S;
-      p.res.qpos = w.qpos;
+      p.res.qpos = w.qpos; res_finish(p.res);
       TRY(run1(p, st));
     }
     {   // PositionwiseFeedForward (neural.py:30-33)
@@ -330,6 +377,7 @@ static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBat
   s.enc = ws + w.enc;
   s.item_scores = ws + w.item_scores; s.word_scores = ws + w.word_scores; s.loss_parts = ws + w.loss_parts;
   s.item_terms = ws + w.item_terms; s.word_terms = ws + w.word_terms;
+  score_finish(s);
 }
 
 extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
@@ -376,7 +424,7 @@ extern "C" int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, c
   TRY(encode_forward(D, *params, *batch, workspace, w, st));
   ScoreArgs s;
   fill_score(D, *params, *batch, workspace, w, s);
-  s.C = D.C; s.item_scores = scores;
+  s.C = D.C; s.item_scores = scores; score_finish(s);
   TRY(launch_score_fwd(s, st));
   return PS_OK;
 }
@@ -447,11 +495,11 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
         TRY(run1(p, st));
         GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};    // dW2 += do2^T . h1
-        TRY(run_wgrads(wg, 1, st));
+        TRY(side_wgrads(wg, 1, st));
         GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
         TRY(run1(q, st));
         GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
-        TRY(run_wgrads(wg1, 1, st));
+        TRY(side_wgrads(wg1, 1, st));
         LnBwdArgs n;
         memset(&n, 0, sizeof(n));
         n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
@@ -468,7 +516,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
         TRY(run1(p, st));
         GemmProblem wg[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
-        TRY(run_wgrads(wg, 1, st));
+        TRY(side_wgrads(wg, 1, st));
         AttnArgs a;
         memset(&a, 0, sizeof(a));
         a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
@@ -483,6 +531,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         a.lddq = qall ? 3 * d : d;
         a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
         a.qscale = 1.f / sqrtf((float)(d / D.H));
+        attn_finish(a);
         TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
         // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
         float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
@@ -490,7 +539,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         x.kseg = d; x.Bseg[1] = Lp.wv; x.Bseg[2] = Lp.wq;
         if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
           x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
-          x.res.S = S; x.res.qpos = w.qpos;
+          x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
         }
         TRY(run1(x, st));
         if (!qall) {
@@ -503,16 +552,17 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
         wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
         if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
         else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
-        TRY(run_wgrads(wg3, 3, st));
+        TRY(side_wgrads(wg3, 3, st));
       }
       if (i != 0) {   // pre-LayerNorm backward -> grad wrt the previous layer's output
+        TRY(side_join(st));   // the next layer reuses the scratch buffers the side-stream GEMMs read
         PS_REQUIRE(Lg.ln_g && Lg.ln_b, "backward: layer %d null pre-LN gradient", i);
         LnBwdArgs n;
         memset(&n, 0, sizeof(n));
         n.dy = ws + w.dxn; n.lddy = d; n.x = xin; n.ldx = d; n.stats = ws + l.pre_stats; n.g = Lp.ln_g;
         n.rows = ns; n.d = d;
         n.res.mode = RES_FANIN; n.res.ptr = ws + w.dy1; n.res.ld = d; n.res.Sq = l.Sq; n.res.fan = l.fan;
-        n.res.S = S; n.res.qpos = w.qpos;
+        n.res.S = S; n.res.qpos = w.qpos; res_finish(n.res);
         n.dx = ws + w.dy2; n.lddx = d;
         if (drop) { n.out2 = ws + w.do2; n.drop2 = make_drop(D, PS_SITE_FF2(i - 1)); }
         n.colsum = G.layer[i - 1].b2; n.dgamma = Lg.ln_g; n.dbeta = Lg.ln_b;
@@ -536,7 +586,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
     TRY(run1(p, st));
     GemmProblem wg[1] = {gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B)};
-    TRY(run_wgrads(wg, 1, st));
+    TRY(side_wgrads(wg, 1, st));
     e.dqmean_d = ws + w.dqmean;
   } else {
     // AVG encoder: query_emb == post-dropout mean; copy rows to a dense [B,d] buffer
@@ -545,6 +595,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     e.dqmean_d = ws + w.dqmean;
   }
   TRY(launch_embed_scatter(e, st));
+  TRY(side_join(st));
   return PS_OK;
 }
 

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Golden fixtures of the RTM path (``ProductRanker``, models/ps_model.py) from the REFERENCE itself.
+
+Same harness as make_golden.py (imported for its torch-side hooks: uint8 masked_fill, injected
+multinomial draws, Philox dropout by call order) plus one more hook: ``torch.bernoulli`` — the
+pvc encoder's token dropout (PVC.py:46-54) — returns the product's Philox mask.
+
+Usage:  python tests/golden/make_golden_rtm.py [case ...]
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg            # noqa: E402  installs the hooks, puts /root/reference on sys.path
+
+import numpy as np                  # noqa: E402
+import torch                        # noqa: E402
+
+from oracle.philox import RtmPhiloxDropout                      # noqa: E402
+from prodsearch_amd import synth, rtm_data                      # noqa: E402
+from prodsearch_amd.config import default_args                  # noqa: E402
+from models.ps_model import ProductRanker, build_optim          # noqa: E402  (reference)
+from data.batch_data import ProdSearchTrainBatch as RefTrain    # noqa: E402  (reference)
+from data.batch_data import ProdSearchTestBatch as RefTest      # noqa: E402  (reference)
+
+_tok = {'gen': None, 'n': 0}
+_orig_bernoulli = torch.bernoulli
+
+
+def _bernoulli(probs, *a, **kw):
+    g = _tok['gen']
+    if g is None:
+        return _orig_bernoulli(probs, *a, **kw)
+    which = 'pos' if _tok['n'] == 0 else 'neg'
+    _tok['n'] += 1
+    m = g.tok(tuple(probs.shape), which)
+    return (m == 0).to(probs.dtype)          # 1 = drop this token
+
+
+torch.bernoulli = _bernoulli
+
+
+def _rtm_site(n, enc, train_pv, layers):
+    """dropout call order inside ProductRanker.forward (training, p > 0)."""
+    head = ['fs'] + (['rev_pv'] if (enc == 'pv' and train_pv) else []) + ['rev_pos', 'rev_neg']
+    if n < len(head):
+        return head[n], 0
+    n -= len(head)
+    c, r = divmod(n, 4 * layers)
+    layer, k = divmod(r, 4)
+    return ('attn', 'ctx', 'ff1', 'ff2')[k], (c, layer)
+
+
+CASES = {
+    'rtm_pv': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32, heads=4,
+                             ff_size=64, inter_layers=1, neg_per_pos=3, dropout=0.0, lr=0.002, pv_window_size=2),
+                   V=400, RC=300, B=12, Q=6, u=3, i=4, WL=12, C=8, steps=2, train_pv=True),
+    'rtm_pv_notrain': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32,
+                                     heads=4, ff_size=64, inter_layers=2, neg_per_pos=3, dropout=0.0, lr=0.002,
+                                     pos_weight=True, use_seg_emb=False),
+                           V=400, RC=300, B=10, Q=6, u=3, i=4, WL=12, C=6, steps=1, train_pv=False),
+    'rtm_pvc': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=32, heads=4,
+                              ff_size=64, inter_layers=1, neg_per_pos=3, dropout=0.0, lr=0.002, corrupt_rate=0.0,
+                              pv_window_size=1),
+                    V=400, RC=300, B=12, Q=6, u=3, i=4, WL=12, C=8, steps=2, train_pv=True),
+    'rtm_pvc_c2': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=128,
+                                 heads=8, ff_size=512, inter_layers=1, neg_per_pos=5, dropout=0.0, lr=0.0005,
+                                 corrupt_rate=0.0),
+                       V=600, RC=400, B=8, Q=8, u=4, i=6, WL=20, C=6, steps=1, train_pv=False),
+    # dropout + token corruption DRAWN (reference defaults 0.1 / 0.9), masks = the product's Philox streams
+    'rtm_pvc_drop': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=32,
+                                   heads=4, ff_size=64, inter_layers=1, neg_per_pos=3, dropout=0.1, lr=0.002,
+                                   corrupt_rate=0.9, seed=666),
+                         V=400, RC=300, B=8, Q=6, u=3, i=4, WL=12, C=6, steps=1, train_pv=True),
+    'rtm_pv_drop': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32,
+                                  heads=4, ff_size=64, inter_layers=2, neg_per_pos=2, dropout=0.2, lr=0.002, seed=5),
+                        V=400, RC=300, B=6, Q=6, u=2, i=3, WL=10, C=6, steps=1, train_pv=True),
+}
+
+
+def run_case(name, spec):
+    args = default_args(**spec['args'])
+    args.device = 'cpu'
+    args.do_subsample_mask = True          # review_words handed over already padded
+    V, RC, B, Q, u, i, WL, C = (spec[k] for k in ('V', 'RC', 'B', 'Q', 'u', 'i', 'WL', 'C'))
+    args.review_word_limit = WL
+    K, R, W = args.neg_per_pos, u + i, args.pv_window_size
+    enc, train_pv = args.review_encoder_name, spec['train_pv']
+    wd = synth.make_word_dists(V, seed=101)
+    review_words = rtm_data.make_review_words(77, RC, V, WL, wd)
+    torch.manual_seed(0)
+    model = ProductRanker(args, 'cpu', V, RC, 50, 40, review_words.tolist(), None, word_dists=wd)
+    ref_sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in ref_sd.items() if not k.endswith('pos_emb.pe')}
+    wseed = 1000 + sum(map(ord, name))
+    pnames = [n for n, _ in model.named_parameters()]          # de-duplicated (aliases appear once)
+    sd = synth.make_state_dict({k: shapes[k] for k in pnames}, wseed, {})
+    model.load_state_dict(sd, strict=False)
+    optim = build_optim(args, model, None)
+
+    bt = rtm_data.make_rtm_batch(2000 + wseed, B, K, RC, V, review_words, Q=Q, u_lim=u, i_lim=i, W=W,
+                                 train_pv=train_pv, encoder=enc, word_dists=wd)
+    rb = RefTrain(*[getattr(bt, k) for k in rtm_data._TRAIN_FIELDS], to_tensor=False)
+    out = {}
+    meta = dict(case=name, args=spec['args'], V=V, RC=RC, B=B, Q=Q, u=u, i=i, WL=WL, C=C, K=K, R=R, W=W,
+                steps=spec['steps'], train_pv=train_pv, weight_seed=wseed, word_dists_seed=101,
+                state_dict_keys=list(ref_sd.keys()), param_names=pnames,
+                param_shapes={k: list(shapes[k]) for k in pnames},
+                weight_checksum={k: synth.checksum(v) for k, v in sd.items()})
+    for k in rtm_data._TRAIN_FIELDS:
+        v = getattr(bt, k)
+        if v is not None:
+            out['in_' + k] = v.numpy()
+    out['in_word_dists'] = wd
+    out['in_review_words'] = review_words.numpy()
+
+    # eval on the initial weights (trainer.py:193,201: get_review_embeddings then test)
+    tb = rtm_data.make_rtm_test_batch(3000 + wseed, B, C, RC, V, Q=Q, u_lim=u, i_lim=i, word_dists=wd)
+    rtb = RefTest(tb.query_idxs, tb.user_idxs, tb.target_prod_idxs, tb.candi_prod_idxs, tb.query_word_idxs,
+                  tb.candi_prod_ridxs, tb.candi_seg_idxs, tb.candi_seq_user_idxs, tb.candi_seq_item_idxs,
+                  to_tensor=False)
+    model.eval()
+    with torch.no_grad():
+        model.get_review_embeddings()
+        out['test_scores'] = model.test(rtb).numpy()
+        out['test_review_embeddings_sum'] = np.float64(model.review_embeddings.double().sum())
+    model.clear_review_embbeddings()
+    out['in_test_query_word_idxs'] = tb.query_word_idxs.numpy()
+    out['in_test_candi_prod_ridxs'] = tb.candi_prod_ridxs.numpy()
+    out['in_test_candi_seg_idxs'] = tb.candi_seg_idxs.numpy()
+
+    model.train()
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    for step in range(spec['steps']):
+        if train_pv:
+            nw = torch.from_numpy(synth.rng_for(3000 + wseed + step).choice(V, size=(B * R, W * K), p=wd).astype(np.int64))
+            out['in_neg_word_idxs_%d' % step] = nw.numpy()
+            mg._draw_queue[:] = [nw]
+        else:
+            mg._draw_queue[:] = []
+        gen = None
+        if args.dropout > 0 or (enc == 'pvc' and args.corrupt_rate > 0):
+            gen = RtmPhiloxDropout(args.dropout, args.seed, step + 1, B, K, args.heads, R + 1, args.inter_layers,
+                                   args.corrupt_rate if enc == 'pvc' else 0.0)
+        if args.dropout > 0:
+            cnt = {'n': 0}
+
+            class _G(object):
+                def __call__(self, x, kind, call):
+                    return gen(x, kind, call)
+            mg._drop['gen'] = _G()
+            mg._drop['n'], mg._drop['layers'] = 0, args.inter_layers
+            # route call order through the RTM site map
+            mg._site_of_call_saved = mg._site_of_call
+            mg._site_of_call = lambda n, layers: _rtm_site(n, enc, train_pv, layers)
+        _tok['gen'], _tok['n'] = (gen if (enc == 'pvc' and args.corrupt_rate > 0) else None), 0
+        del mg._bce_tap[:]
+        loss = model(rb, train_pv=train_pv)
+        assert not mg._draw_queue
+        if args.dropout > 0:
+            mg._drop['gen'] = None
+            mg._site_of_call = mg._site_of_call_saved
+        _tok['gen'] = None
+        model.zero_grad()
+        loss.backward()
+        out['loss_%d' % step] = np.float32(loss.item())
+        if step == 0:
+            taps = [t.numpy() for t in mg._bce_tap]
+            out['prod_scores'] = taps[-1]                       # [B,1+K] (the last BCE call is the ranking loss)
+            if train_pv:
+                out['pv_scores'] = taps[0]                      # [B*R,W,1+K]
+            none_grads = []
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    none_grads.append(n)
+                else:
+                    mg.pack_rows(out, 'grad_' + n, p.grad)
+            meta['none_grads'] = none_grads
+        optim.step()
+        out['lr_%d' % step] = np.float64(optim.learning_rate)
+        if step == spec['steps'] - 1:
+            for n, p in model.named_parameters():
+                mg.pack_rows(out, 'param%d_%s' % (step, n), p.data, base=init[n])
+    out['meta'] = np.asarray(json.dumps(meta))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-16s loss0=%.6f  ->  %s (%.1f KB)' % (name, out['loss_0'], path, os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    for c in (sys.argv[1:] or list(CASES)):
+        run_case(c, CASES[c])
