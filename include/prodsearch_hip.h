@@ -184,6 +184,74 @@ int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper
 /* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
 int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);
 
+/* ------------------------------------------------------------------ RTM (review_transformer)
+ * ProductRanker (models/ps_model.py:53-370) with the pv (models/PV.py) / pvc (models/PVC.py) review
+ * encoders.  Sequences are [query, R reviews]; K negatives per row (training) or C candidates (eval). */
+enum { PS_RENC_PV = 0, PS_RENC_PVC = 1 };
+
+typedef struct PsRtmDesc {
+  int32_t B, K;          /* batch rows, --neg_per_pos                                             */
+  int32_t R;             /* padded reviews per sequence (<= --uprev_review_limit + --iprev_review_limit) */
+  int32_t Q;             /* padded query length                                                   */
+  int32_t W;             /* PV window (--pv_window_size), words predicted per positive review     */
+  int32_t WL;            /* words per review of the pvc encoder (--review_word_limit)             */
+  int32_t C;             /* candidates per row, eval only                                         */
+  int32_t d, H, F, n_layers;
+  int64_t vocab_size;    /* V, pad = V-1                                                          */
+  int64_t review_count;  /* pad review = review_count-1 (ps_model.py:70)                          */
+  int32_t review_encoder;/* PS_RENC_PV / PS_RENC_PVC (--review_encoder_name)                      */
+  int32_t query_encoder; /* PS_QENC_FS / PS_QENC_AVG                                              */
+  int32_t use_pos_emb, use_seg_emb, pos_weight;
+  int32_t train_pv;      /* forward(batch, train_pv): add the PV word-prediction loss (ps_model.py:265-280) */
+  int32_t training;
+  float dropout;         /* --dropout                                                             */
+  float corrupt_rate;    /* --corrupt_rate: token dropout of the pvc encoder (PVC.py:46-54)       */
+  uint64_t seed, step;
+} PsRtmDesc;
+
+typedef struct PsRtmTensors {
+  float *word_emb;       /* word_embeddings.weight [V,d] (= review_encoder.context_embeddings for pvc) */
+  float *review_emb;     /* review_encoder.review_embeddings.weight [review_count,d] (pv) or NULL  */
+  float *seg_emb;        /* seg_embeddings.weight [4,d]                                            */
+  float *fs_w, *fs_b;    /* query_encoder.f_W                                                      */
+  float *pe;             /* transformer_encoder.pos_emb.pe                                         */
+  float *final_ln_g, *final_ln_b;
+  float *wo_w, *wo_b;    /* transformer_encoder.wo [1,d],[1] (transformer.py:69,96)                */
+  PsLayerTensors layer[PS_MAX_LAYERS];
+} PsRtmTensors;
+
+/* ProdSearchTrainBatch / ProdSearchTestBatch (data/batch_data.py:137-223, :94-135) + the PV-loss draw */
+typedef struct PsRtmBatch {
+  const int64_t *query_word_idxs;         /* [B,Q]                                   */
+  const int64_t *pos_prod_ridxs;          /* [B,R]                                   */
+  const int64_t *pos_seg_idxs;            /* [B,R+1]                                 */
+  const int64_t *pos_prod_rword_idxs;     /* [B,R,W] PV target words (train_pv) / [B,R,WL] review words (pvc, !train_pv) */
+  const uint8_t *pos_prod_rword_masks;    /* [B,R,W] uint8                           */
+  const int64_t *neg_prod_ridxs;          /* [B,K,R]                                 */
+  const int64_t *neg_seg_idxs;            /* [B,K,R+1]                               */
+  const int64_t *neg_prod_rword_idxs;     /* [B,K,R,WL] pvc, !train_pv               */
+  const int64_t *pos_prod_rword_idxs_pvc; /* [B,R,WL]   pvc, train_pv                */
+  const int64_t *neg_prod_rword_idxs_pvc; /* [B,K,R,WL] pvc, train_pv                */
+  const int64_t *neg_word_idxs;           /* [B*R, W*K] torch.multinomial(word_dists) of PV.py:57 / PVC.py:81 */
+  const int64_t *candi_prod_ridxs;        /* [B,C,R]   eval                          */
+  const int64_t *candi_seg_idxs;          /* [B,C,R+1] eval                          */
+  const float *review_embeddings;         /* [review_count,d] eval table (get_review_embeddings, ps_model.py:186-203) */
+} PsRtmBatch;
+
+int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int64_t* total);
+/* loss = model(batch, train_pv) -- ProductRanker.forward (ps_model.py:241-358); loss3 = {loss, ps_loss, pv_loss} */
+int ps_rtm_forward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* workspace,
+                   float* loss3, ps_stream_t stream);
+/* loss.backward() (trainer.py:77): accumulates into dense grads */
+int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* workspace,
+                    const PsRtmTensors* grads, float loss_scale, const float* loss_scale_dev, ps_stream_t stream);
+/* scores = model.test(batch) [B,C] -- ProductRanker.test (ps_model.py:205-239) */
+int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* workspace,
+                 float* scores, ps_stream_t stream);
+/* model.get_review_embeddings() for the pvc encoder (ps_model.py:186-203): uncorrupted mean per review, last row 0 */
+int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensors* params, const int64_t* review_words,
+                             float* out, ps_stream_t stream);
+
 /* Host evaluation of the dropout stream (tests pin oracle/philox.py to it): multiplier
  * (0 or 1/(1-p)) of element (row, col) of dropout site `site` at desc->seed/step/dropout. */
 float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint32_t row, uint32_t col);

@@ -58,6 +58,32 @@ class PsAdamHyper(C.Structure):
                 ('warmup_steps', C.c_int32), ('grad_scale', C.c_float)]
 
 
+class PsRtmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('B', 'K', 'R', 'Q', 'W', 'WL', 'C', 'd', 'H', 'F', 'n_layers')] + \
+               [('vocab_size', C.c_int64), ('review_count', C.c_int64)] + \
+               [(n, C.c_int32) for n in ('review_encoder', 'query_encoder', 'use_pos_emb', 'use_seg_emb',
+                                         'pos_weight', 'train_pv', 'training')] + \
+               [('dropout', C.c_float), ('corrupt_rate', C.c_float), ('seed', C.c_uint64), ('step', C.c_uint64)]
+
+
+RTM_TOP_FIELDS = ('word_emb', 'review_emb', 'seg_emb', 'fs_w', 'fs_b', 'pe', 'final_ln_g', 'final_ln_b',
+                  'wo_w', 'wo_b')
+RTM_BATCH_FIELDS = ('query_word_idxs', 'pos_prod_ridxs', 'pos_seg_idxs', 'pos_prod_rword_idxs',
+                    'pos_prod_rword_masks', 'neg_prod_ridxs', 'neg_seg_idxs', 'neg_prod_rword_idxs',
+                    'pos_prod_rword_idxs_pvc', 'neg_prod_rword_idxs_pvc', 'neg_word_idxs',
+                    'candi_prod_ridxs', 'candi_seg_idxs', 'review_embeddings')
+
+
+class PsRtmTensors(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RTM_TOP_FIELDS] + [('layer', PsLayerTensors * PS_MAX_LAYERS)]
+
+
+class PsRtmBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RTM_BATCH_FIELDS]
+
+
+PS_RENC_PV, PS_RENC_PVC = 0, 1
+
 # every symbol include/prodsearch_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     'ps_version': (C.c_char_p, []),
@@ -71,6 +97,15 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p]),
     'ps_tem_score': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_rtm_workspace_floats': (C.c_int, [C.POINTER(PsRtmDesc), C.c_int32, C.POINTER(C.c_int64)]),
+    'ps_rtm_forward': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_rtm_backward': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
+                                  C.c_void_p, C.POINTER(PsRtmTensors), C.c_float, C.c_void_p, C.c_void_p]),
+    'ps_rtm_score': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_rtm_review_embeddings': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     'ps_sample_negatives': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     'ps_build_alias_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

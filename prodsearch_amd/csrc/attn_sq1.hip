@@ -57,7 +57,7 @@ __device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int t
   for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * d + i];
   const int brow = b / a.seq_div;
   for (int s = tid; s < S; s += 256)
-    l.valid[s] = (s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f;
+    l.valid[s] = a.valid ? a.valid[(size_t)brow * S + s] : ((s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f);
 }
 
 // dropout multipliers (or P * multipliers) of replicas j0..j0+nj-1 into Pd[jj][h][s]

@@ -1,0 +1,38 @@
+// encoder.h — pieces of the TEM host orchestration (tem.hip) shared with the RTM path (rtm.hip):
+// the workspace layout and the transformer-encoder layer loops (forward / backward).
+#pragma once
+#include "rowwise.h"
+
+// ------------------------------------------------------------- workspace layout
+struct LayerWs {
+  int n_in, fan, n_out, Sq, M2;
+  int64_t xn, pre_stats, kp, vp, qp, attn, ctx, y1, ff_stats, ln1, a1, h1, y2;
+};
+struct Ws {
+  int R, S, Mf, qpos;
+  int64_t qmean, query_emb, x;
+  LayerWs layer[PS_MAX_LAYERS];
+  int64_t fin_stats, enc;
+  int64_t item_scores, word_scores, loss_parts, item_terms, word_terms;
+  int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
+  int64_t total;
+};
+
+
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int make_ws(const PsTemDesc& D, Ws& w);
+
+// All encoder layers + the final LayerNorm on the consumed position: reads w.x, writes w.enc.
+// Key-padding mask: `valid` [n_seq, S] floats if given, else u_item_idxs != P (TEM).
+int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
+                       const Ws& w, hipStream_t st);
+// Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
+int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
+                        const float* valid, float* ws, const Ws& w, hipStream_t st);
+
+GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M, int N, int K);
+int run1(const GemmProblem& p, hipStream_t st);
+GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in, int rows);
+int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st);
+int side_join(hipStream_t main_st);

@@ -43,6 +43,7 @@ struct AttnArgs {
   int jc;                        // replicas per LDS chunk (sq1 kernels; set by the launcher)
   int seq_div;                   // batch row = n_in_index / seq_div
   int L; int64_t P; const int64_t* ui;   // key-padding mask source (u_item_idxs != P)
+  const float* valid;            // or, if set: valid[seq * S + s] != 0 (RTM: review id != pad)
   const float* kp; const float* vp; const float* qp;   // [n_in*S,d] x2, [n_in*Sq,d] (q pre-scaled)
   float* attn;                   // [n_in,H,Sq,S] softmax (pre-dropout)
   float* ctx;                    // [n_in*fan*Sq, d]

@@ -254,7 +254,7 @@ __device__ inline void attn_load_common(const AttnArgs& a, const AttnLds& l, int
   }
   const int brow = b / a.seq_div;
   for (int s = tid; s < S; s += 64)
-    l.valid[s] = (s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f;
+    l.valid[s] = a.valid ? a.valid[(size_t)brow * S + s] : ((s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f);
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {

@@ -1,0 +1,666 @@
+// rtm.hip — the RTM (review_transformer) ranking-loss step: ProductRanker of the reference
+// (models/ps_model.py:53-370) with the pv (models/PV.py) and pvc (models/PVC.py) review encoders.
+//
+// Sequences are n = b*J + j (J = 1+K in training: j = 0 positive, j = 1+k negative k; J = C in
+// eval), S = R+1 positions: [query, R reviews].  Unlike TEM every sequence is distinct, so the
+// encoder (shared layer loops of tem.hip via encoder.h) runs on B*J sequences with no replica
+// fan-out; only position 0 is consumed (TransformerEncoder.forward, transformer.py:90-98), so the
+// last layer is the one-query-row form.  RTM-specific kernels here:
+//   rtm_embed      review vectors (pv: row gather; pvc: masked mean of <= WL word rows per review with
+//                  Philox token corruption, PVC.py:46-61 — the bandwidth-heavy gather of config 4),
+//                  dropout, segment embedding, key mask, positional add -> x[B*J, S, d]
+//   rtm_score      wo . enc + bias (transformer.py:95-96)
+//   rtm_pv_fwd     PV word-prediction logits (PV.py:59-66 / PVC.py:83-91), gather + dot per task
+//   rtm_loss       weighted BCE over products (ps_model.py:341-356) + PV loss (:277-280), one block
+//   *_bwd          their backward: fp32-atomic scatter-adds into the dense table gradients
+#include "encoder.h"
+#include <string.h>
+
+#define SITE_REV_PV 0x200u
+#define SITE_REV_POS 0x201u
+#define SITE_REV_NEG 0x202u
+#define SITE_TOK_POS 0x203u
+#define SITE_TOK_NEG 0x204u
+
+struct RtmWs {
+  int Bseq, S, J;
+  int64_t qmean, query_emb, valid, vec, cnt, scores, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
+  int64_t enc_base;         // the shared encoder workspace (Ws) starts here
+  int64_t total;
+};
+
+struct RtmK {              // kernel-side view of one call
+  int B, J, K, R, S, Q, W, WL, d;
+  int64_t V, RC;
+  int pvc, use_pos, use_seg, pos_weight, train_pv, training, eval;
+  FDiv fJ, fS, fK1;
+  DropSpec d_pv, d_pos, d_neg, t_pos, t_neg;
+  // batch
+  const int64_t *pos_r, *neg_r, *pos_seg, *neg_seg, *pos_words, *neg_words_rev, *pos_pvc, *neg_pvc, *neg_word_idxs;
+  const uint8_t* pos_masks;
+  // tensors
+  const float *word_emb, *table, *seg_emb, *pe, *wo_w, *wo_b;
+  // workspace
+  float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *pv_scores, *pv_terms, *nvalid;
+  float* loss3;
+  // backward
+  float scale; const float* scale_dev;
+  const float *dx; float *denc, *dvec, *dqe;
+  float *g_word_emb, *g_table, *g_seg_emb, *g_wo_w, *g_wo_b;
+};
+
+static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
+
+static int rtm_check(const PsRtmDesc& D) {
+  PS_REQUIRE(D.B > 0 && D.K >= 0 && D.R > 0 && D.Q > 0 && D.d > 0, "rtm desc: bad sizes");
+  PS_REQUIRE(D.d % 32 == 0 && D.d <= 512 && D.d / 4 <= 64 * 2, "rtm desc: embedding_size %d", D.d);
+  PS_REQUIRE(D.R + 1 <= 64, "rtm desc: %d reviews per sequence (S <= 64)", D.R);
+  PS_REQUIRE(D.review_encoder == PS_RENC_PV || D.review_encoder == PS_RENC_PVC, "rtm desc: review encoder %d", D.review_encoder);
+  PS_REQUIRE(D.review_encoder != PS_RENC_PVC || D.WL > 0, "rtm desc: pvc needs WL");
+  PS_REQUIRE(D.dropout >= 0.f && D.dropout < 1.f && D.corrupt_rate >= 0.f && D.corrupt_rate < 1.f, "rtm desc: rates");
+  return PS_OK;
+}
+
+static PsTemDesc enc_desc(const PsRtmDesc& D, int J) {
+  PsTemDesc E;
+  memset(&E, 0, sizeof(E));
+  E.B = D.B * J; E.K = 0; E.L = D.R; E.Q = 1; E.W = 0; E.C = 0;
+  E.d = D.d; E.H = D.H; E.F = D.F; E.n_layers = D.n_layers;
+  E.product_size = 1; E.vocab_size = 2;
+  E.model = PS_MODEL_TEM; E.query_encoder = PS_QENC_AVG;
+  E.use_pos_emb = D.use_pos_emb; E.training = D.training; E.dropout = D.dropout; E.seed = D.seed; E.step = D.step;
+  return E;
+}
+
+static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc& E) {
+  TRY(rtm_check(D));
+  const int J = eval ? D.C : D.K + 1;
+  PS_REQUIRE(J > 0, "rtm: no sequences per row");
+  E = enc_desc(D, J);
+  if (eval) E.training = 0;
+  r.J = J; r.Bseq = D.B * J; r.S = D.R + 1;
+  const int d = D.d;
+  int64_t cur = 0;
+  r.qmean = rtake(cur, (int64_t)D.B * d);
+  r.query_emb = rtake(cur, (int64_t)D.B * d);
+  r.valid = rtake(cur, (int64_t)r.Bseq * r.S);
+  r.vec = rtake(cur, (int64_t)D.B * D.R * d);
+  r.cnt = rtake(cur, (int64_t)r.Bseq * D.R);
+  r.scores = rtake(cur, r.Bseq);
+  const int64_t npv = (int64_t)D.B * D.R * (D.W > 0 ? D.W : 1) * (D.K + 1);
+  r.pv_scores = rtake(cur, npv);
+  r.pv_terms = rtake(cur, npv);
+  r.nvalid = rtake(cur, 4);
+  r.dvec = rtake(cur, (int64_t)D.B * D.R * d);
+  r.dqe = rtake(cur, (int64_t)D.B * d);
+  r.dqpre = rtake(cur, (int64_t)D.B * d);
+  r.dqmean = rtake(cur, (int64_t)D.B * d);
+  r.enc_base = cur;
+  TRY(make_ws(E, w));
+  r.total = cur + w.total;
+  return PS_OK;
+}
+
+extern "C" int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int64_t* total) {
+  PS_REQUIRE(desc && total, "rtm workspace: null argument");
+  RtmWs r; Ws w; PsTemDesc E;
+  TRY(rtm_make_ws(*desc, eval != 0, r, w, E));
+  *total = r.total;
+  return PS_OK;
+}
+
+__device__ inline int64_t rclamp(int64_t i, int64_t hi) { return i < 0 ? hi : (i > hi ? hi : i); }
+
+// ------------------------------------------------------------------ embed forward
+// one wave per (sequence, position); lanes: half = lane>>5 picks every other word row, c = lane&31 the float4
+// chunk of the row (d <= 128: one chunk per lane; wider rows loop).
+__device__ inline void seq_decode(const RtmK& a, int n, int s, int& b, int& j, int64_t& ridx, int& revrow, int& seg) {
+  b = fdiv(n, a.fJ); j = n - b * a.J;
+  const int r = s - 1;
+  if (a.eval || j > 0) {
+    const int jj = a.eval ? j : j - 1, JN = a.eval ? a.J : a.K;
+    const size_t base = ((size_t)b * JN + jj);
+    ridx = s > 0 ? a.neg_r[base * a.R + r] : 0;
+    seg = (int)a.neg_seg[base * a.S + s];
+    revrow = (int)(base * a.R + r);
+  } else {
+    ridx = s > 0 ? a.pos_r[(size_t)b * a.R + r] : 0;
+    seg = (int)a.pos_seg[(size_t)b * a.S + s];
+    revrow = b * a.R + r;
+  }
+}
+
+__global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (slot >= a.B * a.J * a.S) return;
+  const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+  const int d = a.d, nch = d >> 2;
+  int b, j, revrow, seg; int64_t ridx;
+  seq_decode(a, n, s, b, j, ridx, revrow, seg);
+  const bool pos = !a.eval && j == 0;
+  const int64_t rpad = a.RC - 1;
+  const bool ok = s == 0 || ridx != rpad;
+  if (lane == 0) a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f;
+  for (int cc = c; cc < nch; cc += 32) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vcor = v;
+    float cnt = 1.f;
+    if (s == 0) {
+      if (half == 0) v = *reinterpret_cast<const float4*>(a.query_emb + (size_t)b * d + 4 * cc);
+    } else if (ok) {
+      const int r = s - 1;
+      if (!a.pvc) {
+        if (half == 0) v = *reinterpret_cast<const float4*>(a.table + (size_t)rclamp(ridx, rpad) * d + 4 * cc);
+        vcor = v;
+      } else {
+        // masked mean of the review's word rows; corrupted and (positive, train_pv) uncorrupted sums
+        const int64_t* words;
+        if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + r) * a.WL;
+        else words = ((a.train_pv || a.eval) ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
+        const DropSpec& ts = pos ? a.t_pos : a.t_neg;
+        int nw = 0;
+        for (int w0 = 0; w0 < a.WL; w0 += 8) {                 // 8 word rows in flight per wave
+          float4 rowv[4]; float mt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int w = w0 + 2 * u + half;
+            int64_t wi = w < a.WL ? words[w] : a.V - 1;
+            rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f); mt[u] = 0.f;
+            if (wi != a.V - 1 && wi >= 0 && wi < a.V) {
+              rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
+              mt[u] = drop_mult(ts, (uint32_t)revrow, (uint32_t)w);
+              ++nw;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v.x += rowv[u].x; v.y += rowv[u].y; v.z += rowv[u].z; v.w += rowv[u].w;
+            vcor.x += rowv[u].x * mt[u]; vcor.y += rowv[u].y * mt[u]; vcor.z += rowv[u].z * mt[u]; vcor.w += rowv[u].w * mt[u];
+          }
+        }
+        nw += __shfl_xor(nw, 32, 64);
+        cnt = (float)(nw > 0 ? nw : 1);
+      }
+    }
+    // combine the two half-waves
+    v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+    vcor.x += __shfl_xor(vcor.x, 32, 64); vcor.y += __shfl_xor(vcor.y, 32, 64);
+    vcor.z += __shfl_xor(vcor.z, 32, 64); vcor.w += __shfl_xor(vcor.w, 32, 64);
+    if (half != 0) continue;
+    float o[4];
+    if (s == 0) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else {
+      const float inv = 1.f / cnt;
+      float unc[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+      float cor[4] = {vcor.x * inv, vcor.y * inv, vcor.z * inv, vcor.w * inv};
+      const int rr = s - 1;
+      if (a.pvc && lane == 0 && cc == 0) a.cnt[(size_t)n * a.R + rr] = cnt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t col = (uint32_t)(4 * cc + e);
+        float val;
+        if (!a.pvc) {
+          val = unc[e];
+          if (pos && a.train_pv) {                               // PV.forward: drop_layer(review_emb) (PV.py:54)
+            val *= drop_mult(a.d_pv, (uint32_t)revrow, col);
+            a.vec[(size_t)revrow * d + col] = ok ? val : 0.f;
+          }
+        } else if (pos && a.train_pv) {
+          val = unc[e];                                          // the sequence gets the UNcorrupted mean (PVC.py:76,95)
+          a.vec[(size_t)revrow * d + col] = ok ? cor[e] : 0.f;    // the PV loss the corrupted one (PVC.py:78)
+        } else {
+          val = cor[e];
+        }
+        val *= drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);     // dropout_layer (ps_model.py:303-304)
+        o[e] = val;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = 4 * cc + e;
+      float val = o[e];
+      if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
+      val = ok ? val : 0.f;
+      if (a.use_pos) val += a.pe[(size_t)s * d + col];
+      o[e] = val;
+    }
+    *reinterpret_cast<float4*>(a.x + ((size_t)n * a.S + s) * d + 4 * cc) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  // padded positive reviews still own a (zero) PV vector
+  if (!ok && pos && a.train_pv && s > 0 && half == 0)
+    for (int cc = c; cc < nch; cc += 32)
+      *reinterpret_cast<float4*>(a.vec + (size_t)revrow * d + 4 * cc) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------ scores
+__global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (n >= a.B * a.J) return;
+  float s = 0.f;
+  for (int e = lane; e < a.d; e += 64) s += a.enc[(size_t)n * a.d + e] * a.wo_w[e];
+  s = wave_sum(s);
+  if (lane == 0) out[n] = s + a.wo_b[0];
+}
+
+// PV logits: task t = ((b*R + r)*W + w)*(1+K) + j
+#define PV_U 4
+__global__ __launch_bounds__(256) void rtm_pv_fwd_kernel(const RtmK a, int ntask, int lpr) {
+  const int tid = threadIdx.x, c = tid % lpr;
+  const int grp = blockIdx.x * (256 / lpr) + tid / lpr;
+  const int K1 = a.K + 1, nch = a.d >> 2;
+  const float* rows[PV_U]; const float* vecs[PV_U]; int tt[PV_U]; float sgn[PV_U];
+#pragma unroll
+  for (int u = 0; u < PV_U; ++u) {
+    const int t = grp * PV_U + u;
+    tt[u] = t; rows[u] = nullptr; vecs[u] = nullptr; sgn[u] = 1.f;
+    if (t < ntask) {
+      const int tw = fdiv(t, a.fK1), j = t - tw * K1;
+      const int rev = tw / a.W, w = tw - rev * a.W;
+      int64_t idx = j == 0 ? a.pos_words[(size_t)rev * a.W + w] : a.neg_word_idxs[(size_t)rev * a.W * a.K + (size_t)w * a.K + j - 1];
+      idx = rclamp(idx, a.V - 1);
+      rows[u] = a.word_emb + (size_t)idx * a.d;
+      vecs[u] = a.vec + (size_t)rev * a.d;
+      sgn[u] = j == 0 ? -1.f : 1.f;
+    }
+  }
+  float4 r[PV_U], v[PV_U];
+#pragma unroll
+  for (int u = 0; u < PV_U; ++u) {
+    r[u] = make_float4(0.f, 0.f, 0.f, 0.f); v[u] = r[u];
+    if (rows[u] && c < nch) {
+      r[u] = *reinterpret_cast<const float4*>(rows[u] + 4 * c);
+      v[u] = *reinterpret_cast<const float4*>(vecs[u] + 4 * c);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PV_U; ++u) {
+    float s = r[u].x * v[u].x + r[u].y * v[u].y + r[u].z * v[u].z + r[u].w * v[u].w;
+    if (rows[u])
+      for (int cc = c + lpr; cc < nch; cc += lpr) {
+        float4 rr = *reinterpret_cast<const float4*>(rows[u] + 4 * cc);
+        float4 vv = *reinterpret_cast<const float4*>(vecs[u] + 4 * cc);
+        s += rr.x * vv.x + rr.y * vv.y + rr.z * vv.z + rr.w * vv.w;
+      }
+    s = group_sum(s, lpr);
+    if (c == 0 && rows[u]) {
+      a.pv_scores[tt[u]] = s;
+      a.pv_terms[tt[u]] = softplus_f(sgn[u] < 0.f ? -s : s);
+    }
+  }
+}
+
+// Loss: ps = mean_b sum_j weight * bce ; pv = sum_rev masked-mean_w(sum_j bce) / #non-pad positive reviews
+__global__ __launch_bounds__(256) void rtm_loss_kernel(const RtmK a) {
+  __shared__ float s1[256], s2[256], s3[256];
+  const int tid = threadIdx.x, K1 = a.K + 1;
+  float ps = 0.f, pv = 0.f, nv = 0.f;
+  for (int b = tid; b < a.B; b += 256) {
+    const float* sc = a.scores + (size_t)b * K1;
+    ps += (a.pos_weight ? (float)a.K : 1.f) * softplus_f(-sc[0]);
+    for (int k = 0; k < a.K; ++k) {
+      bool any = false;
+      for (int r = 0; r < a.R; ++r) any = any || (a.neg_r[((size_t)b * a.K + k) * a.R + r] != a.RC - 1);
+      if (any) ps += softplus_f(sc[1 + k]);
+    }
+  }
+  if (a.train_pv) {
+    for (int rev = tid; rev < a.B * a.R; rev += 256) {
+      nv += (a.pos_r[rev] != a.RC - 1) ? 1.f : 0.f;
+      float sum = 0.f; int cnt = 0;
+      for (int w = 0; w < a.W; ++w) {
+        if (a.pos_masks[(size_t)rev * a.W + w]) {
+          ++cnt;
+          const float* t = a.pv_terms + ((size_t)rev * a.W + w) * K1;
+          for (int j = 0; j < K1; ++j) sum += t[j];
+        }
+      }
+      pv += sum / (float)(cnt > 0 ? cnt : 1);
+    }
+  }
+  s1[tid] = ps; s2[tid] = pv; s3[tid] = nv;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { s1[tid] += s1[tid + o]; s2[tid] += s2[tid + o]; s3[tid] += s3[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float psl = s1[0] / (float)a.B;
+    const float pvl = a.train_pv ? s2[0] / s3[0] : 0.f;
+    a.loss3[0] = psl + pvl; a.loss3[1] = psl; a.loss3[2] = pvl;
+    a.nvalid[0] = s3[0];
+  }
+}
+
+// ------------------------------------------------------------------ backward kernels
+__global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a) {
+  extern __shared__ float acc[];                  // [d] partial of d wo_w, + 1 for d wo_b
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, K1 = a.K + 1;
+  for (int e = threadIdx.x; e <= a.d; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  const float sc = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+  const int nw = gridDim.x * 4;
+  for (int n = blockIdx.x * 4 + wv; n < a.B * K1; n += nw) {
+    const int b = fdiv(n, a.fK1), j = n - b * K1;
+    float wgt;
+    if (j == 0) wgt = a.pos_weight ? (float)a.K : 1.f;
+    else {
+      bool any = false;
+      for (int r = 0; r < a.R; ++r) any = any || (a.neg_r[((size_t)b * a.K + j - 1) * a.R + r] != a.RC - 1);
+      wgt = any ? 1.f : 0.f;
+    }
+    const float s = a.scores[n];
+    const float ds = wgt * (sigmoid_f(s) - (j == 0 ? 1.f : 0.f)) * sc;
+    for (int e = lane; e < a.d; e += 64) {
+      a.denc[(size_t)n * a.d + e] = ds * a.wo_w[e];
+      atomicAdd(&acc[e], ds * a.enc[(size_t)n * a.d + e]);
+    }
+    if (lane == 0) atomicAdd(&acc[a.d], ds);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < a.d; e += 256) atomicAdd(&a.g_wo_w[e], acc[e]);
+  if (threadIdx.x == 0) atomicAdd(&a.g_wo_b[0], acc[a.d]);
+}
+
+// PV backward: one wave per positive review; d vec (dense) and word-row scatter-adds
+__global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const int rev = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (rev >= a.B * a.R) return;
+  const int d = a.d, epl = d >> 5, K1 = a.K + 1;
+  int cnt = 0;
+  for (int w = 0; w < a.W; ++w) cnt += a.pos_masks[(size_t)rev * a.W + w] ? 1 : 0;
+  const float sc = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / ((float)(cnt > 0 ? cnt : 1) * a.nvalid[0]);
+  float dv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dv[k] = 0.f;
+  const float* vec = a.vec + (size_t)rev * d;
+  for (int t = half; t < a.W * K1; t += 2) {
+    const int w = t / K1, j = t - w * K1;
+    if (!a.pos_masks[(size_t)rev * a.W + w]) continue;
+    int64_t idx = j == 0 ? a.pos_words[(size_t)rev * a.W + w] : a.neg_word_idxs[(size_t)rev * a.W * a.K + (size_t)w * a.K + j - 1];
+    idx = rclamp(idx, a.V - 1);
+    const float s = a.pv_scores[((size_t)rev * a.W + w) * K1 + j];
+    const float ds = (sigmoid_f(s) - (j == 0 ? 1.f : 0.f)) * sc;
+    const float* wrow = a.word_emb + (size_t)idx * d;
+    float* grow = a.g_word_emb + (size_t)idx * d;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < epl) {
+        const int e = c + 32 * k;
+        if (idx != a.V - 1) atomicAdd(&grow[e], ds * vec[e]);
+        dv[k] += ds * wrow[e];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < epl) {
+      float v = dv[k] + __shfl_xor(dv[k], 32, 64);
+      if (half == 0) a.dvec[(size_t)rev * d + c + 32 * k] = v;
+    }
+}
+
+// Backward of rtm_embed: one wave per (sequence, position), grid-strided so that the 4 segment-embedding rows
+// are reduced in LDS before touching the (very contended) global atomics.
+__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
+  extern __shared__ float segacc[];               // [4][d]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
+  const int d = a.d, epl = d >> 5;
+  for (int e = threadIdx.x; e < 4 * d; e += 256) segacc[e] = 0.f;
+  __syncthreads();
+  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
+  const int64_t rpad = a.RC - 1;
+  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
+    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+    int b, j, revrow, seg; int64_t ridx;
+    seq_decode(a, n, s, b, j, ridx, revrow, seg);
+    const bool pos = j == 0;
+    const bool ok = s == 0 || ridx != rpad;
+    if (!ok) continue;
+    const float* g = a.dx + ((size_t)n * a.S + s) * d;
+    float gk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gk[k] = k < epl ? g[c + 32 * k] : 0.f;
+    if (a.use_seg && half == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < epl) atomicAdd(&segacc[seg * d + c + 32 * k], gk[k]);
+    }
+    if (s == 0) {
+      if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < epl) atomicAdd(&a.dqe[(size_t)b * d + c + 32 * k], gk[k]);
+      }
+      continue;
+    }
+    // through dropout_layer (and, pv positive with train_pv, the PV drop_layer + the PV-loss gradient)
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < epl) {
+        const uint32_t col = (uint32_t)(c + 32 * k);
+        float t = gk[k] * drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);
+        if (pos && a.train_pv) {
+          t += a.dvec[(size_t)revrow * d + col];
+          if (!a.pvc) t *= drop_mult(a.d_pv, (uint32_t)revrow, col);
+        }
+        gk[k] = t;
+      }
+    if (!a.pvc) {
+      if (half == 0) {
+        float* grow = a.g_table + (size_t)rclamp(ridx, rpad) * d;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < epl) atomicAdd(&grow[c + 32 * k], gk[k]);
+      }
+    } else {
+      // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
+      const float inv = 1.f / a.cnt[(size_t)n * a.R + s - 1];
+      const int64_t* words;
+      if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
+      else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
+      for (int w = half; w < a.WL; w += 2) {
+        const int64_t wi = words[w];
+        if (wi == a.V - 1 || wi < 0 || wi >= a.V) continue;
+        float* grow = a.g_word_emb + (size_t)wi * d;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < epl) atomicAdd(&grow[c + 32 * k], gk[k] * inv);
+      }
+    }
+  }
+  __syncthreads();
+  if (a.use_seg)
+    for (int e = threadIdx.x; e < 3 * d; e += 256)      // row 3 is the padding_idx of seg_embeddings: no gradient
+      atomicAdd(&a.g_seg_emb[e], segacc[e]);
+}
+
+// uncorrupted pvc review table for eval: out[i] = mean of the review's word rows, last row 0 (ps_model.py:186-203)
+__global__ __launch_bounds__(256) void rtm_review_table_kernel(const float* word_emb, const int64_t* review_words, float* out,
+                                                               int64_t RC, int WL, int d, int64_t V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rev = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (rev >= RC) return;
+  for (int e = lane; e < d; e += 64) {
+    float s = 0.f; int cnt = 0;
+    if (rev < RC - 1)
+      for (int w = 0; w < WL; ++w) {
+        const int64_t wi = review_words[rev * WL + w];
+        if (wi != V - 1 && wi >= 0 && wi < V) { s += word_emb[(size_t)wi * d + e]; ++cnt; }
+      }
+    out[rev * d + e] = s / (float)(cnt > 0 ? cnt : 1);
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& Bt, float* ws, const RtmWs& r, const Ws& w,
+                   bool eval, RtmK& k) {
+  memset(&k, 0, sizeof(k));
+  k.B = D.B; k.J = r.J; k.K = D.K; k.R = D.R; k.S = r.S; k.Q = D.Q; k.W = D.W > 0 ? D.W : 1; k.WL = D.WL; k.d = D.d;
+  k.V = D.vocab_size; k.RC = D.review_count;
+  k.pvc = D.review_encoder == PS_RENC_PVC && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
+  k.pos_weight = D.pos_weight; k.train_pv = eval ? 0 : D.train_pv; k.training = eval ? 0 : D.training; k.eval = eval;
+  k.fJ = make_fdiv(r.J); k.fS = make_fdiv(r.S); k.fK1 = make_fdiv(D.K + 1);
+  PsTemDesc dd;
+  memset(&dd, 0, sizeof(dd));
+  dd.training = k.training; dd.dropout = D.dropout; dd.seed = D.seed; dd.step = D.step;
+  k.d_pv = make_drop(dd, SITE_REV_PV); k.d_pos = make_drop(dd, SITE_REV_POS); k.d_neg = make_drop(dd, SITE_REV_NEG);
+  dd.dropout = D.corrupt_rate;
+  k.t_pos = make_drop(dd, SITE_TOK_POS); k.t_neg = make_drop(dd, SITE_TOK_NEG);
+  if (eval) {
+    k.neg_r = Bt.candi_prod_ridxs; k.neg_seg = Bt.candi_seg_idxs; k.table = Bt.review_embeddings;
+  } else {
+    k.pos_r = Bt.pos_prod_ridxs; k.neg_r = Bt.neg_prod_ridxs; k.pos_seg = Bt.pos_seg_idxs; k.neg_seg = Bt.neg_seg_idxs;
+    k.pos_words = Bt.pos_prod_rword_idxs; k.neg_words_rev = Bt.neg_prod_rword_idxs;
+    k.pos_pvc = Bt.pos_prod_rword_idxs_pvc; k.neg_pvc = Bt.neg_prod_rword_idxs_pvc;
+    k.neg_word_idxs = Bt.neg_word_idxs; k.pos_masks = Bt.pos_prod_rword_masks;
+    k.table = P.review_emb;
+  }
+  k.word_emb = P.word_emb; k.seg_emb = P.seg_emb; k.pe = P.pe; k.wo_w = P.wo_w; k.wo_b = P.wo_b;
+  float* we = ws + r.enc_base;
+  k.query_emb = ws + r.query_emb; k.x = we + w.x; k.valid = ws + r.valid; k.vec = ws + r.vec; k.cnt = ws + r.cnt;
+  k.enc = we + w.enc; k.scores = ws + r.scores; k.pv_scores = ws + r.pv_scores; k.pv_terms = ws + r.pv_terms;
+  k.nvalid = ws + r.nvalid;
+  k.dx = we + w.dx; k.denc = we + w.denc; k.dvec = ws + r.dvec; k.dqe = ws + r.dqe;
+}
+
+static void to_tem_tensors(const PsRtmTensors& R, PsTemTensors& T) {
+  memset(&T, 0, sizeof(T));
+  T.word_emb = R.word_emb; T.fs_w = R.fs_w; T.fs_b = R.fs_b; T.pe = R.pe;
+  T.final_ln_g = R.final_ln_g; T.final_ln_b = R.final_ln_b;
+  for (int i = 0; i < PS_MAX_LAYERS; ++i) T.layer[i] = R.layer[i];
+}
+
+static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& Bt, float* ws, const RtmWs& r,
+                      const Ws& w, const PsTemDesc& E, bool eval, RtmK& k, hipStream_t st) {
+  const int B = D.B, d = D.d;
+  PS_REQUIRE(P.word_emb && P.seg_emb && P.wo_w && P.wo_b && Bt.query_word_idxs, "rtm: null tensors");
+  fill_k(D, P, Bt, ws, r, w, eval, k);
+  PS_REQUIRE(k.neg_r && k.neg_seg && (eval || (k.pos_r && k.pos_seg)), "rtm: null review index tensors");
+  PS_REQUIRE(k.pvc || k.table, "rtm: null review embedding table");
+  if (k.pvc) PS_REQUIRE(k.train_pv ? (k.pos_pvc && k.neg_pvc) : (k.pos_words && k.neg_words_rev), "rtm: null review word tensors");
+  if (k.train_pv) PS_REQUIRE(k.pos_words && k.pos_masks && k.neg_word_idxs, "rtm: null PV-loss tensors");
+  // query encoder (shared kernels): masked mean (+FS dropout) then tanh(f_W . + b)
+  PsTemDesc dq;
+  memset(&dq, 0, sizeof(dq));
+  dq.training = k.training; dq.dropout = D.dropout; dq.seed = D.seed; dq.step = D.step;
+  EmbedArgs e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.Q = D.Q; e.L = 0; e.S = 1; e.d = d; e.P = 1; e.V = D.vocab_size; e.tem = 0;
+  e.fs = D.query_encoder == PS_QENC_FS; e.qw = Bt.query_word_idxs; e.word_emb = P.word_emb;
+  e.drop_fs = make_drop(dq, PS_SITE_FS);
+  e.qmean_d = ws + r.qmean; e.query_emb = ws + r.query_emb;
+  TRY(launch_embed_fwd(e, st));
+  if (e.fs) {
+    PS_REQUIRE(P.fs_w && P.fs_b, "rtm: null FS encoder weights");
+    GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);
+    p.bias = P.fs_b; p.act = ACT_TANH;
+    TRY(run1(p, st));
+  }
+  PS_REQUIRE(!D.use_pos_emb || P.pe, "rtm: null positional table");
+  const int nslots = r.Bseq * r.S;
+  hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+  PS_LAUNCH_CHECK();
+  PsTemTensors T;
+  to_tem_tensors(P, T);
+  TRY(enc_layers_forward(E, T, nullptr, ws + r.valid, ws + r.enc_base, w, st));
+  return PS_OK;
+}
+
+extern "C" int ps_rtm_forward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
+                              float* loss3, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && ws && loss3, "rtm forward: null argument");
+  RtmWs r; Ws w; PsTemDesc E; RtmK k;
+  TRY(rtm_make_ws(*desc, false, r, w, E));
+  hipStream_t st = (hipStream_t)stream;
+  TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, false, k, st));
+  k.loss3 = loss3;
+  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, k.scores);
+  PS_LAUNCH_CHECK();
+  if (k.train_pv) {
+    const int ntask = k.B * k.R * k.W * (k.K + 1);
+    int lpr = 1; while (lpr < k.d / 4 && lpr < 64) lpr <<= 1;
+    hipLaunchKernelGGL(rtm_pv_fwd_kernel, dim3(ps_cdiv(ps_cdiv(ntask, PV_U), 256 / lpr)), dim3(256), 0, st, k, ntask, lpr);
+    PS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rtm_loss_kernel, dim3(1), dim3(256), 0, st, k);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
+                            float* scores, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && ws && scores, "rtm score: null argument");
+  PS_REQUIRE(desc->C > 0 && batch->candi_prod_ridxs && batch->candi_seg_idxs && batch->review_embeddings,
+             "rtm score: needs candidates and the review-embedding table");
+  RtmWs r; Ws w; PsTemDesc E; RtmK k;
+  TRY(rtm_make_ws(*desc, true, r, w, E));
+  hipStream_t st = (hipStream_t)stream;
+  TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, true, k, st));
+  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, scores);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensors* params, const int64_t* review_words,
+                                        float* out, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && review_words && out && params->word_emb && desc->WL > 0, "rtm review table: bad argument");
+  hipLaunchKernelGGL(rtm_review_table_kernel, dim3(ps_cdiv(desc->review_count, 4)), dim3(256), 0, (hipStream_t)stream,
+                     params->word_emb, review_words, out, desc->review_count, desc->WL, desc->d, desc->vocab_size);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
+                               const PsRtmTensors* grads, float loss_scale, const float* loss_scale_dev,
+                               ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && ws && grads, "rtm backward: null argument");
+  const PsRtmDesc& D = *desc;
+  RtmWs r; Ws w; PsTemDesc E; RtmK k;
+  TRY(rtm_make_ws(D, false, r, w, E));
+  hipStream_t st = (hipStream_t)stream;
+  fill_k(D, *params, *batch, ws, r, w, false, k);
+  const PsRtmTensors& G = *grads;
+  PS_REQUIRE(G.word_emb && (!D.use_seg_emb || G.seg_emb) && G.wo_w && G.wo_b && (k.pvc || G.review_emb),
+             "rtm backward: null gradients");
+  k.scale = loss_scale; k.scale_dev = loss_scale_dev;
+  k.g_word_emb = G.word_emb; k.g_table = G.review_emb; k.g_seg_emb = G.seg_emb; k.g_wo_w = G.wo_w; k.g_wo_b = G.wo_b;
+  const int B = D.B, d = D.d;
+  int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k);
+  PS_LAUNCH_CHECK();
+  if (k.train_pv) {
+    hipLaunchKernelGGL(rtm_pv_bwd_kernel, dim3(ps_cdiv(B * k.R, 4)), dim3(256), 0, st, k);
+    PS_LAUNCH_CHECK();
+  }
+  PsTemTensors T, TG;
+  to_tem_tensors(*params, T);
+  to_tem_tensors(G, TG);
+  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st));
+  PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)B * d, st));
+  int eb = ps_cdiv(r.Bseq * r.S, 4); if (eb > 1024) eb = 1024;
+  hipLaunchKernelGGL(rtm_embed_bwd_kernel, dim3(eb), dim3(256), (size_t)4 * d * sizeof(float), st, k);
+  PS_LAUNCH_CHECK();
+  // query encoder backward (shared kernels) + scatter to the query word rows
+  PsTemDesc dq;
+  memset(&dq, 0, sizeof(dq));
+  dq.training = k.training; dq.dropout = D.dropout; dq.seed = D.seed; dq.step = D.step;
+  EmbedBwdArgs e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.Q = D.Q; e.L = 0; e.S = 1; e.d = d; e.P = 1; e.V = D.vocab_size; e.tem = 0;
+  e.qw = batch->query_word_idxs; e.drop_fs = make_drop(dq, PS_SITE_FS); e.g_word_emb = G.word_emb;
+  if (D.query_encoder == PS_QENC_FS) {
+    PS_REQUIRE(G.fs_w && G.fs_b, "rtm backward: null FS gradients");
+    TRY(launch_tanh_bwd(ws + r.dqe, d, ws + r.query_emb, ws + r.dqpre, G.fs_b, B, d, st));
+    GemmProblem p = gp(ws + r.dqpre, d, 0, params->fs_w, d, 1, ws + r.dqmean, d, B, d, d);
+    TRY(run1(p, st));
+    GemmProblem wg[1] = {gp_wgrad(ws + r.dqpre, d, ws + r.qmean, d, G.fs_w, d, d, B)};
+    TRY(side_wgrads(wg, 1, st));
+    e.dqmean_d = ws + r.dqmean;
+  } else {
+    e.dqmean_d = ws + r.dqe;
+  }
+  TRY(launch_embed_scatter(e, st));
+  TRY(side_join(st));
+  return PS_OK;
+}

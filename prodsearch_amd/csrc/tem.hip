@@ -15,7 +15,7 @@
 //   * the LAST layer only produces the one output position that is consumed
 //     (x[:, 0] or x[:, -1], item_transformer.py:482-492), so its query/attention/FFN rows
 //     are n_out x 1 instead of n_out x S.
-#include "rowwise.h"
+#include "encoder.h"
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -31,21 +31,6 @@ void ps_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ps_last_error(void) { return g_err; }
 extern "C" const char* ps_version(void) { return "prodsearch_hip 0.1 (gfx950, fp32 MFMA)"; }
-
-// ------------------------------------------------------------- workspace layout
-struct LayerWs {
-  int n_in, fan, n_out, Sq, M2;
-  int64_t xn, pre_stats, kp, vp, qp, attn, ctx, y1, ff_stats, ln1, a1, h1, y2;
-};
-struct Ws {
-  int R, S, Mf, qpos;
-  int64_t qmean, query_emb, x;
-  LayerWs layer[PS_MAX_LAYERS];
-  int64_t fin_stats, enc;
-  int64_t item_scores, word_scores, loss_parts, item_terms, word_terms;
-  int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
-  int64_t total;
-};
 
 static int check_desc(const PsTemDesc& D) {
   PS_REQUIRE(D.B > 0 && D.K >= 0 && D.Q > 0 && D.W >= 0 && D.d > 0, "desc: bad sizes B=%d K=%d Q=%d W=%d d=%d",
@@ -71,7 +56,7 @@ static inline int64_t take(int64_t& cur, int64_t n) {
   return o;
 }
 
-static int make_ws(const PsTemDesc& D, Ws& w) {
+int make_ws(const PsTemDesc& D, Ws& w) {
   int rc = check_desc(D);
   if (rc) return rc;
   memset(&w, 0, sizeof(w));
@@ -163,7 +148,7 @@ extern "C" int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out
 }
 
 // ----------------------------------------------------------------- GEMM helpers
-static GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M,
+GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M,
                       int N, int K) {
   GemmProblem p;
   memset(&p, 0, sizeof(p));
@@ -173,14 +158,14 @@ static GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb,
   p.alpha = 1.f; p.ksplit = 1;
   return p;
 }
-static int run1(const GemmProblem& p, hipStream_t st) {
+int run1(const GemmProblem& p, hipStream_t st) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.n = 1; g.p[0] = p;
   return ps_launch_gemm(g, st);
 }
 // weight gradient  dW[N_out, K_in] += dY[rows, N_out]^T . X[rows, K_in]   (atomic, split over rows)
-static GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in,
+GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in,
                             int rows) {
   GemmProblem p = gp(dY, lddy, 1, X, ldx, 1, dW, k_in, n_out, k_in, rows);
   p.accumulate = 2;
@@ -205,7 +190,6 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
   for (int i = 0; i < n; ++i) { g.p[i] = ps[i]; g.p[i].ksplit = ks; }
   return ps_launch_gemm(g, st);
 }
-#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 // ---- weight-gradient GEMMs run on a side stream: they are off the dX critical path (nothing in
 // the backward consumes dW), so they overlap the latency-bound main chain.  Fork = event recorded on
@@ -234,7 +218,7 @@ static SideCtx* side_ctx() {
   }
   return state == 1 ? &ctx : nullptr;
 }
-static int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
+int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c) return run_wgrads(ps, n, main_st);
   hipEvent_t ev = c->ev[c->next];
@@ -244,7 +228,7 @@ static int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
   c->used = true;
   return run_wgrads(ps, n, c->stream);
 }
-static int side_join(hipStream_t main_st) {
+int side_join(hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c || !c->used) return PS_OK;
   PS_CHECK_HIP(hipEventRecord(c->join, c->stream));
@@ -253,33 +237,9 @@ static int side_join(hipStream_t main_st) {
   return PS_OK;
 }
 
-// -------------------------------------------------------------- encoder forward
-static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
-                          hipStream_t st) {
-  const bool tem = D.model == PS_MODEL_TEM;
-  const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0;
-  const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
-  PS_REQUIRE(P.word_emb && P.product_emb && hist, "forward: null embedding table");
-  EmbedArgs e;
-  memset(&e, 0, sizeof(e));
-  e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size;
-  e.tem = tem; e.fs = D.query_encoder == PS_QENC_FS; e.use_pos = D.use_pos_emb;
-  e.qw = Bt.query_word_idxs; e.ui = Bt.u_item_idxs;
-  e.word_emb = P.word_emb; e.hist_tab = hist; e.pe = P.pe;
-  e.drop_fs = make_drop(D, PS_SITE_FS);
-  e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
-  PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
-  PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
-  TRY(launch_embed_fwd(e, st));
-  if (e.fs) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
-    PS_REQUIRE(P.fs_w && P.fs_b, "forward: null FS encoder weights");
-    GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
-    p.bias = P.fs_b; p.act = ACT_TANH;
-    if (tem) { p.out2 = ws + w.x; p.ld2 = S * d; p.add2 = D.use_pos_emb ? P.pe : nullptr; }
-    TRY(run1(p, st));
-  }
-  if (!tem) return PS_OK;
-
+int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
+                       const Ws& w, hipStream_t st) {
+  const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
   const float qscale = 1.f / sqrtf((float)(d / (D.H > 0 ? D.H : 1)));
   bool fused_final = false;
   for (int i = 0; i < NL; ++i) {
@@ -309,7 +269,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
-    a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = Bt.u_item_idxs;
+    a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = ui; a.valid = valid;
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
     attn_finish(a);
@@ -363,6 +323,36 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   }
   TRY(launch_ln_fwd(f, st));
   return PS_OK;
+}
+
+// -------------------------------------------------------------- encoder forward
+static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
+                          hipStream_t st) {
+  const bool tem = D.model == PS_MODEL_TEM;
+  const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0;
+  const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
+  PS_REQUIRE(P.word_emb && P.product_emb && hist, "forward: null embedding table");
+  EmbedArgs e;
+  memset(&e, 0, sizeof(e));
+  e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size;
+  e.tem = tem; e.fs = D.query_encoder == PS_QENC_FS; e.use_pos = D.use_pos_emb;
+  e.qw = Bt.query_word_idxs; e.ui = Bt.u_item_idxs;
+  e.word_emb = P.word_emb; e.hist_tab = hist; e.pe = P.pe;
+  e.drop_fs = make_drop(D, PS_SITE_FS);
+  e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
+  PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
+  PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
+  TRY(launch_embed_fwd(e, st));
+  if (e.fs) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
+    PS_REQUIRE(P.fs_w && P.fs_b, "forward: null FS encoder weights");
+    GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
+    p.bias = P.fs_b; p.act = ACT_TANH;
+    if (tem) { p.out2 = ws + w.x; p.ld2 = S * d; p.add2 = D.use_pos_emb ? P.pe : nullptr; }
+    TRY(run1(p, st));
+  }
+  if (!tem) return PS_OK;
+
+  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st);
 }
 
 static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
@@ -429,6 +419,122 @@ extern "C" int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, c
   return PS_OK;
 }
 
+int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
+                        const float* valid, float* ws, const Ws& w, hipStream_t st) {
+  const bool drop = D.training && D.dropout > 0.f;
+  const int B = D.B, d = D.d, S = w.S, NL = D.n_layers, F = D.F;
+  PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
+  // 2. final LayerNorm backward
+  LnBwdArgs f;
+  memset(&f, 0, sizeof(f));
+  f.dy = ws + w.denc; f.lddy = d; f.stats = ws + w.fin_stats; f.g = P.final_ln_g; f.d = d;
+  f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
+  if (NL > 0) {
+    const LayerWs& l = w.layer[NL - 1];
+    f.x = ws + l.y2; f.ldx = d; f.rows = w.Mf; f.dx = ws + w.dy2; f.lddx = d;
+    f.colsum = G.layer[NL - 1].b2;
+    if (drop) { f.out2 = ws + w.do2; f.drop2 = make_drop(D, PS_SITE_FF2(NL - 1)); }
+    TRY(launch_ln_bwd(f, st));
+  } else {
+    PS_CHECK_HIP(hipMemsetAsync(ws + w.dx, 0, sizeof(float) * (size_t)B * S * d, st));
+    f.x = ws + w.x + (size_t)w.qpos * d; f.ldx = S * d; f.rows = B;
+    f.dx = ws + w.dx + (size_t)w.qpos * d; f.lddx = S * d;
+    TRY(launch_ln_bwd(f, st));
+  }
+  // 3. layers, last to first
+  for (int i = NL - 1; i >= 0; --i) {
+    const LayerWs& l = w.layer[i];
+    const PsLayerTensors& Lp = P.layer[i];
+    const PsLayerTensors& Lg = G.layer[i];
+    PS_REQUIRE(Lg.wk && Lg.wv && Lg.wq && Lg.wo && Lg.w1 && Lg.w2 && Lg.bk && Lg.bv && Lg.bq && Lg.bo && Lg.b1 &&
+               Lg.b2 && Lg.ff_ln_g && Lg.ff_ln_b, "backward: layer %d has null gradients", i);
+    const float* xin = i == 0 ? ws + w.x : ws + w.layer[i - 1].y2;
+    const float* xn = ws + l.xn;
+    const int ns = l.n_in * S, M2 = l.M2;
+    const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
+    // FFN backward
+    {
+      GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
+      p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
+      TRY(run1(p, st));
+      GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};    // dW2 += do2^T . h1
+      TRY(side_wgrads(wg, 1, st));
+      GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
+      TRY(run1(q, st));
+      GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
+      TRY(side_wgrads(wg1, 1, st));
+      LnBwdArgs n;
+      memset(&n, 0, sizeof(n));
+      n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
+      n.rows = M2; n.d = d;
+      n.res.mode = RES_DIRECT; n.res.ptr = ws + w.dy2; n.res.ld = d;            // residual  output + x
+      n.dx = ws + w.dy1; n.lddx = d;
+      if (drop) { n.out2 = ws + w.do_; n.drop2 = make_drop(D, PS_SITE_CTX(i)); }
+      n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
+      TRY(launch_ln_bwd(n, st));
+    }
+    const float* dout = drop ? ws + w.do_ : ws + w.dy1;
+    // attention backward
+    {
+      GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
+      TRY(run1(p, st));
+      GemmProblem wg[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
+      TRY(side_wgrads(wg, 1, st));
+      AttnArgs a;
+      memset(&a, 0, sizeof(a));
+      a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
+      a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = ui; a.valid = valid;
+      a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn;
+      a.drop = make_drop(D, PS_SITE_ATTN(i));
+      a.dctx = ws + w.dctx;
+      const bool qall = l.Sq == S;
+      a.lddkv = qall ? 3 * d : 2 * d;
+      a.dkv = ws + w.dkv;
+      a.dq = qall ? ws + w.dkv + 2 * d : ws + w.dq;
+      a.lddq = qall ? 3 * d : d;
+      a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
+      a.qscale = 1.f / sqrtf((float)(d / D.H));
+      attn_finish(a);
+      TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
+      // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
+      float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
+      GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);
+      x.kseg = d; x.Bseg[1] = Lp.wv; x.Bseg[2] = Lp.wq;
+      if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
+        x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
+        x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
+      }
+      TRY(run1(x, st));
+      if (!qall) {
+        GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
+        xq.accumulate = 1;
+        TRY(run1(xq, st));
+      }
+      GemmProblem wg3[3];
+      wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
+      wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
+      if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
+      else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
+      TRY(side_wgrads(wg3, 3, st));
+    }
+    if (i != 0) {   // pre-LayerNorm backward -> grad wrt the previous layer's output
+      TRY(side_join(st));   // the next layer reuses the scratch buffers the side-stream GEMMs read
+      PS_REQUIRE(Lg.ln_g && Lg.ln_b, "backward: layer %d null pre-LN gradient", i);
+      LnBwdArgs n;
+      memset(&n, 0, sizeof(n));
+      n.dy = ws + w.dxn; n.lddy = d; n.x = xin; n.ldx = d; n.stats = ws + l.pre_stats; n.g = Lp.ln_g;
+      n.rows = ns; n.d = d;
+      n.res.mode = RES_FANIN; n.res.ptr = ws + w.dy1; n.res.ld = d; n.res.Sq = l.Sq; n.res.fan = l.fan;
+      n.res.S = S; n.res.qpos = w.qpos; res_finish(n.res);
+      n.dx = ws + w.dy2; n.lddx = d;
+      if (drop) { n.out2 = ws + w.do2; n.drop2 = make_drop(D, PS_SITE_FF2(i - 1)); }
+      n.colsum = G.layer[i - 1].b2; n.dgamma = Lg.ln_g; n.dbeta = Lg.ln_b;
+      TRY(launch_ln_bwd(n, st));
+    }
+  }
+  return PS_OK;
+}
+
 // --------------------------------------------------------------------- backward
 extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
                                float* ws, const PsTemTensors* grads, float loss_scale, const float* loss_scale_dev,
@@ -460,115 +566,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
   int lddqe = d;
   if (tem) {
-    PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
-    // 2. final LayerNorm backward
-    LnBwdArgs f;
-    memset(&f, 0, sizeof(f));
-    f.dy = ws + w.denc; f.lddy = d; f.stats = ws + w.fin_stats; f.g = P.final_ln_g; f.d = d;
-    f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
-    if (NL > 0) {
-      const LayerWs& l = w.layer[NL - 1];
-      f.x = ws + l.y2; f.ldx = d; f.rows = w.Mf; f.dx = ws + w.dy2; f.lddx = d;
-      f.colsum = G.layer[NL - 1].b2;
-      if (drop) { f.out2 = ws + w.do2; f.drop2 = make_drop(D, PS_SITE_FF2(NL - 1)); }
-      TRY(launch_ln_bwd(f, st));
-    } else {
-      PS_CHECK_HIP(hipMemsetAsync(ws + w.dx, 0, sizeof(float) * (size_t)B * S * d, st));
-      f.x = ws + w.x + (size_t)w.qpos * d; f.ldx = S * d; f.rows = B;
-      f.dx = ws + w.dx + (size_t)w.qpos * d; f.lddx = S * d;
-      TRY(launch_ln_bwd(f, st));
-    }
-    // 3. layers, last to first
-    for (int i = NL - 1; i >= 0; --i) {
-      const LayerWs& l = w.layer[i];
-      const PsLayerTensors& Lp = P.layer[i];
-      const PsLayerTensors& Lg = G.layer[i];
-      PS_REQUIRE(Lg.wk && Lg.wv && Lg.wq && Lg.wo && Lg.w1 && Lg.w2 && Lg.bk && Lg.bv && Lg.bq && Lg.bo && Lg.b1 &&
-                 Lg.b2 && Lg.ff_ln_g && Lg.ff_ln_b, "backward: layer %d has null gradients", i);
-      const float* xin = i == 0 ? ws + w.x : ws + w.layer[i - 1].y2;
-      const float* xn = ws + l.xn;
-      const int ns = l.n_in * S, M2 = l.M2;
-      const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
-      // FFN backward
-      {
-        GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
-        p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
-        TRY(run1(p, st));
-        GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};    // dW2 += do2^T . h1
-        TRY(side_wgrads(wg, 1, st));
-        GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
-        TRY(run1(q, st));
-        GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
-        TRY(side_wgrads(wg1, 1, st));
-        LnBwdArgs n;
-        memset(&n, 0, sizeof(n));
-        n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
-        n.rows = M2; n.d = d;
-        n.res.mode = RES_DIRECT; n.res.ptr = ws + w.dy2; n.res.ld = d;            // residual  output + x
-        n.dx = ws + w.dy1; n.lddx = d;
-        if (drop) { n.out2 = ws + w.do_; n.drop2 = make_drop(D, PS_SITE_CTX(i)); }
-        n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
-        TRY(launch_ln_bwd(n, st));
-      }
-      const float* dout = drop ? ws + w.do_ : ws + w.dy1;
-      // attention backward
-      {
-        GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
-        TRY(run1(p, st));
-        GemmProblem wg[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
-        TRY(side_wgrads(wg, 1, st));
-        AttnArgs a;
-        memset(&a, 0, sizeof(a));
-        a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
-        a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = batch->u_item_idxs;
-        a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn;
-        a.drop = make_drop(D, PS_SITE_ATTN(i));
-        a.dctx = ws + w.dctx;
-        const bool qall = l.Sq == S;
-        a.lddkv = qall ? 3 * d : 2 * d;
-        a.dkv = ws + w.dkv;
-        a.dq = qall ? ws + w.dkv + 2 * d : ws + w.dq;
-        a.lddq = qall ? 3 * d : d;
-        a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
-        a.qscale = 1.f / sqrtf((float)(d / D.H));
-        attn_finish(a);
-        TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
-        // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
-        float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
-        GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);
-        x.kseg = d; x.Bseg[1] = Lp.wv; x.Bseg[2] = Lp.wq;
-        if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
-          x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
-          x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
-        }
-        TRY(run1(x, st));
-        if (!qall) {
-          GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
-          xq.accumulate = 1;
-          TRY(run1(xq, st));
-        }
-        GemmProblem wg3[3];
-        wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
-        wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
-        if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
-        else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
-        TRY(side_wgrads(wg3, 3, st));
-      }
-      if (i != 0) {   // pre-LayerNorm backward -> grad wrt the previous layer's output
-        TRY(side_join(st));   // the next layer reuses the scratch buffers the side-stream GEMMs read
-        PS_REQUIRE(Lg.ln_g && Lg.ln_b, "backward: layer %d null pre-LN gradient", i);
-        LnBwdArgs n;
-        memset(&n, 0, sizeof(n));
-        n.dy = ws + w.dxn; n.lddy = d; n.x = xin; n.ldx = d; n.stats = ws + l.pre_stats; n.g = Lp.ln_g;
-        n.rows = ns; n.d = d;
-        n.res.mode = RES_FANIN; n.res.ptr = ws + w.dy1; n.res.ld = d; n.res.Sq = l.Sq; n.res.fan = l.fan;
-        n.res.S = S; n.res.qpos = w.qpos; res_finish(n.res);
-        n.dx = ws + w.dy2; n.lddx = d;
-        if (drop) { n.out2 = ws + w.do2; n.drop2 = make_drop(D, PS_SITE_FF2(i - 1)); }
-        n.colsum = G.layer[i - 1].b2; n.dgamma = Lg.ln_g; n.dbeta = Lg.ln_b;
-        TRY(launch_ln_bwd(n, st));
-      }
-    }
+    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st));
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }

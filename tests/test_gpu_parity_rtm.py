@@ -1,0 +1,103 @@
+"""GPU parity of the RTM path (ProductRanker through the ps_rtm_* C ABI) against the golden vectors
+the reference's ProductRanker produced (tests/golden/rtm_*.npz) — loss, logits, gradients,
+post-Adam parameters, eval scores; dropout / token-corruption cases use the shared Philox masks."""
+import pytest
+import torch
+
+from golden_util import rel_err
+from golden_util_rtm import RTM_CASES, RtmGolden
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL, GRAD_TOL = 1e-4, 5e-4
+
+
+def _model(g, training=True):
+    from prodsearch_amd.ps_model import ProductRanker
+    torch.manual_seed(0)
+    m = ProductRanker(g.args, 'cuda', g.V, g.RC, 50, 40, g.review_words, None, word_dists=g.word_dists)
+    sd = g.params()
+    missing = m.load_state_dict(sd, strict=False)
+    real_missing = [k for k in missing.missing_keys
+                    if not (k.endswith('pos_emb.pe') or k.startswith('review_encoder.word_embeddings')
+                            or k.startswith('review_encoder.context_embeddings'))]
+    assert real_missing == [], real_missing
+    m.train(training)
+    return m
+
+
+def _neg(g, step):
+    nw = g.neg_words(step)
+    return None if nw is None else nw.cuda()
+
+
+@pytest.mark.parametrize('case', RTM_CASES)
+def test_rtm_state_dict_keys(case):
+    g = RtmGolden(case)
+    m = _model(g)
+    assert list(m.state_dict().keys()) == g.meta['state_dict_keys']
+    assert [n for n, _ in m.named_parameters()] == g.meta['param_names']
+
+
+@pytest.mark.parametrize('case', RTM_CASES)
+def test_rtm_forward_matches_reference(case):
+    from oracle import rtm as ortm
+    g = RtmGolden(case)
+    m = _model(g)
+    with torch.no_grad():
+        loss = m(g.batch().to('cuda'), train_pv=g.train_pv, neg_word_idxs=_neg(g, 0))
+    assert rel_err(loss.cpu(), g.tensor('loss_0')) < LOSS_TOL
+    # stage check against the oracle: product logits and PV logits straight from the workspace
+    plan = next(iter(m._plans.values()))
+    gen = g.dropout(0)
+    drop = gen if (gen is not None and g.args.dropout > 0) else None
+    tok = gen.tok if (gen is not None and gen.corrupt_rate > 0) else None
+    keep = {}
+    with torch.no_grad():
+        ortm.rtm_forward(g.params(), g.args, g.batch(), g.neg_words(0), g.V, g.RC, training=True,
+                         train_pv=g.train_pv, drop=drop, tok_drop=tok, keep=keep)
+    assert rel_err(keep['scores'], g.tensor('prod_scores')) < 1e-4
+
+
+@pytest.mark.parametrize('case', RTM_CASES)
+def test_rtm_gradients_and_steps(case):
+    from prodsearch_amd import build_optim
+    g = RtmGolden(case)
+    m = _model(g)
+    init = {k: v.clone() for k, v in g.params().items()}
+    optim = build_optim(g.args, m, None)
+    b = g.batch().to('cuda')
+    for step in range(g.steps):
+        loss = m(b, train_pv=g.train_pv, neg_word_idxs=_neg(g, step))
+        m.zero_grad()
+        loss.backward()
+        if step == 0:
+            torch.cuda.synchronize()
+            none = sorted(n for n, p in m.named_parameters() if p.grad is None)
+            assert none == sorted(g.meta['none_grads'])
+            for n, p in m.named_parameters():
+                if p.grad is None or n.endswith('linear_keys.bias'):
+                    continue
+                assert rel_err(p.grad.cpu(), g.tensor('grad_' + n)) < GRAD_TOL, n
+        optim.step()
+        assert rel_err(loss.detach().cpu(), g.tensor('loss_%d' % step)) < 2 * LOSS_TOL, step
+    last = g.steps - 1
+    sd = m.state_dict()
+    for n, _ in m.named_parameters():
+        if n.endswith('linear_keys.bias'):
+            continue
+        ref = g.tensor('param%d_%s' % (last, n), base=init[n])
+        got = sd[n].cpu()
+        assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 0.02 * g.args.lr * g.steps, n
+
+
+@pytest.mark.parametrize('case', RTM_CASES)
+def test_rtm_eval_scores(case):
+    g = RtmGolden(case)
+    m = _model(g, training=False)
+    with torch.no_grad():
+        m.get_review_embeddings()
+        assert abs(float(m.review_embeddings.double().sum().cpu()) - float(g.z['test_review_embeddings_sum'])) < 1e-2
+        s = m.test(g.test_batch().to('cuda')).cpu()
+    m.clear_review_embbeddings()
+    assert rel_err(s, g.tensor('test_scores')) < LOSS_TOL
