@@ -10,6 +10,8 @@
 // processed in chunks of JC so that the Philox masks are generated once per element.
 #include "rowwise.h"
 
+#define SQ1_LDS_MAX (128 * 1024)   // dynamic LDS these kernels may request (160 KB per CU on gfx950)
+
 // replicas are processed JC at a time (all of them when the LDS budget allows: one global round trip)
 static inline int sq1_pick_jc(int S, int d, int H, int fan);
 #define KLD(d) ((d) + 1)     // K/V rows are padded by one float in LDS: threads that walk over keys s at a
@@ -144,19 +146,25 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
 
 static inline int sq1_pick_jc(int S, int d, int H, int fan) {
   int jc = fan < 24 ? fan : 24;
-  while (jc > 1 && sq1_lds_bytes(S, d, H, true, jc) > 64 * 1024) jc = (jc + 1) / 2;
+  while (jc > 1 && sq1_lds_bytes(S, d, H, true, jc) > SQ1_LDS_MAX) jc = (jc + 1) / 2;
   return jc;
 }
 bool attn_sq1_fits(const AttnArgs& a) {
-  return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true, 1) <= 64 * 1024;
+  return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true, 1) <= SQ1_LDS_MAX;
 }
 
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
   AttnArgs b = a;
   b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
   size_t lds = sq1_lds_bytes(a.S, a.d, a.H, false, b.jc);
-  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention(sq1): S=%d d=%d needs %zu B LDS",
+  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= SQ1_LDS_MAX, "attention(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
+  static bool attr_f = false;
+  if (!attr_f) {
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_sq1_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SQ1_LDS_MAX));
+    attr_f = true;
+  }
   hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
@@ -238,8 +246,14 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
   AttnArgs b = a;
   b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
   size_t lds = sq1_lds_bytes(a.S, a.d, a.H, true, b.jc);
-  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= 64 * 1024, "attention bwd(sq1): S=%d d=%d needs %zu B LDS",
+  PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= SQ1_LDS_MAX, "attention bwd(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
+  static bool attr_b = false;
+  if (!attr_b) {
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_sq1_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SQ1_LDS_MAX));
+    attr_b = true;
+  }
   hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -24,7 +24,7 @@
 
 struct RtmWs {
   int Bseq, S, J;
-  int64_t qmean, query_emb, valid, vec, cnt, scores, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
+  int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
   int64_t enc_base;         // the shared encoder workspace (Ws) starts here
   int64_t total;
 };
@@ -41,7 +41,7 @@ struct RtmK {              // kernel-side view of one call
   // tensors
   const float *word_emb, *table, *seg_emb, *pe, *wo_w, *wo_b;
   // workspace
-  float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *pv_scores, *pv_terms, *nvalid;
+  float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *weight, *pv_scores, *pv_terms, *nvalid;
   float* loss3;
   // backward
   float scale; const float* scale_dev;
@@ -87,6 +87,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.vec = rtake(cur, (int64_t)D.B * D.R * d);
   r.cnt = rtake(cur, (int64_t)r.Bseq * D.R);
   r.scores = rtake(cur, r.Bseq);
+  r.weight = rtake(cur, r.Bseq);
   const int64_t npv = (int64_t)D.B * D.R * (D.W > 0 ? D.W : 1) * (D.K + 1);
   r.pv_scores = rtake(cur, npv);
   r.pv_terms = rtake(cur, npv);
@@ -142,15 +143,17 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
   const int64_t rpad = a.RC - 1;
   const bool ok = s == 0 || ridx != rpad;
   if (lane == 0) a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f;
-  for (int cc = c; cc < nch; cc += 32) {
+  for (int cc0 = 0; cc0 < nch; cc0 += 32) {          // wave-uniform trip count: the shuffles below need every lane
+    const int cc = cc0 + c;
+    const bool act = cc < nch;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f), vcor = v;
     float cnt = 1.f;
     if (s == 0) {
-      if (half == 0) v = *reinterpret_cast<const float4*>(a.query_emb + (size_t)b * d + 4 * cc);
+      if (half == 0 && act) v = *reinterpret_cast<const float4*>(a.query_emb + (size_t)b * d + 4 * cc);
     } else if (ok) {
       const int r = s - 1;
       if (!a.pvc) {
-        if (half == 0) v = *reinterpret_cast<const float4*>(a.table + (size_t)rclamp(ridx, rpad) * d + 4 * cc);
+        if (half == 0 && act) v = *reinterpret_cast<const float4*>(a.table + (size_t)rclamp(ridx, rpad) * d + 4 * cc);
         vcor = v;
       } else {
         // masked mean of the review's word rows; corrupted and (positive, train_pv) uncorrupted sums
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
         if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + r) * a.WL;
         else words = ((a.train_pv || a.eval) ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
         const DropSpec& ts = pos ? a.t_pos : a.t_neg;
+        // one Philox evaluation per (review, word slot): lane l owns slots l and l+64, the loop reads them by shuffle
+        const float tm0 = drop_mult(ts, (uint32_t)revrow, (uint32_t)lane);
+        const float tm1 = a.WL > 64 ? drop_mult(ts, (uint32_t)revrow, (uint32_t)(lane + 64)) : 1.f;
         int nw = 0;
         for (int w0 = 0; w0 < a.WL; w0 += 8) {                 // 8 word rows in flight per wave
           float4 rowv[4]; float mt[4];
@@ -166,9 +172,11 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
             const int w = w0 + 2 * u + half;
             int64_t wi = w < a.WL ? words[w] : a.V - 1;
             rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f); mt[u] = 0.f;
+            const float tmw = w < 64 ? __shfl(tm0, w & 63, 64) : (w < 128 ? __shfl(tm1, (w - 64) & 63, 64)
+                                                                          : drop_mult(ts, (uint32_t)revrow, (uint32_t)w));
             if (wi != a.V - 1 && wi >= 0 && wi < a.V) {
-              rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
-              mt[u] = drop_mult(ts, (uint32_t)revrow, (uint32_t)w);
+              if (act) rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
+              mt[u] = tmw;
               ++nw;
             }
           }
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
     v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
     vcor.x += __shfl_xor(vcor.x, 32, 64); vcor.y += __shfl_xor(vcor.y, 32, 64);
     vcor.z += __shfl_xor(vcor.z, 32, 64); vcor.w += __shfl_xor(vcor.w, 32, 64);
-    if (half != 0) continue;
+    if (half != 0 || !act) continue;
     float o[4];
     if (s == 0) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
     else {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
       float unc[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
       float cor[4] = {vcor.x * inv, vcor.y * inv, vcor.z * inv, vcor.w * inv};
       const int rr = s - 1;
-      if (a.pvc && lane == 0 && cc == 0) a.cnt[(size_t)n * a.R + rr] = cnt;
+      if (a.pvc && lane == 0 && cc0 == 0) a.cnt[(size_t)n * a.R + rr] = cnt;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t col = (uint32_t)(4 * cc + e);
@@ -233,6 +241,8 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
 }
 
 // ------------------------------------------------------------------ scores
+// also writes the loss weight of the sequence (ps_model.py:344-345): pos_weight for the positive, and for a
+// negative 1 iff it has at least one real review
 __global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out) {
   const int lane = threadIdx.x & 63;
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -241,6 +251,17 @@ __global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out
   for (int e = lane; e < a.d; e += 64) s += a.enc[(size_t)n * a.d + e] * a.wo_w[e];
   s = wave_sum(s);
   if (lane == 0) out[n] = s + a.wo_b[0];
+  if (!a.eval) {
+    const int b = fdiv(n, a.fJ), j = n - b * a.J;
+    float wgt;
+    if (j == 0) wgt = a.pos_weight ? (float)a.K : 1.f;
+    else {
+      bool any = false;
+      for (int r = lane; r < a.R; r += 64) any = any || (a.neg_r[((size_t)b * a.K + j - 1) * a.R + r] != a.RC - 1);
+      wgt = __ballot(any) != 0ull ? 1.f : 0.f;
+    }
+    if (lane == 0) a.weight[n] = wgt;
+  }
 }
 
 // PV logits: task t = ((b*R + r)*W + w)*(1+K) + j
@@ -297,12 +318,9 @@ __global__ __launch_bounds__(256) void rtm_loss_kernel(const RtmK a) {
   float ps = 0.f, pv = 0.f, nv = 0.f;
   for (int b = tid; b < a.B; b += 256) {
     const float* sc = a.scores + (size_t)b * K1;
-    ps += (a.pos_weight ? (float)a.K : 1.f) * softplus_f(-sc[0]);
-    for (int k = 0; k < a.K; ++k) {
-      bool any = false;
-      for (int r = 0; r < a.R; ++r) any = any || (a.neg_r[((size_t)b * a.K + k) * a.R + r] != a.RC - 1);
-      if (any) ps += softplus_f(sc[1 + k]);
-    }
+    const float* wg = a.weight + (size_t)b * K1;
+    ps += wg[0] * softplus_f(-sc[0]);
+    for (int k = 0; k < a.K; ++k) ps += wg[1 + k] * softplus_f(sc[1 + k]);
   }
   if (a.train_pv) {
     for (int rev = tid; rev < a.B * a.R; rev += 256) {
@@ -342,13 +360,7 @@ __global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a) {
   const int nw = gridDim.x * 4;
   for (int n = blockIdx.x * 4 + wv; n < a.B * K1; n += nw) {
     const int b = fdiv(n, a.fK1), j = n - b * K1;
-    float wgt;
-    if (j == 0) wgt = a.pos_weight ? (float)a.K : 1.f;
-    else {
-      bool any = false;
-      for (int r = 0; r < a.R; ++r) any = any || (a.neg_r[((size_t)b * a.K + j - 1) * a.R + r] != a.RC - 1);
-      wgt = any ? 1.f : 0.f;
-    }
+    const float wgt = a.weight[n];
     const float s = a.scores[n];
     const float ds = wgt * (sigmoid_f(s) - (j == 0 ? 1.f : 0.f)) * sc;
     for (int e = lane; e < a.d; e += 64) {
@@ -519,7 +531,7 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   k.word_emb = P.word_emb; k.seg_emb = P.seg_emb; k.pe = P.pe; k.wo_w = P.wo_w; k.wo_b = P.wo_b;
   float* we = ws + r.enc_base;
   k.query_emb = ws + r.query_emb; k.x = we + w.x; k.valid = ws + r.valid; k.vec = ws + r.vec; k.cnt = ws + r.cnt;
-  k.enc = we + w.enc; k.scores = ws + r.scores; k.pv_scores = ws + r.pv_scores; k.pv_terms = ws + r.pv_terms;
+  k.enc = we + w.enc; k.scores = ws + r.scores; k.weight = ws + r.weight; k.pv_scores = ws + r.pv_scores; k.pv_terms = ws + r.pv_terms;
   k.nvalid = ws + r.nvalid;
   k.dx = we + w.dx; k.denc = we + w.denc; k.dvec = ws + r.dvec; k.dqe = ws + r.dqe;
 }
