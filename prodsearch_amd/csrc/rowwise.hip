@@ -5,6 +5,7 @@
 // fp32 work: rows are read with 16-byte lanes (coalesced 128 B..1 KiB per row),
 // reductions are wavefront shuffles, nothing here is reshaped into a GEMM.
 #include "rowwise.h"
+#include <stdlib.h>
 
 static inline int lpr_for(int d) {   // lanes per row for float4 lanes: pow2 >= d/4, <= 64
   int n = d / 4, l = 1;
@@ -459,7 +460,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
   return k;
 }
 
-#define SCORE_U 4
+template <int SCORE_U, int NT>
 __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int ntask, int lpr) {
   const int tid = threadIdx.x;
   const int gpb = 256 / lpr;                       // row groups per block
@@ -480,8 +481,15 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     v[u] = r[u];
     if (tk[u].row && c < nch) {
-      r[u] = *reinterpret_cast<const float4*>(tk[u].row + 4 * c);
-      v[u] = *reinterpret_cast<const float4*>(tk[u].vec + 4 * c);
+      const float4* rp = reinterpret_cast<const float4*>(tk[u].row + 4 * c);
+      const float4* vp = reinterpret_cast<const float4*>(tk[u].vec + 4 * c);
+      if (NT) {
+        typedef float nf4 __attribute__((ext_vector_type(4)));
+        nf4 a4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(rp));
+        nf4 b4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(vp));
+        r[u] = make_float4(a4.x, a4.y, a4.z, a4.w); v[u] = make_float4(b4.x, b4.y, b4.z, b4.w);
+      }
+      else { r[u] = *rp; v[u] = *vp; }
     }
   }
 #pragma unroll
@@ -507,9 +515,21 @@ int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
   int lpr = lpr_for(a.d);
-  int groups = ps_cdiv(ntask, SCORE_U);
+  // rows in flight per row group: measured on MI355X (profiles/r01_gather_score_tuning.txt) the latency-bound C2
+  // launch (12.8 MB) is fastest with ONE task per group (most waves), the HBM-bound C5 shape with two.
+  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;     // tuning experiments
+  static const int NT = getenv("PS_SCORE_NT") ? atoi(getenv("PS_SCORE_NT")) : 0;
+  const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
+  int groups = ps_cdiv(ntask, U);
   int blocks = ps_cdiv(groups, 256 / lpr);
-  hipLaunchKernelGGL(score_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
+  dim3 g(blocks), b(256);
+  if (U == 1) hipLaunchKernelGGL((score_fwd_kernel<1, 0>), g, b, 0, st, a, ntask, lpr);
+  else if (U == 2 && !NT) hipLaunchKernelGGL((score_fwd_kernel<2, 0>), g, b, 0, st, a, ntask, lpr);
+  else if (U == 8 && !NT) hipLaunchKernelGGL((score_fwd_kernel<8, 0>), g, b, 0, st, a, ntask, lpr);
+  else if (U == 2) hipLaunchKernelGGL((score_fwd_kernel<2, 1>), g, b, 0, st, a, ntask, lpr);
+  else if (U == 8) hipLaunchKernelGGL((score_fwd_kernel<8, 1>), g, b, 0, st, a, ntask, lpr);
+  else if (NT) hipLaunchKernelGGL((score_fwd_kernel<4, 1>), g, b, 0, st, a, ntask, lpr);
+  else hipLaunchKernelGGL((score_fwd_kernel<4, 0>), g, b, 0, st, a, ntask, lpr);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
