@@ -135,6 +135,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     ns = readme_tem_args(dropout=a.dropout)

@@ -26,9 +26,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('PS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            # one process per GPU; the modulo only matters for single-GPU dry runs of the N>1 path (gloo)
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
