@@ -31,6 +31,10 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 P_ITEMS, V_WORDS = 18357, 32387
 B, K, L, Q, W, D = 384, 20, 20, 8, 1, 128
+FF = 512
+# --workload c5: one GPU's shard of BASELINE configs[4] (50 M-item table, d=256, bs=1024/GPU);
+# 51 GB table + dense gradient + Adam moments = 205 GB of HBM, row-sparse optimizer (dense Adam would stream 1.4 TB)
+C5 = dict(P_ITEMS=50_000_000, B=1024, D=256, FF=1024)
 
 
 def parse():
@@ -42,6 +46,11 @@ def parse():
     ap.add_argument('--cpu-steps', type=int, default=3, help='CPU-baseline sample (0 = skip)')
     ap.add_argument('--kernel-iters', type=int, default=300)
     ap.add_argument('--no-extras', action='store_true', help='skip roofline / cpu_baseline legs')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c5'],
+                    help='c2 = BASELINE configs[1] (the metric); c5 = per-GPU shard of configs[4]')
+    ap.add_argument('--items', type=int, default=0, help='override the catalogue size (c5 dry runs)')
+    ap.add_argument('--row-sparse', action='store_true',
+                    help='touched-rows-only zero/clip/Adam/exchange (args.row_sparse_adam); always on for c5')
     return ap.parse_args()
 
 
@@ -138,11 +147,16 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    ns = readme_tem_args(dropout=a.dropout)
+    if a.workload == 'c5':
+        globals().update(C5)
+        a.row_sparse = True
+    if a.items:
+        globals().update(P_ITEMS=a.items)
+    ns = readme_tem_args(dropout=a.dropout, embedding_size=D, ff_size=FF, row_sparse_adam=a.row_sparse)
     model, optim, wd = make_model(ns, 'cuda', seed=1234)
     model._seed = pdist.rank_seed(ns.seed, rank)
     pdist.broadcast_parameters(model)
-    exchange = pdist.GradExchange(lambda: model._grad_flat, optim)
+    exchange = pdist.make_exchange(model, optim)
     model.train()
     batches = [synth.make_tem_batch(1000 + 97 * rank + i, B, P_ITEMS, V_WORDS, Q=Q, L=L, W=W, word_dists=wd).to(dev)
                for i in range(8)]
@@ -171,13 +185,15 @@ def main():
     last_loss = float(loss.detach())
 
     out = {
-        "metric": "train (u,q,i,neg) tuples/sec at bs=384, 20 neg, d=128",
+        "metric": "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (B, D),
         "value": world * B * K * a.steps / elapsed, "unit": "tuples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "item_transformer d=128 1 layer 8 heads ff=512 uprev=20 bs=384/GPU 20 neg "
-                               "Q=8 W=1 P=18357 V=32387 dropout=%.2f (BASELINE configs[1])" % a.dropout,
+        "config": {"workload": "item_transformer d=%d 1 layer 8 heads ff=%d uprev=20 bs=%d/GPU 20 neg "
+                               "Q=8 W=1 P=%d V=32387 dropout=%.2f%s (BASELINE configs[%d])"
+                               % (D, FF, B, P_ITEMS, a.dropout, " row-sparse Adam" if a.row_sparse else "",
+                                  4 if a.workload == 'c5' else 1),
                    "global_batch": world * B, "parallelism": "dp%d" % world,
                    "step": "sample+fwd+bwd+%sclip/Adam via nn.Module API (trainer.py:74-78)"
                            % ("allreduce+" if world > 1 else ""),
@@ -191,14 +207,14 @@ def main():
         traffic = None          # PMC passes cannot run inside this process: taken from the committed profile
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'gather_score_traffic.json')))
-            traffic = tj.get('R%d_bytes_per_launch' % plan.layout.R)
+            traffic = tj.get('R%d_bytes_per_launch' % plan.layout.R) if a.workload == 'c2' else None
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "achieved": nbytes / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": nbytes / t_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "score_fwd_kernel (embedding gather + score)",
                            "bytes_per_launch": nbytes, "us_per_launch": t_k * 1e6}
-        if world == 1 and a.cpu_steps > 0:
+        if world == 1 and a.cpu_steps > 0 and a.workload == 'c2':
             out["cpu_baseline"] = cpu_baseline(ns, a.cpu_steps)
     if world > 1:
         torch.distributed.barrier()

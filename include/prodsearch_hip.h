@@ -184,6 +184,43 @@ int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper
 /* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
 int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);
 
+/* ------------------------------------------------------------------ row-sparse optimizer path
+ * For tables too large to stream every step (BASELINE configs[4]: 50 M x 256).  The gradient tensors
+ * stay dense, like nn.Embedding(sparse=False) gives the reference (item_transformer.py:46,70); the
+ * optimizer, the zeroing and the data-parallel exchange only visit the rows a step touched.
+ * Replaces: the table part of Optimizer.step (optimizers.py:241-243) and model.zero_grad (trainer.py:76).
+ * Semantics of untouched rows: p, m, v unchanged (torch.optim.SparseAdam's rule), NOT dense Adam's decay. */
+typedef struct PsIdxList { const int64_t* idx; int64_t n; } PsIdxList;   /* device pointer, element count */
+
+/* Sorted unique row ids (!= pad_row) over up to 8 index lists -> rows_out[0..*count).  ws = ps_coalesce_ws_bytes
+ * bytes, zeroed once by the caller and left zeroed by every call.  cap >= min(sum n, n_rows). */
+int64_t ps_coalesce_ws_bytes(int64_t n_rows);
+int ps_coalesce_rows(const PsIdxList* lists_host, int32_t n_lists, int64_t n_rows, int64_t pad_row, void* ws_dev,
+                     int64_t* rows_out_dev, int64_t cap, int32_t* count_out_dev, ps_stream_t stream);
+/* values[u,:] = table[rows[u],:] and the inverse, u < *count_dev (or < cap when count_dev is NULL); d % 4 == 0 */
+int ps_gather_rows(const float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev, int64_t cap,
+                   float* values_out_dev, ps_stream_t stream);
+int ps_scatter_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev, int64_t cap,
+                    const float* values_dev, ps_stream_t stream);
+int ps_zero_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev, int64_t cap,
+                 ps_stream_t stream);
+
+typedef struct PsRowTable {
+  float* p; float* g; float* m; float* v;   /* [n_rows, d] parameter, dense gradient, Adam moments */
+  const int64_t* rows;                      /* touched rows (device)                                 */
+  const int32_t* count;                     /* number of valid entries of rows (device)              */
+  int64_t cap;                              /* launch bound: *count <= cap                           */
+  int32_t d;
+  int32_t pad_;
+} PsRowTable;
+
+/* clip_grad_norm_ over (tensors of the dense plan + touched rows of the tables) then Adam on exactly those;
+ * touched gradient rows are zeroed in the same pass.  plan = ps_adam_plan_* over the small tensors.
+ * state_dev: 2 int64 {step, -} followed by ps_adam_rowsparse_state_floats() floats of scratch. */
+int64_t ps_adam_rowsparse_state_floats(int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables);
+int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
+                           const PsAdamHyper* hyper, int64_t* state_dev, float* gnorm_out_dev, ps_stream_t stream);
+
 /* ------------------------------------------------------------------ RTM (review_transformer)
  * ProductRanker (models/ps_model.py:53-370) with the pv (models/PV.py) / pvc (models/PVC.py) review
  * encoders.  Sequences are [query, R reviews]; K negatives per row (training) or C candidates (eval). */

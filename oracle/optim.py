@@ -31,9 +31,15 @@ class ClipAdam(object):
         self.state = {}       # name -> dict(step, m, v)
         self.last_total_norm = None
 
-    def step(self, P, grads):
+    def step(self, P, grads, touched=None):
         """In-place update of the tensors in ``P`` (name -> tensor) from ``grads``
-        (name -> tensor or None).  Returns the pre-clip global grad norm."""
+        (name -> tensor or None).  Returns the pre-clip global grad norm.
+
+        ``touched`` (name -> int64 row ids) selects the ROW-SPARSE rule for those tables (not the
+        reference's: ``torch.optim.SparseAdam`` semantics with the global step in the bias correction):
+        only the listed rows of p, m, v move; all other rows are left alone.  The clip norm is
+        unchanged — untouched rows have a zero gradient."""
+        touched = touched or {}
         self._step += 1
         if self.decay_method == 'noam':                      # optimizers.py:214-219
             self.learning_rate = self.original_lr * min(
@@ -56,13 +62,23 @@ class ClipAdam(object):
             st = self.state.setdefault(n, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
             st['step'] += 1
             t = st['step']
+            bc1 = 1 - b1 ** t
+            bc2 = 1 - b2 ** t
+            step_size = lr / bc1
+            if n in touched:
+                rows = torch.as_tensor(touched[n], dtype=torch.int64)
+                pr, gr, mr, vr = p[rows], g[rows], st['m'][rows], st['v'][rows]
+                if self.weight_decay != 0:
+                    gr = gr + self.weight_decay * pr
+                mr.lerp_(gr, 1 - b1)
+                vr.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+                pr.addcdiv_(mr, (vr.sqrt() / math.sqrt(bc2)).add_(self.eps), value=-step_size)
+                p[rows], st['m'][rows], st['v'][rows] = pr, mr, vr
+                continue
             if self.weight_decay != 0:
                 g = g + self.weight_decay * p
             st['m'].lerp_(g, 1 - b1)
             st['v'].mul_(b2).addcmul_(g, g, value=1 - b2)
-            bc1 = 1 - b1 ** t
-            bc2 = 1 - b2 ** t
-            step_size = lr / bc1
             denom = (st['v'].sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(st['m'], denom, value=-step_size)
         return self.last_total_norm

@@ -58,6 +58,16 @@ class PsAdamHyper(C.Structure):
                 ('warmup_steps', C.c_int32), ('grad_scale', C.c_float)]
 
 
+class PsIdxList(C.Structure):
+    _fields_ = [('idx', C.c_void_p), ('n', C.c_int64)]
+
+
+class PsRowTable(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p),
+                ('rows', C.c_void_p), ('count', C.c_void_p), ('cap', C.c_int64), ('d', C.c_int32),
+                ('pad_', C.c_int32)]
+
+
 class PsRtmDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('B', 'K', 'R', 'Q', 'W', 'WL', 'C', 'd', 'H', 'F', 'n_layers')] + \
                [('vocab_size', C.c_int64), ('review_count', C.c_int64)] + \
@@ -117,6 +127,15 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p]),
     'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
     'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_coalesce_ws_bytes': (C.c_int64, [C.c_int64]),
+    'ps_coalesce_rows': (C.c_int, [C.POINTER(PsIdxList), C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'ps_gather_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'ps_scatter_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'ps_zero_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_adam_rowsparse_state_floats': (C.c_int64, [C.c_int32, C.POINTER(PsRowTable), C.c_int32]),
+    'ps_clip_adam_rowsparse': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsRowTable), C.c_int32,
+                                         C.POINTER(PsAdamHyper), C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
                               C.c_void_p]),

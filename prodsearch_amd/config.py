@@ -11,6 +11,7 @@ from argparse import Namespace
 # reference main.py:26-137 defaults (hot-path flags only)
 _DEFAULTS = dict(
     seed=666,
+    row_sparse_adam=False,             # extension (no reference flag): touched-rows-only Adam/zero/exchange for huge tables
     train_from='',
     model_name='item_transformer',     # main.py:29 (default there is review_transformer)
     sep_prod_emb=False,                # main.py:31

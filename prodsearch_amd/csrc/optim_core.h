@@ -1,0 +1,117 @@
+// optim_core.h — pieces shared by the dense (optim.hip) and row-sparse (optim_rows.hip) clip+Adam.
+#pragma once
+#include "common.h"
+#include <math.h>
+
+#define ADAM_CHUNK 8192     // elements per block
+
+struct AdamPlanHeader {
+  int32_t n_tensors;
+  int32_t n_chunks;
+  int64_t off_p, off_g, off_m, off_v, off_numel, off_chunk0;   // byte offsets inside the plan
+};
+
+__device__ inline int find_tensor(const int32_t* chunk0, int n, int chunk) {
+  int lo = 0, hi = n;                 // chunk0[lo] <= chunk < chunk0[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (chunk0[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ inline float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+
+// Sum of (g*grad_scale)^2 over one ADAM_CHUNK of the plan (block-wide result).
+__device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad_scale, float* sh) {
+  const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
+  const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
+  const int t = find_tensor(chunk0, h->n_tensors, chunk);
+  const float* g = ((float* const*)(plan + h->off_g))[t];
+  const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
+  const int64_t beg = (int64_t)(chunk - chunk0[t]) * ADAM_CHUNK;
+  const int64_t end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+  float s = 0.f;
+  if ((((uintptr_t)g) & 15) == 0 && end - beg == ADAM_CHUNK) {
+    const float4* g4 = (const float4*)(g + beg);
+#pragma unroll
+    for (int i = 0; i < ADAM_CHUNK / 4 / 256; ++i) {
+      float4 x = g4[threadIdx.x + 256 * i];
+      x.x *= grad_scale; x.y *= grad_scale; x.z *= grad_scale; x.w *= grad_scale;
+      s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+  } else {
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) { float x = g[i] * grad_scale; s += x * x; }
+  }
+  return block_sum_256(s, sh);
+}
+
+// clip coefficient, bias-corrected step size, 1/sqrt(bias_correction2), lr -> out[0..3]; one thread.
+__device__ inline void adam_scalars(const PsAdamHyper& hp, float total_sumsq, int64_t step, float* out, float* norm_out) {
+  const float norm = sqrtf(total_sumsq);
+  float coef = 1.f;
+  if (hp.max_grad_norm > 0.f) coef = fminf(hp.max_grad_norm / (norm + 1e-6f), 1.f);
+  const double t = (double)step;
+  double lr = (double)hp.lr;
+  if (hp.noam) lr = (double)hp.lr * fmin(pow(t, -0.5), t * pow((double)hp.warmup_steps, -1.5));
+  const double bc1 = 1.0 - pow((double)hp.beta1, t);
+  const double bc2 = 1.0 - pow((double)hp.beta2, t);
+  out[0] = coef * hp.grad_scale;
+  out[1] = (float)(lr / bc1);
+  out[2] = (float)(1.0 / sqrt(bc2));
+  out[3] = (float)lr;
+  *norm_out = norm;
+}
+
+struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; };
+
+__device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& mm, float& vv) {
+  gg *= a.gmul;
+  if (a.wd != 0.f) gg += a.wd * pp;
+  mm = mm + (gg - mm) * (1.f - a.b1);           // exp_avg.lerp_(grad, 1-beta1)
+  vv = vv * a.b2 + ((1.f - a.b2) * gg) * gg;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  const float denom = sqrtf(vv) * a.inv_sbc2 + a.eps;
+  pp = pp - a.step_size * (mm / denom);         // param.addcdiv_(exp_avg, denom, -step_size)
+}
+
+// clip + Adam over one ADAM_CHUNK of the plan.
+__device__ inline void adam_update_chunk(const char* plan, int chunk, const AdamScal& a) {
+  const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
+  const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
+  const int t = find_tensor(chunk0, h->n_tensors, chunk);
+  float* p = ((float* const*)(plan + h->off_p))[t];
+  const float* g = ((float* const*)(plan + h->off_g))[t];
+  float* m = ((float* const*)(plan + h->off_m))[t];
+  float* v = ((float* const*)(plan + h->off_v))[t];
+  const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
+  const int64_t beg = (int64_t)(chunk - chunk0[t]) * ADAM_CHUNK;
+  const int64_t end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+  const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 &&
+                   end - beg == ADAM_CHUNK;
+  if (vec) {
+    float4* p4 = (float4*)(p + beg); const float4* g4 = (const float4*)(g + beg);
+    float4* m4 = (float4*)(m + beg); float4* v4 = (float4*)(v + beg);
+#pragma unroll 2
+    for (int i = 0; i < ADAM_CHUNK / 4 / 256; ++i) {
+      const int k = threadIdx.x + 256 * i;
+      float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+      adam_elem(a, pp.x, gg.x, mm.x, vv.x); adam_elem(a, pp.y, gg.y, mm.y, vv.y);
+      adam_elem(a, pp.z, gg.z, mm.z, vv.z); adam_elem(a, pp.w, gg.w, mm.w, vv.w);
+      p4[k] = pp; m4[k] = mm; v4[k] = vv;
+    }
+  } else {
+    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+      float pp = p[i], mm = m[i], vv = v[i];
+      adam_elem(a, pp, g[i], mm, vv);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+  }
+}

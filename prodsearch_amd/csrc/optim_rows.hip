@@ -1,0 +1,334 @@
+// optim_rows.hip — row-sparse path of the optimizer for tables too large to stream densely
+// (SURVEY.md §8b ps_coalesce_rows / ps_adam_rowsparse, §8d config 5: 50 M × 256 table).
+//
+// The embedding gradients stay DENSE tensors, as nn.Embedding(sparse=False) gives the reference
+// (models/item_transformer.py:46,70); what becomes sparse is who touches them:
+//   ps_coalesce_rows      sorted unique non-pad row ids of a step's index lists.  Bitmap of one bit per
+//                         table row (atomicOr), popcount per 256-word segment, ordered emit that also
+//                         clears the bitmap.  Deterministic, no sort, 3 launches, 6 MB of bitmap at 50 M rows.
+//   ps_gather_rows        values[u,:] = grad[rows[u],:]  (payload of the sparse gradient exchange)
+//   ps_scatter_rows       grad[rows[u],:] = values[u,:]  (merged gradient back into the dense tensor)
+//   ps_clip_adam_rowsparse  global-norm clip over (dense small tensors + touched rows) and Adam on exactly
+//                         those; touched gradient rows are re-zeroed in the same pass, so zero_grad never
+//                         streams the table.  Untouched rows keep p, m, v (the lazy "SparseAdam" rule;
+//                         dense Adam would keep decaying their moments — DESIGN.md §5b).
+#include "optim_core.h"
+
+#define CO_WORDS_PER_THREAD 1
+#define CO_WORDS_PER_BLOCK (256 * CO_WORDS_PER_THREAD)
+#define PS_MAX_IDX_LISTS 8
+
+struct IdxLists { PsIdxList l[PS_MAX_IDX_LISTS]; int32_t n; int64_t total; };
+
+__global__ __launch_bounds__(256) void co_mark_kernel(IdxLists L, int64_t n_rows, int64_t pad_row,
+                                                      unsigned long long* bitmap, int32_t* bad) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L.total) return;
+  int k = 0;
+  while (k < L.n - 1 && i >= L.l[k].n) { i -= L.l[k].n; ++k; }
+  const int64_t r = L.l[k].idx[i];
+  if (r == pad_row) return;
+  if (r < 0 || r >= n_rows) { *bad = 1; return; }
+  atomicOr(&bitmap[r >> 6], 1ull << (r & 63));
+}
+
+__global__ __launch_bounds__(256) void co_count_kernel(const unsigned long long* bitmap, int64_t n_words,
+                                                       int32_t* blocksum) {
+  __shared__ float shf[4];
+  (void)shf;
+  __shared__ int sh[4];
+  const int64_t w0 = (int64_t)blockIdx.x * CO_WORDS_PER_BLOCK + (int64_t)threadIdx.x * CO_WORDS_PER_THREAD;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < CO_WORDS_PER_THREAD; ++j)
+    if (w0 + j < n_words) c += __popcll(bitmap[w0 + j]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void co_emit_kernel(unsigned long long* bitmap, int64_t n_words,
+                                                      const int32_t* blocksum, int64_t* rows, int64_t cap,
+                                                      int32_t* count_out, int32_t* bad) {
+  __shared__ int sh[256];
+  __shared__ int base_sh;
+  // rows emitted by earlier blocks
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blocksum[i];
+  sh[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) base_sh = sh[0];
+  __syncthreads();
+  const int base = base_sh;
+  __syncthreads();
+  const int64_t w0 = (int64_t)blockIdx.x * CO_WORDS_PER_BLOCK + (int64_t)threadIdx.x * CO_WORDS_PER_THREAD;
+  unsigned long long w[CO_WORDS_PER_THREAD];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < CO_WORDS_PER_THREAD; ++j) {
+    w[j] = (w0 + j < n_words) ? bitmap[w0 + j] : 0ull;
+    c += __popcll(w[j]);
+  }
+  // exclusive scan of c over the block (Hillis-Steele in LDS)
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    int add = ((int)threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t pos = (int64_t)base + sh[threadIdx.x] - c;
+  if (c) {
+#pragma unroll
+    for (int j = 0; j < CO_WORDS_PER_THREAD; ++j) {
+      unsigned long long x = w[j];
+      while (x) {
+        const int b = __ffsll((long long)x) - 1;
+        x &= x - 1;
+        if (pos < cap) rows[pos] = (w0 + j) * 64 + b; else *bad = 2;
+        ++pos;
+      }
+      if (w[j]) bitmap[w0 + j] = 0ull;          // leave the bitmap clean for the next step
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *count_out = base + sh[255];
+}
+
+static inline int64_t co_words(int64_t n_rows) { return (n_rows + 63) / 64; }
+static inline int64_t co_blocks(int64_t n_rows) { return (co_words(n_rows) + CO_WORDS_PER_BLOCK - 1) / CO_WORDS_PER_BLOCK; }
+
+// workspace: bitmap words | blocksum int32[blocks] | bad flag int32 — zero it ONCE; calls leave it zeroed.
+extern "C" int64_t ps_coalesce_ws_bytes(int64_t n_rows) {
+  if (n_rows <= 0) return 0;
+  return 8 * co_words(n_rows) + 4 * co_blocks(n_rows) + 16;
+}
+
+extern "C" int ps_coalesce_rows(const PsIdxList* lists_host, int32_t n_lists, int64_t n_rows, int64_t pad_row,
+                                void* ws_dev, int64_t* rows_out_dev, int64_t cap, int32_t* count_out_dev,
+                                ps_stream_t stream) {
+  PS_REQUIRE(lists_host && n_lists > 0 && n_lists <= PS_MAX_IDX_LISTS, "coalesce: 1..%d index lists", PS_MAX_IDX_LISTS);
+  PS_REQUIRE(n_rows > 0 && n_rows < ((int64_t)1 << 37) && ws_dev && rows_out_dev && count_out_dev && cap > 0,
+             "coalesce: bad argument");
+  IdxLists L;
+  L.n = n_lists; L.total = 0;
+  for (int i = 0; i < n_lists; ++i) {
+    PS_REQUIRE(lists_host[i].n >= 0 && (lists_host[i].n == 0 || lists_host[i].idx), "coalesce: list %d null", i);
+    L.l[i] = lists_host[i];
+    L.total += lists_host[i].n;
+  }
+  const int64_t need = L.total < n_rows ? L.total : n_rows;
+  PS_REQUIRE(cap >= need, "coalesce: rows_out capacity %lld < %lld", (long long)cap, (long long)need);
+  PS_REQUIRE(L.total < ((int64_t)1 << 31), "coalesce: too many indices");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* bitmap = (unsigned long long*)ws_dev;
+  const int64_t nw = co_words(n_rows), nb = co_blocks(n_rows);
+  int32_t* blocksum = (int32_t*)(bitmap + nw);
+  int32_t* bad = blocksum + nb;
+  if (L.total > 0) {
+    hipLaunchKernelGGL(co_mark_kernel, dim3((unsigned)((L.total + 255) / 256)), dim3(256), 0, st, L, n_rows, pad_row,
+                       bitmap, bad);
+    PS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(co_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nw, blocksum);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(co_emit_kernel, dim3((unsigned)nb), dim3(256), 0, st, bitmap, nw, blocksum, rows_out_dev, cap,
+                     count_out_dev, bad);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ---------------------------------------------------------------- gather / scatter of touched rows
+// 32 lanes per row, 16 B per lane; 8 rows per 256-thread block.
+template <int MODE>   // 0: vals = tab[rows]   1: tab[rows] = vals
+__global__ __launch_bounds__(256) void rows_copy_kernel(float* tab, const int64_t* rows, const int32_t* count,
+                                                        int64_t fixed_count, float* vals, int d) {
+  const int64_t n = count ? (int64_t)*count : fixed_count;
+  const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (u >= n) return;
+  const int lane = threadIdx.x & 31;
+  float4* t4 = (float4*)(tab + rows[u] * (int64_t)d);
+  float4* v4 = (float4*)(vals + u * (int64_t)d);
+  for (int j = lane; j < d / 4; j += 32) {
+    if (MODE == 0) v4[j] = t4[j]; else t4[j] = v4[j];
+  }
+}
+
+static int rows_copy(int mode, float* tab, const int64_t* rows, const int32_t* count, int64_t cap, float* vals,
+                     int32_t d, ps_stream_t stream) {
+  PS_REQUIRE(tab && rows && vals && cap >= 0 && d > 0 && d % 4 == 0, "rows copy: bad argument");
+  PS_REQUIRE(((((uintptr_t)tab) | ((uintptr_t)vals)) & 15) == 0, "rows copy: 16-byte alignment");
+  if (cap == 0) return PS_OK;
+  const unsigned grid = (unsigned)((cap + 7) / 8);
+  if (mode == 0)
+    hipLaunchKernelGGL(rows_copy_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, tab, rows, count, cap, vals, d);
+  else
+    hipLaunchKernelGGL(rows_copy_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, tab, rows, count, cap, vals, d);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+extern "C" int ps_gather_rows(const float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev,
+                              int64_t cap, float* values_out_dev, ps_stream_t stream) {
+  return rows_copy(0, (float*)table_dev, rows_dev, count_dev, cap, values_out_dev, d, stream);
+}
+
+extern "C" int ps_scatter_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev,
+                               int64_t cap, const float* values_dev, ps_stream_t stream) {
+  return rows_copy(1, table_dev, rows_dev, count_dev, cap, (float*)values_dev, d, stream);
+}
+
+// ---------------------------------------------------------------- row-sparse clip + Adam
+#define RS_MAX_TABLES 4
+#define RS_ROWS_PER_BLOCK 8
+struct RowTables { PsRowTable t[RS_MAX_TABLES]; int32_t blk0[RS_MAX_TABLES + 1]; int32_t n; };
+
+__device__ inline int rs_find(const RowTables& T, int blk) {
+  int k = 0;
+  while (k < T.n - 1 && blk >= T.blk0[k + 1]) ++k;
+  return k;
+}
+
+// grid = n_chunks dense chunks, then the row blocks of every table.  partial[block] = its sum of squares.
+__global__ __launch_bounds__(256) void rs_sumsq_kernel(const char* plan, int n_chunks, RowTables T, float grad_scale,
+                                                       int64_t* state, float* partial) {
+  __shared__ float sh[4];
+  const int blk = blockIdx.x;
+  float s;
+  if (blk < n_chunks) {
+    s = adam_sumsq_chunk(plan, blk, grad_scale, sh);
+  } else {
+    const int k = rs_find(T, blk - n_chunks);
+    const PsRowTable& tb = T.t[k];
+    const int64_t u = (int64_t)(blk - n_chunks - T.blk0[k]) * RS_ROWS_PER_BLOCK + (threadIdx.x >> 5);
+    const int64_t n = *tb.count;
+    float acc = 0.f;
+    if (u < n) {
+      const float4* g4 = (const float4*)(tb.g + tb.rows[u] * (int64_t)tb.d);
+      for (int j = threadIdx.x & 31; j < tb.d / 4; j += 32) {
+        float4 x = g4[j];
+        x.x *= grad_scale; x.y *= grad_scale; x.z *= grad_scale; x.w *= grad_scale;
+        acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      }
+    }
+    s = block_sum_256(acc, sh);
+  }
+  if (threadIdx.x == 0) {
+    partial[blk] = s;
+    if (blk == 0) state[0] += 1;
+  }
+}
+
+// one block: fixed-order reduction of every partial -> clip coefficient and step scalars.
+__global__ __launch_bounds__(1024) void rs_finalize_kernel(const PsAdamHyper hp, const int64_t* state,
+                                                           const float* partial, int n_partial, float* scal,
+                                                           float* gnorm_out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_partial; i += 1024) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int i = 0; i < 16; ++i) total += sh[i];
+    float norm;
+    adam_scalars(hp, total, state[0], scal, &norm);
+    if (gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void rs_update_kernel(const char* plan, int n_chunks, RowTables T,
+                                                        const PsAdamHyper hp, const float* scal) {
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay};
+  const int blk = blockIdx.x;
+  if (blk < n_chunks) { adam_update_chunk(plan, blk, a); return; }
+  const int k = rs_find(T, blk - n_chunks);
+  const PsRowTable& tb = T.t[k];
+  const int64_t u = (int64_t)(blk - n_chunks - T.blk0[k]) * RS_ROWS_PER_BLOCK + (threadIdx.x >> 5);
+  if (u >= (int64_t)*tb.count) return;
+  const int64_t off = tb.rows[u] * (int64_t)tb.d;
+  float4* p4 = (float4*)(tb.p + off); float4* g4 = (float4*)(tb.g + off);
+  float4* m4 = (float4*)(tb.m + off); float4* v4 = (float4*)(tb.v + off);
+  for (int j = threadIdx.x & 31; j < tb.d / 4; j += 32) {
+    float4 pp = p4[j], gg = g4[j], mm = m4[j], vv = v4[j];
+    adam_elem(a, pp.x, gg.x, mm.x, vv.x); adam_elem(a, pp.y, gg.y, mm.y, vv.y);
+    adam_elem(a, pp.z, gg.z, mm.z, vv.z); adam_elem(a, pp.w, gg.w, mm.w, vv.w);
+    p4[j] = pp; m4[j] = mm; v4[j] = vv;
+    g4[j] = make_float4(0.f, 0.f, 0.f, 0.f);     // zero_grad of the touched row, fused
+  }
+}
+
+static int rs_pack(const PsRowTable* tabs, int32_t n_tables, RowTables* T) {
+  PS_REQUIRE(n_tables >= 0 && n_tables <= RS_MAX_TABLES && (n_tables == 0 || tabs), "rowsparse: 0..%d tables", RS_MAX_TABLES);
+  T->n = n_tables;
+  int64_t b = 0;
+  for (int i = 0; i < n_tables; ++i) {
+    const PsRowTable& t = tabs[i];
+    PS_REQUIRE(t.p && t.g && t.m && t.v && t.rows && t.count && t.d > 0 && t.d % 4 == 0 && t.cap >= 0,
+               "rowsparse: table %d bad field", i);
+    PS_REQUIRE(((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v)) & 15) == 0,
+               "rowsparse: table %d not 16-byte aligned", i);
+    T->t[i] = t;
+    T->blk0[i] = (int32_t)b;
+    b += (t.cap + RS_ROWS_PER_BLOCK - 1) / RS_ROWS_PER_BLOCK;
+    PS_REQUIRE(b < (1 << 30), "rowsparse: too many rows");
+  }
+  for (int i = n_tables; i <= RS_MAX_TABLES; ++i) T->blk0[i] = (int32_t)b;
+  return PS_OK;
+}
+
+// floats of scratch after the 2 int64 of state: 4 scalars + one partial per block.
+extern "C" int64_t ps_adam_rowsparse_state_floats(int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables) {
+  RowTables T;
+  if (rs_pack(tables_host, n_tables, &T) != PS_OK) return -1;
+  return 4 + (int64_t)n_chunks + T.blk0[RS_MAX_TABLES];
+}
+
+extern "C" int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host,
+                                      int32_t n_tables, const PsAdamHyper* hyper, int64_t* state_dev,
+                                      float* gnorm_out_dev, ps_stream_t stream) {
+  PS_REQUIRE(hyper && state_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev), "clip_adam_rowsparse: bad argument");
+  RowTables T;
+  int rc = rs_pack(tables_host, n_tables, &T);
+  if (rc != PS_OK) return rc;
+  const int n_blocks = n_chunks + T.blk0[RS_MAX_TABLES];
+  PS_REQUIRE(n_blocks > 0, "clip_adam_rowsparse: nothing to update");
+  hipStream_t st = (hipStream_t)stream;
+  float* scal = (float*)(state_dev + 2);
+  float* partial = scal + 4;
+  PsAdamHyper hp = *hyper;
+  if (hp.grad_scale == 0.f) hp.grad_scale = 1.f;
+  hipLaunchKernelGGL(rs_sumsq_kernel, dim3(n_blocks), dim3(256), 0, st, (const char*)plan_dev, n_chunks, T,
+                     hp.grad_scale, state_dev, partial);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rs_finalize_kernel, dim3(1), dim3(1024), 0, st, hp, state_dev, partial, n_blocks, scal,
+                     gnorm_out_dev);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rs_update_kernel, dim3(n_blocks), dim3(256), 0, st, (const char*)plan_dev, n_chunks, T, hp, scal);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// zero_grad() of rows a backward touched but no optimizer step consumed.
+__global__ __launch_bounds__(256) void rows_zero_kernel(float* tab, const int64_t* rows, const int32_t* count, int d) {
+  const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (u >= (int64_t)*count) return;
+  float4* t4 = (float4*)(tab + rows[u] * (int64_t)d);
+  for (int j = threadIdx.x & 31; j < d / 4; j += 32) t4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int ps_zero_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev,
+                            int64_t cap, ps_stream_t stream) {
+  PS_REQUIRE(table_dev && rows_dev && count_dev && d > 0 && d % 4 == 0 && cap >= 0, "zero_rows: bad argument");
+  if (cap == 0) return PS_OK;
+  hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((cap + 7) / 8)), dim3(256), 0, (hipStream_t)stream, table_dev,
+                     rows_dev, count_dev, d);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

@@ -151,9 +151,11 @@ class ItemTransformerRanker(nn.Module):
         d = self.embedding_size
 
         # same registration order as the reference => same state_dict key order
-        self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
+        # tables above 0.5 GB (config 5: 51 GB) are created on the device, never staged through host memory
+        emb_dev = device if (product_size + 1) * d > (1 << 27) else None
+        self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx, device=emb_dev)
         if args.sep_prod_emb:
-            self.hist_product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
+            self.hist_product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx, device=emb_dev)
         self.product_bias = nn.Parameter(torch.zeros(product_size + 1), requires_grad=True)
         self.word_bias = nn.Parameter(torch.zeros(vocab_size), requires_grad=True)
         self.word_embeddings = nn.Embedding(vocab_size, d, padding_idx=self.word_pad_idx)
@@ -300,7 +302,8 @@ class ItemTransformerRanker(nn.Module):
             ps.pe = self.transformer_encoder.pos_emb.pe.data_ptr()
         # one flat gradient buffer: small tensors first, tables last; 16-byte aligned slices
         graded = [(path, p) for path, p in hot if self._has_grad(path)]
-        graded.sort(key=lambda t: t[1].numel())
+        sparse = self._SPARSE_PATHS if self._row_sparse() else ()
+        graded.sort(key=lambda t: (t[0] in sparse, t[1].numel()))
         offs, cur = [], 0
         for _, p in graded:
             offs.append(cur)
@@ -312,6 +315,10 @@ class ItemTransformerRanker(nn.Module):
             self._grad_views.append((p, v))
             self._set_field(gs, path, v.data_ptr())
         self._n_small = sum((p.numel() + 3) // 4 * 4 for _, p in graded if p.numel() < (1 << 20))
+        # row-sparse mode: the flat buffer is [dense tensors | row-sparse tables]; only the first part is
+        # ever memset, table rows are re-zeroed by the optimizer (or zero_grad) through their touched list
+        self._n_dense_grad = sum((p.numel() + 3) // 4 * 4 for path, p in graded if path not in sparse)
+        self._sparse_tabs = [(path, p, v) for (path, p), (_, v) in zip(graded, self._grad_views) if path in sparse]
         self._params_struct, self._grads_struct = ps, gs
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)
         return ps, gs
@@ -429,6 +436,74 @@ class ItemTransformerRanker(nn.Module):
                                       self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
         return plan, loss3
 
+    # ------------------------------------------------------------ row-sparse optimizer support
+    _SPARSE_PATHS = (('product_emb',), ('word_emb',), ('hist_product_emb',))
+
+    def _row_sparse(self):
+        """``args.row_sparse_adam`` (extension, default False): table gradients stay dense tensors but
+        zeroing / clip / Adam / exchange only visit the rows a step touched (BASELINE configs[4])."""
+        return bool(getattr(self.args, 'row_sparse_adam', False))
+
+    def _index_lists(self, path, plan):
+        """Index tensors of the step that address ``path``'s rows, and that table's pad row."""
+        tg, pw, ni, nw = plan.keep[2:6]
+        qw, ui = plan.keep[0], plan.keep[1]
+        tem = self.args.model_name == 'item_transformer'
+        if path == ('product_emb',):
+            return [tg, ni] + ([ui] if tem and not self.args.sep_prod_emb else []), self.prod_pad_idx
+        if path == ('hist_product_emb',):
+            return ([ui] if tem else []), self.prod_pad_idx
+        return [qw, pw, nw], self.word_pad_idx
+
+    def _coalesce_touched(self, plan):
+        lib = _lib.load()
+        dev, st = self._dev(), self._stream()
+        for path, p, gview in self._sparse_tabs:
+            lists, pad = self._index_lists(path, plan)
+            info = getattr(p, '_ps_rows', None)
+            total = sum(t.numel() for t in lists)
+            cap = max(1, min(total, p.shape[0]))
+            if info is None or info['rows'].numel() < cap or info['grad_ptr'] != gview.data_ptr():
+                info = dict(rows=torch.empty(cap, device=dev, dtype=torch.int64),
+                            count=torch.zeros(1, device=dev, dtype=torch.int32),
+                            ws=torch.zeros(lib.ps_coalesce_ws_bytes(p.shape[0]), device=dev, dtype=torch.uint8),
+                            grad_ptr=gview.data_ptr(), dirty=False)
+                p._ps_rows = info
+            info['cap'] = cap
+            if not lists:
+                info['count'].zero_()
+                continue
+            arr = (_lib.PsIdxList * len(lists))()
+            for i, t in enumerate(lists):
+                arr[i].idx, arr[i].n = t.data_ptr(), t.numel()
+            _lib.check(lib.ps_coalesce_rows(arr, len(lists), p.shape[0], pad, info['ws'].data_ptr(),
+                                            info['rows'].data_ptr(), info['rows'].numel(),
+                                            info['count'].data_ptr(), st), 'ps_coalesce_rows')
+            info['dirty'] = True
+
+    def touched_rows(self):
+        """{state_dict key: sorted unique row ids} of the last backward (row-sparse mode; host sync)."""
+        out = {}
+        for name, p in self.named_parameters():
+            info = getattr(p, '_ps_rows', None)
+            if info is not None:
+                out[name] = info['rows'][:int(info['count'][0])].clone()
+        return out
+
+    def _zero_for_backward(self):
+        lib = _lib.load()
+        st = self._stream()
+        if not self._row_sparse():
+            _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(), st), 'ps_zero_floats')
+            return
+        _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._n_dense_grad, st), 'ps_zero_floats')
+        for path, p, gview in self._sparse_tabs:
+            info = getattr(p, '_ps_rows', None)
+            if info is not None and info['dirty']:       # touched by a backward no optimizer step consumed
+                _lib.check(lib.ps_zero_rows(gview.data_ptr(), p.shape[1], info['rows'].data_ptr(),
+                                            info['count'].data_ptr(), info['cap'], st), 'ps_zero_rows')
+                info['dirty'] = False
+
     def _assign_grads(self):
         """Give every reachable parameter its dense ``.grad`` view; returns True if the flat
         buffer must be zeroed first (i.e. zero_grad() ran, trainer.py:76)."""
@@ -446,10 +521,24 @@ class ItemTransformerRanker(nn.Module):
         ps, gs = self._structs()
         st = self._stream()
         if self._assign_grads():
-            _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(), st), 'ps_zero_floats')
+            self._zero_for_backward()
+        elif self._row_sparse() and any(getattr(p, '_ps_rows', {}).get('dirty') for _, p, _ in self._sparse_tabs):
+            raise NotImplementedError("row_sparse_adam: gradient accumulation over several backwards is not "
+                                      "supported; call model.zero_grad() (trainer.py:76) or optim.step() first")
+        if self._row_sparse():
+            # the touched lists only need the step's indices: built on a side stream under the backward
+            main = torch.cuda.current_stream(self._dev())
+            side = getattr(self, '_side_stream', None)
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(self._dev())
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._coalesce_touched(plan)
         go = grad_out.contiguous().float()
         _lib.check(lib.ps_tem_backward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), gs, 1.0,
                                        go.data_ptr(), st), 'ps_tem_backward')
+        if self._row_sparse():
+            main.wait_stream(side)
 
     def _run_score(self, batch):
         lib = _lib.load()

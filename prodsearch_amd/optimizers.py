@@ -18,7 +18,7 @@ class Optimizer(object):
     def __init__(self, method, learning_rate, max_grad_norm,
                  lr_decay=1, start_decay_steps=None, decay_steps=None,
                  beta1=0.9, beta2=0.999, adagrad_accum=0.0,
-                 decay_method=None, warmup_steps=4000, weight_decay=0.):
+                 decay_method=None, warmup_steps=4000, weight_decay=0., row_sparse=False):
         if method != 'adam':
             raise NotImplementedError("only method='adam' is on the hot path (main.py:62)")
         self.last_ppl = None
@@ -37,6 +37,7 @@ class Optimizer(object):
         self.weight_decay = weight_decay
         self.eps = 1e-9                      # optimizers.py:186-187
         self.grad_scale = 1.0                # 1/world_size under data parallelism
+        self.row_sparse = bool(row_sparse)   # extension: tables updated by touched rows only
         self.params = []
         self._plan = None
 
@@ -55,6 +56,11 @@ class Optimizer(object):
         dev = live[0].device
         if not live[0].is_cuda:
             raise RuntimeError("Optimizer.step() needs parameters on a gfx950 device (no CPU fallback)")
+        all_live = live
+        rows_live = [p for p in live if self.row_sparse and getattr(p, '_ps_rows', None) is not None]
+        live = [p for p in live if not any(p is q for q in rows_live)]
+        if not live:
+            raise RuntimeError("Optimizer.step(): row-sparse mode needs at least one dense tensor")
         n = len(live)
         numel = torch.tensor([p.numel() for p in live], dtype=torch.int64)
         sizes = [(p.numel() + 3) // 4 * 4 for p in live]
@@ -67,20 +73,29 @@ class Optimizer(object):
             ms.append(self._m_flat[o:o + p.numel()].view_as(p))
             vs.append(self._v_flat[o:o + p.numel()].view_as(p))
             o += s
+        for p in rows_live:          # full-size moments; only touched rows are ever read or written
+            live.append(p)
+            if old is not None and id(p) in old:
+                ms.append(old[id(p)][0]); vs.append(old[id(p)][1])
+            else:
+                ms.append(torch.zeros_like(p)); vs.append(torch.zeros_like(p))
+        n_dense = n
         if old is not None:          # keep moments of parameters that were already being updated
-            for p, m, v in zip(live, ms, vs):
+            for p, m, v in zip(live[:n_dense], ms, vs):
                 if id(p) in old:
                     m.copy_(old[id(p)][0]); v.copy_(old[id(p)][1])
         self._state_tensors = {id(p): (m, v) for p, m, v in zip(live, ms, vs)}
         addr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64)
-        pa, ga, ma, va = addr(live), addr([p.grad for p in live]), addr(ms), addr(vs)
+        dl = live[:n_dense]
+        pa, ga, ma, va = addr(dl), addr([p.grad for p in dl]), addr(ms[:n_dense]), addr(vs[:n_dense])
         nbytes = lib.ps_adam_plan_bytes(n, numel.data_ptr())
         host = torch.zeros(nbytes, dtype=torch.uint8)
         _lib.check(lib.ps_adam_plan_write_host(n, pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(),
                                                numel.data_ptr(), host.data_ptr()), 'ps_adam_plan_write_host')
         n_chunks = lib.ps_adam_plan_chunks_host(host.data_ptr())
-        plan = dict(dev=host.to(dev), n_chunks=n_chunks, live=live,
-                    sig=tuple((p.data_ptr(), p.grad.data_ptr()) for p in live),
+        plan = dict(dev=host.to(dev), n_chunks=n_chunks, live=all_live,
+                    rows=[(p, self._state_tensors[id(p)]) for p in rows_live],
+                    sig=tuple((p.data_ptr(), p.grad.data_ptr()) for p in all_live),
                     state=torch.zeros(2 + (n_chunks + 1) // 2, device=dev, dtype=torch.int64),
                     gnorm=torch.zeros(2, device=dev, dtype=torch.float32))
         plan['state'][0] = self._step
@@ -115,8 +130,32 @@ class Optimizer(object):
         hp.grad_scale = self.grad_scale
         dev = plan['live'][0].device
         st = torch.cuda.current_stream(dev).cuda_stream
+        if plan['rows']:
+            return self._step_rows(lib, plan, hp, dev, st)
         _lib.check(lib.ps_clip_adam_dense(plan['dev'].data_ptr(), plan['n_chunks'], hp, plan['state'].data_ptr(),
                                           plan['gnorm'].data_ptr(), st), 'ps_clip_adam_dense')
+
+    def _step_rows(self, lib, plan, hp, dev, st):
+        """Row-sparse step: dense plan for the small tensors + touched rows of every table, one global
+        norm, three launches (``ps_clip_adam_rowsparse``); touched gradient rows come back zeroed."""
+        tabs = (_lib.PsRowTable * len(plan['rows']))()
+        for i, (p, (m, v)) in enumerate(plan['rows']):
+            info = p._ps_rows
+            t = tabs[i]
+            t.p, t.g, t.m, t.v = p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()
+            t.rows, t.count, t.cap, t.d = info['rows'].data_ptr(), info['count'].data_ptr(), info['cap'], p.shape[1]
+        need = lib.ps_adam_rowsparse_state_floats(plan['n_chunks'], tabs, len(tabs))
+        if need < 0:
+            _lib.check(1, 'ps_adam_rowsparse_state_floats')
+        words = 2 + (need + 1) // 2
+        if plan['state'].numel() < words:
+            plan['state'] = torch.zeros(words, device=dev, dtype=torch.int64)
+            plan['state'][0] = self._step - 1
+        _lib.check(lib.ps_clip_adam_rowsparse(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), hp,
+                                              plan['state'].data_ptr(), plan['gnorm'].data_ptr(), st),
+                   'ps_clip_adam_rowsparse')
+        for p, _ in plan['rows']:
+            p._ps_rows['dirty'] = False
 
     @property
     def last_grad_norm(self):
@@ -154,7 +193,8 @@ def build_optim(args, model, checkpoint):
                       beta1=args.beta1, beta2=args.beta2,
                       decay_method=args.decay_method,
                       warmup_steps=args.warmup_steps,
-                      weight_decay=args.l2_lambda)
+                      weight_decay=args.l2_lambda,
+                      row_sparse=getattr(args, 'row_sparse_adam', False))
     optim.set_parameters(list(model.named_parameters()))
     if getattr(args, 'train_from', '') != '' and checkpoint is not None:
         optim.load_state_dict(checkpoint['optim'])

@@ -38,6 +38,18 @@ def make_word_dists(vocab_size, seed=7):
 
 
 def _zipf_ids(rng, n_ids, size, a=1.05, perm_seed=11):
+    if n_ids > (1 << 21):
+        # huge catalogues (config 5: 50 M items): no n_ids-sized weight / permutation arrays — bounded Zipf
+        # ranks by rejection, scattered over the id space by an odd multiplier coprime to n_ids
+        n = int(np.prod(size))
+        out = np.empty(0, dtype=np.int64)
+        while out.size < n:
+            r = rng.zipf(a, size=4 * n + 64)
+            out = np.concatenate([out, r[r <= n_ids].astype(np.int64)])
+        mult = 2654435761
+        while np.gcd(mult, n_ids) != 1:
+            mult += 2
+        return (((out[:n] - 1) * mult) % n_ids).reshape(size)
     w = 1.0 / np.power(np.arange(1, n_ids + 1, dtype=np.float64), a)
     w /= w.sum()
     perm = rng_for(perm_seed).permutation(n_ids)

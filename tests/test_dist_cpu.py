@@ -70,6 +70,50 @@ def test_gloo_world2_gradient_exchange():
     assert res[0][4] == 666                                 # rank 0 keeps the base seed
 
 
+def _sparse_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    pdist.init_from_env(backend='gloo')
+    n_rows, d = 500, 16
+    gen = torch.Generator().manual_seed(7 + rank)
+    # ragged: rank 0 touches 37 rows, rank 1 touches 90 (some shared), plus an empty-list round
+    out = []
+    for n_touch in ((37, 90)[rank], 0 if rank == 0 else 5):
+        rows = torch.sort(torch.randperm(n_rows, generator=gen)[:n_touch]).values
+        vals = torch.randn(n_touch, d, generator=gen)
+        dense = torch.zeros(n_rows, d)
+        dense[rows] = vals
+        union, acc = pdist.exchange_rows(rows, vals)
+        dist.all_reduce(dense)                               # what a dense exchange would have produced
+        merged = torch.zeros(n_rows, d)
+        merged[union] = acc
+        rows_all = [None] * world
+        dist.all_gather_object(rows_all, rows.tolist())
+        want_union = sorted(set(sum(rows_all, [])))
+        gathered = [torch.zeros_like(merged) for _ in range(world)]
+        dist.all_gather(gathered, merged)
+        out.append((union.tolist() == want_union, bool(torch.allclose(merged, dense, atol=1e-6)),
+                    all(torch.equal(gathered[0], x) for x in gathered)))      # bitwise identical replicas
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sparse_row_exchange():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert all(all(t) for t in out), out
+
+
 def test_single_process_is_a_no_op():
     flat = torch.ones(8)
     opt = _FakeOptim()

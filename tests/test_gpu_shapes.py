@@ -1,0 +1,47 @@
+"""GPU parity at shapes no golden fixture covers (oracle-driven, synthetic): d=256 / ff=1024 — the shape of
+BASELINE configs[4] — and d=512, both through the module API.  Tolerances as test_gpu_parity.py."""
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('d,F,B,K,dropout', [(256, 1024, 24, 6, 0.0), (512, 1024, 9, 4, 0.0), (256, 1024, 16, 5, 0.1)])
+def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
+    from oracle import tem as otem, philox
+    from prodsearch_amd import ItemTransformerRanker, default_args, synth
+    P_, V = 3000, 2000
+    a = default_args(model_name='item_transformer', embedding_size=d, ff_size=F, heads=8, inter_layers=1,
+                     neg_per_pos=K, dropout=dropout, uprev_review_limit=20)
+    wd = synth.make_word_dists(V)
+    sd = synth.make_state_dict(synth.tem_param_shapes(a, V, P_), 5, {'product_emb.weight': P_})
+    m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    batch = synth.make_tem_batch(3, B, P_, V, Q=8, L=20, W=1, word_dists=wd)
+    ni, nw = synth.sample_negatives(4, B, K, 1, P_, wd)
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    Pm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = {}
+    if dropout > 0:
+        kw = dict(replicate=True, drop=philox.PhiloxDropout(dropout, m._seed, m._fwd_step, B, K, 8, 21, 1,
+                                                            20 if a.use_item_pos else 0))
+    oloss, _, _ = otem.tem_forward(Pm, a, batch, ni, nw, V, P_, training=True, **kw)
+    assert rel_err(loss.detach().cpu(), oloss.detach()) < 1e-4
+    grads = otem.grads_of(oloss, Pm, otem.tem_pad_rows(a, V, P_))
+    for n, p in m.named_parameters():
+        ref = grads.get(n)
+        assert (p.grad is None) == (ref is None), n
+        if ref is None:
+            continue
+        got = p.grad.cpu()
+        if n.endswith('linear_keys.bias'):
+            continue
+        assert rel_err(got, ref) < 5e-4, n
+        if ref.dim() == 2 and ref.shape[0] > 256:
+            assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n

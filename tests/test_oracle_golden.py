@@ -120,3 +120,26 @@ def test_eval_scores_and_ranklist(case, replicate):
     # the oracle's own scores give the same ranklist wherever the reference's top gaps exceed fp noise
     o2, mrr2, _ = otem.rank_metrics(s, b.candi_prod_idxs, b.target_prod_idxs)
     assert abs(mrr2 - mrr) < 1e-9
+
+
+def test_row_sparse_clip_adam_equals_dense_on_touched_rows_and_freezes_the_rest():
+    """oracle/optim.py ``touched=``: first step identical to dense Adam on the touched rows (zero moments
+    everywhere), later steps leave untouched rows alone where dense Adam keeps moving them."""
+    torch.manual_seed(3)
+    P1 = {'t': torch.randn(50, 8), 'w': torch.randn(4, 4)}
+    P2 = {k: v.clone() for k, v in P1.items()}
+    o1, o2 = ooptim.ClipAdam(0.01), ooptim.ClipAdam(0.01)
+    rows_a, rows_b = torch.tensor([1, 7, 20]), torch.tensor([7, 30])
+    for it, rows in enumerate([rows_a, rows_b]):
+        g = {'t': torch.zeros(50, 8), 'w': torch.randn(4, 4)}
+        g['t'][rows] = torch.randn(len(rows), 8)
+        o1.step(P1, {k: v.clone() for k, v in g.items()})
+        o2.step(P2, {k: v.clone() for k, v in g.items()}, touched={'t': rows})
+        assert torch.equal(P1['w'], P2['w'])
+        if it == 0:
+            assert torch.equal(P1['t'], P2['t'])
+    frozen = torch.tensor([1, 20])                  # touched at step 1 only
+    assert not torch.equal(P1['t'][frozen], P2['t'][frozen])        # dense Adam kept applying momentum
+    untouched = torch.ones(50, dtype=torch.bool)
+    untouched[torch.cat([rows_a, rows_b])] = False
+    assert torch.equal(P1['t'][untouched], P2['t'][untouched])      # never-touched rows: identical (no motion)
