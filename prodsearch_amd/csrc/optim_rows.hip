@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) void co_mark_kernel(IdxLists L, int64_t n_rows
   const int64_t r = L.l[k].idx[i];
   if (r == pad_row) return;
   if (r < 0 || r >= n_rows) { *bad = 1; return; }
-  atomicOr(&bitmap[r >> 6], 1ull << (r & 63));
+  const unsigned long long bit = 1ull << (r & 63);
+  // popular rows (Zipf words) repeat thousands of times: skip the atomic once the bit is visible
+  if (__builtin_nontemporal_load(&bitmap[r >> 6]) & bit) return;
+  atomicOr(&bitmap[r >> 6], bit);
 }
 
 __global__ __launch_bounds__(256) void co_count_kernel(const unsigned long long* bitmap, int64_t n_words,
