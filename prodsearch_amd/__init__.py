@@ -7,6 +7,7 @@ Everything numerical runs in libprodsearch_hip.so (hand-written HIP kernels, C A
 include/prodsearch_hip.h); this package is the thin host side.  No CPU fallback.
 """
 from .batch import ItemPVBatch
+from .dataloader import ItemPVDataloader
 from .config import default_args, readme_tem_args
 from .item_transformer import ItemTransformerRanker
 from .optimizers import Optimizer, build_optim

@@ -141,7 +141,54 @@ SYMBOLS = {
                               C.c_void_p]),
 }
 
+class PsCorpusView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('n_reviews', 'n_users', 'n_products', 'n_queries')] + \
+               [(n, C.c_void_p) for n in ('review_u_p', 'u_seq_ptr', 'u_seq', 'train_review', 'review_loc',
+                                          'pq_ptr', 'pq_idx', 'query_words')] + \
+               [('Q', C.c_int32), ('pad_', C.c_int32)]
+
+
+class PsCollateArgs(C.Structure):
+    _fields_ = [('uprev_review_limit', C.c_int32), ('do_seq', C.c_int32), ('fix', C.c_int32), ('pad_', C.c_int32),
+                ('prod_pad', C.c_int64)]
+
+
+# include/prodsearch_data.h (host-only library)
+DATA_SYMBOLS = {
+    'ps_rng_create': (C.c_void_p, [C.c_uint64]),
+    'ps_rng_destroy': (None, [C.c_void_p]),
+    'ps_rng_randbelow': (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    'ps_rng_random': (C.c_double, [C.c_void_p]),
+    'ps_collate_train': (C.c_int, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 8),
+    'ps_collate_test': (C.c_int, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6),
+    'ps_data_last_error': (C.c_char_p, []),
+}
+
 _lib = None
+_data_lib = None
+
+
+def load_data():
+    """Load the host-side batch builder (builds it with g++ on first use; needs no GPU)."""
+    global _data_lib
+    if _data_lib is not None:
+        return _data_lib
+    from . import build as _build
+    path = _build.build_data()
+    lib = C.CDLL(path)
+    for name, (res, args) in DATA_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _data_lib = lib
+    return lib
+
+
+def check_data(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, load_data().ps_data_last_error().decode('utf-8', 'replace')))
 
 
 def lib_path():

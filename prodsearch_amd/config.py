@@ -27,6 +27,8 @@ _DEFAULTS = dict(
     fix_emb=False,                     # main.py:43
     do_subsample_mask=False,           # main.py:72
     do_seq_review_train=False,
+    do_seq_review_test=False,          # main.py:42
+    num_workers=4,                     # main.py:92 (the native batch builder needs none)
     fix_train_review=False,
     dropout=0.1,                       # main.py:60
     optim='adam',                      # main.py:62

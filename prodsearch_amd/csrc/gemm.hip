@@ -299,7 +299,8 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
   static const int repeat = getenv("PS_DEBUG_REPEAT") ? atoi(getenv("PS_DEBUG_REPEAT")) : 1;   // timing experiments only
   for (int r = 0; r < repeat; ++r) {
     // few workgroups (latency-bound chain): one deep slab per round trip; many: shallow slabs, 4 wgs per CU
-    const bool deep = (size_t)grid.x * grid.y * grid.z <= 64;
+    static const int deep_max = getenv("PS_GEMM_DEEP_MAX") ? atoi(getenv("PS_GEMM_DEEP_MAX")) : 64;         // tuning experiments
+    const bool deep = (size_t)grid.x * grid.y * grid.z <= (size_t)deep_max;
     if (full && deep) launch<1, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);
     else if (full) launch<1, 32>(g.p[0].ta, g.p[0].tb, grid, stream, g);
     else if (deep) launch<0, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);

@@ -176,3 +176,68 @@ def checksum(t):
     """sha256 of the raw little-endian bytes of a tensor/array (fixture pinning)."""
     a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+# ------------------------------------------------------------------ synthetic corpus (batch builder, SURVEY §8f N1)
+class _NS(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def make_corpus(seed, n_users=60, n_products=200, n_queries=40, vocab_size=500, Q=6, W=1,
+                max_reviews_per_user=120, train_frac=0.8):
+    """Python structures shaped like the reference's ``global_data`` / ``prod_data`` (data/data_util.py) and an
+    ``ItemPVDataset``-like object over them: lists of lists, sets, (user, product) tuples.  User activity is
+    heavy-tailed so that histories shorter than, around and far above ``uprev_review_limit`` all occur."""
+    rng = rng_for(seed)
+    V = vocab_size
+    review_u_p, u_r_seq, review_loc_time = [], [], []
+    n_rev_u = np.minimum(max_reviews_per_user, rng.geometric(0.06, size=n_users))
+    n_rev_u[0] = max_reviews_per_user                   # one very active user, one with a single review
+    n_rev_u[1] = 1
+    for u in range(n_users):
+        seq = []
+        for loc in range(int(n_rev_u[u])):
+            r = len(review_u_p)
+            review_u_p.append((u, int(rng.integers(0, n_products))))
+            review_loc_time.append((loc, 0, r))
+            seq.append(r)
+        u_r_seq.append(seq)
+    n_reviews = len(review_u_p)
+    is_train = rng.random(n_reviews) < train_frac
+    u_reviews = [set(r for r in seq if is_train[r]) for seq in u_r_seq]
+    query_words = []
+    for _ in range(n_queries):
+        n = int(rng.integers(1, Q + 1))
+        query_words.append([int(x) for x in rng.integers(0, V - 1, size=n)] + [V - 1] * (Q - n))
+    product_query_idx = [[int(x) for x in rng.integers(0, n_queries, size=int(rng.integers(1, 4)))]
+                         for _ in range(n_products)]
+    gd = _NS(product_size=n_products, vocab_size=V, review_u_p=review_u_p, u_r_seq=u_r_seq,
+             review_loc_time=review_loc_time, query_words=query_words, user_ids=['u%d' % u for u in range(n_users)])
+    train_pd = _NS(set_name='train', u_reviews=u_reviews, product_query_idx=product_query_idx)
+    test_pd = _NS(set_name='test', u_reviews=u_reviews, product_query_idx=product_query_idx)
+    train_data = []
+    for r in np.flatnonzero(is_train):
+        for _ in range(int(rng.integers(1, 3))):
+            words = [int(x) for x in rng.integers(0, V - 1, size=W)]
+            train_data.append([words, int(r)])
+    test_data = []
+    for r in np.flatnonzero(~is_train)[:200]:
+        u, p = review_u_p[r]
+        q = product_query_idx[p][0]
+        n_c = int(rng.integers(3, 12))
+        cands = [int(x) for x in rng.integers(0, n_products, size=n_c - 1)] + [p]
+        test_data.append([q, u, p, int(r), cands])
+
+    class _Dataset(object):
+        def __init__(self, pd, data):
+            self.prod_pad_idx, self.word_pad_idx, self.seg_pad_idx = n_products, V - 1, 3
+            self.global_data, self.prod_data, self._data = gd, pd, data
+
+        def __len__(self):
+            return len(self._data)
+
+        def __getitem__(self, i):
+            return self._data[i]
+
+    return _Dataset(train_pd, train_data), _Dataset(test_pd, test_data)

@@ -1,0 +1,130 @@
+"""Batch builder: oracle and C++ product against batches produced by the REFERENCE's
+ItemPVDataloader (tests/golden/collate_*.npz, made by tests/golden/make_golden_collate.py).  Index work: bit-exact.
+Host-only code, so everything here runs without a GPU."""
+import ast
+import glob
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+
+from oracle import collate as ocollate
+from prodsearch_amd import _lib, default_args, synth
+from prodsearch_amd.dataloader import ItemPVDataloader
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLD, 'collate_*.npz')))
+
+
+def _case(name):
+    z = np.load(os.path.join(GOLD, name + '.npz'))
+    ckw = ast.literal_eval(str(z['corpus_kw']))
+    over = ast.literal_eval(str(z['args_over']))
+    train_ds, test_ds = synth.make_corpus(int(z['corpus_seed']), **ckw)
+    return z, over, train_ds, test_ds
+
+
+def test_cases_present():
+    assert len(CASES) >= 6
+
+
+def test_header_symbols_exported():
+    lib = _lib.load_data()
+    hdr = open(os.path.join(os.path.dirname(GOLD), '..', 'include', 'prodsearch_data.h')).read()
+    declared = set(re.findall(r'\b(ps_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.DATA_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_mersenne_twister_is_cpythons():
+    lib = _lib.load_data()
+    for seed in (0, 1, 666, 2 ** 31, 2 ** 32 + 5, 123456789012345):
+        r = lib.ps_rng_create(seed)
+        random.seed(seed)
+        for n in (1, 2, 3, 5, 21, 85, 86, 1000, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1):
+            assert lib.ps_rng_randbelow(r, n) == random._inst._randbelow(n)
+        assert lib.ps_rng_random(r) == random.random()
+        lib.ps_rng_destroy(r)
+
+
+def _sampler(ds, B, shuffle):
+    torch.empty((), dtype=torch.int64).random_()          # DataLoader iterator's base seed comes first
+    return BatchSampler(RandomSampler(ds) if shuffle else SequentialSampler(ds), B, False)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_matches_reference_batches(case):
+    z, over, train_ds, test_ds = _case(case)
+    args = default_args(**over)
+    random.seed(int(z['py_seed']))
+    torch.manual_seed(int(z['torch_seed']))
+    for n, ids in zip(range(int(z['n_train'])), _sampler(train_ds, int(z['batch_size']), bool(z['shuffle']))):
+        got = ocollate.train_batch(train_ds, args, [train_ds[i] for i in ids])
+        for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs'):
+            want = z['train%d_%s' % (n, k)]
+            assert np.array_equal(np.asarray(got[k], dtype=np.int64).reshape(want.shape), want), (n, k)
+    for do_seq in (0, 1):
+        targs = default_args(**dict(over, do_seq_review_test=bool(do_seq), train_review_only=not do_seq))
+        for i, ids in zip(range(2), BatchSampler(SequentialSampler(test_ds), 9, False)):
+            got = ocollate.test_batch(test_ds, targs, [test_ds[j] for j in ids])
+            for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'candi_prod_idxs', 'query_idxs', 'user_idxs'):
+                want = z['test%d_seq%d_%s' % (i, do_seq, k)]
+                assert np.array_equal(np.asarray(got[k], dtype=np.int64).reshape(want.shape), want), (i, do_seq, k)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_native_loader_matches_reference_batches(case):
+    """The C++ collate behind the ItemPVDataloader mirror, iterated like the reference's DataLoader."""
+    z, over, train_ds, test_ds = _case(case)
+    args = default_args(**over)
+    dl = ItemPVDataloader(args, train_ds, batch_size=int(z['batch_size']), shuffle=bool(z['shuffle']),
+                          seed=int(z['py_seed']))
+    torch.manual_seed(int(z['torch_seed']))
+    n = 0
+    for b in dl:
+        for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs'):
+            want = z['train%d_%s' % (n, k)]
+            got = getattr(b, k)
+            assert got.dtype == torch.int64 and got.is_contiguous()
+            assert np.array_equal(got.numpy().reshape(want.shape), want), (n, k)
+        n += 1
+        if n == int(z['n_train']):
+            break
+    assert n == int(z['n_train'])
+    for do_seq in (0, 1):
+        targs = default_args(**dict(over, do_seq_review_test=bool(do_seq), train_review_only=not do_seq))
+        tl = ItemPVDataloader(targs, test_ds, batch_size=9, shuffle=False)
+        for i, b in zip(range(2), tl):
+            for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'candi_prod_idxs'):
+                want = z['test%d_seq%d_%s' % (i, do_seq, k)]
+                assert np.array_equal(getattr(b, k).numpy().reshape(want.shape), want), (i, do_seq, k)
+            assert b.query_idxs == z['test%d_seq%d_query_idxs' % (i, do_seq)].tolist()
+            assert b.user_idxs == z['test%d_seq%d_user_idxs' % (i, do_seq)].tolist()
+
+
+def test_collate_entry_lists_like_the_reference_collate_fn():
+    """get_train_batch(batch) takes the dataset entries themselves, as DataLoader hands them to collate_fn."""
+    z, over, train_ds, _ = _case('collate_rand20')
+    args = default_args(**over)
+    dl = ItemPVDataloader(args, train_ds, batch_size=8, seed=5)
+    entries = [train_ds[i] for i in (3, 1, 4, 1, 5)]
+    random.seed(5)
+    want = ocollate.train_batch(train_ds, args, entries)
+    got = dl.get_train_batch(entries)
+    assert np.array_equal(got.u_item_idxs.numpy(), np.asarray(want['u_item_idxs']))
+    assert np.array_equal(got.query_word_idxs.numpy(), np.asarray(want['query_word_idxs']))
+
+
+def test_bad_ids_raise_instead_of_faulting():
+    _, over, train_ds, _ = _case('collate_fix')
+    dl = ItemPVDataloader(default_args(**over), train_ds, batch_size=4, seed=1)
+    with pytest.raises(RuntimeError, match='out of range'):
+        dl.train_batch_from_ids([0, len(train_ds) + 7])
+    dl.sample_review[2] = 10 ** 9
+    with pytest.raises(RuntimeError, match='review id'):
+        dl.train_batch_from_ids([2])
