@@ -11,7 +11,7 @@ from prodsearch_amd.batch import ItemPVBatch
 from prodsearch_amd.config import default_args
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and not f.startswith('rtm_'))
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith(('tem_', 'qem_')))
 TEM_CASES = [c for c in CASES if c.startswith('tem_')]
 
 
