@@ -184,6 +184,22 @@ int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper
 /* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
 int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);
 
+/* ------------------------------------------------------------------ full-catalogue evaluation
+ * Trainer.test / validate over ALL products (trainer.py:125-226 with test_candi_size < 1): encode each (user, query)
+ * row once, score it against every row of the table with one fp32 MFMA GEMM per table panel, and select the top-k and
+ * the target's rank on the device.  ps_tem_encode = the eval-mode sequence representation of item_transformer.py:118-131
+ * (descriptor as for ps_tem_score, C >= 1; candidates are not read). */
+int ps_tem_encode(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch, float* workspace,
+                  float* enc_out /* [B,d] */, ps_stream_t stream);
+/* scores[b,p] = q[b]·table[p] (+ bias[p]), p in [0, n_rows).  top_idx/top_score [B,topk]: best first, ties by lower
+ * row id (unfilled slots: -1 / -inf when n_rows < topk).  rank[b] (optional, needs target) = 1 + number of rows ranked
+ * ahead of target[b] under the same order = position in `argsort(scores)[::-1]` (trainer.py:137,172-180); 0 if the
+ * target is not a table row.  topk <= 256.  scratch: ps_rank_scratch_bytes() bytes, 256-byte aligned. */
+int64_t ps_rank_scratch_bytes(int32_t B, int64_t n_rows, int32_t d, int32_t topk);
+int ps_rank_all(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
+                const int64_t* target, int32_t topk, int64_t* top_idx, float* top_score, int32_t* rank,
+                void* scratch, int64_t scratch_bytes, ps_stream_t stream);
+
 /* ------------------------------------------------------------------ row-sparse optimizer path
  * For tables too large to stream every step (BASELINE configs[4]: 50 M x 256).  The gradient tensors
  * stay dense, like nn.Embedding(sparse=False) gives the reference (item_transformer.py:46,70); the

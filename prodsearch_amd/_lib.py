@@ -127,6 +127,11 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p]),
     'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
     'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_tem_encode': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_rank_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    'ps_rank_all': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'ps_coalesce_ws_bytes': (C.c_int64, [C.c_int64]),
     'ps_coalesce_rows': (C.c_int, [C.POINTER(PsIdxList), C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

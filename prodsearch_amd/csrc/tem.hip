@@ -419,6 +419,22 @@ extern "C" int ps_tem_score(const PsTemDesc* desc, const PsTemTensors* params, c
   return PS_OK;
 }
 
+// model.eval() sequence representation the dot-product heads consume (item_transformer.py:118-131): one encode per
+// (user, query) row, replicas collapse (R = 1).  Feeds ps_rank_all (full-catalogue evaluation).
+extern "C" int ps_tem_encode(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                             float* workspace, float* enc_out, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace && enc_out, "encode: null argument");
+  PsTemDesc D = *desc;
+  PS_REQUIRE(D.C > 0, "encode: build the descriptor in eval mode (C >= 1)");
+  D.training = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  TRY(encode_forward(D, *params, *batch, workspace, w, st));
+  PS_CHECK_HIP(hipMemcpyAsync(enc_out, workspace + w.enc, sizeof(float) * (size_t)D.B * D.d, hipMemcpyDeviceToDevice, st));
+  return PS_OK;
+}
+
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
                         const float* valid, float* ws, const Ws& w, hipStream_t st) {
   const bool drop = D.training && D.dropout > 0.f;

@@ -1,0 +1,67 @@
+"""Full-catalogue evaluation on the device: what ``Trainer.test`` / ``validate`` compute with
+``test_candi_size < 1`` (trainer.py:125-226) — every product scored for every (user, query) row, top-``cutoff``
+ranklist, MRR and P@1 — without re-encoding the sequence per candidate chunk and without moving the score matrix to the
+host.  ``rank_all`` = ``ps_tem_encode`` (one encode per row) + ``ps_rank_all`` (fp32 MFMA GEMM per table panel, radix-select
+top-k, rank of the target)."""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def rank_all(model, batch, topk=100):
+    """-> (top_idx [B,k] int64, top_score [B,k] fp32, rank [B] int32; 1-based, 0 = target not a product), on device."""
+    lib = _lib.load()
+    was_training = model.training
+    model.eval()
+    try:
+        enc = model.encode(batch)
+    finally:
+        model.train(was_training)
+    B, d = enc.shape
+    P = model.product_size
+    table = model.product_emb.weight                       # rows 0..P-1; the pad row P is not a candidate
+    bias = model.product_bias if model.args.sim_func == 'bias_product' else None
+    target = batch.target_prod_idxs
+    if not (torch.is_tensor(target) and target.is_cuda and target.dtype == torch.int64):
+        raise RuntimeError("batch.target_prod_idxs must be an int64 tensor on the model's device")
+    k = int(topk)
+    nbytes = lib.ps_rank_scratch_bytes(B, P, d, k)
+    if nbytes < 0:
+        raise RuntimeError("rank_all: unsupported sizes (topk must be 1..256)")
+    scratch = getattr(model, '_rank_scratch', None)
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = model.__dict__['_rank_scratch'] = torch.empty(nbytes, dtype=torch.uint8, device=enc.device)
+    top_idx = torch.empty(B, k, dtype=torch.int64, device=enc.device)
+    top_score = torch.empty(B, k, dtype=torch.float32, device=enc.device)
+    rank = torch.empty(B, dtype=torch.int32, device=enc.device)
+    _lib.check(lib.ps_rank_all(enc.data_ptr(), B, d, table.data_ptr(), P, _lib.ptr(bias), target.contiguous().data_ptr(), k,
+                               top_idx.data_ptr(), top_score.data_ptr(), rank.data_ptr(), scratch.data_ptr(),
+                               scratch.numel(), torch.cuda.current_stream(enc.device).cuda_stream), 'ps_rank_all')
+    return top_idx, top_score, rank
+
+
+def calc_metrics(rank, cutoff=100):
+    """``Trainer.calc_metrics`` (trainer.py:172-187) from the 1-based ranks of ``rank_all``."""
+    r = torch.as_tensor(rank).detach().cpu().numpy().astype(np.int64)
+    hit = (r > 0) & ((cutoff < 0) | (r <= cutoff))
+    mrr = float(np.where(hit, 1.0 / np.maximum(r, 1), 0.0).sum() / len(r))
+    return mrr, float((r == 1).sum() / len(r))
+
+
+def ranklist_lines(user_ids, query_idxs, product_ids, top_idx, top_score, tag="ReviewTransformer"):
+    """Lines of the TREC-style ranklist ``Trainer.test`` writes (trainer.py:160-170)."""
+    ti = torch.as_tensor(top_idx).cpu().numpy()
+    ts = torch.as_tensor(top_score).cpu().numpy()
+    for i in range(ti.shape[0]):
+        for r in range(ti.shape[1]):
+            if ti[i, r] < 0:
+                break
+            yield "%s_%d Q0 %s %d %f %s\n" % (user_ids[i], query_idxs[i], product_ids[int(ti[i, r])], r + 1,
+                                              float(ts[i, r]), tag)
+
+
+def evaluate(model, batches, topk=100, cutoff=100):
+    """MRR / P@1 over an iterable of eval batches (``Trainer.test`` without the host-side argsort)."""
+    ranks = [rank_all(model, b, topk)[2] for b in batches]
+    return calc_metrics(torch.cat(ranks), cutoff)

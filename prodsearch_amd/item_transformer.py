@@ -336,7 +336,8 @@ class ItemTransformerRanker(nn.Module):
         L = ui.shape[1]
         C = 0
         if eval_mode:
-            C = batch.candi_prod_idxs.shape[1]
+            ca = getattr(batch, 'candi_prod_idxs', None)
+            C = ca.shape[1] if (torch.is_tensor(ca) and ca.dim() == 2 and ca.shape[1] > 0) else 1   # 1: encode-only use
             W = max(1, getattr(a, 'pv_window_size', 1))
         else:
             W = batch.pos_iword_idxs.shape[1]
@@ -376,9 +377,13 @@ class ItemTransformerRanker(nn.Module):
         keep = [qw, ui]
         b.query_word_idxs, b.u_item_idxs = qw.data_ptr(), ui.data_ptr()
         if eval_mode:
-            ca = self._check_idx(batch.candi_prod_idxs, 'candi_prod_idxs')
-            b.candi_prod_idxs = ca.data_ptr()
-            keep.append(ca)
+            ca = getattr(batch, 'candi_prod_idxs', None)
+            if torch.is_tensor(ca) and ca.dim() == 2 and ca.shape[1] > 0:
+                ca = self._check_idx(ca, 'candi_prod_idxs')
+                b.candi_prod_idxs = ca.data_ptr()
+                keep.append(ca)
+            else:
+                b.candi_prod_idxs = None
         else:
             tg = self._check_idx(batch.target_prod_idxs, 'target_prod_idxs')
             pw = self._check_idx(batch.pos_iword_idxs, 'pos_iword_idxs')
@@ -540,11 +545,25 @@ class ItemTransformerRanker(nn.Module):
         if self._row_sparse():
             main.wait_stream(side)
 
+    def encode(self, batch):
+        """Eval-mode sequence representation [B,d] that the dot-product head scores items with
+        (item_transformer.py:118-131): one encode per (user, query) row.  Used by ``evaluate.rank_all``."""
+        lib = _lib.load()
+        ps, _ = self._structs()
+        plan = self._plan_for(batch, eval_mode=True)
+        self._fill_batch(plan, batch, True)
+        enc = torch.empty(plan.desc.B, plan.desc.d, device=self._dev(), dtype=torch.float32)
+        _lib.check(lib.ps_tem_encode(plan.desc, ps, plan.batch, plan.ws.data_ptr(), enc.data_ptr(), self._stream()),
+                   'ps_tem_encode')
+        return enc
+
     def _run_score(self, batch):
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=True)
         self._fill_batch(plan, batch, True)
+        if not plan.batch.candi_prod_idxs:
+            raise RuntimeError("test(): batch.candi_prod_idxs [B,C] is required")
         d = plan.desc
         scores = torch.empty(d.B, d.C, device=self._dev(), dtype=torch.float32)
         _lib.check(lib.ps_tem_score(d, ps, plan.batch, plan.ws.data_ptr(), scores.data_ptr(), self._stream()),
