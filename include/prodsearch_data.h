@@ -47,6 +47,7 @@ typedef struct PsCollateArgs {
 /* CPython-compatible Mersenne Twister (random.seed(int) for 0 <= seed < 2**64). */
 void* ps_rng_create(uint64_t seed);
 void ps_rng_destroy(void* rng);
+void ps_rng_seed(void* rng, uint64_t seed);            /* re-seed in place: random.seed(seed) */
 uint32_t ps_rng_randbelow(void* rng, uint32_t n);      /* random._randbelow(n), n >= 1 (test hook)  */
 double ps_rng_random(void* rng);                       /* random.random() (test hook)               */
 
@@ -68,6 +69,18 @@ int ps_collate_test(const PsCorpusView* corpus, const PsCollateArgs* args,
                     const int64_t* candi_ptr /* [B+1] */, const int64_t* candi_items, int32_t candi_width,
                     int64_t* out_query_words, int64_t* out_target, int64_t* out_u_items, int64_t* out_candi,
                     int32_t* out_hist_len, int32_t* out_lmax);
+
+/* ItemPVDataset.collect_train_samples (data/item_pv_dataset.py:73-93): for every train review, in review_info order,
+ * random.shuffle its words IN PLACE (the shuffled order persists into later epochs, as there), keep word w when
+ * rand[entry] <= sub_rate[w] (entry advances only on kept words, :84-88), and cut the kept stream — which runs across
+ * review boundaries — into windows of W; a window is labelled with the review that completed it, the tail is padded with
+ * word_pad.  rand = np.random.random(sum(review_length)) drawn by the caller.  Outputs: out_words [cap,W], out_review [cap];
+ * *out_n windows written (cap >= total_words/W + 1). */
+void ps_rng_shuffle(void* rng, int64_t* x, int64_t n);          /* random.shuffle(x) */
+int ps_collect_train_samples(const int64_t* rw_ptr, int64_t* rw_words, int64_t n_reviews,
+                             const int64_t* train_reviews, int64_t n_train, const double* rand, int64_t n_rand,
+                             const double* sub_rate, int64_t vocab_size, int32_t W, int64_t word_pad, void* rng,
+                             int64_t* out_words, int64_t* out_review, int64_t cap, int64_t* out_n);
 
 const char* ps_data_last_error(void);
 

@@ -6,7 +6,7 @@ ranking-loss training step behind the reference's own nn.Module / Optimizer API.
 Everything numerical runs in libprodsearch_hip.so (hand-written HIP kernels, C ABI in
 include/prodsearch_hip.h); this package is the thin host side.  No CPU fallback.
 """
-from . import evaluate
+from . import corpus, evaluate, pyrandom, trainer
 from .batch import ItemPVBatch
 from .dataloader import ItemPVDataloader
 from .config import default_args, readme_tem_args

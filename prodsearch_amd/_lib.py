@@ -162,12 +162,17 @@ class PsCollateArgs(C.Structure):
 DATA_SYMBOLS = {
     'ps_rng_create': (C.c_void_p, [C.c_uint64]),
     'ps_rng_destroy': (None, [C.c_void_p]),
+    'ps_rng_seed': (None, [C.c_void_p, C.c_uint64]),
     'ps_rng_randbelow': (C.c_uint32, [C.c_void_p, C.c_uint32]),
     'ps_rng_random': (C.c_double, [C.c_void_p]),
     'ps_collate_train': (C.c_int, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 8),
     'ps_collate_test': (C.c_int, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6),
+    'ps_rng_shuffle': (None, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'ps_collect_train_samples': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p]),
     'ps_data_last_error': (C.c_char_p, []),
 }
 

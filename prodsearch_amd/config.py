@@ -58,6 +58,23 @@ _DEFAULTS = dict(
     train_pv_epoch=0,
     neg_per_pos=5,                     # main.py:125
     device='cuda',
+    # data / trainer flags (main.py:70-124) used by prodsearch_amd.corpus and prodsearch_amd.trainer
+    token_dropout=0.1,
+    subsampling_rate=1e-5,             # main.py:70
+    prod_freq_neg_sample=False,        # main.py:74
+    has_valid=False,                   # main.py:82
+    valid_candi_size=500,              # main.py:86
+    test_candi_size=-1,                # main.py:88
+    data_dir='/tmp',
+    input_train_dir='',
+    save_dir='/tmp',
+    log_file='train.log',
+    rankfname='test.best_model.ranklist',
+    shuffle_review_words=True,
+    max_train_epoch=20,                # main.py:118
+    start_epoch=0,
+    steps_per_checkpoint=200,
+    materialize_candidates=False,      # extension: build the reference's chunked all-product candidate lists
 )
 
 

@@ -62,10 +62,13 @@ struct PsRng {
   }
 };
 
-extern "C" void* ps_rng_create(uint64_t seed) {                 // random.seed(int): key = 32-bit digits of |seed|
-  PsRng* r = new PsRng;
+extern "C" void ps_rng_seed(void* rng, uint64_t seed) {         // random.seed(int): key = 32-bit digits of |seed|
   uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
-  r->init_by_array(key, key[1] ? 2 : 1);
+  ((PsRng*)rng)->init_by_array(key, key[1] ? 2 : 1);
+}
+extern "C" void* ps_rng_create(uint64_t seed) {
+  PsRng* r = new PsRng;
+  ps_rng_seed(r, seed);
   return r;
 }
 extern "C" void ps_rng_destroy(void* rng) { delete (PsRng*)rng; }
@@ -201,8 +204,9 @@ extern "C" int ps_collate_test(const PsCorpusView* c, const PsCollateArgs* a, co
                                int64_t* out_qw, int64_t* out_target, int64_t* out_u_items, int64_t* out_candi,
                                int32_t* out_hist_len, int32_t* out_lmax) {
   if (check_corpus(c, a)) return 1;
-  if (!quad || B < 1 || !candi_ptr || !candi_items || candi_width < 1) return fail("collate_test: bad arguments");
-  if (!out_qw || !out_target || !out_u_items || !out_candi || !out_hist_len || !out_lmax)
+  if (!quad || B < 1 || !candi_ptr || candi_width < 0 || (candi_width > 0 && !candi_items))
+    return fail("collate_test: bad arguments");
+  if (!out_qw || !out_target || !out_u_items || (candi_width > 0 && !out_candi) || !out_hist_len || !out_lmax)
     return fail("collate_test: null output");
   std::vector<int64_t> tmp;
   std::vector<int> pos;
@@ -220,10 +224,55 @@ extern "C" int ps_collate_test(const PsCorpusView* c, const PsCollateArgs* a, co
     if (n > lmax) lmax = n;
     const int64_t cb = candi_ptr[b], ce = candi_ptr[b + 1];
     if (ce - cb > candi_width || ce < cb) return fail("collate_test: candidate list %d longer than width", b);
+    if (candi_width == 0) continue;                                                     // full-catalogue entries
     int64_t* row = out_candi + (size_t)b * candi_width;
     memcpy(row, candi_items + cb, sizeof(int64_t) * (size_t)(ce - cb));
     for (int64_t i = ce - cb; i < candi_width; ++i) row[i] = a->prod_pad;               // util.pad (:46)
   }
   *out_lmax = lmax;
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- epoch sample collection
+extern "C" void ps_rng_shuffle(void* rng_, int64_t* x, int64_t n) {          // Random.shuffle, CPython 3.10
+  PsRng* rng = (PsRng*)rng_;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    const int64_t j = (int64_t)rng->randbelow((uint32_t)(i + 1));
+    const int64_t t = x[i]; x[i] = x[j]; x[j] = t;
+  }
+}
+
+extern "C" int ps_collect_train_samples(const int64_t* rw_ptr, int64_t* rw_words, int64_t n_reviews,
+                                        const int64_t* train_reviews, int64_t n_train, const double* rnd, int64_t n_rand,
+                                        const double* sub_rate, int64_t vocab_size, int32_t W, int64_t word_pad, void* rng,
+                                        int64_t* out_words, int64_t* out_review, int64_t cap, int64_t* out_n) {
+  if (!rw_ptr || !rw_words || !train_reviews || !rnd || !sub_rate || !rng || !out_words || !out_review || !out_n || W < 1)
+    return fail("collect_train_samples: bad argument");
+  int64_t entry = 0, n_out = 0, last_review = -1;
+  int fill = 0;
+  for (int64_t t = 0; t < n_train; ++t) {
+    const int64_t r = train_reviews[t];
+    if (r < 0 || r >= n_reviews) return fail("collect_train_samples: review id %lld out of range", (long long)r);
+    last_review = r;
+    int64_t* w = rw_words + rw_ptr[r];
+    const int64_t len = rw_ptr[r + 1] - rw_ptr[r];
+    ps_rng_shuffle(rng, w, len);                                              // :81
+    for (int64_t i = 0; i < len; ++i) {
+      const int64_t word = w[i];
+      if (word < 0 || word >= vocab_size) return fail("collect_train_samples: word id %lld out of range", (long long)word);
+      if (entry >= n_rand) return fail("collect_train_samples: rand stream exhausted");
+      if (rnd[entry] > sub_rate[word]) continue;                             // entry NOT advanced (:84-85)
+      if (n_out >= cap) return fail("collect_train_samples: output capacity %lld too small", (long long)cap);
+      out_words[n_out * W + fill] = word;
+      if (++fill == W) { out_review[n_out++] = r; fill = 0; }
+      ++entry;
+    }
+  }
+  if (fill > 0) {                                                             // :91-92
+    if (n_out >= cap) return fail("collect_train_samples: output capacity %lld too small", (long long)cap);
+    for (int i = fill; i < W; ++i) out_words[n_out * W + i] = word_pad;
+    out_review[n_out++] = last_review;
+  }
+  *out_n = n_out;
   return 0;
 }

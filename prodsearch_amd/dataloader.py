@@ -16,7 +16,7 @@ import numpy as np
 import torch
 from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
 
-from . import _lib
+from . import _lib, pyrandom
 from .batch import ItemPVBatch
 
 
@@ -74,8 +74,9 @@ class ItemPVDataloader(object):
         self.prefetch = int(prefetch)
         sampler = RandomSampler(dataset) if shuffle else SequentialSampler(dataset)
         self.batch_sampler = BatchSampler(sampler, batch_size, drop_last)     # len() and the reference's semantics
-        self._rng = self._lib.ps_rng_create(int(seed) if seed is not None else
-                                            int(torch.empty((), dtype=torch.int64).random_().item()) & (2 ** 63 - 1))
+        # seed=None: the process-wide generator (pyrandom.seed(s) == the reference's random.seed(s)), shared with
+        # the dataset's epoch shuffles; seed=int: a private stream
+        self._own_rng = self._lib.ps_rng_create(int(seed)) if seed is not None else None
         self._pin = bool(pin_memory) and torch.cuda.is_available()
         # staging buffers rotate over 3 slots; a slot is reused only after the copies issued from it have finished
         self._slots = [dict() for _ in range(3)]
@@ -85,14 +86,21 @@ class ItemPVDataloader(object):
 
     def __del__(self):
         try:
-            self._lib.ps_rng_destroy(self._rng)
+            if self._own_rng is not None:
+                self._lib.ps_rng_destroy(self._own_rng)
         except Exception:
             pass
 
+    @property
+    def _rng(self):
+        return self._own_rng if self._own_rng is not None else pyrandom.handle()
+
     def reseed(self, seed):
         """``random.seed(seed)`` for the query / history draws."""
-        self._lib.ps_rng_destroy(self._rng)
-        self._rng = self._lib.ps_rng_create(int(seed))
+        if self._own_rng is None:
+            pyrandom.seed(seed)
+        else:
+            self._lib.ps_rng_seed(self._own_rng, int(seed))
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -100,13 +108,16 @@ class ItemPVDataloader(object):
     # ------------------------------------------------------------------ dataset -> arrays (once per epoch)
     def _flatten_dataset(self):
         data = self.dataset._data
-        if self._train:
+        if self._train and hasattr(self.dataset, 'sample_words'):       # prodsearch_amd.corpus.ItemPVDataset: already flat
+            self.sample_words, self.sample_review = self.dataset.sample_words, self.dataset.sample_review
+            self._index_of = None
+        elif self._train:
             self.sample_words = np.ascontiguousarray(np.asarray([e[0] for e in data], dtype=np.int64).reshape(len(data), -1))
             self.sample_review = np.asarray([e[1] for e in data], dtype=np.int64)
             self._index_of = None
         else:
             self.entry_quad = np.ascontiguousarray(np.asarray([e[:4] for e in data], dtype=np.int64).reshape(len(data), 4))
-            self.candi_ptr, self.candi_items = _csr([e[4] for e in data])
+            self.candi_ptr, self.candi_items = _csr([e[4] if e[4] is not None else () for e in data])
 
     def _next_slot(self):
         self._slot = (self._slot + 1) % len(self._slots)
@@ -149,11 +160,13 @@ class ItemPVDataloader(object):
         return t.to(self.device, non_blocking=True)
 
     # ------------------------------------------------------------------ collates
-    def train_batch_from_ids(self, ids):
+    def train_batch_from_ids(self, ids, sample_words=None, sample_review=None):
         """``get_train_batch`` (item_pv_dataloader.py:121-143) for dataset rows ``ids``."""
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64))
         self._next_slot()
-        B, W, Q = len(ids), self.sample_words.shape[1], self.corpus.view.Q
+        sample_words = self.sample_words if sample_words is None else sample_words
+        sample_review = self.sample_review if sample_review is None else sample_review
+        B, W, Q = len(ids), sample_words.shape[1], self.corpus.view.Q
         lim = int(self.args.uprev_review_limit)
         qw, tg = self._buf('qw', (B, Q)), self._buf('tg', (B,))
         ui, pw = self._buf('ui', (B, lim)), self._buf('pw', (B, W))
@@ -162,8 +175,8 @@ class ItemPVDataloader(object):
         lmax = C.c_int32(0)
         a = self._args(self.args.do_seq_review_train, self.args.fix_train_review)
         _lib.check_data(self._lib.ps_collate_train(
-            self.corpus.view, a, self._rng, self.sample_words.ctypes.data, self.sample_review.ctypes.data,
-            len(self.sample_review), W, ids.ctypes.data, B, qw.data_ptr(), tg.data_ptr(), ui.data_ptr(), pw.data_ptr(),
+            self.corpus.view, a, self._rng, sample_words.ctypes.data, sample_review.ctypes.data,
+            len(sample_review), W, ids.ctypes.data, B, qw.data_ptr(), tg.data_ptr(), ui.data_ptr(), pw.data_ptr(),
             qi.data_ptr(), us.data_ptr(), hl.ctypes.data, C.addressof(lmax)), 'ps_collate_train')
         L = lmax.value                                   # util.pad: width of the longest history in the batch
         out = ItemPVBatch(self._ship(qw), self._ship(tg), self._ship(ui[:, :L]).contiguous(), self._ship(pw),
@@ -184,9 +197,9 @@ class ItemPVDataloader(object):
         citems = np.concatenate([self.candi_items[self.candi_ptr[i]:self.candi_ptr[i + 1]] for i in ids]) \
             if B else np.zeros(0, np.int64)
         citems = np.ascontiguousarray(citems)
-        width = int(lens.max())
+        width = int(lens.max())                          # 0: full-catalogue entries (evaluate.rank_all needs no list)
         qw, tg = self._buf('qw', (B, Q)), self._buf('tg', (B,))
-        ui, ca = self._buf('ui', (B, lim)), self._buf('ca', (B, width))
+        ui, ca = self._buf('ui', (B, lim)), self._buf('ca', (B, max(width, 1)))
         hl = np.zeros(B, dtype=np.int32)
         lmax = C.c_int32(0)
         do_seq = getattr(self.args, 'do_seq_review_test', False) and not self.args.train_review_only
@@ -198,7 +211,8 @@ class ItemPVDataloader(object):
         L = lmax.value
         out = ItemPVBatch(self._ship(qw), self._ship(tg), self._ship(ui[:, :L]).contiguous(),
                           torch.zeros(0, dtype=torch.int64), query_idxs=quad[:, 0].tolist(),
-                          user_idxs=quad[:, 1].tolist(), candi_prod_idxs=self._ship(ca), to_tensor=False)
+                          user_idxs=quad[:, 1].tolist(),
+                          candi_prod_idxs=self._ship(ca if width else ca[:, :0].contiguous()), to_tensor=False)
         self._shipped()
         return out
 
@@ -209,7 +223,10 @@ class ItemPVDataloader(object):
         return [self._index_of[id(e)] for e in batch]
 
     def get_train_batch(self, batch):
-        return self.train_batch_from_ids(self._ids_of(batch))
+        """The reference's collate_fn signature: ``batch`` = dataset entries ``[word ids, review id]``."""
+        sw = np.ascontiguousarray(np.asarray([e[0] for e in batch], dtype=np.int64).reshape(len(batch), -1))
+        sr = np.asarray([e[1] for e in batch], dtype=np.int64)
+        return self.train_batch_from_ids(np.arange(len(batch)), sw, sr)
 
     def get_test_batch(self, batch):
         if getattr(self, '_index_of', None) is None:

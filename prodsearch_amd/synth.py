@@ -241,3 +241,72 @@ def make_corpus(seed, n_users=60, n_products=200, n_queries=40, vocab_size=500, 
             return self._data[i]
 
     return _Dataset(train_pd, train_data), _Dataset(test_pd, test_data)
+
+
+# ------------------------------------------------------------------ synthetic corpus on disk (reference file formats)
+def write_corpus(root, seed, n_users=40, n_products=60, n_words=300, n_queries=25, max_reviews=14, split_dir='split'):
+    """Write a small Amazon-shaped corpus in the gz text formats ``data/data_util.py:166-287`` reads
+    (product/users/vocab/review_text/u_r_seq/p_r_seq/review_uloc_ploc_and_time/review_id/review_u_p in ``root``;
+    query/train/train_id/valid_id/test_id/train_query_idx/test_query_idx in ``root/split``).  Returns
+    (data_path, input_train_dir)."""
+    import gzip
+    import os
+    rng = rng_for(seed)
+    inp = os.path.join(root, split_dir)
+    os.makedirs(inp, exist_ok=True)
+
+    def put(path, lines):
+        with gzip.open(path, 'wt') as f:
+            for ln in lines:
+                f.write(ln + '\n')
+
+    put(os.path.join(root, 'product.txt.gz'), ['B%06d' % i for i in range(n_products)])
+    put(os.path.join(root, 'users.txt.gz'), ['A%05d' % i for i in range(n_users)])
+    put(os.path.join(root, 'vocab.txt.gz'), ['w%d' % i for i in range(n_words)])
+    queries = [[int(x) for x in rng.integers(0, n_words, size=int(rng.integers(1, 6)))] for _ in range(n_queries)]
+    put(os.path.join(inp, 'query.txt.gz'), [' '.join(map(str, q)) for q in queries])
+    pq = [[int(x) for x in rng.integers(0, n_queries, size=int(rng.integers(1, 4)))] for _ in range(n_products)]
+    put(os.path.join(inp, 'train_query_idx.txt.gz'), [' '.join(map(str, q)) for q in pq])
+    put(os.path.join(inp, 'test_query_idx.txt.gz'), [' '.join(map(str, q)) for q in pq])
+    # reviews: (time, user, product, text); the review index is the line number in review_text
+    events = []
+    for u in range(n_users):
+        for _ in range(int(min(max_reviews, 2 + rng.geometric(0.25)))):
+            events.append((float(rng.random()), u, int(rng.integers(0, n_products))))
+    order = rng.permutation(len(events))                      # file order is unrelated to time order
+    events = [events[i] for i in order]
+    n_rev = len(events)
+    text = [[int(x) for x in rng.integers(0, n_words, size=int(rng.integers(3, 25)))] for _ in range(n_rev)]
+    by_time = sorted(range(n_rev), key=lambda r: events[r][0])
+    u_seq = [[] for _ in range(n_users)]
+    p_seq = [[] for _ in range(n_products)]
+    loc = [None] * n_rev
+    for rank, r in enumerate(by_time):
+        _, u, p = events[r]
+        loc[r] = (len(u_seq[u]), len(p_seq[p]), rank)
+        u_seq[u].append(r)
+        p_seq[p].append(r)
+    orig = rng.permutation(n_rev * 3)[:n_rev]                  # original line ids: sparse and shuffled
+    put(os.path.join(root, 'review_text.txt.gz'), [' '.join(map(str, t)) for t in text])
+    put(os.path.join(root, 'u_r_seq.txt.gz'), [' '.join(map(str, s)) for s in u_seq])
+    put(os.path.join(root, 'p_r_seq.txt.gz'), [' '.join(map(str, s)) for s in p_seq])
+    put(os.path.join(root, 'review_uloc_ploc_and_time.txt.gz'), ['%d %d %d' % loc[r] for r in range(n_rev)])
+    put(os.path.join(root, 'review_id.txt.gz'), ['line_%d' % orig[r] for r in range(n_rev)])
+    put(os.path.join(root, 'review_u_p.txt.gz'), ['%d %d' % (events[r][1], events[r][2]) for r in range(n_rev)])
+    train, valid, test = [], [], []
+    for u in range(n_users):
+        s = u_seq[u]
+        test.append(s[-1])
+        if len(s) >= 3:
+            valid.append(s[-2])
+            train += s[:-2]
+        else:
+            train += s[:-1]
+    ident = lambda r: '%d\t%d\tline_%d' % (events[r][1], events[r][2], orig[r])
+    put(os.path.join(inp, 'train_id.txt.gz'), [ident(r) for r in train])
+    put(os.path.join(inp, 'train.txt.gz'), ['%d\t%d\t%s' % (events[r][1], events[r][2], ' '.join(map(str, text[r])))
+                                            for r in train])
+    for name, rows in (('valid', valid), ('test', test)):
+        put(os.path.join(inp, '%s_id.txt.gz' % name),
+            [ident(r) + '\t%d' % pq[events[r][2]][int(rng.integers(0, len(pq[events[r][2]])))] for r in rows])
+    return root, inp
