@@ -13,7 +13,7 @@ struct Ws {
   int64_t qmean, query_emb, x;
   LayerWs layer[PS_MAX_LAYERS];
   int64_t fin_stats, enc;
-  int64_t item_scores, word_scores, loss_parts, item_terms, word_terms;
+  int64_t item_scores, word_scores, loss_parts, item_terms, word_terms, loss_blk;
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
   int64_t total;
 };

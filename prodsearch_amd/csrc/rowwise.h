@@ -82,6 +82,8 @@ struct ScoreArgs {
   float* word_terms;             // [B,W,1+K]
   float* loss3;                  // {total, ps, item}
   float* loss_acc;               // optional running sums {ps, item} (item_transformer.py:516-517)
+  float* loss_blk;               // [2*blocks] per-workgroup loss partials written by the gather+score kernel
+  int loss_nblk;                 // filled by launch_score_fwd
   // backward
   float scale;                   // loss_scale
   const float* scale_dev;        // optional device scalar multiplied into scale
@@ -91,7 +93,7 @@ struct ScoreArgs {
 inline void score_finish(ScoreArgs& a) {
   a.fK1 = make_fdiv(a.K + 1); a.fWK1 = make_fdiv(a.W * (a.K + 1)); a.fC = make_fdiv(a.C > 0 ? a.C : 1);
 }
-int launch_score_fwd(const ScoreArgs& a, hipStream_t st);     // gather + dot ("gather+score kernel")
+int launch_score_fwd(ScoreArgs& a, hipStream_t st);           // gather + dot ("gather+score kernel")
 int launch_loss(const ScoreArgs& a, hipStream_t st);
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
 

@@ -419,6 +419,7 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
 struct Task {
   const float* row; const float* vec; float bias; float* out;
   float* term; float tw;     // loss term = |tw| * softplus(sign(tw) * score): tw < 0 for the positive
+  float lw;                  // weight of the term in the batch loss: item tasks +1; word tasks -(valid / #valid windows)
 };
 __device__ inline Task score_task(const ScoreArgs& a, int t) {
   Task k;
@@ -430,7 +431,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.vec = a.enc + (size_t)b * a.R * a.d;
     k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
     k.out = a.item_scores + t;
-    k.term = nullptr; k.tw = 0.f;
+    k.term = nullptr; k.tw = 0.f; k.lw = 0.f;
     return k;
   }
   const int nitem = a.B * K1;
@@ -443,6 +444,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.out = a.item_scores + t;
     k.term = a.item_terms + t;
     k.tw = j == 0 ? -(a.pos_weight ? (float)a.K : 1.f) : 1.f;
+    k.lw = 1.f;
   } else {
     int u = t - nitem;
     int b = fdiv(u, a.fWK1), r = u - b * (a.W * K1);
@@ -456,6 +458,11 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
     k.out = a.word_scores + u;
     k.term = a.word_terms + u;
     k.tw = j == 0 ? -1.f : 1.f;
+    // masked mean over the window (get_vector_mean, item_transformer.py:281): padded slots drop out
+    int cnt = 0;
+    for (int ww = 0; ww < a.W; ++ww) cnt += a.pos_words[(size_t)b * a.W + ww] != a.V - 1;
+    const bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
+    k.lw = valid ? -1.f / (float)cnt : -0.f;
   }
   return k;
 }
@@ -474,8 +481,9 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
   for (int u = 0; u < SCORE_U; ++u) {
     int t = t0 + u;
     if (t < ntask) tk[u] = score_task(a, t);
-    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; }
+    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; tk[u].lw = 0.f; }
   }
+  float cps = 0.f, cil = 0.f;                      // this row group's share of the two loss sums
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -506,12 +514,28 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
       const float sc = s + tk[u].bias;
       *tk[u].out = sc;
       // BCE-with-logits term of this task (item_transformer.py:510-513, :280): target 1 -> softplus(-s)
-      if (tk[u].term) *tk[u].term = fabsf(tk[u].tw) * softplus_f(tk[u].tw < 0.f ? -sc : sc);
+      if (tk[u].term) {
+        const float term = fabsf(tk[u].tw) * softplus_f(tk[u].tw < 0.f ? -sc : sc);
+        *tk[u].term = term;
+        if (tk[u].lw > 0.f) cps += term; else cil -= term * tk[u].lw;
+      }
     }
+  }
+  if (!a.loss_blk || a.C > 0) return;
+  // per-workgroup loss partials in a fixed order (plain stores: the kernel boundary publishes them); loss_kernel
+  // then only has 2 floats per workgroup to reduce instead of every term
+  __shared__ float rps[64], ril[64];
+  if (c == 0) { rps[tid / lpr] = cps; ril[tid / lpr] = cil; }
+  __syncthreads();
+  if (tid == 0) {
+    float p = 0.f, q = 0.f;
+    for (int g2 = 0; g2 < gpb; ++g2) { p += rps[g2]; q += ril[g2]; }
+    a.loss_blk[2 * blockIdx.x] = p;
+    a.loss_blk[2 * blockIdx.x + 1] = q;
   }
 }
 
-int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
+int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
   int lpr = lpr_for(a.d);
@@ -523,6 +547,7 @@ int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
   int groups = ps_cdiv(ntask, U);
   int blocks = ps_cdiv(groups, 256 / lpr);
   dim3 g(blocks), b(256);
+  a.loss_nblk = blocks;
   if (U == 1) hipLaunchKernelGGL((score_fwd_kernel<1, 0>), g, b, 0, st, a, ntask, lpr);
   else if (U == 2 && !NT) hipLaunchKernelGGL((score_fwd_kernel<2, 0>), g, b, 0, st, a, ntask, lpr);
   else if (U == 8 && !NT) hipLaunchKernelGGL((score_fwd_kernel<8, 0>), g, b, 0, st, a, ntask, lpr);
@@ -534,43 +559,27 @@ int launch_score_fwd(const ScoreArgs& a, hipStream_t st) {
   return PS_OK;
 }
 
-// Loss (item_transformer.py:500-514 weighted BCE-with-logits; :277-282 PV loss): one block,
-// fixed-order tree reduction => bitwise reproducible.
+// Loss (item_transformer.py:500-514 weighted BCE-with-logits; :277-282 PV loss): the gather+score kernel leaves one
+// {ps, il} partial per workgroup (terms already weighted by the window mask); one workgroup reduces them in a fixed
+// tree => bitwise reproducible, a single memory round trip.  (Folding this last step into the score
+// kernel with a last-ticket workgroup was measured 7x slower: the device-scope release each workgroup needs
+// writes back its XCD's L2.)
 __global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
-  __shared__ float sps[256], sil[256];
-  const int tid = threadIdx.x, K1 = a.K + 1;
+  __shared__ float sps[4], sil[4];
+  const int tid = threadIdx.x;
   float aps = 0.f, ail = 0.f;
-  for (int b = tid; b < a.B; b += 256) {
-    const float* s = a.item_terms + (size_t)b * K1;
-    float ps = 0.f;
-    for (int k = 0; k < K1; ++k) ps += s[k];
-    float il = 0.f;
-    int cnt = 0;
-    for (int w = 0; w < a.W; ++w) {
-      bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
-      cnt += valid;
-      if (valid) {
-        const float* ws = a.word_terms + ((size_t)b * a.W + w) * K1;
-        float l = 0.f;
-        for (int k = 0; k < K1; ++k) l += ws[k];
-        il += l;
-      }
-    }
-    il /= (float)(cnt > 0 ? cnt : 1);
-    a.loss_parts[2 * b] = ps;
-    a.loss_parts[2 * b + 1] = il;
-    aps += ps; ail += il;
-  }
-  sps[tid] = aps; sil[tid] = ail;
+  const int n2 = a.loss_nblk >> 1;                                         // two workgroups' {ps, il} per 16 bytes
+  const float4* p4 = reinterpret_cast<const float4*>(a.loss_blk);          // workspace regions are 16-byte aligned
+  for (int t = tid; t < n2; t += 256) { const float4 v = p4[t]; aps += v.x + v.z; ail += v.y + v.w; }
+  if (tid == 0 && (a.loss_nblk & 1)) { aps += a.loss_blk[2 * (a.loss_nblk - 1)]; ail += a.loss_blk[2 * a.loss_nblk - 1]; }
+  aps = wave_sum(aps); ail = wave_sum(ail);
+  if ((tid & 63) == 0) { sps[tid >> 6] = aps; sil[tid >> 6] = ail; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) { sps[tid] += sps[tid + o]; sil[tid] += sil[tid + o]; }
-    __syncthreads();
-  }
   if (tid == 0) {
-    float ps = sps[0] / (float)a.B, il = sil[0] / (float)a.B;
+    const float ps = ((sps[0] + sps[1]) + (sps[2] + sps[3])) / (float)a.B;
+    const float il = ((sil[0] + sil[1]) + (sil[2] + sil[3])) / (float)a.B;
     a.loss3[0] = ps + il; a.loss3[1] = ps; a.loss3[2] = il;
-    if (a.loss_acc) { a.loss_acc[0] += ps; a.loss_acc[1] += il; }     // model.ps_loss / item_loss running sums
+    if (a.loss_acc) { a.loss_acc[0] += ps; a.loss_acc[1] += il; }   // model.ps_loss / item_loss running sums
   }
 }
 

@@ -104,6 +104,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.loss_parts = take(cur, (int64_t)B * 2);
   w.item_terms = take(cur, (int64_t)B * (D.K + 1));
   w.word_terms = take(cur, (int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1));
+  w.loss_blk = take(cur, 2 * ((int64_t)B * (D.K + 1) * (1 + D.W) / 4 + 2));     // >= 2 floats per score workgroup
   // backward scratch (sized for the widest layer)
   w.denc = take(cur, (int64_t)w.Mf * d);
   if (tem) {
@@ -366,7 +367,7 @@ static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBat
   s.product_emb = P.product_emb; s.word_emb = P.word_emb; s.product_bias = P.product_bias; s.word_bias = P.word_bias;
   s.enc = ws + w.enc;
   s.item_scores = ws + w.item_scores; s.word_scores = ws + w.word_scores; s.loss_parts = ws + w.loss_parts;
-  s.item_terms = ws + w.item_terms; s.word_terms = ws + w.word_terms;
+  s.item_terms = ws + w.item_terms; s.word_terms = ws + w.word_terms; s.loss_blk = ws + w.loss_blk;
   score_finish(s);
 }
 
@@ -599,8 +600,6 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
     GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
     TRY(run1(p, st));
-    GemmProblem wg[1] = {gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B)};
-    TRY(side_wgrads(wg, 1, st));
     e.dqmean_d = ws + w.dqmean;
   } else {
     // AVG encoder: query_emb == post-dropout mean; copy rows to a dense [B,d] buffer
@@ -609,6 +608,11 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     e.dqmean_d = ws + w.dqmean;
   }
   TRY(launch_embed_scatter(e, st));
+  if (D.query_encoder == PS_QENC_FS) {
+    // f_W weight gradient: tiny, and the side stream is still busy with the K/V weight gradients — keep it here
+    GemmProblem wg[1] = {gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B)};
+    TRY(run_wgrads(wg, 1, st));
+  }
   TRY(side_join(st));
   return PS_OK;
 }
