@@ -35,4 +35,6 @@ GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb
 int run1(const GemmProblem& p, hipStream_t st);
 GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in, int rows);
 int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st);
+int side_fork(hipStream_t main_st);
+int side_run(GemmProblem* ps, int n, hipStream_t main_st);
 int side_join(hipStream_t main_st);

@@ -219,15 +219,26 @@ static SideCtx* side_ctx() {
   }
   return state == 1 ? &ctx : nullptr;
 }
-int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
+// fork: everything enqueued on the main stream so far is visible to later side-stream work.  Each fork costs the
+// main stream one event packet (~6 us before its next kernel, measured), so callers batch their weight gradients.
+int side_fork(hipStream_t main_st) {
   SideCtx* c = side_ctx();
-  if (!c) return run_wgrads(ps, n, main_st);
+  if (!c) return PS_OK;
   hipEvent_t ev = c->ev[c->next];
   c->next = (c->next + 1) & 7;
   PS_CHECK_HIP(hipEventRecord(ev, main_st));
   PS_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
   c->used = true;
-  return run_wgrads(ps, n, c->stream);
+  return PS_OK;
+}
+// launch on the side stream (after the last fork); on the main stream when the side stream is disabled
+int side_run(GemmProblem* ps, int n, hipStream_t main_st) {
+  SideCtx* c = side_ctx();
+  return run_wgrads(ps, n, c ? c->stream : main_st);
+}
+int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
+  TRY(side_fork(main_st));
+  return side_run(ps, n, main_st);
 }
 int side_join(hipStream_t main_st) {
   SideCtx* c = side_ctx();
@@ -474,12 +485,14 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
       p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
       TRY(run1(p, st));
-      GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};    // dW2 += do2^T . h1
-      TRY(side_wgrads(wg, 1, st));
+      // dW2 += do2^T . h1 and dW1 += da1^T . ln1: one fork (both operands exist once the GEMM above is done)
+      GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
+      GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
+      TRY(side_fork(st));
+      TRY(side_run(wg, 1, st));
+      TRY(side_run(wg1, 1, st));
       GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
       TRY(run1(q, st));
-      GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
-      TRY(side_wgrads(wg1, 1, st));
       LnBwdArgs n;
       memset(&n, 0, sizeof(n));
       n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
@@ -495,8 +508,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     {
       GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
       TRY(run1(p, st));
-      GemmProblem wg[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
-      TRY(side_wgrads(wg, 1, st));
+      GemmProblem wgo[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};   // launched with the K/V/Q ones below
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
@@ -513,6 +525,15 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       a.qscale = 1.f / sqrtf((float)(d / D.H));
       attn_finish(a);
       TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
+      // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
+      GemmProblem wg3[3];
+      wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
+      wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
+      if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
+      else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
+      TRY(side_fork(st));
+      TRY(side_run(wgo, 1, st));
+      TRY(side_run(wg3, 3, st));
       // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
       float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
       GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);
@@ -527,12 +548,6 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         xq.accumulate = 1;
         TRY(run1(xq, st));
       }
-      GemmProblem wg3[3];
-      wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
-      wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
-      if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
-      else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
-      TRY(side_wgrads(wg3, 3, st));
     }
     if (i != 0) {   // pre-LayerNorm backward -> grad wrt the previous layer's output
       TRY(side_join(st));   // the next layer reuses the scratch buffers the side-stream GEMMs read

@@ -431,10 +431,6 @@ class ItemTransformerRanker(nn.Module):
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=False)
-        if torch.is_grad_enabled():
-            ev = torch.cuda.Event()                  # everything before this forward (the last optimizer step)
-            ev.record(torch.cuda.current_stream(self._dev()))
-            self.__dict__['_fwd_start_event'] = ev
         self._fwd_step += 1
         plan.desc.step = self._fwd_step
         if neg_items is None or neg_words is None:
@@ -499,35 +495,7 @@ class ItemTransformerRanker(nn.Module):
                 out[name] = info['rows'][:int(info['count'][0])].clone()
         return out
 
-    def zero_grad(self, set_to_none=True):
-        """``model.zero_grad()`` (trainer.py:76) sits between forward and backward: the forward's kernels are still
-        running when Python gets here, so the memset of the flat gradient buffer is issued on a side stream ordered
-        only after the work that preceded this forward (the previous optimizer step) and joins before the backward."""
-        super().zero_grad(set_to_none=True)
-        self.__dict__['_zero_event'] = None
-        if self._grad_flat is None or not self._grad_flat.is_cuda or self._row_sparse():
-            return
-        start = self.__dict__.get('_fwd_start_event')
-        if start is None:
-            return
-        side = self.__dict__.get('_side_stream')
-        if side is None:
-            side = self.__dict__['_side_stream'] = torch.cuda.Stream(self._dev())
-        side.wait_event(start)
-        with torch.cuda.stream(side):
-            _lib.check(_lib.load().ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(),
-                                                  side.cuda_stream), 'ps_zero_floats')
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self.__dict__['_zero_event'] = ev
-        self.__dict__['_fwd_start_event'] = None
-
     def _zero_for_backward(self):
-        ev = self.__dict__.get('_zero_event')
-        if ev is not None:                       # zero_grad() already issued the memset on the side stream
-            torch.cuda.current_stream(self._dev()).wait_event(ev)
-            self.__dict__['_zero_event'] = None
-            return
         lib = _lib.load()
         st = self._stream()
         if not self._row_sparse():
@@ -557,7 +525,6 @@ class ItemTransformerRanker(nn.Module):
         lib = _lib.load()
         ps, gs = self._structs()
         st = self._stream()
-        self.__dict__['_fwd_start_event'] = None     # a zero_grad() after this point must not overtake the backward
         if self._assign_grads():
             self._zero_for_backward()
         elif self._row_sparse() and any(getattr(p, '_ps_rows', {}).get('dirty') for _, p, _ in self._sparse_tabs):
