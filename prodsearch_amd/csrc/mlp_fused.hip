@@ -8,8 +8,8 @@
 // Unfused this is 3 GEMM + 2 LayerNorm launches whose 64x64 tiles each live for one short,
 // latency-bound round trip.  Here a workgroup (4 waves) owns 32 replica rows for the whole chain:
 // activations stay in LDS/registers, and the 0.6 MB of weights stream through a double-buffered
-// LDS slab ring (32-deep slabs of 128 output columns, prefetched global->registers while the
-// previous slab is multiplied), so the MFMA pipe sees 36 slabs x 16 v_mfma_f32_32x32x2_f32 per
+// LDS slab ring (64-deep slabs of 128 output columns, prefetched global->registers while the
+// previous slab is multiplied), so the MFMA pipe sees 18 slabs x 32 v_mfma_f32_32x32x2_f32 per
 // wave back to back instead of 5 cold starts.  W1/W2 are walked in 128-unit chunks of the hidden
 // layer so h1 never exists as a whole tile: a1 chunk -> gelu/dropout -> LDS -> accumulate into y2.
 // Everything the backward needs (y1, ln1, a1, h1, y2, LN statistics) is still written once.
@@ -29,7 +29,11 @@ __device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 #define MD 128            // model width this kernel is specialised for
 #define MBM 32            // replica rows per workgroup
-#define MBK 32            // reduction depth of one weight slab
+#ifndef MBK
+#define MBK 64            // reduction depth of one weight slab (64: slab MFMA time ~ the L2 latency of the prefetch)
+#endif
+#define SPP (128 / MBK)   // slabs per 128-deep product
+#define WRN (MBK / 8)     // float4 registers per thread holding one prefetched slab
 #define XLD 33            // k-major activation tiles: [k][row + 1]
 #define WLD 129           // weight slabs: [k][col + 1]
 #define YLD 129           // row-major staging tile for the LayerNorms: [row][col + 1]
@@ -42,17 +46,19 @@ struct MlpLds {
 static_assert(MBM * YLD <= MD * XLD, "Y staging must fit the h1 tile");
 
 // global -> registers: slab of 128 output rows x 32 k from a [n][k] (k contiguous) matrix
-__device__ inline void slab_load(const float* __restrict__ W, int ldw, int n0, int k0, float4 (&r)[4], int tid) {
+__device__ inline void slab_load(const float* __restrict__ W, int ldw, int n0, int k0, float4 (&r)[WRN], int tid) {
+  constexpr int KQ = MBK / 4, NPP = 256 / KQ;      // float4 columns per slab row, slab rows per pass
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int n = (tid >> 3) + 32 * u, kq = tid & 7;
+  for (int u = 0; u < WRN; ++u) {
+    const int n = tid / KQ + NPP * u, kq = tid % KQ;
     r[u] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + n) * ldw + k0 + 4 * kq);
   }
 }
-__device__ inline void slab_store(float* Wsb, const float4 (&r)[4], int tid) {
+__device__ inline void slab_store(float* Wsb, const float4 (&r)[WRN], int tid) {
+  constexpr int KQ = MBK / 4, NPP = 256 / KQ;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int n = (tid >> 3) + 32 * u, kk = 4 * (tid & 7);
+  for (int u = 0; u < WRN; ++u) {
+    const int n = tid / KQ + NPP * u, kk = 4 * (tid % KQ);
     Wsb[(kk + 0) * WLD + n] = r[u].x;
     Wsb[(kk + 1) * WLD + n] = r[u].y;
     Wsb[(kk + 2) * WLD + n] = r[u].z;
@@ -83,24 +89,24 @@ __device__ inline void tile_layernorm(const float* Y, const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const MlpFwdArgs a) {
+__global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs a) {
   extern __shared__ float lds_raw[];
   MlpLds& L = *reinterpret_cast<MlpLds*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * MBM, M = a.M;
   const int col = wave * 32 + l31;                 // this lane's output column in every 128-wide product
   const int nchunk = a.F / 128;
-  const int NS = 4 + 8 * nchunk;                   // weight slabs: Wo(4), then per chunk W1c(4) + W2c(4)
+  const int NS = SPP * (1 + 2 * nchunk);           // weight slabs: Wo, then per chunk W1c + W2c (SPP slabs each)
 
   auto slab_src = [&](int s, const float*& W, int& ldw, int& n0, int& k0) {
-    if (s < 4) { W = a.wo; ldw = MD; n0 = 0; k0 = 32 * s; return; }
-    const int t = s - 4, c = t >> 3, r = t & 7;
-    if (r < 4) { W = a.w1; ldw = MD; n0 = 128 * c; k0 = 32 * r; }
-    else { W = a.w2; ldw = a.F; n0 = 0; k0 = 128 * c + 32 * (r - 4); }
+    if (s < SPP) { W = a.wo; ldw = MD; n0 = 0; k0 = MBK * s; return; }
+    const int t = s - SPP, c = t / (2 * SPP), r = t % (2 * SPP);
+    if (r < SPP) { W = a.w1; ldw = MD; n0 = 128 * c; k0 = MBK * r; }
+    else { W = a.w2; ldw = a.F; n0 = 0; k0 = 128 * c + MBK * (r - SPP); }
   };
 
   // ---- prologue: first weight slab, the ctx tile (k-major), the residual rows
-  float4 wr[4];
+  float4 wr[WRN];
   {
     const float* W; int ldw, n0, k0;
     slab_src(0, W, ldw, n0, k0);
@@ -139,27 +145,30 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       slab_load(W, ldw, n0, k0, wr, tid);
     }
     // which product is this slab part of?
-    const int t = s - 4, r8 = t & 7;
-    const bool is_w2 = s >= 4 && r8 >= 4;
-    const int ka = s < 4 ? 32 * s : (is_w2 ? 32 * (r8 - 4) : 32 * r8);     // k offset inside the A tile
+    const int t = s - SPP, r8 = t % (2 * SPP);
+    const bool is_w2 = s >= SPP && r8 >= SPP;
+    const int ka = s < SPP ? MBK * s : (is_w2 ? MBK * (r8 - SPP) : MBK * r8);     // k offset inside the A tile
     const float* A = is_w2 ? L.Hs : L.Xs;
-    const float* ab = A + (ka + h) * XLD + l31;
-    const float* bb = L.Ws[buf] + h * WLD + col;
-    float av[16], bv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLD]; }
-    if (a.dbg & 2) {
-      acc[0] += av[0] * bv[0] + av[15] * bv[15];
-    } else if (is_w2) {
+    for (int half = 0; half < MBK / 32; ++half) {                               // 16 MFMAs (32 k) at a time
+      const float* ab = A + (ka + 32 * half + h) * XLD + l31;
+      const float* bb = L.Ws[buf] + (32 * half + h) * WLD + col;
+      float av[16], bv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
-    } else {
+      for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLD]; }
+      if (a.dbg & 2) {
+        acc[0] += av[0] * bv[0] + av[15] * bv[15];
+      } else if (is_w2) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+      }
     }
 
     // ---- stage boundaries
-    if (s == 3) {
+    if (s == SPP - 1) {
       // y1 = dropout(ctx.Wo^T + bo) + residual ; LayerNorm_ff -> ln1 (k-major in Xs)
       const float bias = a.bo[col];
       float* Y = L.Hs;
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       __syncthreads();                              // Y complete; every wave is done reading ctx from Xs
       tile_layernorm(Y, a.g1, a.be1, L.Xs, a.ln1, a.st1, opaque(m0), M, wave, lane);
       // the end-of-iteration barrier below publishes ln1 before the W1 slabs read it
-    } else if (s >= 4 && r8 == 3) {
+    } else if (s >= SPP && r8 == SPP - 1) {
       // a1 chunk -> gelu -> dropout -> h1 chunk (k-major in Hs)
-      const int c = t >> 3, f = 128 * c + col;
+      const int c = t / (2 * SPP), f = 128 * c + col;
       const float bias = a.b1[f];
       const int mm0 = opaque(m0);
 #pragma unroll

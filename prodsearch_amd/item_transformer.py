@@ -118,6 +118,23 @@ class _RankLossFn(torch.autograd.Function):
         return None, None, None, None
 
 
+class _LossTensor(torch.Tensor):
+    """The 0-dim loss ``forward`` returns.  It is an ordinary autograd tensor (``grad_fn`` = the node above), but the
+    trainer's plain ``loss.backward()`` (trainer.py:77) — no ``gradient``, no ``inputs``, no ``create_graph`` — is
+    d loss/d loss = 1 through a single node, so it calls the HIP backward directly: no autograd-engine round trip on
+    the host and no ``ones_like`` fill kernel on the device.  Anything else (scaled losses, retained graphs) takes the
+    normal autograd path."""
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        fast = self.__dict__.pop('_ps_fast', None)
+        if fast is not None and gradient is None and not create_graph and inputs is None and not retain_graph:
+            model, plan, step = fast
+            if model._fwd_step == step:              # the workspace still holds this forward's activations
+                model._run_backward(plan, None)
+                return None
+        return super().backward(gradient, retain_graph, create_graph, inputs)
+
+
 class _Plan(object):
     """Per-shape cached call state: descriptor, batch struct, workspace."""
     __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep')
@@ -212,7 +229,9 @@ class ItemTransformerRanker(nn.Module):
         plan, loss3 = self._run_forward(batch_data, neg_item_idxs, neg_word_idxs)
         if not torch.is_grad_enabled():
             return loss3[0]
-        return _RankLossFn.apply(self._anchor(), self, plan, loss3)
+        out = _RankLossFn.apply(self._anchor(), self, plan, loss3).as_subclass(_LossTensor)
+        out._ps_fast = (self, plan, self._fwd_step)
+        return out
 
     def test(self, batch_data):
         return self._run_score(batch_data)
@@ -539,9 +558,9 @@ class ItemTransformerRanker(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._coalesce_touched(plan)
-        go = grad_out.contiguous().float()
+        go = None if grad_out is None else grad_out.contiguous().float()      # None: d loss / d loss = 1
         _lib.check(lib.ps_tem_backward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), gs, 1.0,
-                                       go.data_ptr(), st), 'ps_tem_backward')
+                                       _lib.ptr(go), st), 'ps_tem_backward')
         if self._row_sparse():
             main.wait_stream(side)
 

@@ -249,3 +249,21 @@ def test_sampler_distribution_and_ranges():
     freq = counts / n
     wd = torch.from_numpy(g.word_dists)
     assert float((freq - wd).abs().max()) < 5 * float((wd.max() / n) ** 0.5) + 1e-3
+
+
+def test_scaled_loss_takes_the_autograd_path_and_matches_the_direct_one():
+    """loss.backward() short-circuits the engine; (2*loss).backward() must go through autograd and give 2x the grads."""
+    g = Golden('tem_c1')
+    ni, nw = g.negs(0)
+    grads = []
+    for scale in (None, 2.0):
+        m = _model(g)
+        loss = m(g.batch().to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+        assert loss.requires_grad and loss.grad_fn is not None
+        m.zero_grad()
+        (loss if scale is None else loss * scale).backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        if n.endswith('linear_keys.bias'):
+            continue
+        assert rel_err(grads[1][n], 2.0 * grads[0][n]) < 1e-5, n
