@@ -106,6 +106,9 @@ struct EmbedBwdArgs {
   const float* dqmean_d;         // [B,d] grad wrt the post-dropout query mean
   DropSpec drop_fs;
   float* g_hist_tab; float* g_word_emb;
+  // optional: weight gradient of the FS query projection folded into the same launch (extra workgroups):
+  // g_fs_w[o][i] += sum_b fw_dy[b][o] * fw_x[b][i]   (text_encoder.py:38, f_W)
+  const float* fw_dy; const float* fw_x; float* g_fs_w;
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 

@@ -683,11 +683,32 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
 // ========================================================== embedding scatter-add
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask) {
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nfw) {
   const int tid = threadIdx.x, c = tid & 31;
-  const int t = blockIdx.x * 8 + (tid >> 5);
-  if (t >= ntask) return;
   const int d = a.d, epl = d >> 5;
+  if ((int)blockIdx.x < nfw) {
+    // f_W weight gradient (12.6 MFLOP at C2 — not worth a GEMM launch of its own on the tail).  These workgroups
+    // come first in the grid so they run under the scatter: 32 outputs each, the batch sum split over 8 lane
+    // groups (short dependent chains), reduced through LDS.
+    __shared__ float part[8][32];
+    const int g = (int)blockIdx.x * 32 + c, seg = tid >> 5;
+    const bool live = g < d * d;
+    const int o = live ? g / d : 0, i = live ? g - o * d : 0;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int b = seg; b < a.B; b += 8) acc = fmaf(a.fw_dy[(size_t)b * d + o], a.fw_x[(size_t)b * d + i], acc);
+    part[seg][c] = acc;
+    __syncthreads();
+    if (seg == 0 && live) {
+      float s8 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s8 += part[k][c];
+      a.g_fs_w[g] += s8;
+    }
+    return;
+  }
+  const int t = ((int)blockIdx.x - nfw) * 8 + (tid >> 5);
+  if (t >= ntask) return;
   const int nitem = a.tem ? a.B * a.L : 0;
   if (t < nitem) {
     int b = t / a.L, l = t - b * a.L;
@@ -716,7 +737,10 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0, "embed scatter: d %% 32");
   int ntask = (a.tem ? a.B * a.L : 0) + a.B * a.Q;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ps_cdiv(ntask, 8)), dim3(256), 0, st, a, ntask);
+  const int nsb = ps_cdiv(ntask, 8);
+  const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
+  PS_REQUIRE(!a.g_fs_w || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nsb + nfw), dim3(256), 0, st, a, ntask, nfw);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

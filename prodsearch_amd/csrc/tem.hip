@@ -622,12 +622,10 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
                                   hipMemcpyDeviceToDevice, st));
     e.dqmean_d = ws + w.dqmean;
   }
-  TRY(launch_embed_scatter(e, st));
-  if (D.query_encoder == PS_QENC_FS) {
-    // f_W weight gradient: tiny, and the side stream is still busy with the K/V weight gradients — keep it here
-    GemmProblem wg[1] = {gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B)};
-    TRY(run_wgrads(wg, 1, st));
+  if (D.query_encoder == PS_QENC_FS) {     // f_W weight gradient rides in the scatter launch (extra workgroups)
+    e.fw_dy = ws + w.dqpre; e.fw_x = ws + w.qmean; e.g_fs_w = G.fs_w;
   }
+  TRY(launch_embed_scatter(e, st));
   TRY(side_join(st));
   return PS_OK;
 }
