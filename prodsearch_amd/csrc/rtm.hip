@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
         // one Philox evaluation per (review, word slot): lane l owns slots l and l+64, the loop reads them by shuffle
         const float tm0 = drop_mult(ts, (uint32_t)revrow, (uint32_t)lane);
         const float tm1 = a.WL > 64 ? drop_mult(ts, (uint32_t)revrow, (uint32_t)(lane + 64)) : 1.f;
+        // only the positive sequence under train_pv also needs the UNcorrupted sum; everywhere else a word whose
+        // token mask is 0 (90 % of them at the reference's corrupt_rate) contributes nothing and is not fetched
+        const bool need_unc = pos && a.train_pv;
         int nw = 0;
         for (int w0 = 0; w0 < a.WL; w0 += 8) {                 // 8 word rows in flight per wave
           float4 rowv[4]; float mt[4];
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
             const float tmw = w < 64 ? __shfl(tm0, w & 63, 64) : (w < 128 ? __shfl(tm1, (w - 64) & 63, 64)
                                                                           : drop_mult(ts, (uint32_t)revrow, (uint32_t)w));
             if (wi != a.V - 1 && wi >= 0 && wi < a.V) {
-              if (act) rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
+              if (act && (need_unc || tmw != 0.f))
+                rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
               mt[u] = tmw;
               ++nw;
             }
