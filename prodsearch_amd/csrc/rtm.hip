@@ -180,6 +180,38 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
         // token mask is 0 (90 % of them at the reference's corrupt_rate) contributes nothing and is not fetched
         const bool need_unc = pos && a.train_pv;
         int nw = 0;
+        if (a.WL <= 128) {
+          // lane l holds word slots l and l+64 (two coalesced loads); the slots that survive the token mask are
+          // compacted with ballots, so the row loop runs over ~10 % of the review at the reference's corrupt_rate
+          const int64_t wa64 = lane < a.WL ? words[lane] : a.V - 1, wb64 = lane + 64 < a.WL ? words[lane + 64] : a.V - 1;
+          const bool va = wa64 != a.V - 1 && wa64 >= 0 && wa64 < a.V, vb = wb64 != a.V - 1 && wb64 >= 0 && wb64 < a.V;
+          const int wa = va ? (int)wa64 : 0, wb = vb ? (int)wb64 : 0;
+          unsigned long long ma = __ballot(va && (need_unc || tm0 != 0.f)), mb = __ballot(vb && (need_unc || tm1 != 0.f));
+          nw = half == 0 ? __popcll(__ballot(va)) + __popcll(__ballot(vb)) : 0;   // the halves are summed below
+          while (ma | mb) {                                               // 8 word rows in flight per wave
+            float4 rowv[4]; float mt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              int l0 = -1, s0 = 0, l1 = -1, s1 = 0;
+              if (ma) { l0 = __ffsll((long long)ma) - 1; ma &= ma - 1; } else if (mb) { l0 = __ffsll((long long)mb) - 1; mb &= mb - 1; s0 = 1; }
+              if (ma) { l1 = __ffsll((long long)ma) - 1; ma &= ma - 1; } else if (mb) { l1 = __ffsll((long long)mb) - 1; mb &= mb - 1; s1 = 1; }
+              const int l = half ? l1 : l0, sl = half ? s1 : s0, src = l < 0 ? 0 : l;
+              const int wia = __shfl(wa, src, 64), wib = __shfl(wb, src, 64);
+              const float ta = __shfl(tm0, src, 64), tb = __shfl(tm1, src, 64);
+              rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f); mt[u] = 0.f;
+              if (l >= 0) {
+                const int wi = sl ? wib : wia;
+                if (act) rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
+                mt[u] = sl ? tb : ta;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v.x += rowv[u].x; v.y += rowv[u].y; v.z += rowv[u].z; v.w += rowv[u].w;
+              vcor.x += rowv[u].x * mt[u]; vcor.y += rowv[u].y * mt[u]; vcor.z += rowv[u].z * mt[u]; vcor.w += rowv[u].w * mt[u];
+            }
+          }
+        } else
         for (int w0 = 0; w0 < a.WL; w0 += 8) {                 // 8 word rows in flight per wave
           float4 rowv[4]; float mt[4];
 #pragma unroll
