@@ -64,7 +64,7 @@ def make_tem_batch(seed, B, product_size, vocab_size, Q=8, L=20, W=1, C=0,
     if word_dists is None:
         word_dists = make_word_dists(V)
     # queries
-    qlen = rng.integers(2, min(6, Q) + 1, size=B)
+    qlen = rng.integers(min(2, Q), min(6, Q) + 1, size=B)
     qw = np.full((B, Q), V - 1, dtype=np.int64)
     words = rng.choice(V, size=(B, Q), p=word_dists)
     for b in range(B):

@@ -45,3 +45,59 @@ def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
         assert rel_err(got, ref) < 5e-4, n
         if ref.dim() == 2 and ref.shape[0] > 256:
             assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n
+
+
+@pytest.mark.parametrize('B,K,L,Q,W,d,H,zero_hist,dropout', [
+    (1, 1, 1, 1, 1, 32, 1, 0.0, 0.0),        # smallest legal everything
+    (3, 2, 20, 8, 1, 32, 4, 1.0, 0.0),       # every user without history: only the query column is unmasked
+    (5, 33, 7, 3, 2, 64, 8, 0.3, 0.0),       # K+1 above the 32 row groups of the score kernels, pv window 2
+    (130, 3, 12, 5, 1, 96, 8, 0.1, 0.1),     # ragged batch (not a multiple of any tile), d not a power of two, dropout
+    (2, 5, 20, 8, 3, 128, 8, 0.0, 0.1),
+])
+def test_edge_shapes_match_oracle(B, K, L, Q, W, d, H, zero_hist, dropout):
+    """Edge cases of the batch layout: tiny and ragged batches, zero-history users,
+    padded pv windows, wide negative fans — loss, gradients, touched rows and eval scores against the oracle."""
+    from oracle import tem as otem, philox
+    from prodsearch_amd import ItemTransformerRanker, default_args, synth
+    P_, V = 700, 900
+    a = default_args(model_name='item_transformer', embedding_size=d, ff_size=2 * d, heads=H, inter_layers=1,
+                     neg_per_pos=K, dropout=dropout, uprev_review_limit=L, pv_window_size=W)
+    wd = synth.make_word_dists(V)
+    sd = synth.make_state_dict(synth.tem_param_shapes(a, V, P_), 7, {'product_emb.weight': P_})
+    m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    batch = synth.make_tem_batch(11, B, P_, V, Q=Q, L=L, W=W, C=9, word_dists=wd, zero_hist_frac=zero_hist)
+    if zero_hist >= 1.0:
+        assert int((batch.u_item_idxs != P_).sum()) == 0
+    ni, nw = synth.sample_negatives(12, B, K, W, P_, wd)
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    Pm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = {}
+    if dropout > 0:
+        kw = dict(replicate=True, drop=philox.PhiloxDropout(dropout, m._seed, m._fwd_step, B, K, H, L + 1, 1,
+                                                            L if a.use_item_pos else 0))
+    oloss, _, _ = otem.tem_forward(Pm, a, batch, ni, nw, V, P_, training=True, **kw)
+    assert rel_err(loss.detach().cpu(), oloss.detach()) < 1e-4
+    grads = otem.grads_of(oloss, Pm, otem.tem_pad_rows(a, V, P_))
+    for n, p in m.named_parameters():
+        ref = grads.get(n)
+        assert (p.grad is None) == (ref is None), n
+        if ref is None or n.endswith('linear_keys.bias'):
+            continue
+        got = p.grad.cpu()
+        scale = float(ref.abs().max())
+        if scale == 0.0:                       # e.g. history-only parameters when nobody has a history
+            assert float(got.abs().max()) < 1e-6, n
+            continue
+        assert rel_err(got, ref) < 5e-4, n
+        if ref.dim() == 2 and ref.shape[0] > 256:
+            assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n
+    m.eval()
+    with torch.no_grad():
+        s = m.test(batch.to('cuda')).cpu()
+        ref_s = otem.tem_test(sd, a, batch, V, P_)
+    assert rel_err(s, ref_s) < 1e-4
