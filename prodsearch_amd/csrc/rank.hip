@@ -12,6 +12,7 @@
 #include "common.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 extern "C" int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* Cm, int ldc,
                            int M, int N, int K, const float* bias, float alpha, int accumulate, ps_stream_t stream);
@@ -40,7 +41,52 @@ struct SelArgs {
   int final;                  // sort and write top_idx/top_score instead
   int64_t* top_idx; float* top_score;
   const int64_t* target; const float* st; int32_t* rank;   // dense levels only (rank may be null)
+  int32_t* cnt; int64_t cnt_ld;                              // [B, cnt_ld] rows ranked ahead of the target, per dense chunk
 };
+
+// k-th largest of the block's keys that are >= lo (N per lane): MSB-first radix select over LDS histograms.
+// Returns its key in *T and how many keys equal to it are still needed in *need_eq.  All 256 lanes must call.
+template <int N>
+__device__ inline void block_kth_largest(const uint32_t (&key)[N], uint32_t lo, int k, int* hist, int* scan,
+                                         uint32_t* s_prefix, int* s_need, uint32_t* T, int* need_eq) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { *s_prefix = 0u; *s_need = k; }
+  uint32_t mask = 0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = *s_prefix;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (key[j] >= lo && (key[j] & mask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
+    __syncthreads();
+    // suffix sums over the 256 bins (S[b] = keys in bins >= b), all lanes: the bin holding the need-th largest key
+    // is the one with S[b] >= need > S[b+1]
+    const int need = *s_need;
+    scan[tid] = hist[255 - tid];
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int add = tid >= o ? scan[tid - o] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    {
+      const int b = 255 - tid;                          // this lane's bin; scan[tid] = S[b]
+      const int above = tid > 0 ? scan[tid - 1] : 0;    // S[b+1]
+      if ((scan[tid] >= need && above < need) || (b == 0 && scan[255] < need)) {
+        *s_need = need - above;                          // still needed among keys sharing the extended prefix
+        *s_prefix = prefix | ((uint32_t)b << shift);
+      }
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  *T = *s_prefix;
+  *need_eq = *s_need;
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
   __shared__ int hist[256];
@@ -49,7 +95,8 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
   __shared__ int s_need;
   __shared__ unsigned long long srt[SEL_KMAX];
   const int tid = threadIdx.x, b = blockIdx.y, c = blockIdx.x;
-  const int i0 = c * SEL_CHUNK + tid * SEL_EPT;
+  const int i0 = c * SEL_CHUNK + 4 * tid;           // lane-interleaved 16-byte pieces: piece jj of this lane starts at
+                                                    // i0 + 1024*jj, so every wave load covers 1 KB of consecutive scores
   uint32_t key[SEL_EPT];
   int32_t idx[SEL_EPT];
   const float* sp = a.src_score + (size_t)b * a.src_ld;
@@ -60,7 +107,7 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
   const int64_t tgt = count ? a.target[b] : -1;
 #pragma unroll
   for (int j = 0; j < SEL_EPT; j += 4) {
-    const int i = i0 + j;
+    const int i = i0 + 256 * j;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i + 3 < a.n && ((((uintptr_t)(sp + i)) & 15) == 0)) v = *reinterpret_cast<const float4*>(sp + i);
     else {
@@ -81,36 +128,26 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
     }
   }
   if (count) {
+    // one plain store per (row, chunk): thousands of atomics on the row's one rank word serialise at L2
+    __shared__ int wsum[4];
     int cc = cnt_gt_target;
     for (int o = 32; o > 0; o >>= 1) cc += __shfl_down(cc, o, 64);
-    if ((tid & 63) == 0 && cc) atomicAdd(&a.rank[b], cc);
-  }
-  // ---- radix select of the k-th largest key of this chunk
-  if (tid == 0) { s_prefix = 0u; s_need = a.k; }
-  uint32_t mask = 0u;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    hist[tid] = 0;
+    if ((tid & 63) == 0) wsum[tid >> 6] = cc;
     __syncthreads();
-    const uint32_t prefix = s_prefix;
+    if (tid == 0) a.cnt[(size_t)b * a.cnt_ld + a.chunk_off + c] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  }
+  // ---- k-th largest key of this chunk.  First a floor: the k-th largest of the 256 per-lane maxima is <= it (k lanes
+  // each hold a key at least that large), and only the ~k..2k keys above the floor then enter the LDS histograms —
+  // instead of all 8192 (whose LDS atomics were most of this kernel).
+  uint32_t T; int need_eq;
+  {
+    uint32_t mx[1] = {0u};
 #pragma unroll
-    for (int j = 0; j < SEL_EPT; ++j)
-      if ((key[j] & mask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
-    __syncthreads();
-    if (tid == 0) {
-      int need = s_need, bin = 255;
-      for (; bin > 0; --bin) {
-        if (hist[bin] >= need) break;
-        need -= hist[bin];
-      }
-      s_need = need;                       // still needed among keys sharing the extended prefix
-      s_prefix = prefix | ((uint32_t)bin << shift);
-    }
-    mask |= 255u << shift;
-    __syncthreads();
+    for (int j = 0; j < SEL_EPT; ++j) mx[0] = key[j] > mx[0] ? key[j] : mx[0];
+    uint32_t floor_key; int dummy;
+    block_kth_largest<1>(mx, 0u, a.k, hist, scan, &s_prefix, &s_need, &floor_key, &dummy);
+    block_kth_largest<SEL_EPT>(key, floor_key, a.k, hist, scan, &s_prefix, &s_need, &T, &need_eq);
   }
-  const uint32_t T = s_prefix;             // key of the k-th largest (0 when the chunk holds fewer than k live keys)
-  const int need_eq = s_need;
   int ngt = 0, neq = 0;
 #pragma unroll
   for (int j = 0; j < SEL_EPT; ++j) { ngt += key[j] > T; neq += key[j] == T; }
@@ -124,6 +161,9 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
   }
   const int incl = scan[tid], total = scan[255];
   const int tot_gt = total & 0xffff;
+  // more keys equal to T than still needed: which of them survive must go by index (lower first), and lanes do not
+  // hold consecutive indices — rare (exact score ties at the cut), settled by one lane after the parallel emit
+  const bool tie_cut = (total >> 16) > need_eq;
   int pos_gt = (incl & 0xffff) - ngt, pos_eq = (incl >> 16) - neq;
   if (a.final) {
     srt[tid] = 0ull;                       // key 0 / index pattern 0 sorts last
@@ -135,10 +175,23 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
   for (int j = 0; j < SEL_EPT; ++j) {
     int pos = -1;
     if (key[j] > T) pos = pos_gt++;
-    else if (key[j] == T) { if (pos_eq < need_eq) pos = tot_gt + pos_eq; ++pos_eq; }
+    else if (key[j] == T && !tie_cut) { pos = tot_gt + pos_eq; ++pos_eq; }
     if (pos >= 0 && pos < a.k) {
       if (a.final) srt[pos] = ((unsigned long long)key[j] << 32) | (uint32_t)(~(uint32_t)idx[j]);
       else { os[pos] = key2f(key[j]); oi[pos] = idx[j]; }
+    }
+  }
+  if (tie_cut && tid == 0) {
+    int taken = 0;
+    const int end = min(a.n, (c + 1) * SEL_CHUNK);
+    for (int i = c * SEL_CHUNK; i < end && taken < need_eq; ++i) {
+      const int32_t gi = ip ? ip[i] : (int32_t)(a.idx_base + i);
+      if (gi < 0 || f2key(sp[i]) != T) continue;
+      const int pos = tot_gt + taken++;
+      if (pos < a.k) {
+        if (a.final) srt[pos] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)gi);
+        else { os[pos] = key2f(T); oi[pos] = gi; }
+      }
     }
   }
   if (!a.final) return;
@@ -185,12 +238,138 @@ __global__ void rank_diag_kernel(const float* tt, int B, const float* bias, cons
   if (rank) rank[b] = ok ? 1 : 0;           // 0 = target not in the catalogue
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Skinny-M score GEMM for huge catalogues: S[B<=64, rows] = q . table^T streamed ONCE from HBM.  The tiled GEMM of
+// gemm.hip pads M to 64 and gives every 64 table rows their own short-lived workgroup (1.4 TB/s at B = 24, 50 M rows).
+// Here a persistent wave owns 32-row table tiles: coalesced 16-byte loads of the NEXT (tile, 128-deep k chunk) are in
+// flight while the current chunk — transposed through a wave-private LDS slab into the [k][row+1] MFMA layout — is
+// multiplied against q, which sits in LDS for the whole kernel.  Same v_mfma_f32_32x32x2_f32 chain in the same k
+// order as gemm.hip, so the scores are bitwise those of ps_gemm_f32 (the target's score and the tests rely on it).
+#define RS_KC 128                  // k depth of one streamed chunk
+#define RS_LD 33
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MT>                  // MT = 1: B <= 32, 2: B <= 64
+__global__ __launch_bounds__(256, 1) void rank_stream_kernel(const float* __restrict__ q, int B, int d,
+                                                              const float* __restrict__ table, int64_t rows,
+                                                              const float* __restrict__ bias, float* __restrict__ S,
+                                                              int64_t ldc) {
+  extern __shared__ float lds[];
+  float* As = lds;                                       // [d][MT*32 + 1]   q, A-operand layout
+  const int ALD = MT * 32 + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  float* Bw = lds + (size_t)d * ALD + (size_t)wave * RS_KC * RS_LD;   // this wave's [RS_KC][33] slab
+  for (int i = tid; i < d * MT * 32; i += 256) {
+    const int k = i / (MT * 32), m = i - k * (MT * 32);
+    As[k * ALD + m] = m < B ? q[(size_t)m * d + k] : 0.f;
+  }
+  __syncthreads();
+  const int nck = d / RS_KC;
+  const int64_t ntile = (rows + 31) / 32;
+  const int64_t nwave = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+  // lane -> (row within tile, k quad) of the 16 loads of one chunk: load u covers rows 2u, 2u+1
+  const int lrow = lane >> 5, kq = lane & 31;
+  float4 reg[16];
+  auto issue = [&](int64_t tile, int ck) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int64_t r = tile * 32 + 2 * u + lrow;
+      reg[u] = r < rows ? *reinterpret_cast<const float4*>(table + r * (int64_t)d + ck * RS_KC + 4 * kq)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (w0 < ntile) issue(w0, 0);
+  for (int64_t tile = w0; tile < ntile; tile += nwave) {
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int ck = 0; ck < nck; ++ck) {
+      // registers -> wave-private LDS slab (transpose to [k][row])
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = 2 * u + lrow;
+        Bw[(4 * kq + 0) * RS_LD + r] = reg[u].x;
+        Bw[(4 * kq + 1) * RS_LD + r] = reg[u].y;
+        Bw[(4 * kq + 2) * RS_LD + r] = reg[u].z;
+        Bw[(4 * kq + 3) * RS_LD + r] = reg[u].w;
+      }
+      // next chunk's loads go out before the multiply
+      if (ck + 1 < nck) issue(tile, ck + 1);
+      else if (tile + nwave < ntile) issue(tile + nwave, 0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the slab is written (wave-private: no barrier)
+      __builtin_amdgcn_wave_barrier();
+      const float* ab = As + (size_t)(ck * RS_KC + h) * ALD + l31;
+      const float* bb = Bw + h * RS_LD + l31;
+#pragma unroll
+      for (int qd = 0; qd < RS_KC / 32; ++qd) {
+        float av[MT][16], bv[16];
+#pragma unroll
+        for (int sft = 0; sft < 16; ++sft) {
+          bv[sft] = bb[(32 * qd + 2 * sft) * RS_LD];
+#pragma unroll
+          for (int t = 0; t < MT; ++t) av[t][sft] = ab[(size_t)(32 * qd + 2 * sft) * ALD + 32 * t];
+        }
+#pragma unroll
+        for (int sft = 0; sft < 16; ++sft)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][sft], bv[sft], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();                   // every lane is done reading the slab before it is rewritten
+    }
+    const int64_t n = tile * 32 + l31;
+    if (n < rows) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < B) S[(size_t)m * ldc + n] = acc[t][r] + bv;
+        }
+    }
+  }
+}
+
+static int launch_rank_stream(const float* q, int B, int d, const float* table, int64_t rows, const float* bias,
+                              float* S, int64_t ldc, hipStream_t st) {
+  const int MT = B <= 32 ? 1 : 2;
+  const size_t lds = ((size_t)d * (MT * 32 + 1) + 4 * (size_t)RS_KC * RS_LD) * sizeof(float);
+  static bool attr[2] = {false, false};
+  const void* fn = MT == 1 ? reinterpret_cast<const void*>(rank_stream_kernel<1>)
+                           : reinterpret_cast<const void*>(rank_stream_kernel<2>);
+  if (!attr[MT - 1]) {
+    PS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 512)));
+    attr[MT - 1] = true;
+  }
+  PS_REQUIRE(lds <= 160 * 1024 - 512, "rank stream: %zu B of LDS", lds);
+  int64_t tiles = (rows + 31) / 32;
+  int blocks = (int)((tiles + 3) / 4 < 256 ? (tiles + 3) / 4 : 256);
+  if (MT == 1) hipLaunchKernelGGL(rank_stream_kernel<1>, dim3(blocks), dim3(256), lds, st, q, B, d, table, rows, bias, S, ldc);
+  else hipLaunchKernelGGL(rank_stream_kernel<2>, dim3(blocks), dim3(256), lds, st, q, B, d, table, rows, bias, S, ldc);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// rank[b] = 1 + rows ranked ahead of the target over all dense chunks (0 stays 0: target not in the catalogue)
+__global__ __launch_bounds__(256) void rank_sum_kernel(const int32_t* cnt, int64_t ld, int32_t* rank) {
+  __shared__ int wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int s = 0;
+  for (int64_t i = tid; i < ld; i += 256) s += cnt[(size_t)b * ld + i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0 && rank[b] > 0) rank[b] = 1 + (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 static inline int64_t up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 struct RankPlan {
   int64_t panel;                 // table rows scored per GEMM
   int64_t n_panels, chunks1;     // level-1 chunks over all panels
-  int64_t off_S, off_T, off_tt, off_st, off_c0s, off_c0i, off_c1s, off_c1i, total;
+  int64_t off_S, off_T, off_tt, off_st, off_c0s, off_c0i, off_c1s, off_c1i, off_cnt, total;
 };
 
 static int rank_plan(int B, int64_t n_rows, int d, int k, RankPlan* p) {
@@ -215,6 +394,7 @@ static int rank_plan(int B, int64_t n_rows, int d, int k, RankPlan* p) {
   p->off_st = take((int64_t)B * 4);
   p->off_c0s = take(cand0 * 4); p->off_c0i = take(cand0 * 4);
   p->off_c1s = take(cand1 * 4); p->off_c1i = take(cand1 * 4);
+  p->off_cnt = take((int64_t)B * chunks1 * 4);
   p->total = cur;
   return PS_OK;
 }
@@ -245,6 +425,7 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
   float* stv = (float*)(base + p.off_st);
   float* cs[2] = {(float*)(base + p.off_c0s), (float*)(base + p.off_c1s)};
   int32_t* ci[2] = {(int32_t*)(base + p.off_c0i), (int32_t*)(base + p.off_c1i)};
+  int32_t* cntb = (int32_t*)(base + p.off_cnt);
   if (target) {
     // the target's score through the SAME GEMM (bitwise equal to its entry of the score matrix)
     hipLaunchKernelGGL(rank_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, st, table, target, n_rows, d, T, B);
@@ -260,8 +441,13 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
   for (int64_t pi = 0; pi < p.n_panels; ++pi) {
     const int64_t r0 = pi * p.panel;
     const int64_t w = r0 + p.panel <= n_rows ? p.panel : n_rows - r0;
-    int rc = ps_gemm_f32(q, d, 0, table + r0 * (int64_t)d, d, 0, S, (int)p.panel, B, (int)w, d, bias ? bias + r0 : nullptr,
-                         1.f, 0, stream);
+    int rc;
+    const size_t stream_lds = ((size_t)d * ((B <= 32 ? 1 : 2) * 32 + 1) + 4 * (size_t)RS_KC * RS_LD) * sizeof(float);
+    if (B <= 64 && d % RS_KC == 0 && stream_lds <= 160 * 1024 - 512 && n_rows >= ((int64_t)1 << 18))   // huge catalogue, few rows
+      rc = launch_rank_stream(q, B, d, table + r0 * (int64_t)d, w, bias ? bias + r0 : nullptr, S, p.panel, st);
+    else
+      rc = ps_gemm_f32(q, d, 0, table + r0 * (int64_t)d, d, 0, S, (int)p.panel, B, (int)w, d, bias ? bias + r0 : nullptr,
+                       1.f, 0, stream);
     if (rc) return rc;
     SelArgs a;
     memset(&a, 0, sizeof(a));
@@ -269,10 +455,15 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
     a.out_score = cs[0]; a.out_idx = ci[0]; a.out_ld = ld0; a.chunk_off = (int)chunk_off; a.k = topk;
     a.final = single; a.top_idx = top_idx; a.top_score = top_score;
     a.target = target; a.st = stv; a.rank = target ? rank : nullptr;
+    a.cnt = cntb; a.cnt_ld = p.chunks1;
     const int nch = (int)((w + SEL_CHUNK - 1) / SEL_CHUNK);
     hipLaunchKernelGGL(select_kernel, dim3(nch, B), dim3(256), 0, st, a);
     PS_LAUNCH_CHECK();
     chunk_off += nch;
+  }
+  if (target && rank) {
+    hipLaunchKernelGGL(rank_sum_kernel, dim3(B), dim3(256), 0, st, cntb, p.chunks1, rank);
+    PS_LAUNCH_CHECK();
   }
   if (single) return PS_OK;
   // survivors: [B, chunks*k] -> repeat until one chunk remains, which the final pass sorts

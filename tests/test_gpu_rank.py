@@ -67,7 +67,8 @@ def _device_scores(q, table, bias):
 
 
 @pytest.mark.parametrize('B,N,d,k,use_bias', [(7, 300, 32, 100, False), (5, 20000, 64, 100, True), (3, 70001, 32, 10, False),
-                                              (2, 1200007, 32, 100, True), (4, 50, 128, 100, False), (6, 9000, 128, 256, False)])
+                                              (2, 1200007, 32, 100, True), (4, 50, 128, 100, False), (6, 9000, 128, 256, False),
+                                              (5, 300001, 128, 100, True), (40, 270011, 256, 10, False)])   # streamed skinny-M path
 def test_rank_all_selection_is_exact(B, N, d, k, use_bias):
     """Multi-chunk (N > 8192), multi-panel (N > 2**20), k not a multiple of 4, N < k, ties: selection, order and
     target rank must equal numpy's on the device's own scores."""
@@ -83,7 +84,7 @@ def test_rank_all_selection_is_exact(B, N, d, k, use_bias):
     bias = (torch.randn(N, generator=g) * 0.1).cuda() if use_bias else None
     if bias is not None:
         bias[N // 3] = bias[N // 2] = bias[5] = 0.25
-    target = torch.tensor([N // 2, 5, N - 1, 0, N // 3, 17, 3][:B], dtype=torch.int64).cuda()
+    target = torch.tensor(([N // 2, 5, N - 1, 0, N // 3, 17, 3] * (B // 7 + 1))[:B], dtype=torch.int64).cuda()
     nbytes = lib.ps_rank_scratch_bytes(B, N, d, k)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     top_idx = torch.empty(B, k, dtype=torch.int64, device='cuda')
@@ -99,6 +100,30 @@ def test_rank_all_selection_is_exact(B, N, d, k, use_bias):
     assert np.array_equal(top_score.cpu().numpy()[:, :kk], want_score)
     assert (top_idx.cpu().numpy()[:, kk:] == -1).all()
     assert np.array_equal(rank.cpu().numpy(), want_rank)
+
+
+@pytest.mark.parametrize('N,k', [(20000, 100), (300, 256), (70000, 7)])
+def test_rank_all_exact_ties_go_by_lower_index(N, k):
+    """Every product identical => every score equal: the ranklist must be ids 0..k-1 and the target's rank its id + 1
+    (the cut through a run of equal scores is the one place where lanes cannot decide locally)."""
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    B, d = 3, 32
+    q = torch.randn(B, d, device='cuda')
+    table = torch.randn(1, d, device='cuda').expand(N, d).contiguous()
+    target = torch.tensor([0, N - 1, N // 2], dtype=torch.int64, device='cuda')
+    nbytes = lib.ps_rank_scratch_bytes(B, N, d, k)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    ti = torch.empty(B, k, dtype=torch.int64, device='cuda')
+    ts = torch.empty(B, k, device='cuda')
+    rk = torch.empty(B, dtype=torch.int32, device='cuda')
+    _lib.check(lib.ps_rank_all(q.data_ptr(), B, d, table.data_ptr(), N, None, target.data_ptr(), k, ti.data_ptr(),
+                               ts.data_ptr(), rk.data_ptr(), scratch.data_ptr(), nbytes,
+                               torch.cuda.current_stream().cuda_stream), 'ps_rank_all')
+    kk = min(k, N)
+    assert torch.equal(ti[:, :kk].cpu(), torch.arange(kk).expand(B, kk))
+    assert rk.tolist() == [1, N, N // 2 + 1]
+    assert float((ts[:, :kk] - ts[:, :1]).abs().max()) == 0.0
 
 
 def test_rank_all_target_outside_catalogue_and_bad_topk():
