@@ -15,6 +15,7 @@ struct Ws {
   int64_t fin_stats, enc;
   int64_t item_scores, word_scores, loss_parts, item_terms, word_terms, loss_blk;
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
+  int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
   int64_t total;
 };
 
@@ -28,8 +29,10 @@ int make_ws(const PsTemDesc& D, Ws& w);
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
                        const Ws& w, hipStream_t st);
 // Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
+// `fold` (optional): the LayerNorm backwards park their column sums in w.lnpart and append to this list; the caller
+// must hand it to a later launch_embed_scatter (EmbedBwdArgs::fold).  nullptr: plain atomics.
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
-                        const float* valid, float* ws, const Ws& w, hipStream_t st);
+                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold = nullptr);
 
 GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M, int N, int K);
 int run1(const GemmProblem& p, hipStream_t st);

@@ -34,8 +34,18 @@ struct LnBwdArgs {
   DropSpec drop2;
   float* colsum;                 // optional: += column sums of (out2 if out2 else dx)
   float* dgamma; float* dbeta;   // += (atomics)
+  float* partial;                // optional [workgroups][3][d]: column sums are parked here instead (see ColFoldList)
 };
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st);
+int ln_bwd_blocks(int rows);
+
+// Column sums a kernel parked per workgroup ({dgamma, dbeta, colsum} of an LN backward) instead of sending
+// workgroups x 3d atomics to the same 3d addresses (measured ~6 us per LN backward at C2).  Nothing in the backward
+// reads these gradients, so the list rides to the last launch of the backward (embed_scatter), whose extra
+// workgroups add each column up once.
+#define PS_MAX_COLFOLD 8
+struct ColFold { const float* partial; int nblk, d; float* dst[3]; };
+struct ColFoldList { ColFold e[PS_MAX_COLFOLD]; int n; };
 
 struct AttnArgs {
   int n_in, fan, H, S, Sq, d, dh, qpos;
@@ -109,6 +119,7 @@ struct EmbedBwdArgs {
   // optional: weight gradient of the FS query projection folded into the same launch (extra workgroups):
   // g_fs_w[o][i] += sum_b fw_dy[b][o] * fw_x[b][i]   (text_encoder.py:38, f_W)
   const float* fw_dy; const float* fw_x; float* g_fs_w;
+  ColFoldList fold;              // parked column sums to add up (n = 0: none)
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 

@@ -197,17 +197,22 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const LnBwdArgs 
   for (int t = threadIdx.x; t < 3 * a.d; t += blockDim.x) {
     const int which = t / a.d, col = t - which * a.d;
     float* dst = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.colsum);
-    if (!dst) continue;
+    if (!dst && !a.partial) continue;
     float s = 0.f;
     for (int w = 0; w < LNB_WAVES; ++w) s += sh[(which * LNB_WAVES + w) * W + col];
-    atomicAdd(&dst[col], s);
+    if (a.partial) a.partial[((size_t)blockIdx.x * 3 + which) * a.d + col] = s;
+    else atomicAdd(&dst[col], s);
   }
+}
+
+int ln_bwd_blocks(int rows) {
+  int blocks = ps_cdiv(rows, LNB_WAVES);
+  return blocks > 256 ? 256 : blocks;   // rows are grid-strided; bounds the gamma/beta partials
 }
 
 int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d <= 64 * LN_MAXI, "layernorm bwd: d=%d > %d", a.d, 64 * LN_MAXI);
-  int blocks = ps_cdiv(a.rows, LNB_WAVES);
-  if (blocks > 256) blocks = 256;      // rows are grid-strided; bounds the gamma/beta atomics
+  const int blocks = ln_bwd_blocks(a.rows);
   const int dpl = ps_cdiv(a.d, 64);
   const int dp = dpl <= 1 ? 1 : (dpl <= 2 ? 2 : (dpl <= 4 ? 4 : 8));
   const size_t lds = sizeof(float) * 3 * LNB_WAVES * 64 * dp;
@@ -683,7 +688,7 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
 // ========================================================== embedding scatter-add
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nfw) {
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nfw, int nfold) {
   const int tid = threadIdx.x, c = tid & 31;
   const int d = a.d, epl = d >> 5;
   if ((int)blockIdx.x < nfw) {
@@ -707,7 +712,27 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     }
     return;
   }
-  const int t = ((int)blockIdx.x - nfw) * 8 + (tid >> 5);
+  if ((int)blockIdx.x < nfw + nfold) {
+    // parked column sums (ColFoldList): one output column per lane, the workgroups' partials added in order
+    int o = ((int)blockIdx.x - nfw) * 256 + tid;
+    for (int k = 0; k < a.fold.n; ++k) {
+      const ColFold& f = a.fold.e[k];
+      const int span = (3 * f.d + 255) / 256 * 256;   // entries start on workgroup boundaries
+      if (o >= span) { o -= span; continue; }
+      if (o >= 3 * f.d) return;
+      const int which = o / f.d;
+      float* dst = f.dst[which];
+      if (!dst) return;
+      const int col = o - which * f.d;
+      float sum = 0.f;
+#pragma unroll 8
+      for (int b2 = 0; b2 < f.nblk; ++b2) sum += f.partial[((size_t)b2 * 3 + which) * f.d + col];
+      dst[col] += sum;
+      return;
+    }
+    return;
+  }
+  const int t = ((int)blockIdx.x - nfw - nfold) * 8 + (tid >> 5);
   if (t >= ntask) return;
   const int nitem = a.tem ? a.B * a.L : 0;
   if (t < nitem) {
@@ -740,7 +765,9 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   const int nsb = ps_cdiv(ntask, 8);
   const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
   PS_REQUIRE(!a.g_fs_w || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nsb + nfw), dim3(256), 0, st, a, ntask, nfw);
+  int nfold = 0;
+  for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 256);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nsb + nfw + nfold), dim3(256), 0, st, a, ntask, nfw, nfold);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

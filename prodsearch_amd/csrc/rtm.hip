@@ -797,7 +797,9 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   PsTemTensors T, TG;
   to_tem_tensors(*params, T);
   to_tem_tensors(G, TG);
-  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st));
+  ColFoldList fold;
+  fold.n = 0;
+  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold));
   PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)B * d, st));
   int eb = ps_cdiv(r.Bseq * r.S, 4); if (eb > 1024) eb = 1024;
   if (k.pvc) {
@@ -836,6 +838,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   } else {
     e.dqmean_d = ws + r.dqe;
   }
+  e.fold = fold;
   TRY(launch_embed_scatter(e, st));
   TRY(side_join(st));
   return PS_OK;

@@ -123,6 +123,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   }
   w.dqpre = take(cur, (int64_t)B * d);
   w.dqmean = take(cur, (int64_t)B * d);
+  w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
   w.total = cur;
   return PS_OK;
 }
@@ -447,8 +448,18 @@ extern "C" int ps_tem_encode(const PsTemDesc* desc, const PsTemTensors* params, 
   return PS_OK;
 }
 
+// park the {dgamma, dbeta, colsum} column sums of one LN backward (see ColFoldList) when the caller collects them
+static void park_colsums(LnBwdArgs& a, float* ws, const Ws& w, ColFoldList* fold) {
+  if (!fold || fold->n >= PS_MAX_COLFOLD) return;
+  ColFold& f = fold->e[fold->n];
+  a.partial = ws + w.lnpart + (size_t)fold->n * 256 * 3 * a.d;
+  f.partial = a.partial; f.nblk = ln_bwd_blocks(a.rows); f.d = a.d;
+  f.dst[0] = a.dgamma; f.dst[1] = a.dbeta; f.dst[2] = a.colsum;
+  ++fold->n;
+}
+
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
-                        const float* valid, float* ws, const Ws& w, hipStream_t st) {
+                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold) {
   const bool drop = D.training && D.dropout > 0.f;
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers, F = D.F;
   PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
@@ -462,11 +473,13 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     f.x = ws + l.y2; f.ldx = d; f.rows = w.Mf; f.dx = ws + w.dy2; f.lddx = d;
     f.colsum = G.layer[NL - 1].b2;
     if (drop) { f.out2 = ws + w.do2; f.drop2 = make_drop(D, PS_SITE_FF2(NL - 1)); }
+    park_colsums(f, ws, w, fold);
     TRY(launch_ln_bwd(f, st));
   } else {
     PS_CHECK_HIP(hipMemsetAsync(ws + w.dx, 0, sizeof(float) * (size_t)B * S * d, st));
     f.x = ws + w.x + (size_t)w.qpos * d; f.ldx = S * d; f.rows = B;
     f.dx = ws + w.dx + (size_t)w.qpos * d; f.lddx = S * d;
+    park_colsums(f, ws, w, fold);
     TRY(launch_ln_bwd(f, st));
   }
   // 3. layers, last to first
@@ -501,6 +514,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       n.dx = ws + w.dy1; n.lddx = d;
       if (drop) { n.out2 = ws + w.do_; n.drop2 = make_drop(D, PS_SITE_CTX(i)); }
       n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
+      park_colsums(n, ws, w, fold);
       TRY(launch_ln_bwd(n, st));
     }
     const float* dout = drop ? ws + w.do_ : ws + w.dy1;
@@ -561,6 +575,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       n.dx = ws + w.dy2; n.lddx = d;
       if (drop) { n.out2 = ws + w.do2; n.drop2 = make_drop(D, PS_SITE_FF2(i - 1)); }
       n.colsum = G.layer[i - 1].b2; n.dgamma = Lg.ln_g; n.dbeta = Lg.ln_b;
+      park_colsums(n, ws, w, fold);
       TRY(launch_ln_bwd(n, st));
     }
   }
@@ -595,10 +610,12 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   s.g_word_bias = G.word_bias;
   TRY(launch_score_bwd(s, st));
 
+  ColFoldList fold;
+  fold.n = 0;
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
   int lddqe = d;
   if (tem) {
-    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st));
+    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold));
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }
@@ -625,6 +642,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   if (D.query_encoder == PS_QENC_FS) {     // f_W weight gradient rides in the scatter launch (extra workgroups)
     e.fw_dy = ws + w.dqpre; e.fw_x = ws + w.qmean; e.g_fs_w = G.fs_w;
   }
+  e.fold = fold;
   TRY(launch_embed_scatter(e, st));
   TRY(side_join(st));
   return PS_OK;
