@@ -202,6 +202,7 @@ struct GemmProblem {
   ResMap res;                           // residual added after dropout
   float* out2; int ld2; const float* add2;  // if set: out2[row*ld2+col] = v + add2[col] (second copy of the result)
   float* colsum;                        // if set: atomicAdd column sums of the final value into colsum[n]
+  float* colsum_part;                   // if set (with colsum): park them instead, [4*row_tiles][3][N] slot 0 (ColFoldList layout)
   int accumulate;                       // 0: C = v ; 1: C += v (plain) ; 2: atomicAdd(C, v) (split reduction)
   int ksplit;                           // number of reduction splits (grid.z multiplier), >=1
 };

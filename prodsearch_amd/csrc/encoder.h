@@ -16,6 +16,7 @@ struct Ws {
   int64_t item_scores, word_scores, loss_parts, item_terms, word_terms, loss_blk;
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
   int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
+  int64_t gcpart;           // [4 * row tiles][3][F] parked column sums of the FF2 dX GEMM (b1 gradient)
   int64_t total;
 };
 

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     }
     cur = nxt;
   }
-  if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
+  if (P.colsum_part) P.colsum_part[((size_t)(4 * tm + (tid >> 6)) * 3) * N + gcol] = csum;   // one parked row per (tile, row group)
+  else if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
 }
 
 static bool needs_full(const GemmProblem& p) {

@@ -713,21 +713,31 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     return;
   }
   if ((int)blockIdx.x < nfw + nfold) {
-    // parked column sums (ColFoldList): one output column per lane, the workgroups' partials added in order
-    int o = ((int)blockIdx.x - nfw) * 256 + tid;
+    // parked column sums (ColFoldList): 32 output columns per workgroup, the parked partials split over 8 lane
+    // groups (short dependent chains) and reduced through LDS, like the f_W gradient above
+    __shared__ float fpart[8][32];
+    int blk = (int)blockIdx.x - nfw;
     for (int k = 0; k < a.fold.n; ++k) {
       const ColFold& f = a.fold.e[k];
-      const int span = (3 * f.d + 255) / 256 * 256;   // entries start on workgroup boundaries
-      if (o >= span) { o -= span; continue; }
-      if (o >= 3 * f.d) return;
-      const int which = o / f.d;
+      const int span = (3 * f.d + 31) / 32;
+      if (blk >= span) { blk -= span; continue; }
+      const int o = blk * 32 + c, seg = tid >> 5;
+      const bool live = o < 3 * f.d;
+      const int which = live ? o / f.d : 0, col = live ? o - which * f.d : 0;
       float* dst = f.dst[which];
-      if (!dst) return;
-      const int col = o - which * f.d;
       float sum = 0.f;
-#pragma unroll 8
-      for (int b2 = 0; b2 < f.nblk; ++b2) sum += f.partial[((size_t)b2 * 3 + which) * f.d + col];
-      dst[col] += sum;
+      if (live && dst) {
+#pragma unroll 4
+        for (int b2 = seg; b2 < f.nblk; b2 += 8) sum += f.partial[((size_t)b2 * 3 + which) * f.d + col];
+      }
+      fpart[seg][c] = sum;
+      __syncthreads();
+      if (seg == 0 && live && dst) {
+        float s8 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s8 += fpart[q][c];
+        dst[col] += s8;
+      }
       return;
     }
     return;
@@ -766,7 +776,7 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
   PS_REQUIRE(!a.g_fs_w || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
   int nfold = 0;
-  for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 256);
+  for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 32);
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(nsb + nfw + nfold), dim3(256), 0, st, a, ntask, nfw, nfold);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -124,6 +124,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.dqpre = take(cur, (int64_t)B * d);
   w.dqmean = take(cur, (int64_t)B * d);
   w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
+  w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 63) / 64 + 1) * 3 * (tem && NL > 0 ? D.F : 0));
   w.total = cur;
   return PS_OK;
 }
@@ -497,6 +498,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     {
       GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
       p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
+      if (fold && fold->n < PS_MAX_COLFOLD && i == NL - 1) {      // park the b1 column sums (one buffer: last layer only)
+        ColFold& cf = fold->e[fold->n++];
+        p.colsum_part = ws + w.gcpart;
+        cf.partial = p.colsum_part; cf.nblk = 4 * ps_cdiv(M2, 64); cf.d = F;
+        cf.dst[0] = Lg.b1; cf.dst[1] = nullptr; cf.dst[2] = nullptr;
+      }
       TRY(run1(p, st));
       // dW2 += do2^T . h1 and dW1 += da1^T . ln1: one fork (both operands exist once the GEMM above is done)
       GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
