@@ -161,6 +161,8 @@ struct ResMap {           // row map between replica rows and layer-input rows
   FDiv dSq, dfan, dS;     // fast dividers of Sq, fan, S (filled by res_finish)
   int Sq, fan, S, qpos;   // GATHER: out row m=(n_out,i) -> src row (n_out/fan)*S + (Sq==S ? i : qpos)
                           // FANIN : out row m=(n_in,pos) -> sum_j src row ((n_in*fan+j)*Sq + i), only q rows
+  const float* extra;     // FANIN with Sq == 1: one more row per sequence added at the query position
+  int extra_ld;           //   (the dQ.Wq term of the attention backward), [n_in, extra_ld]
 };
 
 __device__ inline float res_value(const ResMap& R, int row, int col) {
@@ -178,6 +180,7 @@ __device__ inline float res_value(const ResMap& R, int row, int col) {
     else return 0.f;
     float s = 0.f;
     for (int j = 0; j < R.fan; ++j) s += R.ptr[(size_t)((nin * R.fan + j) * R.Sq + i) * R.ld + col];
+    if (R.extra) s += R.extra[(size_t)nin * R.extra_ld + col];
     return s;
   }
   return 0.f;

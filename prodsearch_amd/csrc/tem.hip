@@ -552,6 +552,15 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       wg3[1] = gp_wgrad(ws + w.dkv + d, a.lddkv, xn, d, Lg.wv, d, d, ns);
       if (qall) wg3[2] = gp_wgrad(ws + w.dkv + 2 * d, a.lddkv, xn, d, Lg.wq, d, d, ns);
       else wg3[2] = gp_wgrad(ws + w.dq, d, xn + (size_t)w.qpos * d, S * d, Lg.wq, d, d, l.n_in);
+      // first layer, one query row per sequence: dQ.Wq is a [n_in, d] product whose rows join the big dX GEMM below
+      // through its fan-in epilogue — computed here, before the weight gradients start competing for the CUs
+      // (as a trailing accumulate-GEMM it took 26 us on the critical path under them)
+      const bool q_via_res = !qall && i == 0;
+      float* dxq = ws + w.dctx;                      // free again: the attention backward has consumed it
+      if (q_via_res) {
+        GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxq, d, l.n_in, d, d);
+        TRY(run1(xq, st));
+      }
       TRY(side_fork(st));
       TRY(side_run(wgo, 1, st));
       TRY(side_run(wg3, 3, st));
@@ -562,9 +571,10 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
         x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
         x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
+        if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
       }
       TRY(run1(x, st));
-      if (!qall) {
+      if (!qall && !q_via_res) {
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
         xq.accumulate = 1;
         TRY(run1(xq, st));
