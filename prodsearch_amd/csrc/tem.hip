@@ -495,7 +495,6 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     const int ns = l.n_in * S, M2 = l.M2;
     const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
     // FFN backward
-    {
       GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
       p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
       if (fold && fold->n < PS_MAX_COLFOLD && i == NL - 1) {      // park the b1 column sums (one buffer: last layer only)
@@ -505,12 +504,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         cf.dst[0] = Lg.b1; cf.dst[1] = nullptr; cf.dst[2] = nullptr;
       }
       TRY(run1(p, st));
-      // dW2 += do2^T . h1 and dW1 += da1^T . ln1: one fork (both operands exist once the GEMM above is done)
+      // dW2 += do2^T . h1 and dW1 += da1^T . ln1 are launched further down, once the dX chain of the MLP is through
+      // (beside it they slowed every link: 44 vs 33 us for the GEMM below); they then share the machine with the
+      // attention backward and the big dX GEMM instead.  Measured a wash in step time (both orders 0.509 ms): the
+      // backward is throughput-bound once both streams are busy — kept because it needs one fork less per layer.
       GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
-      TRY(side_fork(st));
-      TRY(side_run(wg, 1, st));
-      TRY(side_run(wg1, 1, st));
       GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
       TRY(run1(q, st));
       LnBwdArgs n;
@@ -523,13 +522,17 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
       park_colsums(n, ws, w, fold);
       TRY(launch_ln_bwd(n, st));
-    }
+
     const float* dout = drop ? ws + w.do_ : ws + w.dy1;
     // attention backward
     {
       GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
       TRY(run1(p, st));
-      GemmProblem wgo[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};   // launched with the K/V/Q ones below
+      GemmProblem wgo[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
+      TRY(side_fork(st));                           // fork 1: W2, W1, Wo weight gradients under the attention backward
+      TRY(side_run(wg, 1, st));
+      TRY(side_run(wg1, 1, st));
+      TRY(side_run(wgo, 1, st));
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
@@ -561,8 +564,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxq, d, l.n_in, d, d);
         TRY(run1(xq, st));
       }
-      TRY(side_fork(st));
-      TRY(side_run(wgo, 1, st));
+      TRY(side_fork(st));                           // fork 2: they need the attention backward's dK / dV / dQ
       TRY(side_run(wg3, 3, st));
       // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
       float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
