@@ -507,7 +507,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // dW2 += do2^T . h1 and dW1 += da1^T . ln1 are launched further down, once the dX chain of the MLP is through
       // (beside it they slowed every link: 44 vs 33 us for the GEMM below); they then share the machine with the
       // attention backward and the big dX GEMM instead.  Measured a wash in step time (both orders 0.509 ms): the
-      // backward is throughput-bound once both streams are busy — kept because it needs one fork less per layer.
+      // backward is throughput-bound once both streams are busy.
       GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
       GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
