@@ -175,7 +175,8 @@ GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* 
   return p;
 }
 static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, at least one 128-row slab each
-  int want = 512 / (tiles > 0 ? tiles : 1);
+  static const int target = getenv("PS_WGRAD_BLOCKS") ? atoi(getenv("PS_WGRAD_BLOCKS")) : 512;   // tuning experiments
+  int want = target / (tiles > 0 ? tiles : 1);
   int cap = (rows + 127) / 128;
   int ks = want < cap ? want : cap;
   return ks < 1 ? 1 : ks;
