@@ -127,6 +127,12 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p]),
     'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
     'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_graph_replay_enabled': (C.c_int, []),
+    'ps_tem_staged_batch': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.POINTER(PsTemBatch)]),
+    'ps_tem_forward_step': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch), C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_tem_backward_step': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.c_void_p, C.POINTER(PsTemTensors),
+                                       C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     'ps_tem_encode': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_rank_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),

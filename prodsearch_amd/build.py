@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprodsearch_hip.so')
 SOURCES = ['gemm.hip', 'rowwise.hip', 'attn_sq1.hip', 'mlp_fused.hip', 'optim.hip', 'optim_rows.hip', 'rank.hip', 'tem.hip', 'rtm.hip']
-HEADERS = ['common.h', 'rowwise.h', 'encoder.h', 'optim_core.h', os.path.join('..', '..', 'include', 'prodsearch_hip.h')]
+HEADERS = ['common.h', 'rowwise.h', 'encoder.h', 'optim_core.h', 'graph.h', os.path.join('..', '..', 'include', 'prodsearch_hip.h')]
 
 
 DATA_LIB = os.path.join(LIBDIR, 'libprodsearch_data.so')

@@ -78,7 +78,7 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
     for (int i = tid; i < nj * perq; i += 256) {
       const int jj = fdiv(i, a.fHQS), r = i - jj * perq, g = fdiv(r, a.fS), s = r - g * S;
       const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + 4 * g);
-      const Philox4 w = philox4x32_10((uint32_t)s, row >> 2, a.drop.site, a.drop.step, a.drop.k0, a.drop.k1);
+      const Philox4 w = philox4x32_10((uint32_t)s, row >> 2, a.drop.site, drop_step(a.drop), a.drop.k0, a.drop.k1);
       const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

@@ -57,7 +57,12 @@ struct DropSpec {      // one dropout site
   uint32_t thr;        // keep iff u32 >= thr ; thr = floor(p * 2^32); 0 => disabled
   float scale;         // 1/(1-p)
   uint32_t site, step, k0, k1;
+  const uint32_t* step_ptr;   // if set the step lives in device memory (graph replay: kernel arguments stay constant)
 };
+// the step a kernel keys its Philox counters with
+__device__ inline uint32_t drop_step(const DropSpec& s) { return s.step_ptr ? *s.step_ptr : s.step; }
+// set by an entry point for the duration of its argument building (see graph.h): where the step word lives, or null
+inline const uint32_t*& ps_step_ptr_slot() { static thread_local const uint32_t* p = nullptr; return p; }
 
 __host__ inline DropSpec make_drop(const PsTemDesc& d, uint32_t site) {
   DropSpec s;
@@ -65,7 +70,7 @@ __host__ inline DropSpec make_drop(const PsTemDesc& d, uint32_t site) {
   double p = on ? (double)d.dropout : 0.0;
   s.thr = on ? (uint32_t)(p * 4294967296.0) : 0u;
   s.scale = on ? (float)(1.0 / (1.0 - p)) : 1.f;
-  s.site = site; s.step = (uint32_t)d.step;
+  s.site = site; s.step = (uint32_t)d.step; s.step_ptr = ps_step_ptr_slot();
   s.k0 = (uint32_t)(d.seed & 0xffffffffu); s.k1 = (uint32_t)(d.seed >> 32);
   return s;
 }
@@ -76,7 +81,7 @@ __device__ inline float drop_word(const DropSpec& s, uint32_t word) {
 // multiplier (0 or 1/(1-p)) of element (row, col)
 __device__ inline float drop_mult(const DropSpec& s, uint32_t row, uint32_t col) {
   if (s.thr == 0u) return 1.f;
-  Philox4 r = philox4x32_10(col, row >> 2, s.site, s.step, s.k0, s.k1);
+  Philox4 r = philox4x32_10(col, row >> 2, s.site, drop_step(s), s.k0, s.k1);
   uint32_t sel = row & 3u;
   uint32_t wv = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));
   return drop_word(s, wv);

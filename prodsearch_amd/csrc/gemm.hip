@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     if (rbase >= M) break;
     preload(i + 1, nxt);
     Philox4 rnd = {0u, 0u, 0u, 0u};
-    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop.step, drop.k0, drop.k1);
+    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rbase + q;

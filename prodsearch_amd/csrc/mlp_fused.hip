@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       for (int gq = 0; gq < 4; ++gq) {
         const int rb = mm0 + 8 * gq + 4 * h;
         Philox4 rnd = {0u, 0u, 0u, 0u};
-        if (a.drop_ctx.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ctx.site, a.drop_ctx.step,
+        if (a.drop_ctx.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ctx.site, drop_step(a.drop_ctx),
                                                a.drop_ctx.k0, a.drop_ctx.k1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       for (int gq = 0; gq < 4; ++gq) {
         const int rb = mm0 + 8 * gq + 4 * h;
         Philox4 rnd = {0u, 0u, 0u, 0u};
-        if (a.drop_ff1.thr) rnd = philox4x32_10((uint32_t)f, (uint32_t)rb >> 2, a.drop_ff1.site, a.drop_ff1.step,
+        if (a.drop_ff1.thr) rnd = philox4x32_10((uint32_t)f, (uint32_t)rb >> 2, a.drop_ff1.site, drop_step(a.drop_ff1),
                                                a.drop_ff1.k0, a.drop_ff1.k1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       for (int gq = 0; gq < 4; ++gq) {
         const int rb = mm0 + 8 * gq + 4 * h;
         Philox4 rnd = {0u, 0u, 0u, 0u};
-        if (a.drop_ff2.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ff2.site, a.drop_ff2.step,
+        if (a.drop_ff2.thr) rnd = philox4x32_10((uint32_t)col, (uint32_t)rb >> 2, a.drop_ff2.site, drop_step(a.drop_ff2),
                                                a.drop_ff2.k0, a.drop_ff2.k1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -127,6 +127,20 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
                     hipStream_t st);
 
+// Prologue of a graph-replayed step: the only kernel whose arguments change from call to call.  Copies the caller's index
+// tensors into workspace-resident buffers, draws the negatives there (if a sampler is given) and publishes the Philox
+// step word; every later kernel of the step reads those fixed locations.
+struct StageArgs {
+  const int64_t* src[6]; int64_t* dst[6]; int n[6];   // query words, history, target, pv words, neg items, neg words
+  uint32_t step; uint32_t* step_word;
+  const float* prob; const int32_t* alias;            // sampler (null: negatives are among src)
+  int nitem, nword; int64_t P, V; uint32_t k0, k1;
+};
+int launch_stage(const StageArgs& a, hipStream_t st);
+const void* stage_kernel_handle();
+const void* loss_kernel_handle();
+int score_fwd_blocks(const ScoreArgs& a);
+
 int launch_sample(const PsTemDesc& d, const float* alias_prob, const int32_t* alias_idx, int64_t* neg_items,
                   int64_t* neg_words, hipStream_t st);
 

@@ -540,6 +540,14 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
   }
 }
 
+int score_fwd_blocks(const ScoreArgs& a) {
+  const int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
+  const int lpr = lpr_for(a.d);
+  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;
+  const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
+  return ps_cdiv(ps_cdiv(ntask, U), 256 / lpr);
+}
+
 int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
@@ -587,6 +595,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
     if (a.loss_acc) { a.loss_acc[0] += ps; a.loss_acc[1] += il; }   // model.ps_loss / item_loss running sums
   }
 }
+
+const void* loss_kernel_handle() { return reinterpret_cast<const void*>(loss_kernel); }
 
 int launch_loss(const ScoreArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, a);
@@ -825,6 +835,38 @@ __global__ __launch_bounds__(256) void sample_kernel(int nitem, int nword, int64
     float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
     neg_words[u] = f < prob[i] ? i : (int64_t)alias[i];
   }
+}
+
+__global__ __launch_bounds__(256) void tem_stage_kernel(StageArgs a) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) *a.step_word = a.step;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int n = a.src[k] ? a.n[k] : 0;
+    if (t < n) { a.dst[k][t] = a.src[k][t]; return; }
+    t -= n;
+  }
+  if (!a.prob) return;
+  if (t < a.nitem) {
+    Philox4 r = philox4x32_10((uint32_t)t, 0u, PS_SITE_SAMPLE_ITEM, a.step, a.k0, a.k1);
+    a.dst[4][t] = (int64_t)(((uint64_t)r.x * (uint64_t)a.P) >> 32);
+  } else if (t < a.nitem + a.nword) {
+    const int u = t - a.nitem;
+    Philox4 r = philox4x32_10((uint32_t)u, 0u, PS_SITE_SAMPLE_WORD, a.step, a.k0, a.k1);
+    const int64_t i = (int64_t)(((uint64_t)r.x * (uint64_t)a.V) >> 32);
+    const float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+    a.dst[5][u] = f < a.prob[i] ? i : (int64_t)a.alias[i];
+  }
+}
+
+const void* stage_kernel_handle() { return reinterpret_cast<const void*>(tem_stage_kernel); }
+
+int launch_stage(const StageArgs& a, hipStream_t st) {
+  int total = a.prob ? a.nitem + a.nword : 0;
+  for (int k = 0; k < 6; ++k) total += a.src[k] ? a.n[k] : 0;
+  hipLaunchKernelGGL(tem_stage_kernel, dim3(ps_cdiv(total > 0 ? total : 1, 256)), dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
 }
 
 int launch_sample(const PsTemDesc& d, const float* alias_prob, const int32_t* alias_idx, int64_t* neg_items,

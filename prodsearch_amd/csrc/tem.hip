@@ -16,6 +16,7 @@
 //     (x[:, 0] or x[:, -1], item_transformer.py:482-492), so its query/attention/FFN rows
 //     are n_out x 1 instead of n_out x S.
 #include "encoder.h"
+#include "graph.h"
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -124,6 +125,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.dqpre = take(cur, (int64_t)B * d);
   w.dqmean = take(cur, (int64_t)B * d);
   w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
+  w.stage = take(cur, 4 + 2 * ((int64_t)B * (D.Q + D.L + 1 + D.W + D.K + D.W * D.K) + 8));   // int64 = 2 floats
   w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 63) / 64 + 1) * 3 * (tem && NL > 0 ? D.F : 0));
   w.total = cur;
   return PS_OK;
@@ -666,6 +668,168 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   TRY(launch_embed_scatter(e, st));
   TRY(side_join(st));
   return PS_OK;
+}
+
+// ------------------------------------------------------------------ graph-replayed training step (graph.h)
+// Layout of the staging region: [step word | pad] then the six int64 index arrays, 16-byte aligned each.
+struct StageLayout { uint32_t* step_word; int64_t* p[6]; int n[6]; };
+static StageLayout stage_layout(const PsTemDesc& D, float* ws, const Ws& w) {
+  StageLayout L;
+  L.step_word = reinterpret_cast<uint32_t*>(ws + w.stage);
+  int64_t* base = reinterpret_cast<int64_t*>(ws + w.stage + 4);
+  const int n[6] = {D.B * D.Q, D.B * D.L, D.B, D.B * D.W, D.B * D.K, D.B * D.W * D.K};
+  int64_t off = 0;
+  for (int k = 0; k < 6; ++k) { L.p[k] = base + off; L.n[k] = n[k]; off += (n[k] + 1) & ~1; }
+  return L;
+}
+static PsTemBatch staged_batch(const StageLayout& L) {
+  PsTemBatch b;
+  memset(&b, 0, sizeof(b));
+  b.query_word_idxs = L.p[0]; b.u_item_idxs = L.p[1]; b.target_prod_idxs = L.p[2]; b.pos_iword_idxs = L.p[3];
+  b.neg_item_idxs = L.p[4]; b.neg_word_idxs = L.p[5];
+  return b;
+}
+
+extern "C" int ps_graph_replay_enabled(void) { return ps_graphs_enabled() ? 1 : 0; }
+
+// where ps_tem_forward_step staged the call's index tensors (for an eager ps_tem_backward after a replayed forward)
+extern "C" int ps_tem_staged_batch(const PsTemDesc* desc, float* workspace, PsTemBatch* out) {
+  PS_REQUIRE(desc && workspace && out, "staged_batch: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  *out = staged_batch(stage_layout(D, workspace, w));
+  return PS_OK;
+}
+
+// forward of one training step with the caller-varying inputs routed through the staging prologue, so that the launch
+// sequence can be captured once per shape and replayed.  sampler_prob/alias non-null: negatives are drawn in the
+// prologue (batch->neg_* ignored), else batch->neg_* are staged like the other index tensors.
+static int forward_body(const PsTemDesc& D, const PsTemTensors& P, const StageArgs& sa, const PsTemBatch& Bs, float* ws,
+                        const Ws& w, float* loss3, float* loss_acc, hipStream_t st) {
+  TRY(launch_stage(sa, st));
+  TRY(encode_forward(D, P, Bs, ws, w, st));
+  ScoreArgs s;
+  fill_score(D, P, Bs, ws, w, s);
+  s.loss3 = loss3; s.loss_acc = loss_acc;
+  TRY(launch_score_fwd(s, st));
+  TRY(launch_loss(s, st));
+  return PS_OK;
+}
+
+extern "C" int ps_tem_forward_step(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                                   const float* sampler_prob, const int32_t* sampler_alias, float* workspace,
+                                   float* loss3, float* loss_acc, ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace && loss3, "forward_step: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  const bool sampled = sampler_prob && sampler_alias;
+  PS_REQUIRE(batch->query_word_idxs && batch->target_prod_idxs && (D.model != PS_MODEL_TEM || batch->u_item_idxs) &&
+             (D.W == 0 || batch->pos_iword_idxs), "forward_step: null batch tensors");
+  PS_REQUIRE(sampled || (batch->neg_item_idxs && (D.W == 0 || batch->neg_word_idxs)), "forward_step: no negatives");
+  PS_REQUIRE(params->word_bias && (!D.bias_product || params->product_bias), "forward_step: null bias tensors");
+  const StageLayout L = stage_layout(D, workspace, w);
+  const PsTemBatch Bs = staged_batch(L);
+  StageArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  const int64_t* src[6] = {batch->query_word_idxs, D.model == PS_MODEL_TEM ? batch->u_item_idxs : nullptr,
+                           batch->target_prod_idxs, D.W > 0 ? batch->pos_iword_idxs : nullptr,
+                           sampled ? nullptr : batch->neg_item_idxs, (sampled || D.W == 0) ? nullptr : batch->neg_word_idxs};
+  for (int k = 0; k < 6; ++k) { sa.src[k] = src[k]; sa.dst[k] = L.p[k]; sa.n[k] = L.n[k]; }
+  sa.step = (uint32_t)D.step; sa.step_word = L.step_word;
+  if (sampled) {
+    sa.prob = sampler_prob; sa.alias = sampler_alias; sa.nitem = D.B * D.K; sa.nword = D.B * D.W * D.K;
+    sa.P = D.product_size; sa.V = D.vocab_size;
+    sa.k0 = (uint32_t)(D.seed & 0xffffffffu); sa.k1 = (uint32_t)(D.seed >> 32);
+  }
+  ps_step_ptr_slot() = L.step_word;               // every DropSpec built below reads the step from the workspace
+  int rc = PS_OK;
+  PsGraphEntry* e = nullptr;
+  if (ps_graphs_enabled()) {
+    PsTemDesc Dk = D;
+    Dk.step = 0;
+    uint64_t key = ps_fnv(PS_FNV0, "fwd", 3);
+    key = ps_fnv(key, &Dk, sizeof(Dk)); key = ps_fnv(key, params, sizeof(*params));
+    key = ps_fnv(key, &workspace, sizeof(workspace)); key = ps_fnv(key, &loss_acc, sizeof(loss_acc));
+    key = ps_fnv(key, &sampler_prob, sizeof(sampler_prob)); key = ps_fnv(key, &sampler_alias, sizeof(sampler_alias));
+    for (int k = 0; k < 6; ++k) { const int has = sa.src[k] != nullptr; key = ps_fnv(key, &has, sizeof(has)); }
+    e = ps_graph_lookup(key);
+  }
+  if (e && e->state == 2) {
+    ScoreArgs s;
+    fill_score(D, *params, Bs, workspace, w, s);
+    s.loss3 = loss3; s.loss_acc = loss_acc; s.loss_nblk = score_fwd_blocks(s);
+    void* p0[1] = {(void*)&sa};
+    void* p1[1] = {(void*)&s};
+    rc = ps_graph_patch(e, 0, p0) || ps_graph_patch(e, 1, p1) || ps_graph_launch(e, st);
+    if (rc) ps_set_error("forward_step: graph replay failed");
+  } else {
+    hipStream_t cap = (e && e->state == 1) ? ps_graph_begin() : nullptr;
+    if (cap) {
+      rc = forward_body(D, *params, sa, Bs, workspace, w, loss3, loss_acc, cap);
+      const void* patch[2] = {stage_kernel_handle(), loss_kernel_handle()};
+      if (ps_graph_end(cap, e, patch, 2) == PS_OK && rc == PS_OK) rc = ps_graph_launch(e, st);
+      else { e->state = -1; rc = forward_body(D, *params, sa, Bs, workspace, w, loss3, loss_acc, st); }
+    } else {
+      if (e && e->state == 0) e->state = 1;
+      rc = forward_body(D, *params, sa, Bs, workspace, w, loss3, loss_acc, st);
+    }
+  }
+  ps_step_ptr_slot() = nullptr;
+  return rc;
+}
+
+static int backward_body(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bs, float* ws, const PsTemTensors& G,
+                         float loss_scale, float* zero_ptr, int64_t zero_floats, hipStream_t st) {
+  if (zero_ptr && zero_floats > 0) PS_CHECK_HIP(hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_floats, st));
+  return ps_tem_backward(&D, &P, &Bs, ws, &G, loss_scale, nullptr, st);
+}
+
+// backward of the step ps_tem_forward_step ran last on this workspace (its staged indices and step word are reused);
+// zero_ptr/zero_floats: model.zero_grad() of the flat gradient buffer folded in as the first node (or null).
+extern "C" int ps_tem_backward_step(const PsTemDesc* desc, const PsTemTensors* params, float* ws,
+                                    const PsTemTensors* grads, float loss_scale, float* zero_ptr, int64_t zero_floats,
+                                    ps_stream_t stream) {
+  PS_REQUIRE(desc && params && ws && grads, "backward_step: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  const StageLayout L = stage_layout(D, ws, w);
+  const PsTemBatch Bs = staged_batch(L);
+  ps_step_ptr_slot() = L.step_word;
+  int rc = PS_OK;
+  PsGraphEntry* e = nullptr;
+  if (ps_graphs_enabled()) {
+    PsTemDesc Dk = D;
+    Dk.step = 0;
+    uint64_t key = ps_fnv(PS_FNV0, "bwd", 3);
+    key = ps_fnv(key, &Dk, sizeof(Dk)); key = ps_fnv(key, params, sizeof(*params)); key = ps_fnv(key, grads, sizeof(*grads));
+    key = ps_fnv(key, &ws, sizeof(ws)); key = ps_fnv(key, &loss_scale, sizeof(loss_scale));
+    key = ps_fnv(key, &zero_ptr, sizeof(zero_ptr)); key = ps_fnv(key, &zero_floats, sizeof(zero_floats));
+    e = ps_graph_lookup(key);
+  }
+  if (e && e->state == 2) {
+    rc = ps_graph_launch(e, st);
+    if (rc) ps_set_error("backward_step: graph replay failed");
+  } else {
+    hipStream_t cap = (e && e->state == 1) ? ps_graph_begin() : nullptr;
+    if (cap) {
+      rc = backward_body(D, *params, Bs, ws, *grads, loss_scale, zero_ptr, zero_floats, cap);
+      if (ps_graph_end(cap, e, nullptr, 0) == PS_OK && rc == PS_OK) rc = ps_graph_launch(e, st);
+      else { e->state = -1; rc = backward_body(D, *params, Bs, ws, *grads, loss_scale, zero_ptr, zero_floats, st); }
+    } else {
+      if (e && e->state == 0) e->state = 1;
+      rc = backward_body(D, *params, Bs, ws, *grads, loss_scale, zero_ptr, zero_floats, st);
+    }
+  }
+  ps_step_ptr_slot() = nullptr;
+  return rc;
 }
 
 extern "C" float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint32_t row, uint32_t col) {

@@ -137,7 +137,7 @@ class _LossTensor(torch.Tensor):
 
 class _Plan(object):
     """Per-shape cached call state: descriptor, batch struct, workspace."""
-    __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep')
+    __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep', 'staged')
 
 
 # ------------------------------------------------------------------------ model
@@ -389,7 +389,7 @@ class ItemTransformerRanker(nn.Module):
             self._plans[key] = plan
         return plan
 
-    def _fill_batch(self, plan, batch, eval_mode, neg_items=None, neg_words=None):
+    def _fill_batch(self, plan, batch, eval_mode, neg_items=None, neg_words=None, need_negs=True):
         b = plan.batch
         qw = self._check_idx(batch.query_word_idxs, 'query_word_idxs')
         ui = self._check_idx(batch.u_item_idxs, 'u_item_idxs')
@@ -407,13 +407,17 @@ class ItemTransformerRanker(nn.Module):
             tg = self._check_idx(batch.target_prod_idxs, 'target_prod_idxs')
             pw = self._check_idx(batch.pos_iword_idxs, 'pos_iword_idxs')
             b.target_prod_idxs, b.pos_iword_idxs = tg.data_ptr(), pw.data_ptr()
-            ni = self._check_idx(neg_items, 'neg_item_idxs')
-            nw = self._check_idx(neg_words, 'neg_word_idxs')
-            d = plan.desc
-            if ni.numel() != d.B * d.K or nw.numel() != d.B * d.W * d.K:
-                raise RuntimeError("negative sample shapes: want [%d,%d] and [%d,%d]" % (d.B, d.K, d.B, d.W * d.K))
-            b.neg_item_idxs, b.neg_word_idxs = ni.data_ptr(), nw.data_ptr()
-            keep += [tg, pw, ni, nw]
+            if need_negs:
+                ni = self._check_idx(neg_items, 'neg_item_idxs')
+                nw = self._check_idx(neg_words, 'neg_word_idxs')
+                d = plan.desc
+                if ni.numel() != d.B * d.K or nw.numel() != d.B * d.W * d.K:
+                    raise RuntimeError("negative sample shapes: want [%d,%d] and [%d,%d]" % (d.B, d.K, d.B, d.W * d.K))
+                b.neg_item_idxs, b.neg_word_idxs = ni.data_ptr(), nw.data_ptr()
+                keep += [tg, pw, ni, nw]
+            else:                          # drawn on the device inside the step's prologue
+                b.neg_item_idxs = b.neg_word_idxs = None
+                keep += [tg, pw]
         plan.keep = keep       # keep the index tensors alive until backward has run
 
     def _stream(self):
@@ -446,16 +450,33 @@ class ItemTransformerRanker(nn.Module):
                                            plan.neg_words.data_ptr(), self._stream()), 'ps_sample_negatives')
         return plan.neg_items, plan.neg_words
 
+    def _use_step_api(self):
+        """Graph-replayed step entry points (ps_tem_forward_step / ps_tem_backward_step), opt-in with PS_GRAPHS=1 (they
+        cut host time per step, not device time); the row-sparse mode keeps the eager ones (its touched-row lists read
+        the caller's index tensors)."""
+        return bool(_lib.load().ps_graph_replay_enabled()) and not self._row_sparse()
+
     def _run_forward(self, batch, neg_items=None, neg_words=None):
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=False)
         self._fwd_step += 1
         plan.desc.step = self._fwd_step
+        loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
+        if self._use_step_api():
+            inject = neg_items is not None and neg_words is not None
+            self._fill_batch(plan, batch, False, neg_items if inject else None, neg_words if inject else None,
+                             need_negs=inject)
+            prob, alias = (None, None) if inject else self._alias_tables()
+            _lib.check(lib.ps_tem_forward_step(plan.desc, ps, plan.batch, _lib.ptr(prob), _lib.ptr(alias),
+                                               plan.ws.data_ptr(), loss3.data_ptr(), self._loss_acc.data_ptr(),
+                                               self._stream()), 'ps_tem_forward_step')
+            plan.staged = True
+            return plan, loss3
         if neg_items is None or neg_words is None:
             neg_items, neg_words = self.sample_negatives(plan)
         self._fill_batch(plan, batch, False, neg_items, neg_words)
-        loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
+        plan.staged = False
         _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
                                       self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
         return plan, loss3
@@ -544,6 +565,16 @@ class ItemTransformerRanker(nn.Module):
         lib = _lib.load()
         ps, gs = self._structs()
         st = self._stream()
+        if grad_out is None and getattr(plan, 'staged', False) and self._use_step_api():
+            fresh = self._assign_grads()                   # zero_grad() folded into the replayed backward
+            _lib.check(lib.ps_tem_backward_step(plan.desc, ps, plan.ws.data_ptr(), gs, 1.0,
+                                                self._grad_flat.data_ptr() if fresh else None,
+                                                self._grad_flat.numel() if fresh else 0, st), 'ps_tem_backward_step')
+            return
+        batch_struct = plan.batch
+        if getattr(plan, 'staged', False):           # explicit upstream gradient: eager backward over the staged inputs
+            batch_struct = _lib.PsTemBatch()
+            _lib.check(lib.ps_tem_staged_batch(plan.desc, plan.ws.data_ptr(), batch_struct), 'ps_tem_staged_batch')
         if self._assign_grads():
             self._zero_for_backward()
         elif self._row_sparse() and any(getattr(p, '_ps_rows', {}).get('dirty') for _, p, _ in self._sparse_tabs):
@@ -559,7 +590,7 @@ class ItemTransformerRanker(nn.Module):
             with torch.cuda.stream(side):
                 self._coalesce_touched(plan)
         go = None if grad_out is None else grad_out.contiguous().float()      # None: d loss / d loss = 1
-        _lib.check(lib.ps_tem_backward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), gs, 1.0,
+        _lib.check(lib.ps_tem_backward(plan.desc, ps, batch_struct, plan.ws.data_ptr(), gs, 1.0,
                                        _lib.ptr(go), st), 'ps_tem_backward')
         if self._row_sparse():
             main.wait_stream(side)

@@ -267,3 +267,46 @@ def test_scaled_loss_takes_the_autograd_path_and_matches_the_direct_one():
         if n.endswith('linear_keys.bias'):
             continue
         assert rel_err(grads[1][n], 2.0 * grads[0][n]) < 1e-5, n
+
+
+def test_graph_replayed_step_is_bitwise_the_eager_step():
+    """PS_GRAPHS=1 (ps_tem_forward_step / ps_tem_backward_step: capture on the second call, replay afterwards, inputs
+    through the staging prologue) must reproduce the eager step exactly: same kernels, same order."""
+    import subprocess, sys, os, json
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from golden_util import Golden
+from prodsearch_amd import ItemTransformerRanker, build_optim, _lib
+g = Golden('tem_c2s_drop')
+m = ItemTransformerRanker(g.args, 'cuda', g.V, g.P, None, word_dists=g.word_dists)
+m.load_state_dict(g.params(), strict=False); m.train()
+opt = build_optim(g.args, m, None)
+b = g.batch().to('cuda'); losses = []
+for step in range(5):                      # eager, capture, then three replays (two with device-drawn negatives)
+    if step < 3:
+        ni, nw = g.negs(step %% g.steps)
+        loss = m(b, neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    else:
+        loss = m(b)
+    m.zero_grad(); loss.backward(); opt.step(); losses.append(float(loss))
+sd = m.state_dict()
+print(json.dumps({'graphs': int(_lib.load().ps_graph_replay_enabled()), 'losses': losses,
+                  'sum': {k: float(v.double().sum()) for k, v in sd.items()},
+                  'abs': {k: float(v.double().abs().sum()) for k, v in sd.items()}}))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ('0', '1'):
+        env = dict(os.environ, PS_GRAPHS=flag)
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['0']['graphs'] == 0 and out['1']['graphs'] == 1
+    assert out['0']['losses'][0] == out['1']['losses'][0]            # same parameters, same kernels: identical bits
+    for a, b in zip(out['0']['losses'][:3], out['1']['losses'][:3]):  # later steps see atomically-summed table grads
+        assert abs(a - b) <= 1e-5 * abs(a)
+    for k in out['0']['sum']:
+        if k.endswith('linear_keys.bias'):
+            continue
+        # atomics reassociate table sums run to run; everything else is bitwise
+        assert abs(out['0']['sum'][k] - out['1']['sum'][k]) <= 1e-6 * max(1.0, out['0']['abs'][k]), k
