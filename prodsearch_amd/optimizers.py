@@ -106,10 +106,20 @@ class Optimizer(object):
         pl = self._plan
         if pl is None:
             return False
+        # cheap identity check first: the same Parameter objects carrying the same .grad tensor OBJECTS as last step
+        # (the model re-attaches its persistent flat-buffer views after every zero_grad)
+        fast = pl.get('fast')
+        if fast is not None and all(p.grad is g for p, g in fast) and \
+                all(p.grad is None for p in pl['dead']):
+            return True
         live = [p for p in self.params if p.grad is not None]
         if len(live) != len(pl['live']):
             return False
-        return all(a is b and (a.data_ptr(), a.grad.data_ptr()) == s for a, b, s in zip(live, pl['live'], pl['sig']))
+        ok = all(a is b and (a.data_ptr(), a.grad.data_ptr()) == s for a, b, s in zip(live, pl['live'], pl['sig']))
+        if ok:
+            pl['fast'] = [(p, p.grad) for p in live]
+            pl['dead'] = [p for p in self.params if p.grad is None]
+        return ok
 
     # ------------------------------------------------------------------ step
     def step(self):
