@@ -1,3 +1,4 @@
+"""Does the clock drop under the step's load?  (disproved as the cause of slow tiny kernels: round-1 investigation)"""
 import sys, os, time, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

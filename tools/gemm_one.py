@@ -1,3 +1,4 @@
+"""Time one ps_gemm_f32 shape: python tools/gemm_one.py M N K"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
