@@ -128,3 +128,53 @@ def test_bad_ids_raise_instead_of_faulting():
     dl.sample_review[2] = 10 ** 9
     with pytest.raises(RuntimeError, match='review id'):
         dl.train_batch_from_ids([2])
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_native_collate_equals_oracle_on_random_corpora(seed):
+    """Randomised corpora and flags (history limits 1..25, fixed / random-subset / sequential histories, pv windows,
+    users with no training review at all): the C++ collate must equal the Python restatement bit for bit, with both
+    consuming the same Mersenne-Twister stream."""
+    rng = np.random.default_rng(1000 + seed)
+    limit = int(rng.integers(1, 26))
+    over = dict(uprev_review_limit=limit, fix_train_review=bool(rng.integers(0, 2)),
+                do_seq_review_train=bool(rng.integers(0, 4) == 0), pv_window_size=int(rng.integers(1, 4)))
+    train_ds, test_ds = synth.make_corpus(500 + seed, n_users=int(rng.integers(5, 80)), n_products=int(rng.integers(3, 60)),
+                                          n_queries=int(rng.integers(1, 30)), vocab_size=int(rng.integers(20, 400)),
+                                          Q=int(rng.integers(1, 9)), W=over['pv_window_size'],
+                                          max_reviews_per_user=int(rng.integers(2, 130)),
+                                          train_frac=float(rng.choice([0.3, 0.8, 1.0])))
+    args = default_args(**over)
+    B = int(rng.integers(1, 70))
+    dl = ItemPVDataloader(args, train_ds, batch_size=B, shuffle=True, seed=77 + seed)
+    random.seed(77 + seed)
+    torch.manual_seed(seed)
+    ids_per_batch = []
+    for n, b in enumerate(dl):
+        ids_per_batch.append(b)
+        if n == 3:
+            break
+    torch.manual_seed(seed)
+    for n, ids in zip(range(len(ids_per_batch)), _sampler(train_ds, B, True)):
+        want = ocollate.train_batch(train_ds, args, [train_ds[i] for i in ids])
+        got = ids_per_batch[n]
+        for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs'):
+            w = np.asarray(want[k], dtype=np.int64).reshape(len(ids), -1)
+            g = getattr(got, k).numpy().reshape(len(ids), -1)
+            if k == 'u_item_idxs' and w.shape[1] == 0:
+                assert g.shape[1] == 0 or (g == train_ds.prod_pad_idx).all()
+                continue
+            assert np.array_equal(g, w), (seed, n, k)
+    # evaluation entries
+    targs = default_args(**dict(over, do_seq_review_test=bool(seed % 2), train_review_only=not bool(seed % 2)))
+    if len(test_ds) > 0:
+        tl = ItemPVDataloader(targs, test_ds, batch_size=5, shuffle=False)
+        for i, (b, ids) in enumerate(zip(tl, BatchSampler(SequentialSampler(test_ds), 5, False))):
+            want = ocollate.test_batch(test_ds, targs, [test_ds[j] for j in ids])
+            for k in ('query_word_idxs', 'target_prod_idxs', 'candi_prod_idxs'):
+                assert np.array_equal(getattr(b, k).numpy(), np.asarray(want[k])), (seed, i, k)
+            w = np.asarray(want['u_item_idxs'], dtype=np.int64).reshape(len(ids), -1)
+            if w.shape[1]:
+                assert np.array_equal(b.u_item_idxs.numpy(), w), (seed, i)
+            if i == 2:
+                break
