@@ -3,7 +3,7 @@
 against the Python collate of the reference (restated in oracle/collate.py) on a synthetic Amazon-shaped corpus,
 and — on an MI355X — the training step fed by the native loader against pre-built device batches.
 
-    python tools/bench_collate.py [--users 40000] [--batches 200] [--gpu-steps 300]
+    python tests/perf/bench_collate.py [--users 40000] [--batches 200] [--gpu-steps 300]
 """
 import argparse
 import json
@@ -12,7 +12,7 @@ import random
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from oracle import collate as ocollate  # noqa: E402  (CPU baseline of this tool only)

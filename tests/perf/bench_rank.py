@@ -3,7 +3,7 @@
 procedure (model.test over chunks of 500 candidates with the sequence re-encoded per candidate, host argsort) restated
 by the oracle on the host cores.
 
-    python tools/bench_rank.py [--items 18357] [--batch 24] [--d 128] [--cpu-batches 1]
+    python tests/perf/bench_rank.py [--items 18357] [--batch 24] [--d 128] [--cpu-batches 1]
 """
 import argparse
 import json
@@ -11,7 +11,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
