@@ -1,0 +1,88 @@
+"""Parity at BASELINE.json's full configs[1] size (B=384, K=20, d=128, P=18,357, V=32,387) through properties that do not
+need a full-size replicated oracle run: the dedup'd oracle (exact for dropout 0), determinism, index-set equalities,
+permutation equivariance of the scorer, sortedness and rank consistency of the full-catalogue ranking."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+P_, V, B, K, L, Q, W = 18357, 32387, 384, 20, 20, 8, 1
+
+
+def _setup(dropout, seed=3):
+    from prodsearch_amd import ItemTransformerRanker, readme_tem_args, synth
+    a = readme_tem_args(dropout=dropout)
+    wd = synth.make_word_dists(V)
+    sd = synth.make_state_dict(synth.tem_param_shapes(a, V, P_), seed, {'product_emb.weight': P_})
+    m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    m.load_state_dict(sd, strict=False)
+    batch = synth.make_tem_batch(41, B, P_, V, Q=Q, L=L, W=W, C=64, word_dists=wd)
+    ni, nw = synth.sample_negatives(42, B, K, W, P_, wd)
+    return a, wd, sd, m, batch, ni, nw
+
+
+def test_full_size_loss_and_touched_rows_match_the_dedup_oracle():
+    from oracle import tem as otem
+    a, wd, sd, m, batch, ni, nw = _setup(0.0)
+    m.train()
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    with torch.no_grad():
+        oloss, ops, oil = otem.tem_forward(sd, a, batch, ni, nw, V, P_, training=True)     # one encode per row: exact
+    assert rel_err(loss.detach().cpu(), oloss) < 1e-4
+    assert abs(m.ps_loss - float(ops)) < 1e-4 * abs(float(ops)) and abs(m.item_loss - float(oil)) < 1e-4 * abs(float(oil))
+    # bit-exact index work: the table rows that received a gradient are exactly the rows the batch addresses
+    prod = np.setdiff1d(np.unique(np.concatenate([batch.target_prod_idxs.numpy().ravel(), ni.numpy().ravel(),
+                                                  batch.u_item_idxs.numpy().ravel()])), [P_])
+    word = np.setdiff1d(np.unique(np.concatenate([batch.query_word_idxs.numpy().ravel(), nw.numpy().ravel(),
+                                                  batch.pos_iword_idxs.numpy().ravel()])), [V - 1])
+    got_p = torch.nonzero(m.product_emb.weight.grad.ne(0).any(1)).flatten().cpu().numpy()
+    got_w = torch.nonzero(m.word_embeddings.weight.grad.ne(0).any(1)).flatten().cpu().numpy()
+    assert np.array_equal(got_p, prod) and np.array_equal(got_w, word)
+
+
+def test_full_size_dropout_step_is_deterministic_and_step_dependent():
+    losses = []
+    for rep in range(2):
+        a, wd, sd, m, batch, ni, nw = _setup(0.1)
+        m.train()
+        ls = [float(m(batch.to("cuda"), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda()).detach()) for _ in range(2)]
+        losses.append(ls)
+    assert losses[0] == losses[1]                      # same seed, same step counters: identical bits
+    assert losses[0][0] != losses[0][1]                # the Philox step advances the masks
+
+
+def test_full_size_scorer_is_permutation_equivariant_and_ranking_is_sorted():
+    from prodsearch_amd import evaluate
+    a, wd, sd, m, batch, ni, nw = _setup(0.1)
+    m.eval()
+    b = batch.to('cuda')
+    with torch.no_grad():
+        s = m.test(b)
+        perm = torch.randperm(b.candi_prod_idxs.shape[1], device='cuda')
+        b2 = batch.to('cuda')
+        b2.candi_prod_idxs = b.candi_prod_idxs[:, perm].contiguous()
+        s2 = m.test(b2)
+    assert torch.equal(s2, s[:, perm])                  # same candidate, same bits, wherever it sits
+    top_idx, top_score, rank = evaluate.rank_all(m, b, 100)
+    assert bool((top_score[:, 1:] <= top_score[:, :-1]).all())
+    assert int(top_idx.min()) >= 0 and int(top_idx.max()) < P_
+    for row in range(0, B, 37):                         # no duplicates inside a ranklist
+        assert len(set(top_idx[row].tolist())) == 100
+    # the candidate scorer and the full-catalogue scorer agree on the scores of the listed candidates' products
+    with torch.no_grad():
+        b3 = batch.to('cuda')
+        b3.candi_prod_idxs = top_idx[:, :64].contiguous()
+        s3 = m.test(b3)
+    assert rel_err(s3.cpu(), top_score[:, :64].cpu()) < 1e-4
+    # rank of the target = 1 + number of listed products scoring above it, whenever the target is inside the top 100
+    tgt = b.target_prod_idxs
+    hit = (top_idx == tgt[:, None])
+    pos = hit.float().argmax(1) + 1
+    inside = hit.any(1)
+    assert torch.equal(rank[inside].long(), pos[inside])
+    assert bool((rank[~inside] > 100).all())
