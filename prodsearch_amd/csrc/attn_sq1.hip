@@ -9,6 +9,7 @@
 // Everything is LDS-resident fp32 VALU work (S <= 64, a few KB per sequence); replicas are
 // processed in chunks of JC so that the Philox masks are generated once per element.
 #include "rowwise.h"
+#include <stdlib.h>
 
 #define SQ1_LDS_MAX (128 * 1024)   // dynamic LDS these kernels may request (160 KB per CU on gfx950)
 
@@ -43,28 +44,30 @@ static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd, int JC) {
   return n * sizeof(float);
 }
 
-__device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid) {
-  const int S = a.S, d = a.d, nv = S * d / 4;
-  const float4* k4 = reinterpret_cast<const float4*>(a.kp + (size_t)b * S * d);
-  const float4* v4 = reinterpret_cast<const float4*>(a.vp + (size_t)b * S * d);
+// A workgroup owns the heads h0 .. h0+H-1 of one sequence = columns c0 .. c0+d-1 of its rows (heads are independent
+// in attention); `d`, `H` below are those SUB sizes, D the row stride of the global tensors.
+__device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid, int d, int c0) {
+  const int S = a.S, D = a.d, nv = S * d / 4;
   const int d4 = d >> 2;
   for (int i = tid; i < nv; i += 256) {
     const int sr = fdiv(i, a.fd4), c4 = (i - sr * d4) * 4;
-    const float4 kk = k4[i], vv = v4[i];
+    const float4 kk = *reinterpret_cast<const float4*>(a.kp + ((size_t)b * S + sr) * D + c0 + c4);
+    const float4 vv = *reinterpret_cast<const float4*>(a.vp + ((size_t)b * S + sr) * D + c0 + c4);
     float* lk = l.Ks + sr * KLD(d) + c4;
     float* lv = l.Vs + sr * KLD(d) + c4;
     lk[0] = kk.x; lk[1] = kk.y; lk[2] = kk.z; lk[3] = kk.w;
     lv[0] = vv.x; lv[1] = vv.y; lv[2] = vv.z; lv[3] = vv.w;
   }
-  for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * d + i];
+  for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * D + c0 + i];
   const int brow = b / a.seq_div;
   for (int s = tid; s < S; s += 256)
     l.valid[s] = a.valid ? a.valid[(size_t)brow * S + s] : ((s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f);
 }
 
 // dropout multipliers (or P * multipliers) of replicas j0..j0+nj-1 into Pd[jj][h][s]
-__device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int j0, int nj, int tid, bool times_p) {
-  const int S = a.S, H = a.H, per = H * S;
+__device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int j0, int nj, int tid, bool times_p,
+                                 int H, int h0) {
+  const int S = a.S, HF = a.H, per = H * S;
   if (a.drop.thr == 0u) {
     for (int i = tid; i < nj * per; i += 256) {
       const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
@@ -77,7 +80,7 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
     const int HQ = H >> 2, perq = HQ * S;
     for (int i = tid; i < nj * perq; i += 256) {
       const int jj = fdiv(i, a.fHQS), r = i - jj * perq, g = fdiv(r, a.fS), s = r - g * S;
-      const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + 4 * g);
+      const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * HF + h0 + 4 * g);
       const Philox4 w = philox4x32_10((uint32_t)s, row >> 2, a.drop.site, drop_step(a.drop), a.drop.k0, a.drop.k1);
       const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -92,7 +95,7 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
   }
   for (int i = tid; i < nj * per; i += 256) {
     const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
-    const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * H + h);        // Sq == 1: row = nout*H + h
+    const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * HF + h0 + h);  // Sq == 1: row = nout*H + h
     float m = drop_mult(a.drop, row, (uint32_t)s);
     if (times_p) m *= l.P[h * (S + 1) + s];
     l.Pd[(jj * H + h) * (S + 1) + s] = m;
@@ -101,10 +104,11 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
 
 __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
-  const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int S = a.S, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
   const int JC = a.jc;
   Sq1Lds l = sq1_carve(lds, S, d, H, false, JC);
-  sq1_load(a, l, b, tid);
+  sq1_load(a, l, b, tid, d, c0);
   __syncthreads();
   for (int i = tid; i < H * S; i += 256) {
     const int h = fdiv(i, a.fS), s = i - h * S;
@@ -126,12 +130,12 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   __syncthreads();
   for (int i = tid; i < H * S; i += 256) {
     const int h = fdiv(i, a.fS), s = i - h * S;
-    a.attn[((size_t)b * H + h) * S + s] = l.P[h * (S + 1) + s];
+    a.attn[((size_t)b * HF + h0 + h) * S + s] = l.P[h * (S + 1) + s];
   }
   for (int j0 = 0; j0 < a.fan; j0 += JC) {
     const int nj = min(JC, a.fan - j0);
     __syncthreads();
-    sq1_masks(a, l, b, j0, nj, tid, true);
+    sq1_masks(a, l, b, j0, nj, tid, true, H, h0);
     __syncthreads();
     for (int i = tid; i < nj * d; i += 256) {
       const int jj = fdiv(i, a.fd), c = i - jj * d, h = fdiv(c, a.fdh);
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
       float acc = 0.f;
 #pragma unroll 8
       for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * KLD(d) + c];
-      a.ctx[((size_t)b * a.fan + j0 + jj) * d + c] = acc;
+      a.ctx[((size_t)b * a.fan + j0 + jj) * D + c0 + c] = acc;
     }
   }
 }
@@ -153,10 +157,26 @@ bool attn_sq1_fits(const AttnArgs& a) {
   return a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && sq1_lds_bytes(a.S, a.d, a.H, true, 1) <= SQ1_LDS_MAX;
 }
 
+// head groups per sequence (grid.y): heads are independent, so a sequence's work can be cut into workgroups that each
+// walk the same latency chain over fewer columns; groups of 4 heads keep the shared Philox call of sq1_masks intact
+static inline int sq1_pick_split(const AttnArgs& a) {
+  static const int env = getenv("PS_ATTN_SPLIT") ? atoi(getenv("PS_ATTN_SPLIT")) : 0;     // tuning experiments
+  int hy = env > 0 ? env : 2;
+  while (hy > 1 && (a.H % hy != 0 || (a.H / hy) % 4 != 0 || (a.d / hy) % 4 != 0)) hy >>= 1;
+  return hy < 1 ? 1 : hy;
+}
+static inline void sq1_sub_dividers(AttnArgs& b, int hy) {
+  const int Hs = b.H / hy, ds = b.d / hy;
+  b.fd = make_fdiv(ds); b.fd4 = make_fdiv(ds / 4);
+  b.fHS = make_fdiv(Hs * b.S); b.fHQS = make_fdiv((Hs / 4 > 0 ? Hs / 4 : 1) * b.S);
+}
+
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
   AttnArgs b = a;
-  b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
-  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, false, b.jc);
+  const int hy = sq1_pick_split(a);
+  sq1_sub_dividers(b, hy);
+  b.jc = sq1_pick_jc(a.S, a.d / hy, a.H / hy, a.fan);
+  size_t lds = sq1_lds_bytes(a.S, a.d / hy, a.H / hy, false, b.jc);
   PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= SQ1_LDS_MAX, "attention(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
   static bool attr_f = false;
@@ -165,30 +185,31 @@ int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SQ1_LDS_MAX));
     attr_f = true;
   }
-  hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
+  hipLaunchKernelGGL(attn_fwd_sq1_kernel, dim3(a.n_in, hy), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
-  const int S = a.S, d = a.d, H = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int S = a.S, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
   const int JC = a.jc;
   Sq1Lds l = sq1_carve(lds, S, d, H, true, JC);
-  sq1_load(a, l, b, tid);
+  sq1_load(a, l, b, tid, d, c0);
   for (int i = tid; i < H * S; i += 256) {
     const int h = fdiv(i, a.fS), s = i - h * S;
-    l.P[h * (S + 1) + s] = a.attn[((size_t)b * H + h) * S + s];
+    l.P[h * (S + 1) + s] = a.attn[((size_t)b * HF + h0 + h) * S + s];
     l.dP[h * (S + 1) + s] = 0.f;
   }
   for (int i = tid; i < S * d; i += 256) l.dV[i] = 0.f;
   for (int j0 = 0; j0 < a.fan; j0 += JC) {
     const int nj = min(JC, a.fan - j0);
     __syncthreads();
-    sq1_masks(a, l, b, j0, nj, tid, false);
+    sq1_masks(a, l, b, j0, nj, tid, false, H, h0);
     for (int i = tid; i < nj * d; i += 256) {
       const int jj = fdiv(i, a.fd), c = i - jj * d;
-      l.dC[i] = a.dctx[((size_t)b * a.fan + j0 + jj) * d + c];
+      l.dC[i] = a.dctx[((size_t)b * a.fan + j0 + jj) * D + c0 + c];
     }
     __syncthreads();
     for (int i = tid; i < S * d; i += 256) {                 // dV[s][c] += sum_j P*m_j * dctx_j[c]
@@ -229,23 +250,25 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
       dq += g[s] * l.Ks[s * KLD(d) + c];
       const float dk = g[s] * qc;
       const float dv = l.dV[s * d + c];
-      const size_t off = ((size_t)b * S + s) * a.lddkv + c;
+      const size_t off = ((size_t)b * S + s) * a.lddkv + c0 + c;
       a.dkv[off] = dk;
-      a.dkv[off + d] = dv;
+      a.dkv[off + D] = dv;
       sk += dk; sv += dv;
     }
     dq *= a.qscale;
-    a.dq[(size_t)b * a.lddq + c] = dq;
-    atomicAdd(&a.dbq[c], dq);
-    atomicAdd(&a.dbk[c], sk);
-    atomicAdd(&a.dbv[c], sv);
+    a.dq[(size_t)b * a.lddq + c0 + c] = dq;
+    atomicAdd(&a.dbq[c0 + c], dq);
+    atomicAdd(&a.dbk[c0 + c], sk);
+    atomicAdd(&a.dbv[c0 + c], sv);
   }
 }
 
 int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
   AttnArgs b = a;
-  b.jc = sq1_pick_jc(a.S, a.d, a.H, a.fan);
-  size_t lds = sq1_lds_bytes(a.S, a.d, a.H, true, b.jc);
+  const int hy = sq1_pick_split(a);
+  sq1_sub_dividers(b, hy);
+  b.jc = sq1_pick_jc(a.S, a.d / hy, a.H / hy, a.fan);
+  size_t lds = sq1_lds_bytes(a.S, a.d / hy, a.H / hy, true, b.jc);
   PS_REQUIRE(a.Sq == 1 && a.S <= 64 && a.d % 4 == 0 && lds <= SQ1_LDS_MAX, "attention bwd(sq1): S=%d d=%d needs %zu B LDS",
              a.S, a.d, lds);
   static bool attr_b = false;
@@ -254,7 +277,7 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SQ1_LDS_MAX));
     attr_b = true;
   }
-  hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in), dim3(256), lds, st, b);
+  hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in, hy), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
