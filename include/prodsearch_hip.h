@@ -129,6 +129,11 @@ int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);
  * model.ps_loss / model.item_loss with two .item() syncs per step (item_transformer.py:516-517). */
 int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
                    float* workspace, float* loss3, float* loss_acc, ps_stream_t stream);
+/* The same with the two negative draws (ps_sample_negatives) folded into the forward's first launch: batch->neg_* are
+ * ignored, neg_item_out [B,K] / neg_word_out [B,W*K] receive the draws and are what the backward must be given. */
+int ps_tem_forward_sampled(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                           const float* alias_prob, const int32_t* alias_idx, int64_t* neg_item_out, int64_t* neg_word_out,
+                           float* workspace, float* loss3, float* loss_acc, ps_stream_t stream);
 
 /* loss.backward()                          -- trainer.py:77 (autograd of the above).
  * ACCUMULATES loss_scale * dloss/dparam into `grads` (dense, like the reference's

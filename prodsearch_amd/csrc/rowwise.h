@@ -14,6 +14,10 @@ struct EmbedArgs {
   float* qmean_d;                // [B,d] mean after FS dropout
   float* query_emb;              // [B,d] written here only for AVG
   float* x;                      // [B,S,d]
+  // optional: the step's two negative draws ride in this launch as extra workgroups (nothing here depends on them; the
+  // score kernel that reads them runs much later) instead of a launch of their own in front of it
+  const float* samp_prob; const int32_t* samp_alias; int64_t* samp_items; int64_t* samp_words;
+  int samp_nitem, samp_nword; uint32_t samp_step, samp_k0, samp_k1;
 };
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);
 

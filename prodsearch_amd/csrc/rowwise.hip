@@ -21,6 +21,20 @@ __device__ inline int64_t clamp_idx(int64_t i, int64_t hi) { return i < 0 ? hi :
 // positional add (item_transformer.py:452,466-471, transformer.py:77-81).
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   extern __shared__ float red[];   // [rpp][d]
+  if ((int)blockIdx.x >= a.B) {      // sampling workgroups (see EmbedArgs::samp_*): same draws as sample_kernel
+    const int t = ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x;
+    if (t < a.samp_nitem) {
+      Philox4 r = philox4x32_10((uint32_t)t, 0u, PS_SITE_SAMPLE_ITEM, a.samp_step, a.samp_k0, a.samp_k1);
+      a.samp_items[t] = (int64_t)(((uint64_t)r.x * (uint64_t)a.P) >> 32);
+    } else if (t < a.samp_nitem + a.samp_nword) {
+      const int u = t - a.samp_nitem;
+      Philox4 r = philox4x32_10((uint32_t)u, 0u, PS_SITE_SAMPLE_WORD, a.samp_step, a.samp_k0, a.samp_k1);
+      const int64_t i = (int64_t)(((uint64_t)r.x * (uint64_t)a.V) >> 32);
+      const float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+      a.samp_words[u] = f < a.samp_prob[i] ? i : (int64_t)a.samp_alias[i];
+    }
+    return;
+  }
   const int b = blockIdx.x, tid = threadIdx.x;
   const int d = a.d, nchunk = d >> 2;
   const int rpp = 256 / nchunk;
@@ -83,7 +97,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0 && a.d <= 1024, "embed: d=%d unsupported", a.d);
   int rpp = 256 / (a.d / 4);
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B), dim3(256), (size_t)rpp * a.d * sizeof(float), st, a);
+  const int nsamp = a.samp_prob ? ps_cdiv(a.samp_nitem + a.samp_nword, 256) : 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp), dim3(256), (size_t)rpp * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -343,8 +343,10 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
 }
 
 // -------------------------------------------------------------- encoder forward
+struct SamplerArgs { const float* prob; const int32_t* alias; int64_t* items; int64_t* words; };
+
 static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
-                          hipStream_t st) {
+                          hipStream_t st, const SamplerArgs* samp = nullptr) {
   const bool tem = D.model == PS_MODEL_TEM;
   const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0;
   const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
@@ -359,6 +361,11 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
   PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
   PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
+  if (samp) {
+    e.samp_prob = samp->prob; e.samp_alias = samp->alias; e.samp_items = samp->items; e.samp_words = samp->words;
+    e.samp_nitem = D.B * D.K; e.samp_nword = D.B * D.W * D.K; e.samp_step = (uint32_t)D.step;
+    e.samp_k0 = (uint32_t)(D.seed & 0xffffffffu); e.samp_k1 = (uint32_t)(D.seed >> 32);
+  }
   TRY(launch_embed_fwd(e, st));
   if (e.fs) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
     PS_REQUIRE(P.fs_w && P.fs_b, "forward: null FS encoder weights");
@@ -401,6 +408,33 @@ extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params,
   TRY(encode_forward(D, *params, *batch, workspace, w, st));
   ScoreArgs s;
   fill_score(D, *params, *batch, workspace, w, s);
+  s.loss3 = loss3; s.loss_acc = loss_acc;
+  TRY(launch_score_fwd(s, st));
+  TRY(launch_loss(s, st));
+  return PS_OK;
+}
+
+// forward with the two negative draws folded into its first launch: neg_item_out / neg_word_out receive the draws
+// (they are what batch->neg_* would have held) and must stay alive until the backward has run.
+extern "C" int ps_tem_forward_sampled(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                                      const float* alias_prob, const int32_t* alias_idx, int64_t* neg_item_out,
+                                      int64_t* neg_word_out, float* workspace, float* loss3, float* loss_acc,
+                                      ps_stream_t stream) {
+  PS_REQUIRE(desc && params && batch && workspace && loss3 && alias_prob && alias_idx && neg_item_out && neg_word_out,
+             "forward_sampled: null argument");
+  PsTemDesc D = *desc;
+  D.C = 0;
+  Ws w;
+  TRY(make_ws(D, w));
+  hipStream_t st = (hipStream_t)stream;
+  PS_REQUIRE(batch->target_prod_idxs && (D.W == 0 || batch->pos_iword_idxs), "forward_sampled: null batch tensors");
+  PS_REQUIRE(params->word_bias && (!D.bias_product || params->product_bias), "forward_sampled: null bias tensors");
+  PsTemBatch Bt = *batch;
+  Bt.neg_item_idxs = neg_item_out; Bt.neg_word_idxs = neg_word_out;
+  const SamplerArgs samp = {alias_prob, alias_idx, neg_item_out, neg_word_out};
+  TRY(encode_forward(D, *params, Bt, workspace, w, st, &samp));
+  ScoreArgs s;
+  fill_score(D, *params, Bt, workspace, w, s);
   s.loss3 = loss3; s.loss_acc = loss_acc;
   TRY(launch_score_fwd(s, st));
   TRY(launch_loss(s, st));

@@ -474,10 +474,21 @@ class ItemTransformerRanker(nn.Module):
                                                self._stream()), 'ps_tem_forward_step')
             plan.staged = True
             return plan, loss3
-        if neg_items is None or neg_words is None:
-            neg_items, neg_words = self.sample_negatives(plan)
-        self._fill_batch(plan, batch, False, neg_items, neg_words)
         plan.staged = False
+        if neg_items is None or neg_words is None:
+            # the two draws ride in the forward's first launch; plan.neg_* receive them for the backward
+            d = plan.desc
+            if plan.neg_items is None:
+                plan.neg_items = torch.empty(d.B, d.K, device=self._dev(), dtype=torch.int64)
+                plan.neg_words = torch.empty(d.B, d.W * d.K, device=self._dev(), dtype=torch.int64)
+            self._fill_batch(plan, batch, False, plan.neg_items, plan.neg_words)
+            prob, alias = self._alias_tables()
+            _lib.check(lib.ps_tem_forward_sampled(plan.desc, ps, plan.batch, prob.data_ptr(), alias.data_ptr(),
+                                                  plan.neg_items.data_ptr(), plan.neg_words.data_ptr(),
+                                                  plan.ws.data_ptr(), loss3.data_ptr(), self._loss_acc.data_ptr(),
+                                                  self._stream()), 'ps_tem_forward_sampled')
+            return plan, loss3
+        self._fill_batch(plan, batch, False, neg_items, neg_words)
         _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
                                       self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
         return plan, loss3

@@ -310,3 +310,22 @@ print(json.dumps({'graphs': int(_lib.load().ps_graph_replay_enabled()), 'losses'
             continue
         # atomics reassociate table sums run to run; everything else is bitwise
         assert abs(out['0']['sum'][k] - out['1']['sum'][k]) <= 1e-6 * max(1.0, out['0']['abs'][k]), k
+
+
+def test_folded_sampling_draws_equal_the_standalone_sampler():
+    """The negatives drawn inside the forward's first launch are the ones ps_sample_negatives draws for the same step."""
+    from prodsearch_amd import _lib
+    if _lib.load().ps_graph_replay_enabled():
+        pytest.skip('PS_GRAPHS=1 draws the negatives in the staging prologue (covered by the graph-vs-eager test)')
+    g = Golden('tem_c1')
+    m = _model(g)
+    loss = m(g.batch().to('cuda'))                          # no injected negatives: drawn in the embed launch
+    plan = next(iter(m._plans.values()))
+    got_i, got_w = plan.neg_items.clone(), plan.neg_words.clone()
+    ref_i, ref_w = m.sample_negatives(plan)                 # same desc.step, standalone kernel
+    torch.cuda.synchronize()
+    assert torch.equal(got_i, ref_i) and torch.equal(got_w, ref_w)
+    assert int(got_i.min()) >= 0 and int(got_i.max()) < g.P and int(got_w.max()) < g.V - 1
+    m.zero_grad()
+    loss.backward()                                         # and the backward reads them from the plan
+    assert m.product_emb.weight.grad[got_i.flatten().unique()].abs().sum() > 0
