@@ -59,6 +59,7 @@ class Trainer(object):
     def train(self, args, global_data, train_prod_data, valid_prod_data):
         valid_dataset = self.ExpDataset(args, global_data, valid_prod_data)
         best_mrr, best_path = 0., ''
+        self.model.clear_loss()
         step = 0
         t_log = time.time()
         for epoch in range(args.start_epoch + 1, args.max_train_epoch + 1):
@@ -68,7 +69,6 @@ class Trainer(object):
             prepare_pv = epoch < args.train_pv_epoch + 1
             loader = self.ExpDataloader(args, dataset, prepare_pv=prepare_pv, batch_size=args.batch_size, shuffle=True,
                                         device=args.device, prefetch=getattr(args, 'prefetch', 2))
-            self.model.clear_loss()
             for batch in loader:
                 loss = self.model(batch, train_pv=prepare_pv)
                 self.model.zero_grad()
