@@ -284,6 +284,10 @@ typedef struct PsRtmDesc {
   float dropout;         /* --dropout                                                             */
   float corrupt_rate;    /* --corrupt_rate: token dropout of the pvc encoder (PVC.py:46-54)       */
   uint64_t seed, step;
+  int32_t use_user_emb;  /* --use_user_emb / --use_item_emb: per-position user / item embeddings added  */
+  int32_t use_item_emb;  /*   to every sequence (ps_model.py:325-334, :229-234)                         */
+  int64_t user_size;     /* pad user = user_size, pad item = product_size (ps_model.py:66-67)           */
+  int64_t product_size;
 } PsRtmDesc;
 
 typedef struct PsRtmTensors {
@@ -294,6 +298,8 @@ typedef struct PsRtmTensors {
   float *pe;             /* transformer_encoder.pos_emb.pe                                         */
   float *final_ln_g, *final_ln_b;
   float *wo_w, *wo_b;    /* transformer_encoder.wo [1,d],[1] (transformer.py:69,96)                */
+  float *user_emb;       /* user_emb.weight [user_size+1,d]       (use_user_emb) or NULL           */
+  float *product_emb;    /* product_emb.weight [product_size+1,d] (use_item_emb) or NULL           */
   PsLayerTensors layer[PS_MAX_LAYERS];
 } PsRtmTensors;
 
@@ -313,6 +319,12 @@ typedef struct PsRtmBatch {
   const int64_t *candi_prod_ridxs;        /* [B,C,R]   eval                          */
   const int64_t *candi_seg_idxs;          /* [B,C,R+1] eval                          */
   const float *review_embeddings;         /* [review_count,d] eval table (get_review_embeddings, ps_model.py:186-203) */
+  const int64_t *pos_user_idxs;           /* [B,R+1]   use_user_emb (pad user_size)  */
+  const int64_t *neg_user_idxs;           /* [B,K,R+1]                               */
+  const int64_t *pos_item_idxs;           /* [B,R+1]   use_item_emb (pad product_size) */
+  const int64_t *neg_item_idxs;           /* [B,K,R+1]                               */
+  const int64_t *candi_seq_user_idxs;     /* [B,C,R+1] eval                          */
+  const int64_t *candi_seq_item_idxs;     /* [B,C,R+1] eval                          */
 } PsRtmBatch;
 
 int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int64_t* total);

@@ -104,6 +104,12 @@ def rtm_forward(P, args, batch, neg_word_idxs, vocab_size, review_count, trainin
     if args.use_seg_emb:                                                                          # :326-328
         pos_seq = pos_seq + P['seg_embeddings.weight'][batch.pos_seg_idxs]
         neg_seq = neg_seq + P['seg_embeddings.weight'][batch.neg_seg_idxs]
+    if getattr(args, 'use_item_emb', False):                                                      # :329-333
+        pos_seq = pos_seq + P['product_emb.weight'][batch.pos_item_idxs]
+        neg_seq = neg_seq + P['product_emb.weight'][batch.neg_item_idxs]
+    if getattr(args, 'use_user_emb', False):                                                      # :334-338
+        pos_seq = pos_seq + P['user_emb.weight'][batch.pos_user_idxs]
+        neg_seq = neg_seq + P['user_emb.weight'][batch.neg_user_idxs]
     k0 = {} if keep is not None else None
     te = 'transformer_encoder.'
     top_p = encoder_encode(P, args, pos_seq, pos_mask, pe, drop, 0, k0)                           # :336
@@ -147,6 +153,10 @@ def rtm_test(P, args, batch, review_embeddings, vocab_size, review_count):
     seq = torch.cat((query_emb.unsqueeze(1).expand(-1, C, -1).unsqueeze(2), rev), dim=2)
     if args.use_seg_emb:
         seq = seq + P['seg_embeddings.weight'][batch.candi_seg_idxs]
+    if getattr(args, 'use_user_emb', False):                                                      # :233-235
+        seq = seq + P['user_emb.weight'][batch.candi_seq_user_idxs]
+    if getattr(args, 'use_item_emb', False):                                                      # :236-238
+        seq = seq + P['product_emb.weight'][batch.candi_seq_item_idxs]
     top = encoder_encode(P, args, seq.reshape(B * C, R + 1, d), mask.reshape(B * C, R + 1), pe, no_dropout, 0)
     te = 'transformer_encoder.'
     return F.linear(top[:, 0, :], P[te + 'wo.weight'], P[te + 'wo.bias']).squeeze(-1).view(B, C)

@@ -73,15 +73,18 @@ class PsRtmDesc(C.Structure):
                [('vocab_size', C.c_int64), ('review_count', C.c_int64)] + \
                [(n, C.c_int32) for n in ('review_encoder', 'query_encoder', 'use_pos_emb', 'use_seg_emb',
                                          'pos_weight', 'train_pv', 'training')] + \
-               [('dropout', C.c_float), ('corrupt_rate', C.c_float), ('seed', C.c_uint64), ('step', C.c_uint64)]
+               [('dropout', C.c_float), ('corrupt_rate', C.c_float), ('seed', C.c_uint64), ('step', C.c_uint64)] + \
+               [('use_user_emb', C.c_int32), ('use_item_emb', C.c_int32), ('user_size', C.c_int64),
+                ('product_size', C.c_int64)]
 
 
 RTM_TOP_FIELDS = ('word_emb', 'review_emb', 'seg_emb', 'fs_w', 'fs_b', 'pe', 'final_ln_g', 'final_ln_b',
-                  'wo_w', 'wo_b')
+                  'wo_w', 'wo_b', 'user_emb', 'product_emb')
 RTM_BATCH_FIELDS = ('query_word_idxs', 'pos_prod_ridxs', 'pos_seg_idxs', 'pos_prod_rword_idxs',
                     'pos_prod_rword_masks', 'neg_prod_ridxs', 'neg_seg_idxs', 'neg_prod_rword_idxs',
                     'pos_prod_rword_idxs_pvc', 'neg_prod_rword_idxs_pvc', 'neg_word_idxs',
-                    'candi_prod_ridxs', 'candi_seg_idxs', 'review_embeddings')
+                    'candi_prod_ridxs', 'candi_seg_idxs', 'review_embeddings', 'pos_user_idxs', 'neg_user_idxs',
+                    'pos_item_idxs', 'neg_item_idxs', 'candi_seq_user_idxs', 'candi_seq_item_idxs')
 
 
 class PsRtmTensors(C.Structure):

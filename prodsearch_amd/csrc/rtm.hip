@@ -38,6 +38,9 @@ struct RtmK {              // kernel-side view of one call
   DropSpec d_pv, d_pos, d_neg, t_pos, t_neg;
   // batch
   const int64_t *pos_r, *neg_r, *pos_seg, *neg_seg, *pos_words, *neg_words_rev, *pos_pvc, *neg_pvc, *neg_word_idxs;
+  const int64_t *pos_u, *neg_u, *pos_i, *neg_i;   // per-position user / item ids (use_user_emb / use_item_emb), else null
+  int64_t U, PI;                                  // their pad ids (user_size, product_size)
+  const float *user_emb, *item_emb; float *g_user_emb, *g_item_emb;
   const uint8_t* pos_masks;
   // tensors
   const float *word_emb, *table, *seg_emb, *pe, *wo_w, *wo_b;
@@ -127,7 +130,8 @@ __device__ inline int64_t rclamp(int64_t i, int64_t hi) { return i < 0 ? hi : (i
 // ------------------------------------------------------------------ embed forward
 // one wave per (sequence, position); lanes: half = lane>>5 picks every other word row, c = lane&31 the float4
 // chunk of the row (d <= 128: one chunk per lane; wider rows loop).
-__device__ inline void seq_decode(const RtmK& a, int n, int s, int& b, int& j, int64_t& ridx, int& revrow, int& seg) {
+__device__ inline void seq_decode(const RtmK& a, int n, int s, int& b, int& j, int64_t& ridx, int& revrow, int& seg,
+                                  size_t* spos = nullptr) {
   b = fdiv(n, a.fJ); j = n - b * a.J;
   const int r = s - 1;
   if (a.eval || j > 0) {
@@ -136,10 +140,12 @@ __device__ inline void seq_decode(const RtmK& a, int n, int s, int& b, int& j, i
     ridx = s > 0 ? a.neg_r[base * a.R + r] : 0;
     seg = (int)a.neg_seg[base * a.S + s];
     revrow = (int)(base * a.R + r);
+    if (spos) *spos = base * a.S + s;
   } else {
     ridx = s > 0 ? a.pos_r[(size_t)b * a.R + r] : 0;
     seg = (int)a.pos_seg[(size_t)b * a.S + s];
     revrow = b * a.R + r;
+    if (spos) *spos = (size_t)b * a.S + s;
   }
 }
 
@@ -149,12 +155,17 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
   if (slot >= a.B * a.J * a.S) return;
   const int n = fdiv(slot, a.fS), s = slot - n * a.S;
   const int d = a.d, nch = d >> 2;
-  int b, j, revrow, seg; int64_t ridx;
-  seq_decode(a, n, s, b, j, ridx, revrow, seg);
+  int b, j, revrow, seg; int64_t ridx; size_t spos;
+  seq_decode(a, n, s, b, j, ridx, revrow, seg, &spos);
   const bool pos = !a.eval && j == 0;
   const int64_t rpad = a.RC - 1;
   const bool ok = s == 0 || ridx != rpad;
   if (lane == 0) a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f;
+  // per-position user / item embedding rows (ps_model.py:325-334).  The pad id addresses the table's last row,
+  // which is READ like any other (nn.Embedding's padding_idx only stops its gradient) and never updated.
+  int64_t uid = -1, iid = -1;
+  if (a.user_emb) { uid = (pos ? a.pos_u : a.neg_u)[spos]; if (uid < 0 || uid > a.U) uid = -1; }
+  if (a.item_emb) { iid = (pos ? a.pos_i : a.neg_i)[spos]; if (iid < 0 || iid > a.PI) iid = -1; }
   for (int cc0 = 0; cc0 < nch; cc0 += 32) {          // wave-uniform trip count: the shuffles below need every lane
     const int cc = cc0 + c;
     const bool act = cc < nch;
@@ -276,6 +287,8 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
       const int col = 4 * cc + e;
       float val = o[e];
       if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
+      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
+      if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
       val = ok ? val : 0.f;
       if (a.use_pos) val += a.pe[(size_t)s * d + col];
       o[e] = val;
@@ -472,8 +485,8 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
   const int64_t rpad = a.RC - 1;
   for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
     const int n = fdiv(slot, a.fS), s = slot - n * a.S;
-    int b, j, revrow, seg; int64_t ridx;
-    seq_decode(a, n, s, b, j, ridx, revrow, seg);
+    int b, j, revrow, seg; int64_t ridx; size_t spos;
+    seq_decode(a, n, s, b, j, ridx, revrow, seg, &spos);
     const bool pos = j == 0;
     const bool ok = s == 0 || ridx != rpad;
     if (!ok) continue;
@@ -481,6 +494,16 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
     float gk[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) gk[k] = k < epl ? g[c + 32 * k] : 0.f;
+    if (half == 0 && (a.g_user_emb || a.g_item_emb)) {      // user / item embedding rows of this position
+      const int64_t uid = a.g_user_emb ? (pos ? a.pos_u : a.neg_u)[spos] : -1;
+      const int64_t iid = a.g_item_emb ? (pos ? a.pos_i : a.neg_i)[spos] : -1;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < epl) {
+          if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + c + 32 * k], gk[k]);
+          if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + c + 32 * k], gk[k]);
+        }
+    }
     if (a.use_seg && half == 0) {
 #pragma unroll
       for (int k = 0; k < 16; ++k)
@@ -668,6 +691,9 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   k.d_pv = make_drop(dd, SITE_REV_PV); k.d_pos = make_drop(dd, SITE_REV_POS); k.d_neg = make_drop(dd, SITE_REV_NEG);
   dd.dropout = D.corrupt_rate;
   k.t_pos = make_drop(dd, SITE_TOK_POS); k.t_neg = make_drop(dd, SITE_TOK_NEG);
+  k.U = D.user_size; k.PI = D.product_size;
+  if (D.use_user_emb) { k.user_emb = P.user_emb; k.pos_u = Bt.pos_user_idxs; k.neg_u = eval ? Bt.candi_seq_user_idxs : Bt.neg_user_idxs; }
+  if (D.use_item_emb) { k.item_emb = P.product_emb; k.pos_i = Bt.pos_item_idxs; k.neg_i = eval ? Bt.candi_seq_item_idxs : Bt.neg_item_idxs; }
   if (eval) {
     k.neg_r = Bt.candi_prod_ridxs; k.neg_seg = Bt.candi_seg_idxs; k.table = Bt.review_embeddings;
   } else {
@@ -699,6 +725,8 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   fill_k(D, P, Bt, ws, r, w, eval, k);
   PS_REQUIRE(k.neg_r && k.neg_seg && (eval || (k.pos_r && k.pos_seg)), "rtm: null review index tensors");
   PS_REQUIRE(k.pvc || k.table, "rtm: null review embedding table");
+  PS_REQUIRE(!D.use_user_emb || (k.user_emb && k.neg_u && (eval || k.pos_u)), "rtm: use_user_emb needs user_emb and the user index tensors");
+  PS_REQUIRE(!D.use_item_emb || (k.item_emb && k.neg_i && (eval || k.pos_i)), "rtm: use_item_emb needs product_emb and the item index tensors");
   if (k.pvc) PS_REQUIRE(k.train_pv ? (k.pos_pvc && k.neg_pvc) : (k.pos_words && k.neg_words_rev), "rtm: null review word tensors");
   if (k.train_pv) PS_REQUIRE(k.pos_words && k.pos_masks && k.neg_word_idxs, "rtm: null PV-loss tensors");
   // query encoder (shared kernels): masked mean (+FS dropout) then tanh(f_W . + b)
@@ -786,6 +814,8 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
              "rtm backward: null gradients");
   k.scale = loss_scale; k.scale_dev = loss_scale_dev;
   k.g_word_emb = G.word_emb; k.g_table = G.review_emb; k.g_seg_emb = G.seg_emb; k.g_wo_w = G.wo_w; k.g_wo_b = G.wo_b;
+  if (D.use_user_emb) { PS_REQUIRE(G.user_emb, "rtm backward: null user_emb gradient"); k.g_user_emb = G.user_emb; }
+  if (D.use_item_emb) { PS_REQUIRE(G.product_emb, "rtm backward: null product_emb gradient"); k.g_item_emb = G.product_emb; }
   const int B = D.B, d = D.d;
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k);

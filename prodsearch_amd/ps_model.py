@@ -51,8 +51,8 @@ class ProductRanker(nn.Module):
         super(ProductRanker, self).__init__()
         if args.review_encoder_name not in ('pv', 'pvc'):
             raise NotImplementedError("review_encoder_name %r: only pv / pvc are built" % args.review_encoder_name)
-        if args.use_user_emb or args.use_item_emb or getattr(args, 'fix_emb', False):
-            raise NotImplementedError("use_user_emb / use_item_emb / fix_emb are outside the built path")
+        if getattr(args, 'fix_emb', False):
+            raise NotImplementedError("fix_emb is outside the built path")
         if getattr(args, 'pretrain_emb_dir', '') or getattr(args, 'pretrain_up_emb_dir', ''):
             raise NotImplementedError("pretrained-embedding text loaders are out of scope; load a state_dict")
         self.args = args
@@ -73,6 +73,12 @@ class ProductRanker(nn.Module):
                              "(the reference pads it with others/util.py:pad)")
         self.review_words = rw.to(device)                       # plain attribute, as in the reference (:79)
 
+        # registration order follows ps_model.py:88-126 so state_dicts line up key for key
+        self.use_user_emb, self.use_item_emb = bool(args.use_user_emb), bool(args.use_item_emb)
+        if self.use_user_emb:
+            self.user_emb = nn.Embedding(user_size + 1, d, padding_idx=self.user_pad_idx)
+        if self.use_item_emb:
+            self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
         self.word_embeddings = nn.Embedding(vocab_size, d, padding_idx=self.word_pad_idx)
         self.transformer_encoder = _TransformerEncoder(d, args.ff_size, args.inter_layers)
         self.review_encoder = _ReviewEncoder(self.word_embeddings, self.review_encoder_name, review_count, d)
@@ -166,6 +172,10 @@ class ProductRanker(nn.Module):
                (('wo_w',), te.wo.weight), (('wo_b',), te.wo.bias)]
         if self.review_encoder_name == 'pv':
             out.append((('review_emb',), self.review_encoder.review_embeddings.weight))
+        if self.use_user_emb:
+            out.append((('user_emb',), self.user_emb.weight))
+        if self.use_item_emb:
+            out.append((('product_emb',), self.product_emb.weight))
         if a.query_encoder_name == 'fs':
             out += [(('fs_w',), self.query_encoder.f_W.weight), (('fs_b',), self.query_encoder.f_W.bias)]
         for i, l in enumerate(te.transformer_inter):
@@ -233,7 +243,28 @@ class ProductRanker(nn.Module):
         d.training = int(bool(self.training) and not eval_mode)
         d.dropout, d.corrupt_rate = float(a.dropout), float(a.corrupt_rate)
         d.seed, d.step = self._seed, 0
+        d.use_user_emb, d.use_item_emb = int(self.use_user_emb), int(self.use_item_emb)
+        d.user_size, d.product_size = self.user_pad_idx, self.prod_pad_idx
         return d
+
+    def _seq_ids(self, bt, batch, names, shape, keep):
+        """Per-position user / item ids (ps_model.py:325-334, :233-238): [.., R+1] int64, position 0 = pad."""
+        want = []
+        if self.use_user_emb:
+            want += [n for n in names if 'user' in n]
+        if self.use_item_emb:
+            want += [n for n in names if 'item' in n]
+        for n in names:
+            setattr(bt, n, None)
+        for n in want:
+            t = self._idx(getattr(batch, n, None), n)
+            if t is None:
+                raise RuntimeError("use_user_emb / use_item_emb: the batch lacks %s" % n)
+            exp = shape[n]
+            if tuple(t.shape) != exp:
+                raise RuntimeError("batch.%s has shape %s, expected %s" % (n, tuple(t.shape), exp))
+            setattr(bt, n, t.data_ptr())
+            keep.append(t)
 
     @staticmethod
     def _idx(t, name, dtype=torch.int64):
@@ -325,6 +356,9 @@ class ProductRanker(nn.Module):
                 raise RuntimeError("neg_word_idxs must hold B*R*W*K = %d draws" % (B * R * W * K))
             bt.neg_word_idxs = nw.data_ptr()
             keep.append(nw)
+        self._seq_ids(bt, b, ('pos_user_idxs', 'neg_user_idxs', 'pos_item_idxs', 'neg_item_idxs'),
+                      dict(pos_user_idxs=(B, R + 1), pos_item_idxs=(B, R + 1),
+                           neg_user_idxs=(B, K, R + 1), neg_item_idxs=(B, K, R + 1)), keep)
         plan['keep'] = keep
         loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
         _lib.check(lib.ps_rtm_forward(plan['desc'], ps, bt, plan['ws'].data_ptr(), loss3.data_ptr(), self._stream()),
@@ -363,7 +397,10 @@ class ProductRanker(nn.Module):
         tab = self.review_embeddings.detach().contiguous()
         bt.query_word_idxs, bt.candi_prod_ridxs, bt.candi_seg_idxs = qw.data_ptr(), cr.data_ptr(), cs.data_ptr()
         bt.review_embeddings = tab.data_ptr()
-        plan['keep'] = [qw, cr, cs, tab]
+        keep = [qw, cr, cs, tab]
+        self._seq_ids(bt, batch, ('candi_seq_user_idxs', 'candi_seq_item_idxs'),
+                      dict(candi_seq_user_idxs=(B, C, R + 1), candi_seq_item_idxs=(B, C, R + 1)), keep)
+        plan['keep'] = keep
         scores = torch.empty(B, C, device=self._dev(), dtype=torch.float32)
         _lib.check(lib.ps_rtm_score(plan['desc'], ps, bt, plan['ws'].data_ptr(), scores.data_ptr(), self._stream()),
                    'ps_rtm_score')

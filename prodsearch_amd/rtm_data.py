@@ -105,8 +105,20 @@ def _seq(rng, n_seq, R, u_lim, i_lim, review_count, empty_frac=0.0):
     return rid, seg
 
 
+def _seq_ids(seed, ridxs, pad_rev, size):
+    """Per-position ids [.., R+1] for a review-index tensor [.., R]: position 0 (the query) and padded reviews
+    carry the pad id ``size`` (prod_search_dataloader.py:212-215); a private stream, so adding them leaves the
+    other draws of a seed unchanged."""
+    rng = rng_for(seed)
+    ids = rng.integers(0, size, size=ridxs.shape)
+    ids = np.where(ridxs == pad_rev, size, ids)
+    ids = np.where(rng.random(ridxs.shape) < 0.03, size, ids)        # a pad id on a live position is legal too
+    lead = np.full(ridxs.shape[:-1] + (1,), size, dtype=np.int64)
+    return np.concatenate([lead, ids.astype(np.int64)], axis=-1)
+
+
 def make_rtm_batch(seed, B, K, review_count, vocab_size, review_words, Q=8, u_lim=4, i_lim=6, W=1, train_pv=True,
-                   encoder='pv', word_dists=None):
+                   encoder='pv', word_dists=None, user_size=None, product_size=None):
     """One RTM training batch (CPU tensors).  R = u_lim + i_lim; a few negatives have NO reviews
     (their loss weight is 0, ps_model.py:344-345)."""
     rng = rng_for(seed)
@@ -150,13 +162,22 @@ def make_rtm_batch(seed, B, K, review_count, vocab_size, review_words, Q=8, u_li
         if encoder == 'pvc':
             kw['neg_prod_rword_idxs'] = rw[neg_r]
             kw['neg_prod_rword_masks'] = (rw[neg_r] != V - 1).astype(np.uint8)
-    zeros_p = np.zeros_like(pos_seg)
-    zeros_n = np.zeros_like(neg_seg)
+    pos_u = neg_u = pos_i = neg_i = None
+    if user_size is None:
+        pos_u, neg_u = np.zeros_like(pos_seg), np.zeros_like(neg_seg)
+    else:
+        pos_u, neg_u = _seq_ids(seed + 71, pos_r, pad_rev, user_size), _seq_ids(seed + 72, neg_r, pad_rev, user_size)
+    if product_size is None:
+        pos_i, neg_i = np.zeros_like(pos_seg), np.zeros_like(neg_seg)
+    else:
+        pos_i, neg_i = (_seq_ids(seed + 73, pos_r, pad_rev, product_size),
+                        _seq_ids(seed + 74, neg_r, pad_rev, product_size))
     return ProdSearchTrainBatch(qw, pos_r, pos_seg, pos_words, pos_masks, neg_r, neg_seg,
-                                zeros_p, zeros_n, zeros_p, zeros_n, **kw)
+                                pos_u, neg_u, pos_i, neg_i, **kw)
 
 
-def make_rtm_test_batch(seed, B, C, review_count, vocab_size, Q=8, u_lim=4, i_lim=6, word_dists=None):
+def make_rtm_test_batch(seed, B, C, review_count, vocab_size, Q=8, u_lim=4, i_lim=6, word_dists=None,
+                        user_size=None, product_size=None):
     rng = rng_for(seed)
     V, R = vocab_size, u_lim + i_lim
     wd = make_word_dists(V) if word_dists is None else word_dists
@@ -169,4 +190,6 @@ def make_rtm_test_batch(seed, B, C, review_count, vocab_size, Q=8, u_lim=4, i_li
     cr, cs = cr.reshape(B, C, R), cs.reshape(B, C, R + 1)
     z = np.zeros_like(cs)
     candi = rng.integers(0, 1000, size=(B, C))
-    return ProdSearchTestBatch(list(range(B)), list(range(B)), candi[:, 0].copy(), candi, qw, cr, cs, z, z)
+    su = z if user_size is None else _seq_ids(seed + 75, cr, review_count - 1, user_size)
+    si = z if product_size is None else _seq_ids(seed + 76, cr, review_count - 1, product_size)
+    return ProdSearchTestBatch(list(range(B)), list(range(B)), candi[:, 0].copy(), candi, qw, cr, cs, su, si)

@@ -78,7 +78,21 @@ CASES = {
     'rtm_pv_drop': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32,
                                   heads=4, ff_size=64, inter_layers=2, neg_per_pos=2, dropout=0.2, lr=0.002, seed=5),
                         V=400, RC=300, B=6, Q=6, u=2, i=3, WL=10, C=6, steps=1, train_pv=True),
+    # per-position user / item embeddings (ps_model.py:325-334, :233-238)
+    'rtm_pv_ui': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32, heads=4,
+                                ff_size=64, inter_layers=1, neg_per_pos=3, dropout=0.0, lr=0.002, pv_window_size=2,
+                                use_user_emb=True, use_item_emb=True),
+                      V=400, RC=300, B=10, Q=6, u=3, i=4, WL=12, C=6, steps=2, train_pv=True),
+    'rtm_pvc_item': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=32,
+                                   heads=4, ff_size=64, inter_layers=2, neg_per_pos=3, dropout=0.1, lr=0.002,
+                                   corrupt_rate=0.9, seed=11, use_item_emb=True, use_seg_emb=False),
+                         V=400, RC=300, B=8, Q=6, u=3, i=4, WL=12, C=6, steps=1, train_pv=True),
+    'rtm_pv_user': dict(args=dict(model_name='review_transformer', review_encoder_name='pv', embedding_size=32,
+                                  heads=4, ff_size=64, inter_layers=1, neg_per_pos=2, dropout=0.0, lr=0.002,
+                                  use_user_emb=True, pos_weight=True),
+                        V=400, RC=300, B=6, Q=6, u=2, i=3, WL=10, C=5, steps=1, train_pv=False),
 }
+USER_SIZE, PRODUCT_SIZE = 40, 50
 
 
 def run_case(name, spec):
@@ -92,7 +106,7 @@ def run_case(name, spec):
     wd = synth.make_word_dists(V, seed=101)
     review_words = rtm_data.make_review_words(77, RC, V, WL, wd)
     torch.manual_seed(0)
-    model = ProductRanker(args, 'cpu', V, RC, 50, 40, review_words.tolist(), None, word_dists=wd)
+    model = ProductRanker(args, 'cpu', V, RC, PRODUCT_SIZE, USER_SIZE, review_words.tolist(), None, word_dists=wd)
     ref_sd = model.state_dict()
     shapes = {k: tuple(v.shape) for k, v in ref_sd.items() if not k.endswith('pos_emb.pe')}
     wseed = 1000 + sum(map(ord, name))
@@ -102,7 +116,9 @@ def run_case(name, spec):
     optim = build_optim(args, model, None)
 
     bt = rtm_data.make_rtm_batch(2000 + wseed, B, K, RC, V, review_words, Q=Q, u_lim=u, i_lim=i, W=W,
-                                 train_pv=train_pv, encoder=enc, word_dists=wd)
+                                 train_pv=train_pv, encoder=enc, word_dists=wd,
+                                 user_size=USER_SIZE if args.use_user_emb else None,
+                                 product_size=PRODUCT_SIZE if args.use_item_emb else None)
     rb = RefTrain(*[getattr(bt, k) for k in rtm_data._TRAIN_FIELDS], to_tensor=False)
     out = {}
     meta = dict(case=name, args=spec['args'], V=V, RC=RC, B=B, Q=Q, u=u, i=i, WL=WL, C=C, K=K, R=R, W=W,
@@ -118,7 +134,9 @@ def run_case(name, spec):
     out['in_review_words'] = review_words.numpy()
 
     # eval on the initial weights (trainer.py:193,201: get_review_embeddings then test)
-    tb = rtm_data.make_rtm_test_batch(3000 + wseed, B, C, RC, V, Q=Q, u_lim=u, i_lim=i, word_dists=wd)
+    tb = rtm_data.make_rtm_test_batch(3000 + wseed, B, C, RC, V, Q=Q, u_lim=u, i_lim=i, word_dists=wd,
+                                      user_size=USER_SIZE if args.use_user_emb else None,
+                                      product_size=PRODUCT_SIZE if args.use_item_emb else None)
     rtb = RefTest(tb.query_idxs, tb.user_idxs, tb.target_prod_idxs, tb.candi_prod_idxs, tb.query_word_idxs,
                   tb.candi_prod_ridxs, tb.candi_seg_idxs, tb.candi_seq_user_idxs, tb.candi_seq_item_idxs,
                   to_tensor=False)
@@ -131,6 +149,10 @@ def run_case(name, spec):
     out['in_test_query_word_idxs'] = tb.query_word_idxs.numpy()
     out['in_test_candi_prod_ridxs'] = tb.candi_prod_ridxs.numpy()
     out['in_test_candi_seg_idxs'] = tb.candi_seg_idxs.numpy()
+    if args.use_user_emb:
+        out['in_test_candi_seq_user_idxs'] = tb.candi_seq_user_idxs.numpy()
+    if args.use_item_emb:
+        out['in_test_candi_seq_item_idxs'] = tb.candi_seq_item_idxs.numpy()
 
     model.train()
     init = {k: v.clone() for k, v in model.state_dict().items()}

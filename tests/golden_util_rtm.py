@@ -41,10 +41,11 @@ class RtmGolden(object):
         return rtm_data.ProdSearchTrainBatch(*vals, to_tensor=False)
 
     def test_batch(self):
-        t = lambda k: torch.from_numpy(self.z['in_test_' + k])
+        t = lambda k: torch.from_numpy(self.z['in_test_' + k]) if 'in_test_' + k in self.z.files else None
         B = self.B
         return rtm_data.ProdSearchTestBatch(list(range(B)), list(range(B)), None, None, t('query_word_idxs'),
-                                            t('candi_prod_ridxs'), t('candi_seg_idxs'), None, None, to_tensor=False)
+                                            t('candi_prod_ridxs'), t('candi_seg_idxs'), t('candi_seq_user_idxs'),
+                                            t('candi_seq_item_idxs'), to_tensor=False)
 
     def neg_words(self, step):
         k = 'in_neg_word_idxs_%d' % step

@@ -37,7 +37,8 @@ def test_rtm_gradients_and_adam(case):
     init = {k: v.detach().clone() for k, v in P.items()}
     opt = ooptim.ClipAdam(a.lr, a.max_grad_norm, a.beta1, a.beta2, 1e-9, a.l2_lambda, a.decay_method, a.warmup_steps)
     pad = {'word_embeddings.weight': g.V - 1, 'seg_embeddings.weight': 3,
-           'review_encoder.review_embeddings.weight': g.RC - 1}
+           'review_encoder.review_embeddings.weight': g.RC - 1,
+           'user_emb.weight': -1, 'product_emb.weight': -1}          # padding_idx rows: no gradient
     for step in range(g.steps):
         loss, _, _ = _fwd(g, P, step)
         assert rel_err(loss, g.tensor('loss_%d' % step)) < 1e-5
