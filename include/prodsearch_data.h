@@ -82,6 +82,93 @@ int ps_collect_train_samples(const int64_t* rw_ptr, int64_t* rw_words, int64_t n
                              const double* sub_rate, int64_t vocab_size, int32_t W, int64_t word_pad, void* rng,
                              int64_t* out_words, int64_t* out_review, int64_t cap, int64_t* out_n);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Review-transformer (RTM) batch builder: replaces the Python collate of
+ *   ProdSearchDataLoader.prepare_train_batch / get_train_batch   data/prod_search_dataloader.py:196-262, :275-358
+ *   ProdSearchDataLoader.get_test_batch                           data/prod_search_dataloader.py:44-109
+ *   get_user_review_idxs / get_item_review_idxs                   data/prod_search_dataloader.py:135-194
+ *   ProdSearchDataset.bisect_right, slide_padded_matrices_for_pv  data/prod_search_dataset.py:103-158
+ * Sequences of REVIEW ids: [query | the user's previous reviews | the item's previous reviews], with the segment,
+ * user and item id of every position.  `random.choice` / `random.sample` are drawn from the PsRng above; the
+ * paragraph-vector branch also consumes numpy's legacy global generator (np.random.shuffle / permutation / random:
+ * numpy/random/mtrand.pyx + distributions.c random_interval, MT19937 — third-party, pinned to numpy 2.2), whose raw
+ * state the caller round-trips through ps_rng_get_state / ps_rng_set_state. */
+typedef struct PsRtmCorpusView {
+  int64_t n_reviews, n_users, n_products, n_queries;
+  const int64_t* review_u_p;    /* [n_reviews,2] (user, product)                                             */
+  const int64_t* u_seq_ptr;     /* [n_users+1]    CSR of global_data.u_r_seq (all reviews, time order)       */
+  const int64_t* u_seq;
+  const int64_t* i_seq_ptr;     /* [n_products+1] CSR of global_data.i_r_seq                                 */
+  const int64_t* i_seq;
+  const int64_t* ut_seq_ptr;    /* the same two sequences restricted to TRAIN reviews (`x in u_reviews[u]`,   */
+  const int64_t* ut_seq;        /* `x in p_reviews[p]`), order kept — built once by the caller                */
+  const int64_t* it_seq_ptr;
+  const int64_t* it_seq;
+  const int64_t* loc_time;      /* [n_reviews,3] review_loc_time: position in user seq, in item seq, time     */
+  const int64_t* pq_ptr;        /* [n_products+1] CSR of prod_data.product_query_idx (train collate only)     */
+  const int64_t* pq_idx;
+  const int64_t* query_words;   /* [n_queries,Q]                                                              */
+  int32_t Q;
+  int32_t pad_;
+} PsRtmCorpusView;
+
+typedef struct PsRtmCollateArgs {
+  int32_t uprev_review_limit;   /* --uprev_review_limit                                                       */
+  int32_t iprev_review_limit;   /* --iprev_review_limit                                                       */
+  int32_t do_seq;               /* train: --do_seq_review_train; test: --do_seq_review_test and not
+                                   --train_review_only                                                       */
+  int32_t neg_per_pos;          /* columns of neg_sample_products                                             */
+  int64_t user_pad, prod_pad, review_pad;   /* user_size, product_size, review_count-1; the segment pad is 3  */
+} PsRtmCollateArgs;
+
+/* prepare_train_batch + the padding of get_train_batch.  rows = dataset entries (line_id, user, product, review);
+ * neg_products = prod_data.neg_sample_products [n_lines, neg_per_pos].  Entries whose item has no usable review, or
+ * whose negatives all have none, are dropped (:208-209, :243-245) AFTER consuming their random draws.  Outputs are
+ * written COMPACTLY with the batch's own widths, returned in dims = {Bk, Rp, Kk, Rn}:
+ *   query_words [Bk,Q]   pos_ridxs [Bk,Rp]       pos_seg / pos_user / pos_item [Bk,Rp+1]
+ *   kept [Bk] (index into rows)  neg_ridxs [Bk,Kk,Rn]    neg_seg / neg_user / neg_item [Bk,Kk,Rn+1]
+ * Buffers must hold the worst case: B rows, neg_per_pos negatives, uprev+iprev reviews. */
+int ps_rtm_collate_train(const PsRtmCorpusView* corpus, const PsRtmCollateArgs* args, void* rng,
+                         const int64_t* rows /* [B,4] */, int32_t B,
+                         const int64_t* neg_products, int64_t n_lines,
+                         int64_t* out_query_words, int64_t* out_kept,
+                         int64_t* out_pos_ridxs, int64_t* out_pos_seg, int64_t* out_pos_user, int64_t* out_pos_item,
+                         int64_t* out_neg_ridxs, int64_t* out_neg_seg, int64_t* out_neg_user, int64_t* out_neg_item,
+                         int32_t dims[4]);
+
+/* get_test_batch: entries (query, user, product, review) + ragged candidate lists (CSR over the batch).
+ * dims = {C, Rc}: C = longest candidate list, Rc = longest review sequence.  Compact outputs:
+ *   query_words [B,Q]  candi [B,C] (pad -1, :95)  candi_ridxs [B,C,Rc]  candi_seg / candi_user / candi_item [B,C,Rc+1]
+ * Buffers must hold B * C * (uprev+iprev+1) elements. */
+int ps_rtm_collate_test(const PsRtmCorpusView* corpus, const PsRtmCollateArgs* args,
+                        const int64_t* entry_quad /* [B,4] */, int32_t B,
+                        const int64_t* candi_ptr /* [B+1] */, const int64_t* candi_items,
+                        int64_t* out_query_words, int64_t* out_candi,
+                        int64_t* out_ridxs, int64_t* out_seg, int64_t* out_user, int64_t* out_item, int32_t dims[2]);
+
+/* The paragraph-vector branch of get_train_batch (:301-345), for N = Bk*Rp review slots of WL words:
+ *   words [Bk,Rp,WL] (review_words[pos_ridxs], gathered by the caller) is shuffled IN PLACE exactly as
+ *   shuffle_words_in_reviews does it — np.random.shuffle on each [Rp,WL] slice permutes that entry's REVIEW ROWS;
+ *   masks [Bk,Rp,WL] = (word != word_pad) [& np.random.random < sub_rate[word] when sub_rate != NULL], taken BEFORE the
+ *   shuffle (:289-291), so they stay in the unshuffled order like the reference's;
+ *   both are cut into windows of W words (right-padded to a multiple of W), giving seg = ceil(WL/W) sub-batches whose
+ *   rows are mixed by np.random.permutation(Bk*seg) when `permute` (the DataLoader's shuffle flag).
+ * Outputs: slide_words / slide_masks [seg,Bk,Rp,W], batch_index [seg,Bk] (row of the collated batch each sub-batch
+ * row comes from).  np_rng holds numpy's global MT19937 state (ps_rng_set_state) and is advanced. */
+int ps_rtm_pv_windows(void* np_rng, int64_t* words, uint8_t* masks, int32_t Bk, int32_t Rp, int32_t WL, int32_t W,
+                      int64_t word_pad, const double* sub_rate, int64_t vocab_size, int32_t shuffle_rows, int32_t permute,
+                      int64_t* slide_words, uint8_t* slide_masks, int64_t* batch_index);
+
+/* get_pv_word_masks of the non-PV branch (:347-349) when sub_rate != NULL: masks = (word != pad) & (rand < rate[word]) */
+int ps_rtm_word_masks(void* np_rng, const int64_t* words, int64_t n, int64_t word_pad, const double* sub_rate,
+                      int64_t vocab_size, uint8_t* masks);
+
+/* Raw MT19937 state (624 words + position) — `random.getstate()[1]` / `np.random.get_state()[1:3]` layout. */
+void ps_rng_get_state(void* rng, uint32_t key[624], int32_t* pos);
+void ps_rng_set_state(void* rng, const uint32_t key[624], int32_t pos);
+/* numpy legacy draws (test hooks): random_interval(max) and random_sample() */
+uint64_t ps_rng_np_interval(void* rng, uint64_t max);
+
 const char* ps_data_last_error(void);
 
 #ifdef __cplusplus

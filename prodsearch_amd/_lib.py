@@ -170,8 +170,31 @@ class PsCollateArgs(C.Structure):
                 ('prod_pad', C.c_int64)]
 
 
+class PsRtmCorpusView(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('n_reviews', 'n_users', 'n_products', 'n_queries')] + \
+               [(n, C.c_void_p) for n in ('review_u_p', 'u_seq_ptr', 'u_seq', 'i_seq_ptr', 'i_seq', 'ut_seq_ptr', 'ut_seq',
+                                          'it_seq_ptr', 'it_seq', 'loc_time', 'pq_ptr', 'pq_idx', 'query_words')] + \
+               [('Q', C.c_int32), ('pad_', C.c_int32)]
+
+
+class PsRtmCollateArgs(C.Structure):
+    _fields_ = [('uprev_review_limit', C.c_int32), ('iprev_review_limit', C.c_int32), ('do_seq', C.c_int32),
+                ('neg_per_pos', C.c_int32), ('user_pad', C.c_int64), ('prod_pad', C.c_int64), ('review_pad', C.c_int64)]
+
+
 # include/prodsearch_data.h (host-only library)
 DATA_SYMBOLS = {
+    'ps_rtm_collate_train': (C.c_int, [C.POINTER(PsRtmCorpusView), C.POINTER(PsRtmCollateArgs), C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_void_p, C.c_int64] + [C.c_void_p] * 11),
+    'ps_rtm_collate_test': (C.c_int, [C.POINTER(PsRtmCorpusView), C.POINTER(PsRtmCollateArgs), C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p] + [C.c_void_p] * 7),
+    'ps_rtm_pv_windows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    'ps_rtm_word_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_rng_get_state': (None, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    'ps_rng_set_state': (None, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'ps_rng_np_interval': (C.c_uint64, [C.c_void_p, C.c_uint64]),
     'ps_rng_create': (C.c_void_p, [C.c_uint64]),
     'ps_rng_destroy': (None, [C.c_void_p]),
     'ps_rng_seed': (None, [C.c_void_p, C.c_uint64]),

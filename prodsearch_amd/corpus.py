@@ -160,11 +160,47 @@ class ProdSearchData(object):
         return wf / wf.sum()
 
     def initialize_epoch(self):
-        if self.args.model_name != 'item_transformer':
-            raise NotImplementedError("initialize_epoch: only the TEM pipeline is built (SURVEY.md §8f)")
+        """data_util.py:92-117.  TEM: nothing.  RTM: the epoch's negative products and, unless ``do_subsample_mask``,
+        the sub-sampled review texts cut/padded to ``review_word_limit`` (``global_data.padded_review_words``, here a
+        ``[review_count, limit]`` int64 array).  The reference never advances ``entry_id`` in its filter loop
+        (:104-112), so EVERY word is tested against the first of the ``sum(review_length)`` numbers it draws — kept
+        as is, it decides what the reference trains on."""
+        if self.args.model_name == 'item_transformer':
+            return
+        self.neg_sample_products = np.random.choice(self.product_size, size=(self.set_review_size, self.neg_per_pos),
+                                                    replace=True, p=self.product_dists)
+        if self.args.do_subsample_mask:
+            return
+        gd = self.global_data
+        rand_numbers = np.random.random(sum(gd.review_length))
+        ptr, flat = _rtm_review_csr(gd)
+        keep = ~(rand_numbers[0] > np.asarray(self.sub_sampling_rate)[flat])
+        n_rev, limit, pad = len(ptr) - 1, int(self.args.review_word_limit), gd.word_pad_idx
+        out = np.full((n_rev + 1, limit), pad, dtype=np.int64)
+        rid = np.repeat(np.arange(n_rev), np.diff(ptr))[keep]
+        kept = np.bincount(rid, minlength=n_rev)
+        start = np.concatenate([[0], np.cumsum(kept)[:-1]])
+        col = np.arange(rid.size) - start[rid]
+        m = col < limit
+        out[rid[m], col[m]] = flat[keep][m]
+        gd.set_padded_review_words(out)
+
+
+def _rtm_review_csr(global_data):
+    """CSR of the review texts without the appended pad review (review_transformer corpus, un-padded lists)."""
+    csr = getattr(global_data, '_rtm_csr', None)
+    if csr is None:
+        rw = global_data.review_words[:len(global_data.review_length)]
+        ptr = np.zeros(len(rw) + 1, dtype=np.int64)
+        ptr[1:] = np.cumsum([len(x) for x in rw])
+        flat = np.fromiter((w for x in rw for w in x), dtype=np.int64, count=int(ptr[-1]))
+        csr = global_data._rtm_csr = (ptr, flat)
+    return csr
 
 
 class ItemPVDataset(object):
+    _always_materialize = False
+
     def __init__(self, args, global_data, prod_data):
         self.args = args
         self.valid_candi_size = args.valid_candi_size
@@ -223,7 +259,7 @@ class ItemPVDataset(object):
                 if (user_idx, query_idx) in seen:
                     continue
                 seen.add((user_idx, query_idx))
-                if full and not getattr(self.args, 'materialize_candidates', False):
+                if full and not (self._always_materialize or getattr(self.args, 'materialize_candidates', False)):
                     out.append([query_idx, user_idx, prod_idx, review_idx, None])
                     continue
                 if prod_data.uq_pids is None:
@@ -263,3 +299,33 @@ class _TrainSamples(object):
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
+
+
+class ProdSearchDataset(ItemPVDataset):
+    """``data/prod_search_dataset.py:ProdSearchDataset``: train entries are ``prod_data.review_info`` rows
+    ``(line, user, product, review)`` (:86-89); evaluation entries are the (user, query) pairs with their candidate
+    chunks (:43-83, the same walk as the TEM dataset — always materialised: every candidate is its own sequence)."""
+    _always_materialize = True
+
+    def __init__(self, args, global_data, prod_data):
+        self.args = args
+        self.valid_candi_size = args.valid_candi_size
+        self.user_pad_idx = global_data.user_size
+        self.prod_pad_idx = global_data.product_size
+        self.word_pad_idx = global_data.vocab_size - 1
+        self.review_pad_idx = global_data.review_count - 1
+        self.seg_pad_idx = 3
+        self.shuffle_review_words = args.shuffle_review_words
+        self.review_encoder_name = args.review_encoder_name
+        self.pv_window_size = args.pv_window_size
+        self.corrupt_rate = args.corrupt_rate
+        self.train_review_only = args.train_review_only
+        self.uprev_review_limit = args.uprev_review_limit
+        self.iprev_review_limit = args.iprev_review_limit
+        self.total_review_limit = self.uprev_review_limit + self.iprev_review_limit
+        self.global_data = global_data
+        self.prod_data = prod_data
+        if prod_data.set_name == 'train':
+            self._data = prod_data.review_info
+        else:
+            self._data = self.collect_test_samples(global_data, prod_data, args.candi_batch_size)

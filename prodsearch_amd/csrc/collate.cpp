@@ -276,3 +276,310 @@ extern "C" int ps_collect_train_samples(const int64_t* rw_ptr, int64_t* rw_words
   *out_n = n_out;
   return 0;
 }
+
+// ============================================================================= review-transformer batches
+// numpy's legacy draws on the same MT19937 (numpy/random/src/distributions/distributions.c: random_interval;
+// src/mt19937/mt19937.h: mt19937_next_double) — the caller loads np.random's state with ps_rng_set_state.
+static uint64_t np_interval(PsRng* g, uint64_t max) {
+  if (max == 0) return 0;
+  uint64_t mask = max, value;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+  if (max <= 0xffffffffull) {
+    while ((value = ((uint64_t)g->next() & mask)) > max) {}
+  } else {
+    while ((value = ((((uint64_t)g->next() << 32) | g->next()) & mask)) > max) {}
+  }
+  return value;
+}
+static inline double np_double(PsRng* g) {
+  const uint32_t a = g->next() >> 5, b = g->next() >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+extern "C" uint64_t ps_rng_np_interval(void* rng, uint64_t max) { return np_interval((PsRng*)rng, max); }
+extern "C" void ps_rng_get_state(void* rng, uint32_t key[624], int32_t* pos) {
+  PsRng* g = (PsRng*)rng;
+  memcpy(key, g->mt, sizeof(g->mt));
+  *pos = g->idx;
+}
+extern "C" void ps_rng_set_state(void* rng, const uint32_t key[624], int32_t pos) {
+  PsRng* g = (PsRng*)rng;
+  memcpy(g->mt, key, sizeof(g->mt));
+  g->idx = pos < 0 ? 0 : (pos > 624 ? 624 : pos);
+}
+
+static int check_rtm(const PsRtmCorpusView* c, const PsRtmCollateArgs* a) {
+  if (!c || !a) return fail("rtm collate: null corpus/args");
+  if (!c->review_u_p || !c->u_seq_ptr || !c->u_seq || !c->i_seq_ptr || !c->i_seq || !c->query_words)
+    return fail("rtm collate: corpus array missing");
+  if (a->do_seq ? !c->loc_time : (!c->ut_seq_ptr || !c->ut_seq || !c->it_seq_ptr || !c->it_seq))
+    return fail("rtm collate: %s missing", a->do_seq ? "review_loc_time" : "train-review sequences");
+  if (a->uprev_review_limit < 1 || a->iprev_review_limit < 1) return fail("rtm collate: review limits must be >= 1");
+  if (c->Q < 1) return fail("rtm collate: Q < 1");
+  return 0;
+}
+
+// get_user_review_idxs / get_item_review_idxs (prod_search_dataloader.py:135-194).  do_seq: the `limit` reviews before
+// position `loc` of the full sequence; else the TRAIN reviews of the owner other than `review`, cut to `limit` by the
+// last ones (fix) or by random.sample with the sequence order kept.
+static void prev_reviews(const int64_t* fptr, const int64_t* fseq, const int64_t* tptr, const int64_t* tseq, int64_t id,
+                         int64_t review, bool do_seq, int64_t loc, int limit, bool fix, PsRng* rng,
+                         std::vector<int64_t>& out, std::vector<int>& pos) {
+  out.clear();
+  if (do_seq) {
+    const int64_t beg = fptr[id], n = fptr[id + 1] - beg;
+    if (loc > n) loc = n;                                         // a Python slice clamps
+    if (loc <= 0) return;
+    for (int64_t i = loc > limit ? loc - limit : 0; i < loc; ++i) out.push_back(fseq[beg + i]);      // [:loc][-limit:]
+    return;
+  }
+  for (int64_t i = tptr[id]; i < tptr[id + 1]; ++i)
+    if (tseq[i] != review) out.push_back(tseq[i]);
+  const int n = (int)out.size();
+  if (n <= limit) return;
+  if (fix) { out.erase(out.begin(), out.end() - limit); return; }
+  py_sample_positions(rng, n, limit, pos);
+  static thread_local std::vector<uint8_t> keep;
+  keep.assign(n, 0);
+  for (int p : pos) keep[p] = 1;
+  int w = 0;
+  for (int i = 0; i < n; ++i) if (keep[i]) out[w++] = out[i];
+  out.resize(w);
+}
+
+// ProdSearchDataset.bisect_right (prod_search_dataset.py:133-151) on the time column
+static int64_t bisect_time(const PsRtmCorpusView* c, int64_t prod, int64_t ts) {
+  const int64_t* arr = c->i_seq + c->i_seq_ptr[prod];
+  int64_t lo = 0, hi = c->i_seq_ptr[prod + 1] - c->i_seq_ptr[prod];
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) / 2;
+    if (ts < c->loc_time[3 * arr[mid] + 2]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+struct RtmSeq { size_t off; int nu, ni; int64_t user, item; };     // [user's reviews | item's reviews] in `flat`
+
+// one padded row of the four per-position tensors (:212-219, :232-239)
+static void write_seq(const PsRtmCorpusView* c, const PsRtmCollateArgs* a, const std::vector<int64_t>& flat,
+                      const RtmSeq* s, int R, int64_t* ridx, int64_t* seg, int64_t* usr, int64_t* itm) {
+  const int nu = s ? s->nu : 0, ni = s ? s->ni : 0;
+  seg[0] = s ? 0 : 3; usr[0] = a->user_pad; itm[0] = a->prod_pad;
+  for (int r = 0; r < R; ++r) {
+    if (r < nu + ni) {
+      const int64_t x = flat[s->off + r];
+      ridx[r] = x;
+      seg[r + 1] = r < nu ? 1 : 2;
+      usr[r + 1] = r < nu ? s->user : c->review_u_p[2 * x];
+      itm[r + 1] = r < nu ? c->review_u_p[2 * x + 1] : s->item;
+    } else {
+      ridx[r] = a->review_pad; seg[r + 1] = 3; usr[r + 1] = a->user_pad; itm[r + 1] = a->prod_pad;
+    }
+  }
+}
+
+static int check_reviews(const PsRtmCorpusView* c, const std::vector<int64_t>& v) {
+  for (int64_t x : v) if (x < 0 || x >= c->n_reviews) return 1;
+  return 0;
+}
+
+extern "C" int ps_rtm_collate_train(const PsRtmCorpusView* c, const PsRtmCollateArgs* a, void* rng_,
+                                    const int64_t* rows, int32_t B, const int64_t* neg_products, int64_t n_lines,
+                                    int64_t* out_qw, int64_t* out_kept, int64_t* out_pos_ridxs, int64_t* out_pos_seg,
+                                    int64_t* out_pos_user, int64_t* out_pos_item, int64_t* out_neg_ridxs,
+                                    int64_t* out_neg_seg, int64_t* out_neg_user, int64_t* out_neg_item, int32_t dims[4]) {
+  if (check_rtm(c, a)) return 1;
+  PsRng* rng = (PsRng*)rng_;
+  if (!rng || !c->pq_ptr || !c->pq_idx) return fail("rtm collate_train: rng / product-query CSR missing");
+  if (!rows || B < 1 || !neg_products || a->neg_per_pos < 1) return fail("rtm collate_train: bad arguments");
+  if (!out_qw || !out_kept || !out_pos_ridxs || !out_pos_seg || !out_pos_user || !out_pos_item || !out_neg_ridxs ||
+      !out_neg_seg || !out_neg_user || !out_neg_item || !dims)
+    return fail("rtm collate_train: null output");
+  static thread_local std::vector<int64_t> flat, up, ip, np_;
+  static thread_local std::vector<RtmSeq> posq, negq;
+  static thread_local std::vector<int> negcnt, pos;
+  static thread_local std::vector<int64_t> qsel;
+  flat.clear(); posq.clear(); negq.clear(); negcnt.clear(); qsel.clear();
+  const int K = a->neg_per_pos, Q = c->Q;
+  const bool seq = a->do_seq != 0;
+  int Bk = 0, Rp = 0, Kk = 0, Rn = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t line = rows[4 * b], user = rows[4 * b + 1], prod = rows[4 * b + 2], review = rows[4 * b + 3];
+    if (line < 0 || line >= n_lines || user < 0 || user >= c->n_users || prod < 0 || prod >= c->n_products ||
+        review < 0 || review >= c->n_reviews)
+      return fail("rtm collate_train: row %d out of range", b);
+    const int64_t nq = c->pq_ptr[prod + 1] - c->pq_ptr[prod];
+    if (nq < 1) return fail("rtm collate_train: product %lld has no query", (long long)prod);
+    const int64_t q = c->pq_idx[c->pq_ptr[prod] + rng->randbelow((uint32_t)nq)];             // random.choice (:201)
+    if (q < 0 || q >= c->n_queries) return fail("rtm collate_train: query id %lld out of range", (long long)q);
+    prev_reviews(c->u_seq_ptr, c->u_seq, c->ut_seq_ptr, c->ut_seq, user, review, seq,
+                 seq ? c->loc_time[3 * review] : 0, a->uprev_review_limit, false, rng, up, pos);          // :203
+    prev_reviews(c->i_seq_ptr, c->i_seq, c->it_seq_ptr, c->it_seq, prod, review, seq,
+                 seq ? c->loc_time[3 * review + 1] : 0, a->iprev_review_limit, false, rng, ip, pos);      // :204
+    if (ip.empty()) continue;                                                                 // :208-209
+    if (check_reviews(c, up) || check_reviews(c, ip)) return fail("rtm collate_train: corrupt review sequence");
+    const int64_t ts = seq ? c->loc_time[3 * review + 2] : 0;
+    const size_t flat0 = flat.size(), neg0 = negq.size();
+    RtmSeq ps = {flat.size(), (int)up.size(), (int)ip.size(), user, prod};
+    flat.insert(flat.end(), up.begin(), up.end());
+    flat.insert(flat.end(), ip.begin(), ip.end());
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {                                                             // :226-242
+      const int64_t neg = neg_products[line * K + k];
+      if (neg < 0 || neg >= c->n_products) return fail("rtm collate_train: negative product %lld out of range", (long long)neg);
+      prev_reviews(c->i_seq_ptr, c->i_seq, c->it_seq_ptr, c->it_seq, neg, -1, seq, seq ? bisect_time(c, neg, ts) : 0,
+                   a->iprev_review_limit, false, rng, np_, pos);
+      if (np_.empty()) continue;
+      if (check_reviews(c, np_)) return fail("rtm collate_train: corrupt review sequence");
+      RtmSeq ns = {flat.size(), (int)up.size(), (int)np_.size(), user, neg};
+      flat.insert(flat.end(), up.begin(), up.end());
+      flat.insert(flat.end(), np_.begin(), np_.end());
+      negq.push_back(ns);
+      if (ns.nu + ns.ni > Rn) Rn = ns.nu + ns.ni;
+      ++cnt;
+    }
+    if (cnt == 0) { flat.resize(flat0); negq.resize(neg0); continue; }                        // :243-245
+    posq.push_back(ps);
+    negcnt.push_back(cnt);
+    qsel.push_back(q);
+    out_kept[Bk++] = b;
+    if (ps.nu + ps.ni > Rp) Rp = ps.nu + ps.ni;
+    if (cnt > Kk) Kk = cnt;
+  }
+  dims[0] = Bk; dims[1] = Rp; dims[2] = Kk; dims[3] = Rn;
+  size_t nq_ = 0;
+  for (int b = 0; b < Bk; ++b) {
+    memcpy(out_qw + (size_t)b * Q, c->query_words + (size_t)qsel[b] * Q, sizeof(int64_t) * Q);
+    write_seq(c, a, flat, &posq[b], Rp, out_pos_ridxs + (size_t)b * Rp, out_pos_seg + (size_t)b * (Rp + 1),
+              out_pos_user + (size_t)b * (Rp + 1), out_pos_item + (size_t)b * (Rp + 1));
+    for (int k = 0; k < Kk; ++k) {
+      const size_t row = (size_t)b * Kk + k;
+      write_seq(c, a, flat, k < negcnt[b] ? &negq[nq_ + k] : nullptr, Rn, out_neg_ridxs + row * Rn,
+                out_neg_seg + row * (Rn + 1), out_neg_user + row * (Rn + 1), out_neg_item + row * (Rn + 1));
+    }
+    nq_ += negcnt[b];
+  }
+  return 0;
+}
+
+extern "C" int ps_rtm_collate_test(const PsRtmCorpusView* c, const PsRtmCollateArgs* a, const int64_t* quad, int32_t B,
+                                   const int64_t* candi_ptr, const int64_t* candi_items, int64_t* out_qw,
+                                   int64_t* out_candi, int64_t* out_ridxs, int64_t* out_seg, int64_t* out_user,
+                                   int64_t* out_item, int32_t dims[2]) {
+  if (check_rtm(c, a)) return 1;
+  if (!quad || B < 1 || !candi_ptr || !candi_items) return fail("rtm collate_test: bad arguments");
+  if (!out_qw || !out_candi || !out_ridxs || !out_seg || !out_user || !out_item || !dims)
+    return fail("rtm collate_test: null output");
+  static thread_local std::vector<int64_t> flat, up, ip;
+  static thread_local std::vector<RtmSeq> seqs;
+  static thread_local std::vector<int> pos;
+  flat.clear(); seqs.clear();
+  const bool seq = a->do_seq != 0;
+  const int Q = c->Q;
+  int C = 0, Rc = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t q = quad[4 * b], user = quad[4 * b + 1], review = quad[4 * b + 3];
+    if (q < 0 || q >= c->n_queries || user < 0 || user >= c->n_users || review < 0 || review >= c->n_reviews)
+      return fail("rtm collate_test: entry %d out of range", b);
+    const int64_t n = candi_ptr[b + 1] - candi_ptr[b];
+    if (n < 0) return fail("rtm collate_test: candidate CSR not monotone");
+    if (n > C) C = (int)n;
+    prev_reviews(c->u_seq_ptr, c->u_seq, c->ut_seq_ptr, c->ut_seq, user, review, seq,
+                 seq ? c->loc_time[3 * review] : 0, a->uprev_review_limit, true, nullptr, up, pos);       // fix=True (:64)
+    if (check_reviews(c, up)) return fail("rtm collate_test: corrupt review sequence");
+    const int64_t ts = seq ? c->loc_time[3 * review + 2] : 0;
+    for (int64_t i = candi_ptr[b]; i < candi_ptr[b + 1]; ++i) {                               // :73-92
+      const int64_t cand = candi_items[i];
+      if (cand < 0 || cand >= c->n_products) return fail("rtm collate_test: candidate %lld out of range", (long long)cand);
+      prev_reviews(c->i_seq_ptr, c->i_seq, c->it_seq_ptr, c->it_seq, cand, -1, seq, seq ? bisect_time(c, cand, ts) : 0,
+                   a->iprev_review_limit, true, nullptr, ip, pos);
+      if (check_reviews(c, ip)) return fail("rtm collate_test: corrupt review sequence");
+      RtmSeq s = {flat.size(), (int)up.size(), (int)ip.size(), user, cand};
+      flat.insert(flat.end(), up.begin(), up.end());
+      flat.insert(flat.end(), ip.begin(), ip.end());
+      seqs.push_back(s);
+      if (s.nu + s.ni > Rc) Rc = s.nu + s.ni;
+    }
+  }
+  dims[0] = C; dims[1] = Rc;
+  size_t si = 0;
+  for (int b = 0; b < B; ++b) {
+    memcpy(out_qw + (size_t)b * Q, c->query_words + (size_t)quad[4 * b] * Q, sizeof(int64_t) * Q);
+    const int n = (int)(candi_ptr[b + 1] - candi_ptr[b]);
+    for (int k = 0; k < C; ++k) {
+      const size_t row = (size_t)b * C + k;
+      out_candi[row] = k < n ? candi_items[candi_ptr[b] + k] : -1;                            // util.pad(.., -1) (:95)
+      write_seq(c, a, flat, k < n ? &seqs[si + k] : nullptr, Rc, out_ridxs + row * Rc, out_seg + row * (Rc + 1),
+                out_user + row * (Rc + 1), out_item + row * (Rc + 1));
+    }
+    si += n;
+  }
+  return 0;
+}
+
+extern "C" int ps_rtm_word_masks(void* np_rng, const int64_t* words, int64_t n, int64_t word_pad, const double* sub_rate,
+                                 int64_t vocab_size, uint8_t* masks) {
+  if (!words || !masks || n < 0) return fail("rtm word_masks: bad arguments");
+  PsRng* g = (PsRng*)np_rng;
+  if (sub_rate && !g) return fail("rtm word_masks: sub-sampling needs the numpy generator state");
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t w = words[i];
+    if (sub_rate) {
+      if (w < 0 || w >= vocab_size) return fail("rtm word_masks: word id %lld out of range", (long long)w);
+      const double r = np_double(g);                              // np.random.random(shape), C order (:91)
+      masks[i] = (w != word_pad) && (r < sub_rate[w]);
+    } else {
+      masks[i] = w != word_pad;
+    }
+  }
+  return 0;
+}
+
+extern "C" int ps_rtm_pv_windows(void* np_rng, int64_t* words, uint8_t* masks, int32_t Bk, int32_t Rp, int32_t WL,
+                                 int32_t W, int64_t word_pad, const double* sub_rate, int64_t vocab_size,
+                                 int32_t shuffle_rows, int32_t permute, int64_t* slide_words, uint8_t* slide_masks,
+                                 int64_t* batch_index) {
+  PsRng* g = (PsRng*)np_rng;
+  if (!words || !masks || !slide_words || !slide_masks || !batch_index || Bk < 1 || Rp < 0 || WL < 1 || W < 1)
+    return fail("rtm pv_windows: bad arguments");
+  if ((sub_rate || shuffle_rows || permute) && !g) return fail("rtm pv_windows: the numpy generator state is required");
+  const size_t row = (size_t)Rp * WL;
+  if (ps_rtm_word_masks(np_rng, words, (int64_t)Bk * row, word_pad, sub_rate, vocab_size, masks)) return 1;   // :289-291
+  if (shuffle_rows && Rp > 1) {                                   // shuffle_words_in_reviews (:307-308): np.random.shuffle of
+    std::vector<int64_t> buf(WL);                                 // a [Rp,WL] slice swaps whole review rows
+    for (int b = 0; b < Bk; ++b) {
+      int64_t* x = words + (size_t)b * row;
+      for (int i = Rp - 1; i >= 1; --i) {
+        const int j = (int)np_interval(g, (uint64_t)i);
+        if (i == j) continue;
+        memcpy(buf.data(), x + (size_t)j * WL, sizeof(int64_t) * WL);
+        memcpy(x + (size_t)j * WL, x + (size_t)i * WL, sizeof(int64_t) * WL);
+        memcpy(x + (size_t)i * WL, buf.data(), sizeof(int64_t) * WL);
+      }
+    }
+  }
+  const int seg = (WL + W - 1) / W;                               // slide_padded_matrices_for_pv (:121-131)
+  const int64_t n = (int64_t)seg * Bk;
+  std::vector<int64_t> perm((size_t)n);
+  for (int64_t i = 0; i < n; ++i) perm[i] = i;
+  if (permute)                                                    // np.random.permutation(n) = shuffle(arange(n)) (:325)
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const int64_t j = (int64_t)np_interval(g, (uint64_t)i);
+      const int64_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t s = perm[i] / Bk, b = perm[i] % Bk;
+    batch_index[i] = b;
+    for (int r = 0; r < Rp; ++r) {
+      const int64_t* wsrc = words + ((size_t)b * Rp + r) * WL;
+      const uint8_t* msrc = masks + ((size_t)b * Rp + r) * WL;
+      int64_t* wd = slide_words + ((size_t)i * Rp + r) * W;
+      uint8_t* md = slide_masks + ((size_t)i * Rp + r) * W;
+      for (int w = 0; w < W; ++w) {
+        const int64_t col = s * W + w;
+        wd[w] = col < WL ? wsrc[col] : word_pad;
+        md[w] = col < WL ? msrc[col] : 0;
+      }
+    }
+  }
+  return 0;
+}

@@ -27,6 +27,23 @@ def _csr(lists):
     return ptr, flat
 
 
+def sampler_batches(n, batch_size, shuffle, drop_last=False):
+    """Row ids per batch, in the order ``DataLoader(shuffle=..., num_workers=0)`` visits them: a DataLoader
+    iterator draws its base seed first, then RandomSampler seeds a private generator from the default one and
+    takes ONE ``torch.randperm`` (torch/utils/data/sampler.py) — reproduced here without the per-index Python
+    generator chain."""
+    torch.empty((), dtype=torch.int64).random_()
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        order = torch.randperm(n, generator=g).numpy()
+    else:
+        order = np.arange(n, dtype=np.int64)
+    stop = n - n % batch_size if drop_last else n
+    for i in range(0, stop, batch_size):
+        yield order[i:i + batch_size]
+
+
 class Corpus(object):
     """Flat-array view of ``global_data`` / ``prod_data`` (host memory, borrowed by the C calls)."""
 
@@ -234,21 +251,7 @@ class ItemPVDataloader(object):
         return self.test_batch_from_ids([self._index_of[id(e)] for e in batch])
 
     def _batch_ids(self):
-        """Row ids per batch, in the order ``DataLoader(shuffle=..., num_workers=0)`` visits them: a DataLoader
-        iterator draws its base seed first, then RandomSampler seeds a private generator from the default one and
-        takes ONE ``torch.randperm`` (torch/utils/data/sampler.py) — reproduced here without the per-index Python
-        generator chain."""
-        n, B = len(self.dataset), self.batch_size
-        torch.empty((), dtype=torch.int64).random_()
-        if self.shuffle:
-            g = torch.Generator()
-            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
-            order = torch.randperm(n, generator=g).numpy()
-        else:
-            order = np.arange(n, dtype=np.int64)
-        stop = n - n % B if self.drop_last else n
-        for i in range(0, stop, B):
-            yield order[i:i + B]
+        return sampler_batches(len(self.dataset), self.batch_size, self.shuffle, self.drop_last)
 
     def _batches(self):
         for ids in self._batch_ids():

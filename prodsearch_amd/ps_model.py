@@ -11,10 +11,12 @@ Mirrors the reference's ``nn.Module`` contract (``models/ps_model.py:53-370``; c
 
 Same ``state_dict`` keys as the reference (incl. the aliases ``review_encoder.word_embeddings.weight``
 and, for pvc, ``review_encoder.context_embeddings.weight``).  Supported review encoders: ``pv`` and
-``pvc`` (the reference default); ``fs`` / ``avg`` review encoders, user/item embeddings and
-``fix_emb`` are outside the built path and raise ``NotImplementedError``.  All numerics run in
+``pvc`` (the reference default), with or without the per-position user / item embeddings
+(``use_user_emb`` / ``use_item_emb``); ``fs`` / ``avg`` review encoders and ``fix_emb`` are outside
+the built path and raise ``NotImplementedError``.  All numerics run in
 ``libprodsearch_hip.so`` (``ps_rtm_*`` entry points); the torch modules are parameter holders.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -67,7 +69,13 @@ class ProductRanker(nn.Module):
         self.seg_pad_idx = 3
         self.review_pad_idx = review_count - 1
         self.review_encoder_name = args.review_encoder_name
-        rw = torch.as_tensor(review_words, dtype=torch.int64)
+        if not torch.is_tensor(review_words) and not getattr(args, 'do_subsample_mask', False) and \
+                len({len(x) for x in review_words}) > 1:
+            # ps_model.py:75-78: ragged review texts are cut / padded to review_word_limit (others/util.py:pad)
+            lim = int(args.review_word_limit)
+            review_words = [list(x[:lim]) + [self.word_pad_idx] * (lim - len(x)) for x in review_words]
+        rw = torch.as_tensor(np.asarray(review_words), dtype=torch.int64) if not torch.is_tensor(review_words) \
+            else review_words.to(torch.int64)
         if rw.dim() != 2:
             raise ValueError("review_words must be a padded [review_count, review_word_limit] table "
                              "(the reference pads it with others/util.py:pad)")
@@ -315,15 +323,47 @@ class ProductRanker(nn.Module):
                                            plan['neg_words'].data_ptr(), self._stream()), 'ps_sample_negatives')
         return plan['neg_words']
 
+    _POS_SEQ = (('pos_prod_ridxs', 1, 'review'), ('pos_seg_idxs', 1, 'seg'), ('pos_user_idxs', 1, 'user'),
+                ('pos_item_idxs', 1, 'item'), ('pos_prod_rword_idxs', 1, 'word3'), ('pos_prod_rword_masks', 1, 'mask3'),
+                ('pos_prod_rword_idxs_pvc', 1, 'word3'))
+    _NEG_SEQ = (('neg_prod_ridxs', 2, 'review'), ('neg_seg_idxs', 2, 'seg'), ('neg_user_idxs', 2, 'user'),
+                ('neg_item_idxs', 2, 'item'), ('neg_prod_rword_idxs', 2, 'word3'), ('neg_prod_rword_masks', 2, 'mask3'),
+                ('neg_prod_rword_idxs_pvc', 2, 'word3'))
+
+    def _same_width(self, batch):
+        """The reference pads the positive and the negative sequences of a batch separately (prod_search_dataloader.py:
+        283-300), so their review counts can differ; the kernels run every sequence of a step at one width.  The
+        shorter side is padded here with the pad ids — masked positions, no effect on the loss or any gradient."""
+        rp, rn = batch.pos_prod_ridxs.shape[1], batch.neg_prod_ridxs.shape[2]
+        if rp == rn:
+            return batch
+        pads = dict(review=self.review_pad_idx, seg=self.seg_pad_idx, user=self.user_pad_idx, item=self.prod_pad_idx,
+                    word3=self.word_pad_idx, mask3=0)
+        grow, by = (self._POS_SEQ, rn - rp) if rp < rn else (self._NEG_SEQ, rp - rn)
+
+        class _Padded(object):
+            pass
+        out = _Padded()
+        out.__dict__.update(batch.__dict__)
+        for name, dim, kind in grow:
+            t = getattr(batch, name, None)
+            if t is None:
+                continue
+            spec = [0, 0] * (t.dim() - 1 - dim) + [0, by]      # F.pad lists the last dimension first
+            setattr(out, name, torch.nn.functional.pad(t, spec, value=pads[kind]))
+        return out
+
     def _run_forward(self, batch, train_pv, neg_word_idxs=None):
         lib = _lib.load()
         ps, _ = self._structs()
-        b = batch
+        b = self._same_width(batch)
         qw = self._idx(b.query_word_idxs, 'query_word_idxs')
         pr = self._idx(b.pos_prod_ridxs, 'pos_prod_ridxs')
         nr = self._idx(b.neg_prod_ridxs, 'neg_prod_ridxs')
         B, Q = qw.shape
         R, K = pr.shape[1], nr.shape[1]
+        if tuple(nr.shape) != (B, K, R):
+            raise RuntimeError("neg_prod_ridxs has shape %s, expected %s" % (tuple(nr.shape), (B, K, R)))
         pvc = self.review_encoder_name == 'pvc'
         pw = self._idx(b.pos_prod_rword_idxs, 'pos_prod_rword_idxs')
         W = pw.shape[2] if train_pv else max(1, self.args.pv_window_size)
@@ -346,6 +386,10 @@ class ProductRanker(nn.Module):
                             ('pos_prod_rword_masks', torch.uint8), ('neg_prod_rword_idxs', torch.int64),
                             ('pos_prod_rword_idxs_pvc', torch.int64), ('neg_prod_rword_idxs_pvc', torch.int64)):
             t = self._idx(getattr(b, name, None), name, dtype)
+            lead = {'pos_seg_idxs': (B, R + 1), 'neg_seg_idxs': (B, K, R + 1)}.get(
+                name, (B, K, R) if name.startswith('neg') else (B, R))
+            if t is not None and tuple(t.shape[:len(lead)]) != lead:
+                raise RuntimeError("batch.%s has shape %s, expected %s + word axis" % (name, tuple(t.shape), lead))
             setattr(bt, name, None if t is None else t.data_ptr())
             keep.append(t)
         if train_pv:

@@ -1,4 +1,4 @@
-"""Trainer — the reference's training / validation / test driver for the TEM path.
+"""Trainer — the reference's training / validation / test driver, TEM and review-transformer.
 
 Mirror of ``trainer.py:17-227`` and ``main.py:141-191`` (``create_model``, ``train``) with the same call sequence per
 step — ``loss = model(batch); model.zero_grad(); loss.backward(); optim.step()`` (``trainer.py:74-78``) — the same
@@ -23,16 +23,23 @@ from . import corpus, evaluate, pyrandom
 from .dataloader import ItemPVDataloader
 from .item_transformer import ItemTransformerRanker
 from .optimizers import build_optim
+from .ps_model import ProductRanker
+from .rtm_loader import ProdSearchDataLoader
 
 logger = logging.getLogger('prodsearch_amd')
 
 
 def create_model(args, global_data, prod_data, load_path=''):
-    """``create_model`` (main.py:141-165) for item_transformer / QEM."""
-    if args.model_name not in ('item_transformer', 'QEM'):
-        raise NotImplementedError("trainer: only the TEM / QEM pipeline is built (SURVEY.md §8)")
-    model = ItemTransformerRanker(args, args.device, global_data.vocab_size, global_data.product_size,
-                                  global_data.words, word_dists=prod_data.word_dists)
+    """``create_model`` (main.py:141-165)."""
+    if args.model_name == 'review_transformer':
+        model = ProductRanker(args, args.device, global_data.vocab_size, global_data.review_count,
+                              global_data.product_size, global_data.user_size, global_data.review_words,
+                              global_data.words, word_dists=prod_data.word_dists)
+    elif args.model_name in ('item_transformer', 'QEM'):
+        model = ItemTransformerRanker(args, args.device, global_data.vocab_size, global_data.product_size,
+                                      global_data.words, word_dists=prod_data.word_dists)
+    else:
+        raise NotImplementedError("trainer: model_name %r is not built (SURVEY.md §8)" % args.model_name)
     if load_path and os.path.exists(load_path):
         logger.info('Loading checkpoint from %s', load_path)
         ckpt = torch.load(load_path, map_location='cpu', weights_only=False)
@@ -52,14 +59,17 @@ class Trainer(object):
         self.optim = optim
         if model is not None:
             logger.info('* number of parameters: %d', sum(p.nelement() for p in model.parameters()))
-        self.ExpDataset = corpus.ItemPVDataset
-        self.ExpDataloader = ItemPVDataloader
+        self.rtm = args.model_name == 'review_transformer'       # trainer.py:31-36
+        self.ExpDataset = corpus.ProdSearchDataset if self.rtm else corpus.ItemPVDataset
+        self.ExpDataloader = ProdSearchDataLoader if self.rtm else ItemPVDataloader
 
     # ------------------------------------------------------------------ training (trainer.py:37-110)
     def train(self, args, global_data, train_prod_data, valid_prod_data):
         valid_dataset = self.ExpDataset(args, global_data, valid_prod_data)
         best_mrr, best_path = 0., ''
-        self.model.clear_loss()
+        if not self.rtm:
+            self.model.clear_loss()
+        acc = None                                               # RTM: running loss sum on the device
         step = 0
         t_log = time.time()
         for epoch in range(args.start_epoch + 1, args.max_train_epoch + 1):
@@ -70,18 +80,29 @@ class Trainer(object):
             loader = self.ExpDataloader(args, dataset, prepare_pv=prepare_pv, batch_size=args.batch_size, shuffle=True,
                                         device=args.device, prefetch=getattr(args, 'prefetch', 2))
             for batch in loader:
-                loss = self.model(batch, train_pv=prepare_pv)
-                self.model.zero_grad()
-                loss.backward()
-                self.optim.step()
-                step += 1
-                if step % args.steps_per_checkpoint == 0:        # the only host sync of the loop
-                    n = args.steps_per_checkpoint
-                    ps, iw = self.model.ps_loss / n, self.model.item_loss / n
-                    logger.info("Epoch %d lr = %5.6f loss = %6.2f ps_loss: %3.2f iw_loss: %3.2f time %.2f",
-                                epoch, self.optim.learning_rate, ps + iw, ps, iw, time.time() - t_log)
-                    self.model.clear_loss()
-                    t_log = time.time()
+                if batch is None:                                # no usable entry in this batch (trainer.py:66-67)
+                    continue
+                # the paragraph-vector epochs of the review transformer yield a sequence of window sub-batches (:68-71)
+                for b in (batch if hasattr(batch, '__len__') and not hasattr(batch, 'query_word_idxs') else (batch,)):
+                    loss = self.model(b, train_pv=prepare_pv)
+                    self.model.zero_grad()
+                    loss.backward()
+                    self.optim.step()
+                    step += 1
+                    if self.rtm:
+                        acc = loss.detach().clone() if acc is None else acc.add_(loss.detach())
+                    if step % args.steps_per_checkpoint == 0:    # the only host sync of the loop
+                        n = args.steps_per_checkpoint
+                        if self.rtm:
+                            ps, iw, tot = 0., 0., float(acc) / n
+                            acc = None
+                        else:
+                            ps, iw = self.model.ps_loss / n, self.model.item_loss / n
+                            tot = ps + iw
+                            self.model.clear_loss()
+                        logger.info("Epoch %d lr = %5.6f loss = %6.2f ps_loss: %3.2f iw_loss: %3.2f time %.2f",
+                                    epoch, self.optim.learning_rate, tot, ps, iw, time.time() - t_log)
+                        t_log = time.time()
             path = os.path.join(args.save_dir, 'model_epoch_%d.ckpt' % epoch)
             self._save(epoch, path)
             mrr, prec = self.validate(args, global_data, valid_dataset)
@@ -109,26 +130,32 @@ class Trainer(object):
                 users += list(b.user_idxs); queries += list(b.query_idxs)
         return torch.cat(tops), torch.cat(scores), torch.cat(ranks), users, queries
 
-    def _scores_candidates(self, args, dataset, candidate_size):
-        """Sampled-candidate evaluation as ``get_prod_scores`` does it (trainer.py:189-226), ranks on the device."""
+    def _scores_candidates(self, args, dataset, candidate_size, topk=0):
+        """Candidate-list evaluation as ``get_prod_scores`` does it (trainer.py:189-226), ranks on the device.
+        Returns the rank of the target per (user, query) entry (0 = not among the candidates) and, with ``topk``,
+        the ids / scores of the best ``topk`` candidates plus the entries' user and query ids."""
         loader = self.ExpDataloader(args, dataset, batch_size=args.valid_batch_size, shuffle=False, device=args.device)
         seg = (candidate_size - 1) // args.candi_batch_size + 1
-        sc, ids, tg = [], [], []
+        sc, ids, tg, users, queries = [], [], [], [], []
         self.model.eval()
         with torch.no_grad():
+            if self.rtm:
+                self.model.get_review_embeddings()               # trainer.py:192-193
             for b in loader:
                 s = self.model.test(b)
-                width = args.candi_batch_size
-                pad = width - s.shape[1]
+                cand = torch.as_tensor(b.candi_prod_idxs).to(s.device)
+                pad = args.candi_batch_size - s.shape[1]
                 if pad:                                          # ragged last chunk of this batch
                     s = torch.nn.functional.pad(s, (0, pad), value=float('-inf'))
-                    cand = torch.nn.functional.pad(b.candi_prod_idxs, (0, pad), value=self.model.prod_pad_idx)
-                else:
-                    cand = b.candi_prod_idxs
-                sc.append(s); ids.append(cand); tg.append(b.target_prod_idxs)
+                    cand = torch.nn.functional.pad(cand, (0, pad), value=-1)
+                sc.append(s); ids.append(cand); tg.append(torch.as_tensor(b.target_prod_idxs).to(s.device))
+                users += list(b.user_idxs); queries += list(b.query_idxs)
+            if self.rtm:
+                self.model.clear_review_embbeddings()
         sc = torch.cat(sc).reshape(-1, seg * args.candi_batch_size)[:, :candidate_size]
         ids = torch.cat(ids).reshape(-1, seg * args.candi_batch_size)[:, :candidate_size]
         tg = torch.cat(tg).reshape(-1, seg)[:, 0]
+        sc = sc.masked_fill(ids < 0, float('-inf'))              # padding of ragged candidate lists (util.pad(.., -1))
         hit = ids == tg[:, None]
         found = hit.any(1)
         pos = hit.float().argmax(1)                              # first occurrence, like np.where(...)[0][0] after sorting ties
@@ -136,9 +163,15 @@ class Trainer(object):
         col = torch.arange(sc.shape[1], device=sc.device)[None, :]
         ahead = (sc > st) | ((sc == st) & (col < pos[:, None]))
         rank = torch.where(found, ahead.sum(1) + 1, torch.zeros_like(pos))
-        return rank
+        if not topk:
+            return rank
+        ts, ti = sc.topk(min(topk, sc.shape[1]), dim=1)
+        return rank, ids.gather(1, ti), ts, users[::seg], queries[::seg]
 
     def validate(self, args, global_data, valid_dataset):
+        if self.rtm:
+            size = args.valid_candi_size if args.valid_candi_size >= 1 else global_data.product_size   # trainer.py:127-129
+            return evaluate.calc_metrics(self._scores_candidates(args, valid_dataset, size), 100)
         if args.valid_candi_size < 1 or getattr(valid_dataset.prod_data, 'uq_pids', None) is None and \
                 all(e[4] is None for e in valid_dataset._data[:1]):
             _, _, rank, _, _ = self._scores_all(args, valid_dataset, 100)
@@ -148,13 +181,17 @@ class Trainer(object):
 
     def test(self, args, global_data, test_prod_data, rankfname="test.best_model.ranklist", cutoff=100):
         dataset = self.ExpDataset(args, global_data, test_prod_data)
-        if args.test_candi_size >= 1 and test_prod_data.uq_pids is not None:
+        if self.rtm:
+            size = args.test_candi_size if args.test_candi_size >= 1 else global_data.product_size     # trainer.py:141-143
+            rank, top_idx, top_score, users, queries = self._scores_candidates(args, dataset, size, topk=min(cutoff, size))
+        elif args.test_candi_size >= 1 and test_prod_data.uq_pids is not None:
             rank = self._scores_candidates(args, dataset, args.test_candi_size)
             mrr, prec = evaluate.calc_metrics(rank, cutoff)
             logger.info("Test: MRR:%s P@1:%s", mrr, prec)
             return mrr, prec
-        k = min(cutoff, global_data.product_size, 256)
-        top_idx, top_score, rank, users, queries = self._scores_all(args, dataset, k)
+        else:
+            k = min(cutoff, global_data.product_size, 256)
+            top_idx, top_score, rank, users, queries = self._scores_all(args, dataset, k)
         mrr, prec = evaluate.calc_metrics(rank, cutoff)
         logger.info("Test: MRR:%s P@1:%s", mrr, prec)
         with open(os.path.join(args.save_dir, rankfname), 'w') as f:

@@ -101,3 +101,40 @@ def test_rtm_eval_scores(case):
         s = m.test(g.test_batch().to('cuda')).cpu()
     m.clear_review_embbeddings()
     assert rel_err(s, g.tensor('test_scores')) < LOSS_TOL
+
+
+@pytest.mark.parametrize('case', ['rtm_pvc', 'rtm_pv_ui'])
+def test_rtm_unequal_sequence_widths(case):
+    """The reference's loader pads positives and negatives to their own longest sequence; widening one side with
+    pad positions (as ProductRanker._same_width does for the narrower one) must not move the loss or any gradient."""
+    import torch.nn.functional as F
+    g = RtmGolden(case)
+    m = _model(g)
+    b = g.batch().to('cuda')
+    loss = m(b, train_pv=g.train_pv, neg_word_idxs=_neg(g, 0))
+    m.zero_grad(); loss.backward()
+    torch.cuda.synchronize()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert rel_err(loss.detach().cpu(), g.tensor('loss_0')) < LOSS_TOL
+    pads = dict(neg_prod_ridxs=g.RC - 1, neg_seg_idxs=3, neg_user_idxs=40, neg_item_idxs=50,
+                neg_prod_rword_idxs=g.V - 1, neg_prod_rword_masks=0, neg_prod_rword_idxs_pvc=g.V - 1)
+    for name, val in pads.items():
+        t = getattr(b, name, None)
+        if t is None:
+            continue
+        spec = [0, 0] * (t.dim() - 3) + [0, 2]
+        setattr(b, name, F.pad(t, spec, value=val))
+    assert b.neg_prod_ridxs.shape[2] == b.pos_prod_ridxs.shape[1] + 2
+    if g.train_pv:       # the PV-loss draws are laid out per positive review slot: recompute them at the new width
+        R2 = b.neg_prod_ridxs.shape[2]
+        nw = _neg(g, 0).view(g.B, g.R, -1)
+        nw = F.pad(nw, (0, 0, 0, R2 - g.R), value=0).reshape(g.B * R2, -1)
+    else:
+        nw = None
+    loss2 = m(b, train_pv=g.train_pv, neg_word_idxs=nw)
+    m.zero_grad(); loss2.backward()
+    torch.cuda.synchronize()
+    assert rel_err(loss2.detach().cpu(), loss.detach().cpu()) < 1e-5
+    for n, p in m.named_parameters():
+        if p.grad is not None and not n.endswith('linear_keys.bias'):
+            assert rel_err(p.grad.cpu(), ref[n].cpu()) < 2e-4, n
