@@ -44,6 +44,60 @@ def sampler_batches(n, batch_size, shuffle, drop_last=False):
         yield order[i:i + batch_size]
 
 
+def _device_tensors(obj, depth=0):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif depth < 2:
+        vals = obj.values() if isinstance(obj, dict) else (vars(obj).values() if hasattr(obj, '__dict__') else ())
+        for v in vals:
+            for t in _device_tensors(v, depth + 1):
+                yield t
+
+
+def prefetch_iter(make_batches, depth, device):
+    """Run ``make_batches()`` in ONE producer thread (the RNG order stays the sequential one; the C collate runs
+    without the GIL) on its own HIP stream, ``depth`` batches ahead.  The consumer's stream waits for the batch's
+    copies and every device tensor of the batch is recorded on it, so the caching allocator cannot hand the memory
+    back to the producer while kernels already queued on the consumer's stream still read it."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    dev = torch.cuda.current_device() if (device is not None and torch.cuda.is_available()) else None
+    stream = torch.cuda.Stream() if dev is not None else None
+
+    def work():
+        try:
+            if stream is not None:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(stream):
+                    for b in make_batches():
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        q.put((b, ev))
+            else:
+                for b in make_batches():
+                    q.put((b, None))
+            q.put(None)
+        except BaseException as e:       # surface producer errors in the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is None:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        b, ev = item
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in _device_tensors(b):
+                t.record_stream(cur)
+        yield b
+
+
 class Corpus(object):
     """Flat-array view of ``global_data`` / ``prod_data`` (host memory, borrowed by the C calls)."""
 
@@ -263,37 +317,4 @@ class ItemPVDataloader(object):
         return self._prefetched()
 
     def _prefetched(self):
-        """Single producer thread (the RNG order stays the sequential one); the C collate runs without the GIL."""
-        import queue
-        import threading
-        q = queue.Queue(maxsize=self.prefetch)
-        dev = torch.cuda.current_device() if (self.device is not None and torch.cuda.is_available()) else None
-        stream = torch.cuda.Stream() if dev is not None else None
-
-        def work():
-            try:
-                if stream is not None:
-                    torch.cuda.set_device(dev)
-                    with torch.cuda.stream(stream):
-                        for b in self._batches():
-                            ev = torch.cuda.Event()
-                            ev.record(stream)
-                            q.put((b, ev))
-                else:
-                    for b in self._batches():
-                        q.put((b, None))
-                q.put(None)
-            except BaseException as e:       # surface producer errors in the consumer
-                q.put(e)
-
-        threading.Thread(target=work, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is None:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            b, ev = item
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-            yield b
+        return prefetch_iter(self._batches, self.prefetch, self.device)

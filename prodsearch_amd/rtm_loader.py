@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, pyrandom
-from .dataloader import _csr, sampler_batches
+from .dataloader import _csr, prefetch_iter, sampler_batches
 from .rtm_data import ProdSearchTestBatch, ProdSearchTrainBatch
 
 _np_handle = None
@@ -116,7 +116,7 @@ class _SubBatches(object):
 
 class ProdSearchDataLoader(object):
     def __init__(self, args, dataset, prepare_pv=True, batch_size=1, shuffle=False, drop_last=False, device=None,
-                 pin_memory=True, **_ignored):
+                 pin_memory=True, prefetch=0, **_ignored):
         self.args = args
         self.dataset = dataset
         self.prepare_pv = prepare_pv
@@ -131,6 +131,7 @@ class ProdSearchDataLoader(object):
         self.device = None if device in (None, 'cpu') else torch.device(device)
         self._pin = bool(pin_memory) and self.device is not None and torch.cuda.is_available()
         self._lib = _lib.load_data()
+        self.prefetch = int(prefetch)
         self._train = self.prod_data.set_name == 'train'
         self.corpus = RtmCorpus(self.global_data, self.prod_data)
         if args.do_subsample_mask:                               # :31-36
@@ -281,6 +282,13 @@ class ProdSearchDataLoader(object):
             self._index_of = {id(e): i for i, e in enumerate(self.dataset._data)}
         return self.test_batch_from_ids([self._index_of[id(e)] for e in batch])
 
-    def __iter__(self):
+    def _batches(self):
         for ids in sampler_batches(len(self.dataset), self.batch_size, self.shuffle, self.drop_last):
             yield self.train_batch_from_ids(ids) if self._train else self.test_batch_from_ids(ids)
+
+    def __iter__(self):
+        """``prefetch`` > 0: the batches are built that many ahead by one producer thread on its own stream (the
+        draw order stays sequential).  The paragraph-vector sub-batches are assembled lazily by the consumer."""
+        if self.prefetch <= 0:
+            return self._batches()
+        return prefetch_iter(self._batches, self.prefetch, self.device)
