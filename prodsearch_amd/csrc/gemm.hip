@@ -7,11 +7,14 @@
 // so results are exact fp32 like the reference's mm), tiled for 64-wide waves:
 //
 //   workgroup = 4 waves, tile 64x64 (each wave one 32x32 accumulator = 16 AGPRs);
-//   the reduction advances in 128-deep slabs: the hot path's K is d = 128 (or F = 512),
-//   so a whole projection is ONE global->register->LDS round trip followed by 64
-//   back-to-back MFMAs per wave; the next slab is prefetched into registers while the
-//   current one is multiplied; operands sit in LDS as [k][row+1] so every MFMA operand
-//   fetch is a conflict-free ds_read_b32 per lane, issued 16 steps ahead of its MFMA.
+//   the reduction advances in slabs of 32 (128 for launches of few workgroups: the hot path's K
+//   is d = 128, so a whole projection is then ONE global->register->LDS round trip followed by
+//   64 back-to-back MFMAs per wave); the next slabs are prefetched into registers while the
+//   current one is multiplied — which only holds if nothing touches the loaded registers before
+//   the LDS store (see tile_load: a zero-fill select, a scratch-resident segment table or a load
+//   under a branch each made the compiler drain vmcnt BEFORE the MFMA block; fixing the three
+//   took the step from 0.51 to 0.46 ms); operands sit in LDS as [k][row+1] so every MFMA operand
+//   fetch is a conflict-free ds_read_b32 per lane.
 //
 // One kernel serves forward (A[m][k] . W[n][k]), input-grad (dY[m][n] . W[n][k'])
 // and weight-grad (dY[m][n]^T . X[m][k'], split over the row reduction with fp32
@@ -20,6 +23,12 @@
 // GELU/tanh or their derivatives, Philox dropout, residual direct / gathered from
 // the layer input / fan-in summed over replicas, bias-grad column sums, 2nd output),
 // whose body is a rolled loop over an LDS-staged tile so it exists once in the code.
+//
+// Measured alternatives (MI355X, tools/gemm_bench.py): a 128x128 tile with 2x2 accumulators per wave (half the LDS and
+// L2 bytes per flop) is SLOWER on every hot shape — K is only 128-512 deep, so a workgroup's life is 4-16 slabs and the
+// larger tile just has fewer workgroups to hide its fill/drain behind (78k x 256 x 128: 92 vs 80 us; 78k x 128 x 128:
+// 66 vs 44 us; weight gradients over 78k rows: 65 vs 49 us).  128-deep slabs for every launch cost the review
+// transformer 15 % (one workgroup per CU).
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,64 +40,66 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // TRANS==0: src[row][k] (k contiguous): one instruction = 8 rows x 128 B
 // TRANS==1: src[k][row] (row contiguous): one instruction = 4 k-rows x 256 B
-struct SegTab {              // up to 3 reduction segments of kseg rows each (segment s serves k in [s*kseg, (s+1)*kseg))
-  const float* seg[3];
-  int kseg;
-  bool multi;
-};
 
-// BK = reduction depth of one slab (32 or 128); NLD = float4 loads per thread per operand per slab
+// BK = reduction depth of one slab (32 or 128); NLD = float4 loads per thread per operand per slab.
+// The loaded registers must not be touched before the slab is stored to LDS, or the compiler waits for the loads
+// BEFORE the MFMAs of the current slab and the prefetch overlaps nothing (it did: a v_cndmask zero-fill per load put
+// s_waitcnt vmcnt(0) ahead of the MFMA block).  So rows are clamped instead of masked — rows past the edge are
+// duplicates whose products land in output rows/columns the epilogue never stores — and only a ragged reduction
+// tail (kmask: K not a multiple of the slab, block-uniform) takes the zero-filling path.
 template <int TRANS, int BK>
 __device__ inline void tile_load(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int kend,
-                                 float4 (&reg)[BK / 16], int tid, const SegTab* st = nullptr) {
+                                 float4 (&reg)[BK / 16], int tid, bool kmask, const float* __restrict__ seg1 = nullptr,
+                                 const float* __restrict__ seg2 = nullptr, int kseg = 0) {
   constexpr int NLD = BK / 16;
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
     int r, k;
     if (TRANS == 0) {
-      r = row0 + (tid >> 3) + 32 * (u & 1);
+      r = min(row0 + (tid >> 3) + 32 * (u & 1), nrows - 1);
       k = k0 + 32 * (u >> 1) + 4 * (tid & 7);
     } else {
-      r = row0 + 4 * (tid & 15);
+      r = min(row0 + 4 * (tid & 15), nrows - 4);              // nrows % 4 == 0 (validated)
       k = k0 + (tid >> 4) + 16 * u;
     }
-    const bool ok = r < nrows && k < kend;
-    int kl = k, kl0 = k0;
-    if (st && st->multi) {                     // K-concatenated operand: pick the segment of this k
-      const int sg = ok ? k / st->kseg : k0 / st->kseg;
-      src = st->seg[sg];
-      kl = k - sg * st->kseg;
-      kl0 = k0 - sg * st->kseg;
+    const bool ok = !kmask || k < kend;
+    int kl = ok ? k : k0;
+    const float* base = src;
+    if (kseg > 0) {                            // K-concatenated operand (kseg > 0): pick the segment of this k.  Plain
+      const int sg = (kl >= kseg) + (kl >= 2 * kseg);   // scalars, no table: a table indexed per lane lives in scratch,
+      base = sg == 0 ? src : (sg == 1 ? seg1 : seg2);   // whose loads share vmcnt with the tile loads and serialise them
+      kl -= sg * kseg;
     }
     const size_t off = TRANS == 0 ? (size_t)r * ld + kl : (size_t)kl * ld + r;
-    const size_t safe = TRANS == 0 ? (size_t)row0 * ld + kl0 : (size_t)kl0 * ld + row0;   // always in range
-    float4 v = *reinterpret_cast<const float4*>(src + (ok ? off : safe));   // unconditional load
-    reg[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    reg[u] = *reinterpret_cast<const float4*>(base + off);    // raw: tile_store zero-fills a ragged tail
   }
 }
 
 template <int TRANS, int BK>
-__device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16], int tid) {
+__device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16], int tid, bool kmask, int k0, int kend) {
   constexpr int NLD = BK / 16;
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
+    float4 v = reg[u];
     if (TRANS == 0) {
       const int i = (tid >> 3) + 32 * (u & 1), kk = 32 * (u >> 1) + 4 * (tid & 7);
-      T[kk + 0][i] = reg[u].x;
-      T[kk + 1][i] = reg[u].y;
-      T[kk + 2][i] = reg[u].z;
-      T[kk + 3][i] = reg[u].w;
+      if (kmask && k0 + kk >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      T[kk + 0][i] = v.x;
+      T[kk + 1][i] = v.y;
+      T[kk + 2][i] = v.z;
+      T[kk + 3][i] = v.w;
     } else {
       const int kk = (tid >> 4) + 16 * u, i = 4 * (tid & 15);
-      T[kk][i + 0] = reg[u].x;
-      T[kk][i + 1] = reg[u].y;
-      T[kk][i + 2] = reg[u].z;
-      T[kk][i + 3] = reg[u].w;
+      if (kmask && k0 + kk >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      T[kk][i + 0] = v.x;
+      T[kk][i + 1] = v.y;
+      T[kk][i + 2] = v.z;
+      T[kk][i + 3] = v.w;
     }
   }
 }
 
-template <int TA, int TB, int FULL, int BK>
+template <int TA, int TB, int FULL, int BK, int PF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int NLD = BK / 16;
   __shared__ float As[2][BK][LDT];
@@ -115,6 +126,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int kbeg = split * per * BK;
   const int kend = min(K, kbeg + per * BK);
   if (m0 >= M || n0 >= N || kbeg >= kend) return;   // block-uniform
+  const bool kmask = (kend - kbeg) % BK != 0;       // ragged reduction tail (never on the hot shapes)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -123,45 +135,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float4 ra[NLD], rb[NLD];
+  // PF slabs are in flight in registers (slot u holds slab  u  mod PF of the current group): with one workgroup per
+  // CU — the 8k-row shapes of the step — a single slab of prefetch (1024 MFMA cycles) does not cover a global round trip
+  float4 ra[PF][NLD], rb[PF][NLD];
   const int ldb = P.ldb;
-  SegTab st;
-  st.seg[0] = P.Bseg[0]; st.seg[1] = P.Bseg[1]; st.seg[2] = P.Bseg[2];
-  st.kseg = P.kseg; st.multi = K > P.kseg;
+  const float* const bs0 = P.Bseg[0];
+  const float* const bs1 = P.Bseg[1];
+  const float* const bs2 = P.Bseg[2];
+  const int bkseg = K > P.kseg ? P.kseg : 0;          // 0: B is one segment
 
-  tile_load<TA, BK>(P.A, P.lda, m0, M, kbeg, kend, ra, tid);
-  tile_load<TB, BK>(st.seg[0], ldb, n0, N, kbeg, kend, rb, tid, &st);
-  tile_store<TA, BK>(As[0], ra, tid);
-  tile_store<TB, BK>(Bs[0], rb, tid);
+  // every slot load is UNCONDITIONAL (past the end it re-reads the first slab, a cache hit whose result is dropped): a
+  // load under a branch makes the number of loads in flight unknown at the join, and the compiler then waits for all
+  // of them (vmcnt(0)) where vmcnt(4*(PF-1)) is enough
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int kl = kbeg + u * BK < kend ? kbeg + u * BK : kbeg;
+    tile_load<TA, BK>(P.A, P.lda, m0, M, kl, kend, ra[u], tid, kmask);
+    tile_load<TB, BK>(bs0, ldb, n0, N, kl, kend, rb[u], tid, kmask, bs1, bs2, bkseg);
+  }
+  tile_store<TA, BK>(As[0], ra[0], tid, kmask, kbeg, kend);
+  tile_store<TB, BK>(Bs[0], rb[0], tid, kmask, kbeg, kend);
   __syncthreads();
 
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const int kn = k0 + BK;
-    const bool more = kn < kend;
-    if (more) {                                    // prefetch the next slab while this one is multiplied
-      tile_load<TA, BK>(P.A, P.lda, m0, M, kn, kend, ra, tid);
-      tile_load<TB, BK>(st.seg[0], ldb, n0, N, kn, kend, rb, tid, &st);
-    }
-    const float* a_base = &As[buf][h][wm * 32 + l31];
-    const float* b_base = &Bs[buf][h][wn * 32 + l31];
+  for (int kg = kbeg; kg < kend; kg += PF * BK) {
 #pragma unroll
-    for (int q = 0; q < BK / 32; ++q) {
-      float av[16], bv[16];
+    for (int u = 0; u < PF; ++u) {
+      const int k0 = kg + u * BK;
+      if (k0 >= kend) break;                         // block-uniform
+      const int kp = k0 + PF * BK < kend ? k0 + PF * BK : kbeg;   // slot u is free (its slab sits in LDS): refill it
+      tile_load<TA, BK>(P.A, P.lda, m0, M, kp, kend, ra[u], tid, kmask);            // PF slabs ahead
+      tile_load<TB, BK>(bs0, ldb, n0, N, kp, kend, rb[u], tid, kmask, bs1, bs2, bkseg);
+      const float* a_base = &As[buf][h][wm * 32 + l31];
+      const float* b_base = &Bs[buf][h][wn * 32 + l31];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        av[s] = a_base[(32 * q + 2 * s) * LDT];
-        bv[s] = b_base[(32 * q + 2 * s) * LDT];
+      for (int q = 0; q < BK / 32; ++q) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          av[s] = a_base[(32 * q + 2 * s) * LDT];
+          bv[s] = b_base[(32 * q + 2 * s) * LDT];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      if (k0 + BK < kend) {
+        const int nx = (u + 1) % PF;                 // compile-time after unrolling
+        tile_store<TA, BK>(As[buf ^ 1], ra[nx], tid, kmask, k0 + BK, kend);
+        tile_store<TB, BK>(Bs[buf ^ 1], rb[nx], tid, kmask, k0 + BK, kend);
+      }
+      __syncthreads();
+      buf ^= 1;
     }
-    if (more) {
-      tile_store<TA, BK>(As[buf ^ 1], ra, tid);
-      tile_store<TB, BK>(Bs[buf ^ 1], rb, tid);
-    }
-    __syncthreads();
-    buf ^= 1;
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -274,12 +299,18 @@ static int validate(const GemmProblem& p) {
   return PS_OK;
 }
 
+template <int FULL, int BK, int PF>
+static void launch_pf(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGroup& g) {
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, FULL, BK, PF>), grid, dim3(256), 0, stream, g);
+  else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, FULL, BK, PF>), grid, dim3(256), 0, stream, g);
+  else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, FULL, BK, PF>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0, FULL, BK, PF>), grid, dim3(256), 0, stream, g);
+}
 template <int FULL, int BK>
 static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGroup& g) {
-  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, FULL, BK>), grid, dim3(256), 0, stream, g);
-  else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, FULL, BK>), grid, dim3(256), 0, stream, g);
-  else if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, FULL, BK>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0, FULL, BK>), grid, dim3(256), 0, stream, g);
+  // two 32-deep slabs in flight (measured on MI355X: 1 -> 2 takes the 8064x128x512 product from 24.4 to 20.5 us and
+  // 4096^3 from 104 to 112 TFLOP/s; 3 and 4 give nothing more); a 128-deep slab is a whole reduction already
+  launch_pf<FULL, BK, (BK == 32 ? 2 : 1)>(ta, tb, grid, stream, g);
 }
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {

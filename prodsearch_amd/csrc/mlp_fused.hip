@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
   int buf = 0;
 
   for (int s = 0; s < NS; ++s) {
-    if (s + 1 < NS && !(a.dbg & 1)) {
+    {   // unconditional (the last iteration re-reads its own slab, a cache hit that is dropped): under a branch the
+        // registers become a phi and the compiler copies them — waiting for the loads — before the MFMA block
       const float* W; int ldw, n0, k0;
-      slab_src(s + 1, W, ldw, n0, k0);
+      slab_src(s + 1 < NS ? s + 1 : s, W, ldw, n0, k0);
       slab_load(W, ldw, n0, k0, wr, tid);
     }
     // which product is this slab part of?
@@ -159,9 +160,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       float av[16], bv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLD]; }
-      if (a.dbg & 2) {
-        acc[0] += av[0] * bv[0] + av[15] * bv[15];
-      } else if (is_w2) {
+      if (is_w2) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
       } else {
@@ -266,10 +265,7 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const int dbg = getenv("PS_MLP_DBG") ? atoi(getenv("PS_MLP_DBG")) : 0;
-  MlpFwdArgs b = a;
-  b.dbg = dbg;
-  hipLaunchKernelGGL(mlp_fwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, b);
+  hipLaunchKernelGGL(mlp_fwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

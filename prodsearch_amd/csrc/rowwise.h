@@ -156,7 +156,6 @@ struct MlpFwdArgs {
   const float *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *gf, *bef;
   DropSpec drop_ctx, drop_ff1, drop_ff2;
   float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
-  int dbg;                        // timing experiments only (PS_MLP_DBG): 1 = no slab loads, 2 = no MFMA, 4 = no stores
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool ps_fusion_enabled();

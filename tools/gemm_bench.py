@@ -13,6 +13,9 @@ def run(M, N, K, ta=0, tb=0, acc=0, iters=200):
     Bm = torch.randn(K, N, device='cuda') if tb else torch.randn(N, K, device='cuda')
     C = torch.zeros(M, N, device='cuda')
     args = (A.data_ptr(), M if ta else K, ta, Bm.data_ptr(), N if tb else K, tb, C.data_ptr(), N, M, N, K, None, 1.0, acc, st)
+    lib.ps_gemm_f32(*args)
+    ref = (A.t() if ta else A) @ (Bm if tb else Bm.t())
+    err = float((C - ref).abs().max() / ref.abs().max())
     for _ in range(10):
         lib.ps_gemm_f32(*args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +26,7 @@ def run(M, N, K, ta=0, tb=0, acc=0, iters=200):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters
-    print("M=%6d N=%4d K=%5d ta=%d tb=%d acc=%d : %8.2f us  %7.2f TFLOP/s" % (M, N, K, ta, tb, acc, t * 1e6, 2.0 * M * N * K / t / 1e12))
+    print("M=%6d N=%4d K=%5d ta=%d tb=%d acc=%d : %8.2f us  %7.2f TFLOP/s  err %.1e" % (M, N, K, ta, tb, acc, t * 1e6, 2.0 * M * N * K / t / 1e12, err))
 
 
 if __name__ == '__main__':
@@ -39,3 +42,8 @@ if __name__ == '__main__':
     run(8064, 512, 128, 0, 1)
     run(512, 128, 8064, 1, 1, 2)
     run(128, 128, 8064, 1, 1, 2)
+    # review-transformer shapes (78k sequence positions)
+    run(78336, 256, 128)
+    run(78336, 128, 128)
+    run(128, 128, 78336, 1, 1, 2)
+    run(128, 256, 78336, 1, 1, 2)
