@@ -257,9 +257,14 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     }
     dq *= a.qscale;
     a.dq[(size_t)b * a.lddq + c0 + c] = dq;
-    atomicAdd(&a.dbq[c0 + c], dq);
-    atomicAdd(&a.dbk[c0 + c], sk);
-    atomicAdd(&a.dbv[c0 + c], sv);
+    if (a.bias_part) {                                       // parked: folded by the step's last launch
+      float* bp = a.bias_part + (size_t)b * 3 * D + c0 + c;
+      bp[0] = dq; bp[D] = sk; bp[2 * D] = sv;
+    } else {
+      atomicAdd(&a.dbq[c0 + c], dq);
+      atomicAdd(&a.dbk[c0 + c], sk);
+      atomicAdd(&a.dbv[c0 + c], sv);
+    }
   }
 }
 

@@ -67,6 +67,7 @@ struct AttnArgs {
   float* dq; int lddq;           // grad wrt the un-scaled query linear output
   float* dkv; int lddkv;         // dK at col 0.., dV at col d..
   float* dbq; float* dbk; float* dbv;   // += (atomics)
+  float* bias_part;              // optional [n_in][3][d]: the sq1 backward parks {dbq, dbk, dbv} here instead (ColFoldList)
   float qscale;                  // 1/sqrt(dh)
 };
 inline void attn_finish(AttnArgs& a) {

@@ -127,6 +127,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
   w.stage = take(cur, 4 + 2 * ((int64_t)B * (D.Q + D.L + 1 + D.W + D.K + D.W * D.K) + 8));   // int64 = 2 floats
   w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 63) / 64 + 1) * 3 * (tem && NL > 0 ? D.F : 0));
+  w.abpart = take(cur, (int64_t)NL * (NL > 0 ? w.layer[NL - 1].n_in : 0) * 3 * d);
   w.total = cur;
   return PS_OK;
 }
@@ -585,7 +586,15 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       a.dbq = Lg.bq; a.dbk = Lg.bk; a.dbv = Lg.bv;
       a.qscale = 1.f / sqrtf((float)(d / D.H));
       attn_finish(a);
-      TRY(attn_sq1_fits(a) ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
+      const bool sq1 = attn_sq1_fits(a);
+      if (sq1 && fold && fold->n < PS_MAX_COLFOLD) {
+        // bias gradients: one parked row per sequence instead of n_in same-address atomics per column
+        ColFold& cf = fold->e[fold->n++];
+        a.bias_part = ws + w.abpart + (size_t)i * w.layer[D.n_layers - 1].n_in * 3 * d;
+        cf.partial = a.bias_part; cf.nblk = l.n_in; cf.d = d;
+        cf.dst[0] = Lg.bq; cf.dst[1] = Lg.bk; cf.dst[2] = Lg.bv;
+      }
+      TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
       wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);

@@ -3,7 +3,9 @@ import csv, sys, glob
 f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('sample_kernel')]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(('sample_kernel', 'tem_stage_kernel'))]
+if len(idx) < 2:      # sampling folded into the first kernel of the step
+    idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('embed_fwd_kernel')]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 s, e = idx[k], idx[k + 1]
 t0 = int(rows[s]['Start_Timestamp'])
