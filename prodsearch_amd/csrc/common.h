@@ -111,10 +111,21 @@ __host__ inline FDiv make_fdiv(int d) {
 __device__ inline int fdiv(int n, const FDiv& f) { return f.d == 1 ? n : (int)__umulhi((uint32_t)n, f.m); }
 
 // ------------------------------------------------------------------ wave helpers
+// Sum over the 64 lanes, returned to every lane.  DPP adds, not ds_bpermute shuffles: an inclusive scan inside each
+// row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then row_bcast:15 /
+// row_bcast:31 carry the row totals into lane 63, which is broadcast through an SGPR.  Six ~8-cycle ALU ops instead of
+// six LDS round trips in a dependent chain (a LayerNorm row needs two such sums back to back).
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define PS_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  PS_DPP_ADD(0x111, 0xf);      // row_shr:1
+  PS_DPP_ADD(0x112, 0xf);      // row_shr:2
+  PS_DPP_ADD(0x114, 0xf);      // row_shr:4
+  PS_DPP_ADD(0x118, 0xf);      // row_shr:8   -> lane 15 of each row holds the row total
+  PS_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+  PS_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+#undef PS_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // sum over groups of `width` consecutive lanes (width power of two <= 64)
 __device__ inline float group_sum(float v, int width) {

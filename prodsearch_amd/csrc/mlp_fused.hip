@@ -109,11 +109,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
   };
 
   // ---- prologue: first weight slab, the ctx tile (k-major), the residual rows
-  float4 wr[WRN];
+  // two weight slabs in flight in registers (wr0 / wr1 alternate: the loop body below is instantiated once per slot so
+  // the slots stay static): one slab of MFMAs (~0.85 us) does not cover the round trip of the next slab's loads
+  float4 wr0[WRN], wr1[WRN];
   {
     const float* W; int ldw, n0, k0;
     slab_src(0, W, ldw, n0, k0);
-    slab_load(W, ldw, n0, k0, wr, tid);
+    slab_load(W, ldw, n0, k0, wr0, tid);
+    slab_src(1, W, ldw, n0, k0);
+    slab_load(W, ldw, n0, k0, wr1, tid);
   }
   {
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
     y1v[r] = m < M ? a.xin[((size_t)(m / a.fan) * a.S + a.qpos) * MD + col] : 0.f;
   }
-  slab_store(L.Ws[0], wr, tid);
+  slab_store(L.Ws[0], wr0, tid);
   __syncthreads();
 
   f32x16 acc, acc_o;
@@ -141,12 +145,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
   int buf = 0;
 
-  for (int s = 0; s < NS; ++s) {
-    {   // unconditional (the last iteration re-reads its own slab, a cache hit that is dropped): under a branch the
+  // one slab: refill `wfree` (its slab already sits in LDS) two slabs ahead, multiply slab s, run the stage boundary,
+  // publish `wnext` (slab s + 1) to the other LDS buffer
+  auto slab_step = [&](const int s, float4 (&wfree)[WRN], const float4 (&wnext)[WRN]) {
+    {   // unconditional (past the end it re-reads the last slab, a cache hit that is dropped): under a branch the
         // registers become a phi and the compiler copies them — waiting for the loads — before the MFMA block
       const float* W; int ldw, n0, k0;
-      slab_src(s + 1 < NS ? s + 1 : s, W, ldw, n0, k0);
-      slab_load(W, ldw, n0, k0, wr, tid);
+      slab_src(s + 2 < NS ? s + 2 : NS - 1, W, ldw, n0, k0);
+      slab_load(W, ldw, n0, k0, wfree, tid);
     }
     // which product is this slab part of?
     const int t = s - SPP, r8 = t % (2 * SPP);
@@ -250,9 +256,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
       tile_layernorm(Y, a.gf, a.bef, nullptr, a.enc, a.stf, opaque(m0), M, wave, lane);
     }
 
-    if (s + 1 < NS) slab_store(L.Ws[buf ^ 1], wr, tid);
+    if (s + 1 < NS) slab_store(L.Ws[buf ^ 1], wnext, tid);
     __syncthreads();
     buf ^= 1;
+  };
+  for (int s = 0; s < NS; s += 2) {                 // NS = SPP * (1 + 2 * nchunk) is even
+    slab_step(s, wr0, wr1);
+    slab_step(s + 1, wr1, wr0);
   }
 }
 
