@@ -127,6 +127,18 @@ __device__ inline float wave_sum(float v) {
 #undef PS_DPP_ADD
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over groups of 32 consecutive lanes, valid in the LAST lane of each group (lanes 31 and 63): DPP scan as above
+__device__ inline float half_sum_last(float v) {
+#define PS_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  PS_DPP_ADD(0x111, 0xf);
+  PS_DPP_ADD(0x112, 0xf);
+  PS_DPP_ADD(0x114, 0xf);
+  PS_DPP_ADD(0x118, 0xf);
+  PS_DPP_ADD(0x142, 0xa);
+#undef PS_DPP_ADD
+  return v;
+}
 // sum over groups of `width` consecutive lanes (width power of two <= 64)
 __device__ inline float group_sum(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

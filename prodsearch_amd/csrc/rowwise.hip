@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
     else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; tk[u].lw = 0.f; }
   }
   float cps = 0.f, cil = 0.f;                      // this row group's share of the two loss sums
+  const int wl = lpr == 32 ? 31 : 0;               // the lane of the row group that ends up holding its dot product
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,8 +530,8 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
         float4 vv = *reinterpret_cast<const float4*>(tk[u].vec + 4 * cc);
         s += rr.x * vv.x + rr.y * vv.y + rr.z * vv.z + rr.w * vv.w;
       }
-    s = group_sum(s, lpr);
-    if (c == 0 && tk[u].out) {
+    s = lpr == 32 ? half_sum_last(s) : group_sum(s, lpr);
+    if (c == wl && tk[u].out) {
       const float sc = s + tk[u].bias;
       *tk[u].out = sc;
       // BCE-with-logits term of this task (item_transformer.py:510-513, :280): target 1 -> softplus(-s)
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
   // per-workgroup loss partials in a fixed order (plain stores: the kernel boundary publishes them); loss_kernel
   // then only has 2 floats per workgroup to reduce instead of every term
   __shared__ float rps[64], ril[64];
-  if (c == 0) { rps[tid / lpr] = cps; ril[tid / lpr] = cil; }
+  if (c == wl) { rps[tid / lpr] = cps; ril[tid / lpr] = cil; }
   __syncthreads();
   if (tid == 0) {
     float p = 0.f, q = 0.f;
