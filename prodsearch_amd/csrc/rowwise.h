@@ -6,7 +6,10 @@ struct EmbedArgs {
   int B, Q, L, S, d;
   int64_t P, V;
   int tem;                       // 1: build the [B,S,d] sequence; 0 (QEM): query only
-  int fs;                        // 1: FS encoder (row 0 of x is written by the FS GEMM), 0: AVG
+  int fs;                        // 1: FS encoder (row 0 of x is written by the FS projection), 0: AVG
+  // FS projection folded into this launch when set: query_emb = tanh(fs_w . mean + fs_b) (text_encoder.py:39) as a
+  // per-row mat-vec against the L2-resident [d,d] weight (a GEMM launch of its own cost 15 us for 12.6 MFLOP at C2)
+  const float* fs_w; const float* fs_b;
   int use_pos;
   const int64_t* qw; const int64_t* ui;
   const float* word_emb; const float* hist_tab; const float* pe;
@@ -124,6 +127,11 @@ struct EmbedBwdArgs {
   // optional: weight gradient of the FS query projection folded into the same launch (extra workgroups):
   // g_fs_w[o][i] += sum_b fw_dy[b][o] * fw_x[b][i]   (text_encoder.py:38, f_W)
   const float* fw_dy; const float* fw_x; float* g_fs_w;
+  // optional: the whole FS backward folded into this launch (text_encoder.py:38-39).  One workgroup per batch row takes
+  // dqpre = dqe * (1 - qe^2), d mean = dqpre . f_W as a mat-vec against the L2-resident weight and scatters it to the
+  // row's query words; the f_W workgroups above recompute dqpre on the fly (fw_dy is then unused) and also add up
+  // g_fs_b.  Replaces a tanh-backward launch and a [B,d]x[d,d] GEMM launch on the tail of the backward.
+  const float* fsb_dqe; int fsb_lddqe; const float* fsb_qe; const float* fsb_w; float* g_fs_b;
   ColFoldList fold;              // parked column sums to add up (n = 0: none)
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);

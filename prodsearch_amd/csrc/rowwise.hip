@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   const int rpp = 256 / nchunk;
   const int rg = tid / nchunk, c = tid - rg * nchunk;
   const bool active = rg < rpp;
+  const bool fuse_fs = a.fs && a.fs_w;
+  float* mean_s = red + (size_t)rpp * d;      // [d] post-dropout mean, [d] projection output (fused FS projection only)
   const int64_t wpad = a.V - 1;
   int cnt = 0;
   for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != wpad);
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     for (int e = 0; e < 4; ++e) m[e] *= drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)(4 * c + e));
     float4 md = make_float4(m[0], m[1], m[2], m[3]);
     *reinterpret_cast<float4*>(a.qmean_d + (size_t)b * d + 4 * c) = md;
+    if (fuse_fs) *reinterpret_cast<float4*>(mean_s + 4 * c) = md;
     if (!a.fs) {
       *reinterpret_cast<float4*>(a.query_emb + (size_t)b * d + 4 * c) = md;
       if (a.tem) {
@@ -92,13 +95,56 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
       *reinterpret_cast<float4*>(a.x + ((size_t)b * a.S + 1 + l) * d + 4 * c) = v;
     }
   }
+  if (!fuse_fs) return;
+  // FS projection of this row: out[o] = tanh(sum_i fs_w[o][i] * mean[i] + fs_b[o]).  A group of lpr lanes (16 B per
+  // lane, one coalesced weight row per load) owns the outputs o = grp, grp + ngrp, ...; 4 weight rows in flight.
+  __syncthreads();
+  float* out_s = mean_s + d;
+  {
+    int lpr = 1;
+    while (lpr < nchunk && lpr < 64) lpr <<= 1;
+    const int ngrp = 256 / lpr, grp = tid / lpr, lc = tid - grp * lpr;
+    for (int o0 = grp; o0 < d; o0 += 4 * ngrp) {
+      float part[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u * ngrp;
+        float s = 0.f;
+        if (o < d)
+          for (int cc = lc; cc < nchunk; cc += lpr) {
+            const float4 wv = *reinterpret_cast<const float4*>(a.fs_w + (size_t)o * d + 4 * cc);
+            const float4 mv = *reinterpret_cast<const float4*>(mean_s + 4 * cc);
+            s += wv.x * mv.x + wv.y * mv.y + wv.z * mv.z + wv.w * mv.w;
+          }
+        part[u] = s;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u * ngrp;
+        const float s = lpr == 32 ? half_sum_last(part[u]) : group_sum(part[u], lpr);
+        if (lc == lpr - 1 && o < d) out_s[o] = tanh_fast(s + a.fs_b[o]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nchunk) {
+    float4 y = *reinterpret_cast<const float4*>(out_s + 4 * c);
+    *reinterpret_cast<float4*>(a.query_emb + (size_t)b * d + 4 * c) = y;
+    if (a.tem) {
+      if (a.use_pos) {
+        float4 p = *reinterpret_cast<const float4*>(a.pe + 4 * c);
+        y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w;
+      }
+      *reinterpret_cast<float4*>(a.x + (size_t)b * a.S * d + 4 * c) = y;
+    }
+  }
 }
 
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0 && a.d <= 1024, "embed: d=%d unsupported", a.d);
   int rpp = 256 / (a.d / 4);
   const int nsamp = a.samp_prob ? ps_cdiv(a.samp_nitem + a.samp_nword, 256) : 0;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp), dim3(256), (size_t)rpp * a.d * sizeof(float), st, a);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp), dim3(256), (size_t)(rpp + 2) * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -714,35 +760,96 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
 // ========================================================== embedding scatter-add
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nfw, int nfold) {
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nq, int nfw, int nfold) {
+  extern __shared__ float fsb_s[];               // fused FS backward only: [d] dqpre, [rpp][d] partials, [d] d mean
   const int tid = threadIdx.x, c = tid & 31;
   const int d = a.d, epl = d >> 5;
-  if ((int)blockIdx.x < nfw) {
+  const bool fsb = a.fsb_w != nullptr;
+  if ((int)blockIdx.x < nq) {
+    // FS backward of batch row b, first in the grid: it is the tail of the step's dependent chain
+    const int b = blockIdx.x;
+    const int nchunk = d >> 2, rpp = 256 / nchunk;
+    const int rg = tid / nchunk, cc = tid - rg * nchunk;
+    float* dq_s = fsb_s;
+    float* part_s = fsb_s + d;
+    float* dm_s = part_s + (size_t)rpp * d;
+    for (int e = tid; e < d; e += 256) {
+      const float y = a.fsb_qe[(size_t)b * d + e];
+      dq_s[e] = a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] * (1.f - y * y);
+    }
+    int cnt = 0;
+    for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+    __syncthreads();
+    if (rg < rpp) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int o = rg; o < d; o += rpp) {        // coalesced weight rows, 16 B per lane
+        const float4 wv = *reinterpret_cast<const float4*>(a.fsb_w + (size_t)o * d + 4 * cc);
+        const float s = dq_s[o];
+        acc.x = fmaf(s, wv.x, acc.x); acc.y = fmaf(s, wv.y, acc.y); acc.z = fmaf(s, wv.z, acc.z); acc.w = fmaf(s, wv.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(part_s + (size_t)rg * d + 4 * cc) = acc;
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    for (int e = tid; e < d; e += 256) {
+      float s = 0.f;
+      for (int r = 0; r < rpp; ++r) s += part_s[(size_t)r * d + e];
+      dm_s[e] = s * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)e) * inv;
+    }
+    __syncthreads();
+    for (int q = tid >> 5; q < a.Q; q += 8) {
+      const int64_t idx = a.qw[(size_t)b * a.Q + q];
+      if (idx == a.V - 1 || idx < 0 || idx >= a.V) continue;
+      float* dst = a.g_word_emb + (size_t)idx * d;
+      for (int k = 0; k < epl; ++k) atomicAdd(&dst[c + 32 * k], dm_s[c + 32 * k]);
+    }
+    return;
+  }
+  if ((int)blockIdx.x < nq + nfw) {
     // f_W weight gradient (12.6 MFLOP at C2 — not worth a GEMM launch of its own on the tail).  These workgroups
-    // come first in the grid so they run under the scatter: 32 outputs each, the batch sum split over 8 lane
+    // come early in the grid so they run under the scatter: 32 outputs each, the batch sum split over 8 lane
     // groups (short dependent chains), reduced through LDS.
     __shared__ float part[8][32];
-    const int g = (int)blockIdx.x * 32 + c, seg = tid >> 5;
+    __shared__ float bpart[8];
+    const int g = ((int)blockIdx.x - nq) * 32 + c, seg = tid >> 5;
     const bool live = g < d * d;
     const int o = live ? g / d : 0, i = live ? g - o * d : 0;
-    float acc = 0.f;
+    float acc = 0.f, bacc = 0.f;
+    if (fsb) {
 #pragma unroll 8
-    for (int b = seg; b < a.B; b += 8) acc = fmaf(a.fw_dy[(size_t)b * d + o], a.fw_x[(size_t)b * d + i], acc);
+      for (int b = seg; b < a.B; b += 8) {
+        const float y = a.fsb_qe[(size_t)b * d + o];
+        const float dy = a.fsb_dqe[(size_t)b * a.fsb_lddqe + o] * (1.f - y * y);
+        acc = fmaf(dy, a.fw_x[(size_t)b * d + i], acc);
+        bacc += dy;
+      }
+    } else {
+#pragma unroll 8
+      for (int b = seg; b < a.B; b += 8) acc = fmaf(a.fw_dy[(size_t)b * d + o], a.fw_x[(size_t)b * d + i], acc);
+    }
     part[seg][c] = acc;
+    if (c == 0) bpart[seg] = bacc;
     __syncthreads();
     if (seg == 0 && live) {
       float s8 = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) s8 += part[k][c];
       a.g_fs_w[g] += s8;
+      if (fsb && i == 0) {                       // column o of the bias gradient: this workgroup's lane 0 owns it
+        float sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sb += bpart[k];
+        a.g_fs_b[o] += sb;
+      }
     }
     return;
   }
-  if ((int)blockIdx.x < nfw + nfold) {
+  if ((int)blockIdx.x < nq + nfw + nfold) {
     // parked column sums (ColFoldList): 32 output columns per workgroup, the parked partials split over 8 lane
     // groups (short dependent chains) and reduced through LDS, like the f_W gradient above
     __shared__ float fpart[8][32];
-    int blk = (int)blockIdx.x - nfw;
+    int blk = (int)blockIdx.x - nq - nfw;
     for (int k = 0; k < a.fold.n; ++k) {
       const ColFold& f = a.fold.e[k];
       const int span = (3 * f.d + 31) / 32;
@@ -768,7 +875,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     }
     return;
   }
-  const int t = ((int)blockIdx.x - nfw - nfold) * 8 + (tid >> 5);
+  const int t = ((int)blockIdx.x - nq - nfw - nfold) * 8 + (tid >> 5);
   if (t >= ntask) return;
   const int nitem = a.tem ? a.B * a.L : 0;
   if (t < nitem) {
@@ -797,13 +904,18 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
 
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0, "embed scatter: d %% 32");
-  int ntask = (a.tem ? a.B * a.L : 0) + a.B * a.Q;
+  const bool fsb = a.fsb_w != nullptr;
+  PS_REQUIRE(!fsb || (a.fsb_dqe && a.fsb_qe && a.g_fs_b && a.g_fs_w && a.fw_x && a.d <= 1024),
+             "embed scatter: fused FS backward operands missing");
+  int ntask = (a.tem ? a.B * a.L : 0) + (fsb ? 0 : a.B * a.Q);   // fused: the query words are scattered by the row workgroups
   const int nsb = ps_cdiv(ntask, 8);
+  const int nq = fsb ? a.B : 0;
   const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
-  PS_REQUIRE(!a.g_fs_w || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
+  PS_REQUIRE(!a.g_fs_w || fsb || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
   int nfold = 0;
   for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 32);
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nsb + nfw + nfold), dim3(256), 0, st, a, ntask, nfw, nfold);
+  const size_t lds = fsb ? sizeof(float) * (size_t)(256 / (a.d / 4) + 2) * a.d : 0;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nq + nsb + nfw + nfold), dim3(256), lds, st, a, ntask, nq, nfw, nfold);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

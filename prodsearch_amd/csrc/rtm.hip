@@ -739,9 +739,11 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   e.fs = D.query_encoder == PS_QENC_FS; e.qw = Bt.query_word_idxs; e.word_emb = P.word_emb;
   e.drop_fs = make_drop(dq, PS_SITE_FS);
   e.qmean_d = ws + r.qmean; e.query_emb = ws + r.query_emb;
+  PS_REQUIRE(!e.fs || (P.fs_w && P.fs_b), "rtm: null FS encoder weights");
+  const bool fs_fused = e.fs && ps_fusion_enabled();
+  if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   TRY(launch_embed_fwd(e, st));
-  if (e.fs) {
-    PS_REQUIRE(P.fs_w && P.fs_b, "rtm: null FS encoder weights");
+  if (e.fs && !fs_fused) {
     GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);
     p.bias = P.fs_b; p.act = ACT_TANH;
     TRY(run1(p, st));
@@ -859,12 +861,17 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   e.qw = batch->query_word_idxs; e.drop_fs = make_drop(dq, PS_SITE_FS); e.g_word_emb = G.word_emb;
   if (D.query_encoder == PS_QENC_FS) {
     PS_REQUIRE(G.fs_w && G.fs_b, "rtm backward: null FS gradients");
-    TRY(launch_tanh_bwd(ws + r.dqe, d, ws + r.query_emb, ws + r.dqpre, G.fs_b, B, d, st));
-    GemmProblem p = gp(ws + r.dqpre, d, 0, params->fs_w, d, 1, ws + r.dqmean, d, B, d, d);
-    TRY(run1(p, st));
-    GemmProblem wg[1] = {gp_wgrad(ws + r.dqpre, d, ws + r.qmean, d, G.fs_w, d, d, B)};
-    TRY(side_wgrads(wg, 1, st));
-    e.dqmean_d = ws + r.dqmean;
+    if (ps_fusion_enabled()) {   // whole FS backward inside the scatter launch (EmbedBwdArgs::fsb_*)
+      e.fw_x = ws + r.qmean; e.g_fs_w = G.fs_w;
+      e.fsb_dqe = ws + r.dqe; e.fsb_lddqe = d; e.fsb_qe = ws + r.query_emb; e.fsb_w = params->fs_w; e.g_fs_b = G.fs_b;
+    } else {
+      TRY(launch_tanh_bwd(ws + r.dqe, d, ws + r.query_emb, ws + r.dqpre, G.fs_b, B, d, st));
+      GemmProblem p = gp(ws + r.dqpre, d, 0, params->fs_w, d, 1, ws + r.dqmean, d, B, d, d);
+      TRY(run1(p, st));
+      GemmProblem wg[1] = {gp_wgrad(ws + r.dqpre, d, ws + r.qmean, d, G.fs_w, d, d, B)};
+      TRY(side_wgrads(wg, 1, st));
+      e.dqmean_d = ws + r.dqmean;
+    }
   } else {
     e.dqmean_d = ws + r.dqe;
   }

@@ -367,9 +367,11 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
     e.samp_nitem = D.B * D.K; e.samp_nword = D.B * D.W * D.K; e.samp_step = (uint32_t)D.step;
     e.samp_k0 = (uint32_t)(D.seed & 0xffffffffu); e.samp_k1 = (uint32_t)(D.seed >> 32);
   }
+  PS_REQUIRE(!e.fs || (P.fs_w && P.fs_b), "forward: null FS encoder weights");
+  const bool fs_fused = e.fs && ps_fusion_enabled();   // FS projection as a per-row mat-vec inside the embed launch
+  if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   TRY(launch_embed_fwd(e, st));
-  if (e.fs) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
-    PS_REQUIRE(P.fs_w && P.fs_b, "forward: null FS encoder weights");
+  if (e.fs && !fs_fused) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
     GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
     p.bias = P.fs_b; p.act = ACT_TANH;
     if (tem) { p.out2 = ws + w.x; p.ld2 = S * d; p.add2 = D.use_pos_emb ? P.pe : nullptr; }
@@ -694,18 +696,22 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   e.g_hist_tab = ghist; e.g_word_emb = G.word_emb;
   if (D.query_encoder == PS_QENC_FS) {
     PS_REQUIRE(G.fs_w && G.fs_b, "backward: null FS encoder gradient");
-    TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
-    GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
-    TRY(run1(p, st));
-    e.dqmean_d = ws + w.dqmean;
+    e.fw_x = ws + w.qmean; e.g_fs_w = G.fs_w;   // f_W weight gradient rides in the scatter launch (extra workgroups)
+    if (ps_fusion_enabled()) {
+      // ... and so does the rest of the FS backward: tanh', d mean = dqpre . f_W (per-row mat-vec), bias gradient
+      e.fsb_dqe = dqe; e.fsb_lddqe = lddqe; e.fsb_qe = ws + w.query_emb; e.fsb_w = P.fs_w; e.g_fs_b = G.fs_b;
+    } else {
+      TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
+      GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
+      TRY(run1(p, st));
+      e.dqmean_d = ws + w.dqmean;
+      e.fw_dy = ws + w.dqpre;
+    }
   } else {
     // AVG encoder: query_emb == post-dropout mean; copy rows to a dense [B,d] buffer
     PS_CHECK_HIP(hipMemcpy2DAsync(ws + w.dqmean, sizeof(float) * d, dqe, sizeof(float) * lddqe, sizeof(float) * d, B,
                                   hipMemcpyDeviceToDevice, st));
     e.dqmean_d = ws + w.dqmean;
-  }
-  if (D.query_encoder == PS_QENC_FS) {     // f_W weight gradient rides in the scatter launch (extra workgroups)
-    e.fw_dy = ws + w.dqpre; e.fw_x = ws + w.qmean; e.g_fs_w = G.fs_w;
   }
   e.fold = fold;
   TRY(launch_embed_scatter(e, st));
