@@ -279,3 +279,243 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
+
+// ====================================================================== backward
+// Same ownership as the forward: a workgroup keeps 32 replica rows for the whole chain, weights stream through the slab
+// ring.  Every product here is  grad[m][n] = sum_k g[m][k] * W[k][n]  with W read in its stored order (W2 [d][F],
+// W1 [F][d], Wo [d][d] are all [k][n] for the input-gradient), so slabs are loaded AND stored as 16-byte rows.
+#define WLB 132           // backward weight slabs: [k][col], row stride 528 B (16-byte aligned ds_write_b128)
+
+struct MlpBwdLds {
+  float Xs[MD * XLD];           // A operand of the W2 / Wo products: do2, then dout   (k-major)
+  float Hs[MD * XLD];           // A operand of the W1 product: d a1 chunk (k-major); aliased as Y staging
+  float Ws[2][MBK * WLB];       // weight slab ring
+  float Cs[3][4][MD];           // column sums of the two LayerNorm backwards, per wave
+};
+
+// slab of MBK k-rows x 128 columns from a [k][n] (n contiguous) matrix
+__device__ inline void slab_load_kn(const float* __restrict__ W, int ldw, int k0, int n0, float4 (&r)[WRN], int tid) {
+#pragma unroll
+  for (int u = 0; u < WRN; ++u) r[u] = *reinterpret_cast<const float4*>(W + (size_t)(k0 + (tid >> 5) + 8 * u) * ldw + n0 + 4 * (tid & 31));
+}
+__device__ inline void slab_store_kn(float* Wsb, const float4 (&r)[WRN], int tid) {
+#pragma unroll
+  for (int u = 0; u < WRN; ++u) *reinterpret_cast<float4*>(Wsb + ((tid >> 5) + 8 * u) * WLB + 4 * (tid & 31)) = r[u];
+}
+
+// LayerNorm backward of the 32 x 128 tile: wave w owns rows 8w..8w+7, lane the columns {lane, lane+64}.
+//   dyv(i, j)  : grad wrt the LN output at (row 8w+i, column lane + 64j)
+//   x, stats, g: LN input rows (global, ld = MD), {mean, rstd} per row, gamma
+//   res        : added to dx (or null);  drop: site of the dropout applied to the result for `dropped`
+// Results: dxr[i][j] = dx (+res), dropped value written k-major to Xk and row-major to `out_drop` (global), dx to
+// `out_dx` when given; column sums {dy*xhat, dy, dropped} accumulated into Cs[.][wave][.].
+template <class DyF>
+__device__ inline void tile_ln_bwd(DyF dyv, const float* __restrict__ x, const float* __restrict__ stats,
+                                   const float* __restrict__ g, const float (*res)[2], const DropSpec& drop,
+                                   float (&dxr)[8][2], float* Xk, float* out_dx, float* out_drop, float (*Cs)[4][MD],
+                                   int m0, int M, int wave, int lane) {
+  const float g0 = g[lane], g1 = g[lane + 64];
+  float ag[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f}, ac[2] = {0.f, 0.f};
+#pragma unroll
+  for (int g4 = 0; g4 < 2; ++g4) {
+    const int rb = m0 + wave * 8 + 4 * g4;            // multiple of 4: the four rows share their Philox calls
+    Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (drop.thr) {
+      r0 = philox4x32_10((uint32_t)lane, (uint32_t)rb >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
+      r1 = philox4x32_10((uint32_t)lane + 64u, (uint32_t)rb >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * g4 + q, row = wave * 8 + i, m = rb + q;
+      const bool ok = m < M;
+      const float mean = ok ? stats[2 * (size_t)m] : 0.f, rstd = ok ? stats[2 * (size_t)m + 1] : 0.f;
+      const float x0 = ok ? x[(size_t)m * MD + lane] : 0.f, x1 = ok ? x[(size_t)m * MD + lane + 64] : 0.f;
+      const float dy0 = ok ? dyv(i, 0) : 0.f, dy1 = ok ? dyv(i, 1) : 0.f;
+      const float xh0 = (x0 - mean) * rstd, xh1 = (x1 - mean) * rstd;
+      const float dh0 = dy0 * g0, dh1 = dy1 * g1;
+      const float s1 = wave_sum(dh0 + dh1) * (1.f / MD);
+      const float s2 = wave_sum(dh0 * xh0 + dh1 * xh1) * (1.f / MD);
+      float d0 = rstd * (dh0 - s1 - xh0 * s2), d1 = rstd * (dh1 - s1 - xh1 * s2);
+      if (res) { d0 += res[i][0]; d1 += res[i][1]; }
+      dxr[i][0] = d0; dxr[i][1] = d1;
+      float v0 = d0, v1 = d1;
+      if (drop.thr) {
+        v0 *= drop_word(drop, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+        v1 *= drop_word(drop, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+      }
+      Xk[lane * XLD + row] = v0; Xk[(lane + 64) * XLD + row] = v1;
+      if (ok) {
+        if (out_dx) { out_dx[(size_t)m * MD + lane] = d0; out_dx[(size_t)m * MD + lane + 64] = d1; }
+        if (out_drop) { out_drop[(size_t)m * MD + lane] = v0; out_drop[(size_t)m * MD + lane + 64] = v1; }
+      }
+      ag[0] += dy0 * xh0; ag[1] += dy1 * xh1;
+      ab[0] += dy0; ab[1] += dy1;
+      ac[0] += v0; ac[1] += v1;
+    }
+  }
+  Cs[0][wave][lane] = ag[0]; Cs[0][wave][lane + 64] = ag[1];
+  Cs[1][wave][lane] = ab[0]; Cs[1][wave][lane + 64] = ab[1];
+  Cs[2][wave][lane] = ac[0]; Cs[2][wave][lane + 64] = ac[1];
+}
+// after a barrier: park the workgroup's three column sums  part[blk][3][128]
+__device__ inline void park_cs(const float (*Cs)[4][MD], float* part, int tid) {
+  for (int t = tid; t < 3 * MD; t += 256) {
+    const int which = t >> 7, colx = t & 127;
+    part[((size_t)blockIdx.x * 3 + which) * MD + colx] =
+        (Cs[which][0][colx] + Cs[which][1][colx]) + (Cs[which][2][colx] + Cs[which][3][colx]);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs a) {
+  extern __shared__ float lds_raw[];
+  MlpBwdLds& L = *reinterpret_cast<MlpBwdLds*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * MBM, M = a.M;
+  const int col = wave * 32 + l31;
+  const int nchunk = a.F / 128;
+  const int NC = 2 * SPP * nchunk;                  // slabs of the chunk loop; then SPP slabs of Wo
+  const int NS = NC + SPP;
+
+  auto slab_src = [&](int s, const float*& W, int& ldw, int& k0, int& n0) {
+    if (s >= NC) { W = a.wo; ldw = MD; k0 = MBK * (s - NC); n0 = 0; return; }
+    const int c = s / (2 * SPP), r = s % (2 * SPP);
+    if (r < SPP) { W = a.w2; ldw = a.F; k0 = MBK * r; n0 = 128 * c; }          // d h1[:, chunk] = do2 . W2[:, chunk]
+    else { W = a.w1; ldw = MD; k0 = 128 * c + MBK * (r - SPP); n0 = 0; }       // d ln1 += d a1[:, chunk] . W1[chunk, :]
+  };
+
+  float4 wr0[WRN], wr1[WRN];
+  {
+    const float* W; int ldw, k0, n0;
+    slab_src(0, W, ldw, k0, n0);
+    slab_load_kn(W, ldw, k0, n0, wr0, tid);
+    slab_src(1, W, ldw, k0, n0);
+    slab_load_kn(W, ldw, k0, n0, wr1, tid);
+  }
+  // ---- final LayerNorm backward (transformer.py:86) -> d y2 (kept: residual of the FF LayerNorm), do2 -> Xs
+  float dy2r[8][2];
+  {
+    const float* de = a.denc;
+    auto dyv = [&](int i, int j) { return de[(size_t)(m0 + wave * 8 + i) * MD + lane + 64 * j]; };
+    tile_ln_bwd(dyv, a.y2, a.stf, a.gf, nullptr, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
+  }
+  slab_store_kn(L.Ws[0], wr0, tid);
+  __syncthreads();
+  park_cs(L.Cs, a.part_f, tid);
+
+  f32x16 acc, acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
+  int buf = 0;
+
+  auto slab_step = [&](const int s, float4 (&wfree)[WRN], const float4 (&wnext)[WRN]) {
+    {
+      const float* W; int ldw, k0, n0;
+      slab_src(s + 2 < NS ? s + 2 : NS - 1, W, ldw, k0, n0);
+      slab_load_kn(W, ldw, k0, n0, wfree, tid);
+    }
+    const int r8 = s % (2 * SPP);
+    const bool is_w1 = s < NC && r8 >= SPP;
+    const int ka = s >= NC ? MBK * (s - NC) : (is_w1 ? MBK * (r8 - SPP) : MBK * r8);
+    const float* A = is_w1 ? L.Hs : L.Xs;
+    const bool gelu_stage = s < NC && r8 == SPP - 1;
+    // pre-activations of this chunk's epilogue: requested before the MFMA block, consumed after it
+    float a1v[16];
+    if (gelu_stage) {
+      const int f = 128 * (s / (2 * SPP)) + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        a1v[r] = m < M ? a.a1[(size_t)m * a.F + f] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < MBK / 32; ++half) {
+      const float* ab = A + (ka + 32 * half + h) * XLD + l31;
+      const float* bb = L.Ws[buf] + (32 * half + h) * WLB + col;
+      float av[16], bv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLB]; }
+      if (is_w1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+      }
+    }
+
+    if (gelu_stage) {
+      // d a1 = (do2 . W2) * gelu'(a1) * dropout  (neural.py:30-33 backwards) -> Hs (k-major) + global; b1 column sums
+      const int f = 128 * (s / (2 * SPP)) + col;
+      const int mm0 = opaque(m0);
+      float cs = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int rb = mm0 + 8 * gq + 4 * h;
+        Philox4 rnd = {0u, 0u, 0u, 0u};
+        if (a.drop_ff1.thr) rnd = philox4x32_10((uint32_t)f, (uint32_t)rb >> 2, a.drop_ff1.site, drop_step(a.drop_ff1),
+                                               a.drop_ff1.k0, a.drop_ff1.k1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * gq + q;
+          float v = acc[r] * gelu_tanh_grad(a1v[r]);
+          if (a.drop_ff1.thr) v *= drop_word(a.drop_ff1, q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w)));
+          const int lrow = 8 * gq + 4 * h + q;
+          L.Hs[col * XLD + lrow] = v;
+          if (rb + q < M) a.da1[(size_t)(rb + q) * a.F + f] = v;
+          cs += v;
+          acc[r] = 0.f;
+        }
+      }
+      cs += __shfl_xor(cs, 32, 64);                 // the two half-waves hold the other 16 rows of the same column
+      if (h == 0) a.part_b1[(size_t)blockIdx.x * 3 * a.F + f] = cs;
+    } else if (s == NC - 1) {
+      // d ln1 complete -> FF LayerNorm backward (+ d y2 residual) -> dy1, dout = dropout(dy1) -> Xs
+      float* Y = L.Hs;
+      __syncthreads();                              // every wave is done reading the last d a1 chunk from Hs
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[((r & 3) + 8 * (r >> 2) + 4 * h) * YLD + col] = acc_o[r];
+      __syncthreads();
+      float dy1r[8][2];
+      auto dyv = [&](int i, int j) { return Y[(wave * 8 + i) * YLD + lane + 64 * j]; };
+      const bool same = a.dout == a.dy1;
+      tile_ln_bwd(dyv, a.y1, a.st1, a.g1, dy2r, a.drop_ctx, dy1r, L.Xs, a.dy1, same ? nullptr : a.dout, L.Cs,
+                  opaque(m0), M, wave, lane);
+      __syncthreads();
+      park_cs(L.Cs, a.part_1, tid);
+    } else if (s == NS - 1) {
+      // d ctx = dout . Wo  (neural.py:228-231 backwards)
+      const int mm0 = opaque(m0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) a.dctx[(size_t)m * MD + col] = acc[r];
+      }
+    }
+
+    if (s + 1 < NS) slab_store_kn(L.Ws[buf ^ 1], wnext, tid);
+    __syncthreads();
+    buf ^= 1;
+  };
+  for (int s = 0; s < NS; s += 2) {
+    slab_step(s, wr0, wr1);
+    slab_step(s + 1, wr1, wr0);
+  }
+}
+
+int mlp_bwd_fused_blocks(int M) { return ps_cdiv(M, MBM); }
+
+int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
+  PS_REQUIRE(a.F % 128 == 0 && a.M > 0, "fused mlp backward: F=%d M=%d", a.F, a.M);
+  PS_REQUIRE(a.part_f && a.part_1 && a.part_b1, "fused mlp backward: column sums must be parked");
+  static bool attr_set = false;
+  const size_t lds = sizeof(MlpBwdLds);
+  if (!attr_set) {
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_fused_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

@@ -168,3 +168,26 @@ struct MlpFwdArgs {
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool ps_fusion_enabled();
+
+// ---- backward of the same tail as ONE kernel (mlp_fused.hip; d == 128, parked column sums):
+//   final-LN backward -> (. W2, gelu', dropout) -> (. W1) -> FF-LN backward (+ residual) -> dropout -> (. Wo)
+// replaces 2 LayerNorm-backward + 3 dX GEMM launches; everything the weight gradients read is still written once.
+struct MlpBwdArgs {
+  int M, F;
+  const float* denc;                                   // [M,128] grad wrt enc
+  const float* y2; const float* stf; const float* gf;  // final LN: input, {mean, rstd}, gamma
+  const float* y1; const float* st1; const float* g1;  // FF LN
+  const float* a1;                                     // [M,F] pre-activation of the hidden layer
+  const float *wo, *w1, *w2;
+  DropSpec drop_ctx, drop_ff1, drop_ff2;
+  float* do2;                                          // [M,128] d y2 after the FF2 dropout  (A of dW2)
+  float* da1;                                          // [M,F]   grad wrt a1                 (A of dW1)
+  float* dy1;                                          // [M,128] grad wrt y1 (fan-in residual of the layer input)
+  float* dout;                                         // [M,128] dy1 after the ctx dropout (== dy1 without dropout)
+  float* dctx;                                         // [M,128]
+  float* part_f;                                       // [workgroups][3][128] {dgamma_f, dbeta_f, colsum -> b2}
+  float* part_1;                                       // [workgroups][3][128] {dgamma_1, dbeta_1, colsum -> bo}
+  float* part_b1;                                      // [workgroups][3][F] slot 0: colsum -> b1
+};
+int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);
+int mlp_bwd_fused_blocks(int M);

@@ -42,6 +42,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   const bool active = rg < rpp;
   const bool fuse_fs = a.fs && a.fs_w;
   float* mean_s = red + (size_t)rpp * d;      // [d] post-dropout mean, [d] projection output (fused FS projection only)
+  // d == 128: the 16 weight rows this lane group will multiply are fetched NOW (16 B per lane, row o = rg + 8u), so
+  // their L2 round trips run under the query-word gather instead of behind it
+  const bool fs_pre = fuse_fs && d == 128;
+  float4 wpre[16];
+  float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fs_pre) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wpre[u] = *reinterpret_cast<const float4*>(a.fs_w + (size_t)(rg + 8 * u) * 128 + 4 * c);
+  }
+  if (fuse_fs && tid < nchunk) bpre = *reinterpret_cast<const float4*>(a.fs_b + 4 * c);
   const int64_t wpad = a.V - 1;
   int cnt = 0;
   for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != wpad);
@@ -100,7 +110,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   // lane, one coalesced weight row per load) owns the outputs o = grp, grp + ngrp, ...; 4 weight rows in flight.
   __syncthreads();
   float* out_s = mean_s + d;
-  {
+  if (fs_pre) {
+    const float4 mv = *reinterpret_cast<const float4*>(mean_s + 4 * c);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float4 wv = wpre[u];
+      const float s = half_sum_last(wv.x * mv.x + wv.y * mv.y + wv.z * mv.z + wv.w * mv.w);
+      if (c == 31) out_s[rg + 8 * u] = s;
+    }
+  } else {
     int lpr = 1;
     while (lpr < nchunk && lpr < 64) lpr <<= 1;
     const int ngrp = 256 / lpr, grp = tid / lpr, lc = tid - grp * lpr;
@@ -122,13 +140,14 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
       for (int u = 0; u < 4; ++u) {
         const int o = o0 + u * ngrp;
         const float s = lpr == 32 ? half_sum_last(part[u]) : group_sum(part[u], lpr);
-        if (lc == lpr - 1 && o < d) out_s[o] = tanh_fast(s + a.fs_b[o]);
+        if (lc == lpr - 1 && o < d) out_s[o] = s;
       }
     }
   }
   __syncthreads();
   if (tid < nchunk) {
     float4 y = *reinterpret_cast<const float4*>(out_s + 4 * c);
+    y.x = tanh_fast(y.x + bpre.x); y.y = tanh_fast(y.y + bpre.y); y.z = tanh_fast(y.z + bpre.z); y.w = tanh_fast(y.w + bpre.w);
     *reinterpret_cast<float4*>(a.query_emb + (size_t)b * d + 4 * c) = y;
     if (a.tem) {
       if (a.use_pos) {
@@ -670,10 +689,23 @@ int launch_loss(const ScoreArgs& a, hipStream_t st) {
 // that every fp32 atomic wave-instruction covers two contiguous 128-B row segments.
 #define BW_MAXE 16   // d <= 512
 #define SB_RG 16     // half-wave row groups per workgroup
+// With replicas (R > 1) the item tasks are independent of one another (every task owns its d enc row), so they get
+// workgroups of their own behind the B per-row workgroups: SB_RG tasks each, one round, instead of two dependent
+// rounds inside the row's workgroup — the launch is a chain of memory round trips, not bandwidth.
 __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a) {
   extern __shared__ float red[];                 // [SB_RG][d]
-  const int b = blockIdx.x, tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
+  const int tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
   const int d = a.d, epl = d >> 5, K1 = a.K + 1;
+  const bool split = a.R > 1;
+  const bool item_wg = split && (int)blockIdx.x >= a.B;
+  int b = blockIdx.x, j0 = rg, j1 = K1;
+  if (item_wg) {
+    const int t = ((int)blockIdx.x - a.B) * SB_RG + rg;
+    if (t >= a.B * K1) return;
+    b = fdiv(t, a.fK1); j0 = t - b * K1; j1 = j0 + 1;
+  } else if (split) {
+    j1 = 0;                                      // the row's workgroup only does the word tasks
+  }
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
   const float wpos = a.pos_weight ? (float)a.K : 1.f;
   const int64_t tb = clamp_idx(a.target[b], a.P);
@@ -681,7 +713,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
 #pragma unroll
   for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
   // ---- item tasks
-  for (int j = rg; j < K1; j += SB_RG) {
+  for (int j = j0; j < j1; j += SB_RG) {
     int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
     float s = a.item_scores[(size_t)b * K1 + j];
     float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
@@ -712,6 +744,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
     }
     __syncthreads();
   }
+  if (item_wg) return;
   // ---- word tasks
 #pragma unroll
   for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
@@ -752,7 +785,8 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
 
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0 && a.d <= 32 * BW_MAXE, "score bwd: d=%d unsupported", a.d);
-  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
+  const int item_wgs = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
+  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B + item_wgs), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -773,6 +807,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     float* dq_s = fsb_s;
     float* part_s = fsb_s + d;
     float* dm_s = part_s + (size_t)rpp * d;
+    const bool pre = d == 128;                    // weight rows o = rg + 8u fetched up front, under the dqpre round trip
+    float4 wq[16];
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wq[u] = *reinterpret_cast<const float4*>(a.fsb_w + (size_t)(rg + 8 * u) * 128 + 4 * cc);
+    }
     for (int e = tid; e < d; e += 256) {
       const float y = a.fsb_qe[(size_t)b * d + e];
       dq_s[e] = a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] * (1.f - y * y);
@@ -780,7 +820,15 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     int cnt = 0;
     for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
     __syncthreads();
-    if (rg < rpp) {
+    if (pre) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float s = dq_s[rg + 8 * u];
+        acc.x = fmaf(s, wq[u].x, acc.x); acc.y = fmaf(s, wq[u].y, acc.y); acc.z = fmaf(s, wq[u].z, acc.z); acc.w = fmaf(s, wq[u].w, acc.w);
+      }
+      *reinterpret_cast<float4*>(part_s + (size_t)rg * d + 4 * cc) = acc;
+    } else if (rg < rpp) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
       for (int o = rg; o < d; o += rpp) {        // coalesced weight rows, 16 B per lane

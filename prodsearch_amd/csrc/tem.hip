@@ -552,6 +552,15 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
       GemmProblem q = gp(ws + w.da1, F, 0, Lp.w1, d, 1, ws + w.dln1, d, M2, d, F);  // d ln1 = da1 . W1
       TRY(run1(q, st));
+      // fork 1: the two big weight gradients (W2, W1) start as soon as d a1 exists, under the LN backward, the Wo dX
+      // GEMM and the attention backward.  (Forked one GEMM later, behind d ctx, the side stream's 112 us of weight
+      // gradients ended 13 us after the main chain and the step paid a late join on top.)
+      static const bool wgrad_early = !(getenv("PS_WGRAD_LATE") && atoi(getenv("PS_WGRAD_LATE")) != 0);
+      if (wgrad_early) {
+        TRY(side_fork(st));
+        TRY(side_run(wg, 1, st));
+        TRY(side_run(wg1, 1, st));
+      }
       LnBwdArgs n;
       memset(&n, 0, sizeof(n));
       n.dy = ws + w.dln1; n.lddy = d; n.x = ws + l.y1; n.ldx = d; n.stats = ws + l.ff_stats; n.g = Lp.ff_ln_g;
@@ -569,10 +578,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
       TRY(run1(p, st));
       GemmProblem wgo[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
-      TRY(side_fork(st));                           // fork 1: W2, W1, Wo weight gradients under the attention backward
-      TRY(side_run(wg, 1, st));
-      TRY(side_run(wg1, 1, st));
-      TRY(side_run(wgo, 1, st));
+      if (!wgrad_early) {
+        TRY(side_fork(st));                         // fork 1 (late form): W2, W1, Wo weight gradients under the attention backward
+        TRY(side_run(wg, 1, st));
+        TRY(side_run(wg1, 1, st));
+        TRY(side_run(wgo, 1, st));
+      }
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
@@ -614,6 +625,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       }
       TRY(side_fork(st));                           // fork 2: they need the attention backward's dK / dV / dQ
       TRY(side_run(wg3, 3, st));
+      if (wgrad_early) TRY(side_run(wgo, 1, st));
       // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
       float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
       GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);

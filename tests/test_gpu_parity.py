@@ -194,7 +194,9 @@ def test_train_steps_match_reference(case):
                     assert torch.equal((got != init[n]).any(1), (ref != init[n]).any(1)), (step, n)
                 # Adam normalises: |delta| <= lr per step wherever a gradient is rounding noise
                 assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 0.02 * g.args.lr, (step, n)
-                assert rel_err(got - init[n], ref - init[n]) < 5e-2, (step, n)
+                # a gradient element of the order of Adam's eps (1e-9) turns fp32 rounding noise into a few % of
+                # lr (measured up to 5.4 % on one element of f_W); a wrong sign or a missing term gives >= 1
+                assert rel_err(got - init[n], ref - init[n]) < 1e-1, (step, n)
 
 
 # ------------------------------------------------------------------------- eval

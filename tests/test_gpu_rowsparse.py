@@ -148,7 +148,9 @@ def test_rowsparse_training_matches_oracle(case):
             if n in touched:                                # rows the optimizer moved = touched rows, exactly
                 assert torch.equal((got != init[n]).any(1), (ref != init[n]).any(1)), (step, n)
             assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 0.02 * a.lr * (step + 1), (step, n)
-            assert rel_err(got - init[n], ref - init[n]) < 5e-2, (step, n)
+            # a gradient element of the order of Adam's eps (1e-9) turns fp32 rounding noise into a few % of lr;
+            # a wrong sign or a missing term gives >= 1 (same bound as tests/test_gpu_parity.py)
+            assert rel_err(got - init[n], ref - init[n]) < 1e-1, (step, n)
 
 
 def test_rowsparse_zero_grad_without_step_cleans_touched_rows():
