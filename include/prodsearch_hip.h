@@ -118,6 +118,10 @@ typedef struct PsTemWsLayout {
 
 const char* ps_version(void);
 const char* ps_last_error(void);
+/* Tuning knob (no reference counterpart): the last encoder layer's per-replica backward runs as one fused kernel from
+ * this many replica rows upwards (default 1024, env PS_FUSE_BWD_MIN; below it five short launches are as fast).  The
+ * parity tests set it to 1 to drive the fused kernel through the small golden cases.  Returns the previous value. */
+int ps_set_fuse_bwd_min(int rows);
 
 /* Workspace the caller allocates once per shape (bytes) and its layout. */
 int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);

@@ -300,7 +300,10 @@ __device__ inline void slab_load_kn(const float* __restrict__ W, int ldw, int k0
 }
 __device__ inline void slab_store_kn(float* Wsb, const float4 (&r)[WRN], int tid) {
 #pragma unroll
-  for (int u = 0; u < WRN; ++u) *reinterpret_cast<float4*>(Wsb + ((tid >> 5) + 8 * u) * WLB + 4 * (tid & 31)) = r[u];
+  for (int u = 0; u < WRN; ++u) {   // component-wise: copying r[u] whole keeps the slab registers in a scratch alloca (SROA gives up)
+    const float4 v = make_float4(r[u].x, r[u].y, r[u].z, r[u].w);
+    *reinterpret_cast<float4*>(Wsb + ((tid >> 5) + 8 * u) * WLB + 4 * (tid & 31)) = v;
+  }
 }
 
 // LayerNorm backward of the 32 x 128 tile: wave w owns rows 8w..8w+7, lane the columns {lane, lane+64}.
@@ -309,9 +312,9 @@ __device__ inline void slab_store_kn(float* Wsb, const float4 (&r)[WRN], int tid
 //   res        : added to dx (or null);  drop: site of the dropout applied to the result for `dropped`
 // Results: dxr[i][j] = dx (+res), dropped value written k-major to Xk and row-major to `out_drop` (global), dx to
 // `out_dx` when given; column sums {dy*xhat, dy, dropped} accumulated into Cs[.][wave][.].
-template <class DyF>
-__device__ inline void tile_ln_bwd(DyF dyv, const float* __restrict__ x, const float* __restrict__ stats,
-                                   const float* __restrict__ g, const float (*res)[2], const DropSpec& drop,
+template <bool HAS_RES, class DyF>
+__device__ __forceinline__ void tile_ln_bwd(DyF dyv, const float* __restrict__ x, const float* __restrict__ stats,
+                                   const float* __restrict__ g, const float (&res)[8][2], const DropSpec& drop,
                                    float (&dxr)[8][2], float* Xk, float* out_dx, float* out_drop, float (*Cs)[4][MD],
                                    int m0, int M, int wave, int lane) {
   const float g0 = g[lane], g1 = g[lane + 64];
@@ -336,7 +339,7 @@ __device__ inline void tile_ln_bwd(DyF dyv, const float* __restrict__ x, const f
       const float s1 = wave_sum(dh0 + dh1) * (1.f / MD);
       const float s2 = wave_sum(dh0 * xh0 + dh1 * xh1) * (1.f / MD);
       float d0 = rstd * (dh0 - s1 - xh0 * s2), d1 = rstd * (dh1 - s1 - xh1 * s2);
-      if (res) { d0 += res[i][0]; d1 += res[i][1]; }
+      if (HAS_RES) { d0 += res[i][0]; d1 += res[i][1]; }
       dxr[i][0] = d0; dxr[i][1] = d1;
       float v0 = d0, v1 = d1;
       if (drop.thr) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
   {
     const float* de = a.denc;
     auto dyv = [&](int i, int j) { return de[(size_t)(m0 + wave * 8 + i) * MD + lane + 64 * j]; };
-    tile_ln_bwd(dyv, a.y2, a.stf, a.gf, nullptr, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
+    tile_ln_bwd<false>(dyv, a.y2, a.stf, a.gf, dy2r, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
   }
   slab_store_kn(L.Ws[0], wr0, tid);
   __syncthreads();
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
   int buf = 0;
 
-  auto slab_step = [&](const int s, float4 (&wfree)[WRN], const float4 (&wnext)[WRN]) {
+  auto slab_step = [&](const int s, float4 (&wfree)[WRN], const float4 (&wnext)[WRN]) __attribute__((always_inline)) {
     {
       const float* W; int ldw, k0, n0;
       slab_src(s + 2 < NS ? s + 2 : NS - 1, W, ldw, k0, n0);
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
       float dy1r[8][2];
       auto dyv = [&](int i, int j) { return Y[(wave * 8 + i) * YLD + lane + 64 * j]; };
       const bool same = a.dout == a.dy1;
-      tile_ln_bwd(dyv, a.y1, a.st1, a.g1, dy2r, a.drop_ctx, dy1r, L.Xs, a.dy1, same ? nullptr : a.dout, L.Cs,
+      tile_ln_bwd<true>(dyv, a.y1, a.st1, a.g1, dy2r, a.drop_ctx, dy1r, L.Xs, a.dy1, same ? nullptr : a.dout, L.Cs,
                   opaque(m0), M, wave, lane);
       __syncthreads();
       park_cs(L.Cs, a.part_1, tid);

@@ -499,6 +499,16 @@ static void park_colsums(LnBwdArgs& a, float* ws, const Ws& w, ColFoldList* fold
   ++fold->n;
 }
 
+static int& fuse_bwd_min_slot() {
+  static int v = getenv("PS_FUSE_BWD_MIN") ? atoi(getenv("PS_FUSE_BWD_MIN")) : 1024;
+  return v;
+}
+extern "C" int ps_set_fuse_bwd_min(int rows) {
+  const int old = fuse_bwd_min_slot();
+  fuse_bwd_min_slot() = rows;
+  return old;
+}
+
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
                         const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold) {
   const bool drop = D.training && D.dropout > 0.f;
@@ -509,7 +519,16 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   memset(&f, 0, sizeof(f));
   f.dy = ws + w.denc; f.lddy = d; f.stats = ws + w.fin_stats; f.g = P.final_ln_g; f.d = d;
   f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
-  if (NL > 0) {
+  // The last layer's whole per-replica backward (final LN, FFN, FF LN, Wo) as one kernel (mlp_fused.hip) when the
+  // forward took the fused form too; needs parked column sums (fold) and one parked row per workgroup (<= 256).
+  static const bool bwd_fuse_on = !(getenv("PS_NO_FUSE_BWD") && atoi(getenv("PS_NO_FUSE_BWD")) != 0);
+  const int bwd_fuse_min = fuse_bwd_min_slot();
+  const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 && d == 128 &&
+                         F % 128 == 0 && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
+                         mlp_bwd_fused_blocks(w.Mf) <= 256 && fold->n + 3 <= PS_MAX_COLFOLD;
+  if (fuse_last) {
+    // nothing here: launched inside the layer loop below
+  } else if (NL > 0) {
     const LayerWs& l = w.layer[NL - 1];
     f.x = ws + l.y2; f.ldx = d; f.rows = w.Mf; f.dx = ws + w.dy2; f.lddx = d;
     f.colsum = G.layer[NL - 1].b2;
@@ -534,6 +553,46 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     const float* xn = ws + l.xn;
     const int ns = l.n_in * S, M2 = l.M2;
     const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
+    const bool fused = fuse_last && i == NL - 1;
+    static const bool wgrad_early = !(getenv("PS_WGRAD_LATE") && atoi(getenv("PS_WGRAD_LATE")) != 0);
+    if (fused) {
+      MlpBwdArgs m;
+      memset(&m, 0, sizeof(m));
+      m.M = M2; m.F = F;
+      m.denc = ws + w.denc; m.y2 = ws + l.y2; m.stf = ws + w.fin_stats; m.gf = P.final_ln_g;
+      m.y1 = ws + l.y1; m.st1 = ws + l.ff_stats; m.g1 = Lp.ff_ln_g; m.a1 = ws + l.a1;
+      m.wo = Lp.wo; m.w1 = Lp.w1; m.w2 = Lp.w2;
+      m.drop_ctx = make_drop(D, PS_SITE_CTX(i)); m.drop_ff1 = make_drop(D, PS_SITE_FF1(i));
+      m.drop_ff2 = make_drop(D, PS_SITE_FF2(i));
+      m.do2 = const_cast<float*>(do2); m.da1 = ws + w.da1; m.dy1 = ws + w.dy1;
+      m.dout = drop ? ws + w.do_ : ws + w.dy1; m.dctx = ws + w.dctx;
+      const int nwg = mlp_bwd_fused_blocks(M2);
+      {   // parked column sums: {final LN gamma, beta, b2}, {b1}, {FF LN gamma, beta, bo}
+        ColFold& c0 = fold->e[fold->n];
+        m.part_f = ws + w.lnpart + (size_t)fold->n * 256 * 3 * d;
+        c0.partial = m.part_f; c0.nblk = nwg; c0.d = d;
+        c0.dst[0] = G.final_ln_g; c0.dst[1] = G.final_ln_b; c0.dst[2] = Lg.b2;
+        ++fold->n;
+        ColFold& c1 = fold->e[fold->n];
+        m.part_1 = ws + w.lnpart + (size_t)fold->n * 256 * 3 * d;
+        c1.partial = m.part_1; c1.nblk = nwg; c1.d = d;
+        c1.dst[0] = Lg.ff_ln_g; c1.dst[1] = Lg.ff_ln_b; c1.dst[2] = Lg.bo;
+        ++fold->n;
+        ColFold& c2 = fold->e[fold->n];
+        m.part_b1 = ws + w.gcpart;
+        c2.partial = m.part_b1; c2.nblk = nwg; c2.d = F;
+        c2.dst[0] = Lg.b1; c2.dst[1] = nullptr; c2.dst[2] = nullptr;
+        ++fold->n;
+      }
+      TRY(launch_mlp_bwd_fused(m, st));
+      GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
+      GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
+      GemmProblem wgo[1] = {gp_wgrad(m.dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
+      TRY(side_fork(st));                           // fork 1: W2, W1, Wo weight gradients under the attention backward
+      TRY(side_run(wg, 1, st));
+      TRY(side_run(wg1, 1, st));
+      TRY(side_run(wgo, 1, st));
+    } else {
     // FFN backward
       GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
       p.act = ACT_GELU_BWD; p.act_aux = ws + l.a1; p.drop = make_drop(D, PS_SITE_FF1(i)); p.colsum = Lg.b1;
@@ -555,7 +614,6 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // fork 1: the two big weight gradients (W2, W1) start as soon as d a1 exists, under the LN backward, the Wo dX
       // GEMM and the attention backward.  (Forked one GEMM later, behind d ctx, the side stream's 112 us of weight
       // gradients ended 13 us after the main chain and the step paid a late join on top.)
-      static const bool wgrad_early = !(getenv("PS_WGRAD_LATE") && atoi(getenv("PS_WGRAD_LATE")) != 0);
       if (wgrad_early) {
         TRY(side_fork(st));
         TRY(side_run(wg, 1, st));
@@ -571,19 +629,22 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       n.colsum = Lg.bo; n.dgamma = Lg.ff_ln_g; n.dbeta = Lg.ff_ln_b;
       park_colsums(n, ws, w, fold);
       TRY(launch_ln_bwd(n, st));
+      const float* dout0 = drop ? ws + w.do_ : ws + w.dy1;
+      GemmProblem pc = gp(dout0, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
+      TRY(run1(pc, st));
+      if (!wgrad_early) {
+        GemmProblem wgo0[1] = {gp_wgrad(dout0, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
+        TRY(side_fork(st));                         // fork 1 (late form): W2, W1, Wo weight gradients under the attention backward
+        TRY(side_run(wg, 1, st));
+        TRY(side_run(wg1, 1, st));
+        TRY(side_run(wgo0, 1, st));
+      }
+    }
 
     const float* dout = drop ? ws + w.do_ : ws + w.dy1;
     // attention backward
     {
-      GemmProblem p = gp(dout, d, 0, Lp.wo, d, 1, ws + w.dctx, d, M2, d, d);    // d ctx = do . Wo
-      TRY(run1(p, st));
       GemmProblem wgo[1] = {gp_wgrad(dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
-      if (!wgrad_early) {
-        TRY(side_fork(st));                         // fork 1 (late form): W2, W1, Wo weight gradients under the attention backward
-        TRY(side_run(wg, 1, st));
-        TRY(side_run(wg1, 1, st));
-        TRY(side_run(wgo, 1, st));
-      }
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
@@ -625,7 +686,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       }
       TRY(side_fork(st));                           // fork 2: they need the attention backward's dK / dV / dQ
       TRY(side_run(wg3, 3, st));
-      if (wgrad_early) TRY(side_run(wgo, 1, st));
+      if (wgrad_early && !fused) TRY(side_run(wgo, 1, st));
       // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
       float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
       GemmProblem x = gp(ws + w.dkv, a.lddkv, 0, Lp.wk, d, 1, dxn, d, ns, d, qall ? 3 * d : 2 * d);

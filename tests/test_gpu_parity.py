@@ -165,6 +165,19 @@ def test_gradients_match_reference(case):
             assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n
 
 
+@pytest.mark.parametrize('case', [c for c in CASES if c.startswith('tem')])
+def test_gradients_match_reference_fused_backward(case):
+    """The fused per-replica backward kernel (mlp_fused.hip) normally starts at 1024 replica rows; forced on here so
+    the golden cases (<= 672 rows) check it against the reference's gradients as well."""
+    from prodsearch_amd import _lib
+    old = _lib.load().ps_set_fuse_bwd_min(1)
+    try:
+        test_gradients_match_reference(case)
+        test_train_steps_match_reference(case)
+    finally:
+        _lib.load().ps_set_fuse_bwd_min(old)
+
+
 @pytest.mark.parametrize('case', CASES)
 def test_train_steps_match_reference(case):
     """trainer.py:74-79 call order for every golden step: losses, lr and post-Adam parameters."""

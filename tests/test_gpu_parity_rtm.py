@@ -91,6 +91,17 @@ def test_rtm_gradients_and_steps(case):
         assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 0.02 * g.args.lr * g.steps, n
 
 
+@pytest.mark.parametrize('case', ['rtm_pvc_drop', 'rtm_pv'])
+def test_rtm_gradients_and_steps_fused_backward(case):
+    """Same check with the fused per-replica backward kernel forced on (it normally starts at 1024 replica rows)."""
+    from prodsearch_amd import _lib
+    old = _lib.load().ps_set_fuse_bwd_min(1)
+    try:
+        test_rtm_gradients_and_steps(case)
+    finally:
+        _lib.load().ps_set_fuse_bwd_min(old)
+
+
 @pytest.mark.parametrize('case', RTM_CASES)
 def test_rtm_eval_scores(case):
     g = RtmGolden(case)
