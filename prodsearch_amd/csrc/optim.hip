@@ -14,9 +14,10 @@
 static inline int64_t align16(int64_t x) { return (x + 15) & ~(int64_t)15; }
 
 extern "C" int64_t ps_adam_plan_bytes(int32_t n, const int64_t* numel) {
-  (void)numel;
+  int64_t chunks = 0;
+  for (int i = 0; i < n; ++i) chunks += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
   return align16(sizeof(AdamPlanHeader)) + 4 * align16(8 * (int64_t)n) + align16(8 * (int64_t)n) +
-         align16(4 * (int64_t)(n + 1));
+         align16(4 * (int64_t)(n + 1)) + align16(4 * chunks);
 }
 
 extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const* g, float* const* m,
@@ -30,8 +31,10 @@ extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const*
   h.off_m = off; off += align16(8 * (int64_t)n);
   h.off_v = off; off += align16(8 * (int64_t)n);
   h.off_numel = off; off += align16(8 * (int64_t)n);
-  h.off_chunk0 = off;
+  h.off_chunk0 = off; off += align16(4 * (int64_t)(n + 1));
+  h.off_chunk_tensor = off;
   int32_t* chunk0 = (int32_t*)(base + h.off_chunk0);
+  int32_t* chunk_tensor = (int32_t*)(base + h.off_chunk_tensor);
   int64_t chunks = 0;
   for (int i = 0; i < n; ++i) {
     PS_REQUIRE(p[i] && g[i] && m[i] && v[i] && numel[i] > 0, "adam plan: tensor %d null/empty", i);
@@ -41,7 +44,10 @@ extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const*
     ((float**)(base + h.off_v))[i] = v[i];
     ((int64_t*)(base + h.off_numel))[i] = numel[i];
     chunk0[i] = (int32_t)chunks;
-    chunks += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+    const int64_t nc = (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+    PS_REQUIRE(chunks + nc < (1 << 30), "adam plan: too many chunks");
+    for (int64_t c = 0; c < nc; ++c) chunk_tensor[chunks + c] = i;
+    chunks += nc;
   }
   chunk0[n] = (int32_t)chunks;
   PS_REQUIRE(chunks < (1 << 30), "adam plan: too many chunks");

@@ -9,15 +9,11 @@ struct AdamPlanHeader {
   int32_t n_tensors;
   int32_t n_chunks;
   int64_t off_p, off_g, off_m, off_v, off_numel, off_chunk0;   // byte offsets inside the plan
-};
+  int64_t off_chunk_tensor;           // int32[n_chunks]: the tensor each chunk belongs to (one load instead of a
+};                                    // binary search = log2(n_tensors) dependent loads at the head of every block)
 
-__device__ inline int find_tensor(const int32_t* chunk0, int n, int chunk) {
-  int lo = 0, hi = n;                 // chunk0[lo] <= chunk < chunk0[hi]
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (chunk0[mid] <= chunk) lo = mid; else hi = mid;
-  }
-  return lo;
+__device__ inline int find_tensor(const char* plan, const AdamPlanHeader* h, int chunk) {
+  return ((const int32_t*)(plan + h->off_chunk_tensor))[chunk];
 }
 
 __device__ inline float block_sum_256(float v, float* sh) {
@@ -34,7 +30,7 @@ __device__ inline float block_sum_256(float v, float* sh) {
 __device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad_scale, float* sh) {
   const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
   const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
-  const int t = find_tensor(chunk0, h->n_tensors, chunk);
+  const int t = find_tensor(plan, h, chunk);
   const float* g = ((float* const*)(plan + h->off_g))[t];
   const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
   const int64_t beg = (int64_t)(chunk - chunk0[t]) * ADAM_CHUNK;
@@ -86,7 +82,7 @@ __device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& 
 __device__ inline void adam_update_chunk(const char* plan, int chunk, const AdamScal& a) {
   const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
   const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
-  const int t = find_tensor(chunk0, h->n_tensors, chunk);
+  const int t = find_tensor(plan, h, chunk);
   float* p = ((float* const*)(plan + h->off_p))[t];
   const float* g = ((float* const*)(plan + h->off_g))[t];
   float* m = ((float* const*)(plan + h->off_m))[t];

@@ -621,11 +621,106 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
   }
 }
 
+// ---- HBM-bound launches (>= 64 MB of rows: the C5 shape, 1 KiB rows of a 51 GB table).  Measured there
+// (profiles/r01_gather_score_tuning.txt): the launch is bound by TASKS in flight, not bytes — a word task (1 KiB from
+// HBM, its vector cached) costs as much as an item task (2 KiB) — because every task is two dependent round trips of
+// ~2.5 us under load and a CU holds at most 32 waves.  So the row groups get NARROWER instead of the waves deeper:
+// lpr = d/4/CH lanes per row, CH 16-byte chunks per lane (each wave-instruction still covers 256-B contiguous
+// segments), i.e. CH times the tasks per wave at the same occupancy.  (A persistent, software-pipelined form that
+// prefetches the next indices under the current rows was correct but 25 % slower: its registers halve the occupancy.)
+__device__ inline float row16_sum_last(float v) {   // sum over rows of 16 lanes, valid in lane 15 of each row
+#define PS_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  PS_DPP_ADD(0x111); PS_DPP_ADD(0x112); PS_DPP_ADD(0x114); PS_DPP_ADD(0x118);
+#undef PS_DPP_ADD
+  return v;
+}
+template <int SCORE_U, int CH>
+__global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, int ntask, int lpr) {
+  const int tid = threadIdx.x;
+  const int gpb = 256 / lpr;
+  const int grp = blockIdx.x * gpb + tid / lpr;
+  const int c = tid % lpr;
+  const int t0 = grp * SCORE_U;
+  Task tk[SCORE_U];
+  float4 r[SCORE_U][CH], v[SCORE_U][CH];
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u) {
+    int t = t0 + u;
+    if (t < ntask) tk[u] = score_task(a, t);
+    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; tk[u].lw = 0.f; }
+  }
+  float cps = 0.f, cil = 0.f;
+  const int wl = lpr == 32 ? 31 : (lpr == 16 ? 15 : 0);
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u)
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      r[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u][k] = r[u][k];
+      if (tk[u].row) {
+        r[u][k] = *reinterpret_cast<const float4*>(tk[u].row + 4 * (c + lpr * k));
+        v[u][k] = *reinterpret_cast<const float4*>(tk[u].vec + 4 * (c + lpr * k));
+      }
+    }
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      s += r[u][k].x * v[u][k].x + r[u][k].y * v[u][k].y + r[u][k].z * v[u][k].z + r[u][k].w * v[u][k].w;
+    s = lpr == 32 ? half_sum_last(s) : (lpr == 16 ? row16_sum_last(s) : group_sum(s, lpr));
+    if (c == wl && tk[u].out) {
+      const float sc = s + tk[u].bias;
+      *tk[u].out = sc;
+      if (tk[u].term) {
+        const float term = fabsf(tk[u].tw) * softplus_f(tk[u].tw < 0.f ? -sc : sc);
+        *tk[u].term = term;
+        if (tk[u].lw > 0.f) cps += term; else cil -= term * tk[u].lw;
+      }
+    }
+  }
+  if (!a.loss_blk || a.C > 0) return;
+  __shared__ float rps[64], ril[64];
+  if (c == wl) { rps[tid / lpr] = cps; ril[tid / lpr] = cil; }
+  __syncthreads();
+  if (tid == 0) {
+    float p = 0.f, q = 0.f;
+    for (int g2 = 0; g2 < gpb; ++g2) { p += rps[g2]; q += ril[g2]; }
+    a.loss_blk[2 * blockIdx.x] = p;
+    a.loss_blk[2 * blockIdx.x + 1] = q;
+  }
+}
+
+// wide form: chunks per lane (0 = use the one-chunk kernels above).  Default: 16 lanes per row (d = 128: 2 chunks,
+// 256: 4, 512: 8), 8 lanes per row for launches of >= 256 MB of rows; other widths keep the one-chunk kernels.
+// Measured (MI355X): C5 shape B=1024 22.6 -> 13.6 us (4.99 TB/s), B=8192 167 -> 95.7 us (5.65 TB/s = 0.71 of the HBM
+// peak); the latency-bound C2 launch 5.03 -> 4.23 us back to back (floor of an empty launch: 3.8 us).
+static int score_wide_ch(const ScoreArgs& a, int ntask) {
+  static const int env = getenv("PS_SCORE_CH") ? atoi(getenv("PS_SCORE_CH")) : -1;   // tuning: 0 off, 2 / 4 / 8 force
+  const int nch = a.d / 4;
+  int ch;
+  if (env >= 0) ch = env;
+  else {
+    const bool huge = (size_t)ntask * a.d * 4 >= ((size_t)256 << 20);
+    ch = nch / (huge ? 8 : 16);
+    if (ch > 8) ch = 8;
+  }
+  while (ch > 1 && (nch % ch != 0 || nch / ch < 8 || ((nch / ch) & (nch / ch - 1)) != 0 || nch / ch > 64)) ch >>= 1;
+  return (ch == 2 || ch == 4 || ch == 8) && nch / ch <= 64 ? ch : 0;
+}
+static int score_wide_u() {
+  static const int env = getenv("PS_SCORE_WIDE_U") ? atoi(getenv("PS_SCORE_WIDE_U")) : 1;
+  static const int ch = getenv("PS_SCORE_CH") ? atoi(getenv("PS_SCORE_CH")) : 0;
+  return env == 2 && ch != 8 ? 2 : 1;
+}
+
 int score_fwd_blocks(const ScoreArgs& a) {
   const int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
   const int lpr = lpr_for(a.d);
   static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;
   const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
+  if (const int ch = score_wide_ch(a, ntask)) return ps_cdiv(ps_cdiv(ntask, score_wide_u()), 256 / (a.d / 4 / ch));
   return ps_cdiv(ps_cdiv(ntask, U), 256 / lpr);
 }
 
@@ -638,6 +733,18 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;     // tuning experiments
   static const int NT = getenv("PS_SCORE_NT") ? atoi(getenv("PS_SCORE_NT")) : 0;
   const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
+  if (const int ch = score_wide_ch(a, ntask)) {
+    const int wl = a.d / 4 / ch, wu = score_wide_u();
+    const int wb = ps_cdiv(ps_cdiv(ntask, wu), 256 / wl);
+    a.loss_nblk = wb;
+    if (ch == 8) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 8>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (ch == 4 && wu == 1) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (ch == 4) hipLaunchKernelGGL((score_fwd_wide_kernel<2, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (wu == 1) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else hipLaunchKernelGGL((score_fwd_wide_kernel<2, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   int groups = ps_cdiv(ntask, U);
   int blocks = ps_cdiv(groups, 256 / lpr);
   dim3 g(blocks), b(256);
@@ -697,14 +804,19 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
   const int tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
   const int d = a.d, epl = d >> 5, K1 = a.K + 1;
   const bool split = a.R > 1;
-  const bool item_wg = split && (int)blockIdx.x >= a.B;
+  const bool item_wg = split && (int)blockIdx.x >= 2 * a.B;
   int b = blockIdx.x, j0 = rg, j1 = K1;
+  int wt0 = rg, wstride = SB_RG;                 // word tasks of this workgroup: wt0, wt0 + wstride, ...
   if (item_wg) {
-    const int t = ((int)blockIdx.x - a.B) * SB_RG + rg;
+    const int t = ((int)blockIdx.x - 2 * a.B) * SB_RG + rg;
     if (t >= a.B * K1) return;
     b = fdiv(t, a.fK1); j0 = t - b * K1; j1 = j0 + 1;
   } else if (split) {
-    j1 = 0;                                      // the row's workgroup only does the word tasks
+    // two workgroups per batch row share its W*(K+1) word tasks (21 at C2: one round each instead of two dependent
+    // rounds in one workgroup); each adds its part of the target-item row gradient
+    b = (int)blockIdx.x >> 1;
+    wt0 = rg + ((int)blockIdx.x & 1) * SB_RG; wstride = 2 * SB_RG;
+    j1 = 0;                                      // the row's workgroups only do the word tasks
   }
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
   const float wpos = a.pos_weight ? (float)a.K : 1.f;
@@ -752,7 +864,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
   for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
   const float cf = invB / (float)(cnt > 0 ? cnt : 1);
   const float* prow = a.product_emb + (size_t)tb * d;
-  for (int t = rg; t < a.W * K1; t += SB_RG) {
+  for (int t = wt0; t < a.W * K1; t += wstride) {
     int w = t / K1, j = t - w * K1;
     int64_t pw = a.pos_words[(size_t)b * a.W + w];
     if (pw == a.V - 1) continue;                                  // masked window slot (get_vector_mean)
@@ -786,7 +898,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0 && a.d <= 32 * BW_MAXE, "score bwd: d=%d unsupported", a.d);
   const int item_wgs = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
-  hipLaunchKernelGGL(score_bwd_kernel, dim3(a.B + item_wgs), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
+  hipLaunchKernelGGL(score_bwd_kernel, dim3((a.R > 1 ? 2 : 1) * a.B + item_wgs), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

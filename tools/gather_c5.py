@@ -25,9 +25,10 @@ def main():
     ap.add_argument('--vocab', type=int, default=2_000_000)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--w', type=int, default=1, help='pv_window_size (0: item tasks only)')
     a = ap.parse_args()
     lib = _lib.load()
-    d, B, K, W, P, V = 256, a.batch, 20, 1, a.rows, a.vocab
+    d, B, K, W, P, V = 256, a.batch, 20, a.w, a.rows, a.vocab
     dev = 'cuda'
     gen = torch.Generator(device=dev).manual_seed(1)
     table = torch.empty(P + 1, d, device=dev)
@@ -46,7 +47,7 @@ def main():
     params = _lib.PsTemTensors()
     params.product_emb, params.word_emb, params.word_bias = table.data_ptr(), words.data_ptr(), wbias.data_ptr()
     mk = lambda hi, *shape: torch.randint(0, hi, shape, device=dev, dtype=torch.int64, generator=gen)
-    target, negs, pw, nw = mk(P, B), mk(P, B, K), mk(V - 1, B, W), mk(V - 1, B, W * K)
+    target, negs, pw, nw = mk(P, B), mk(P, B, K), mk(V - 1, B, max(W, 1)), mk(V - 1, B, max(W, 1) * K)
     bt = _lib.PsTemBatch()
     bt.target_prod_idxs, bt.neg_item_idxs = target.data_ptr(), negs.data_ptr()
     bt.pos_iword_idxs, bt.neg_word_idxs = pw.data_ptr(), nw.data_ptr()
