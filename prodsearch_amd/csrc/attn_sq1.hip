@@ -196,6 +196,15 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
   const int JC = a.jc;
   Sq1Lds l = sq1_carve(lds, S, d, H, true, JC);
+  // folded dQ.Wq (AttnArgs::wq; D == 128, d == 64): thread (half, i) owns output column i and 32 of this group's 64
+  // query features; its 32 weights are requested now and used after the whole backward, ~30 us later
+  const bool fold_q = a.wq != nullptr;
+  float wq[32];
+  if (fold_q) {
+    const int i = tid & 127, half = tid >> 7;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(c0 + half * 32 + k) * 128 + i];
+  }
   sq1_load(a, l, b, tid, d, c0);
   for (int i = tid; i < H * S; i += 256) {
     const int h = fdiv(i, a.fS), s = i - h * S;
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     }
     dq *= a.qscale;
     a.dq[(size_t)b * a.lddq + c0 + c] = dq;
+    if (fold_q) l.q[c] = dq;                                 // only this thread read q[c]
     if (a.bias_part) {                                       // parked: folded by the step's last launch
       float* bp = a.bias_part + (size_t)b * 3 * D + c0 + c;
       bp[0] = dq; bp[D] = sk; bp[2 * D] = sv;
@@ -265,6 +275,19 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
       atomicAdd(&a.dbk[c0 + c], sk);
       atomicAdd(&a.dbv[c0 + c], sv);
     }
+  }
+  if (!fold_q) return;
+  __syncthreads();
+  {
+    const int i = tid & 127, half = tid >> 7;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf(l.q[half * 32 + k], wq[k], acc);
+    float* part = l.dV;                                      // free: dK / dV have been written out
+    __syncthreads();
+    if (half == 1) part[i] = acc;
+    __syncthreads();
+    if (half == 0) a.dxq_part[((size_t)blockIdx.y * gridDim.x + b) * 128 + i] = acc + part[i];
   }
 }
 
@@ -282,6 +305,7 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SQ1_LDS_MAX));
     attr_b = true;
   }
+  PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128 && hy == 2), "attention bwd(sq1): folded dQ.Wq needs d == 128 and two head groups");
   hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in, hy), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;

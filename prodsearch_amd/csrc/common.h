@@ -191,6 +191,7 @@ struct ResMap {           // row map between replica rows and layer-input rows
                           // FANIN : out row m=(n_in,pos) -> sum_j src row ((n_in*fan+j)*Sq + i), only q rows
   const float* extra;     // FANIN with Sq == 1: one more row per sequence added at the query position
   int extra_ld;           //   (the dQ.Wq term of the attention backward), [n_in, extra_ld]
+  const float* extra2;    // second partial of the same term (the attention backward's two head groups), or null
 };
 
 __device__ inline float res_value(const ResMap& R, int row, int col) {
@@ -209,6 +210,7 @@ __device__ inline float res_value(const ResMap& R, int row, int col) {
     float s = 0.f;
     for (int j = 0; j < R.fan; ++j) s += R.ptr[(size_t)((nin * R.fan + j) * R.Sq + i) * R.ld + col];
     if (R.extra) s += R.extra[(size_t)nin * R.extra_ld + col];
+    if (R.extra2) s += R.extra2[(size_t)nin * R.extra_ld + col];
     return s;
   }
   return 0.f;

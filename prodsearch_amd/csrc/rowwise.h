@@ -72,6 +72,10 @@ struct AttnArgs {
   float* dbq; float* dbk; float* dbv;   // += (atomics)
   float* bias_part;              // optional [n_in][3][d]: the sq1 backward parks {dbq, dbk, dbv} here instead (ColFoldList)
   float qscale;                  // 1/sqrt(dh)
+  // optional (sq1 backward, d == 128, two head groups): the input gradient of the query projection folded into the
+  // kernel's tail — each head-group workgroup multiplies its 64 dq values into Wq (rows prefetched at kernel start) and
+  // writes one partial row  dxq_part[group][sequence][d];  the dX GEMM's fan-in epilogue adds both (ResMap::extra/extra2)
+  const float* wq; float* dxq_part;
 };
 inline void attn_finish(AttnArgs& a) {
   a.fS = make_fdiv(a.S); a.fd = make_fdiv(a.d); a.fdh = make_fdiv(a.dh); a.fd4 = make_fdiv(a.d / 4);

@@ -668,6 +668,11 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         cf.partial = a.bias_part; cf.nblk = l.n_in; cf.d = d;
         cf.dst[0] = Lg.bq; cf.dst[1] = Lg.bk; cf.dst[2] = Lg.bv;
       }
+      // first layer, one query row per sequence, d == 128: dQ.Wq rides in the attention backward's tail (two partial
+      // rows per sequence in the free d ln1 buffer) instead of a [n_in,128]x[128,128] GEMM launch of its own
+      const bool q_folded = sq1 && !qall && i == 0 && d == 128 && D.H % 8 == 0 && ps_fusion_enabled() &&
+                            (size_t)2 * l.n_in <= (size_t)M2;
+      if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; }
       TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
@@ -680,12 +685,19 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // (as a trailing accumulate-GEMM it took 26 us on the critical path under them)
       const bool q_via_res = !qall && i == 0;
       float* dxq = ws + w.dctx;                      // free again: the attention backward has consumed it
-      if (q_via_res) {
+      if (q_via_res && !q_folded) {
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxq, d, l.n_in, d, d);
         TRY(run1(xq, st));
       }
-      TRY(side_fork(st));                           // fork 2: they need the attention backward's dK / dV / dQ
-      TRY(side_run(wg3, 3, st));
+      // fork 2: they need the attention backward's dK / dV / dQ.  With the fused backward the side stream already
+      // holds W2 / W1 / Wo (~90 us, the step's tail): the K/V/Q weight gradients then follow the dX GEMM on the MAIN
+      // stream instead — one event less, and the side stream ends before the scatter does.
+      static const bool wg3_main_on = !(getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) != 0);
+      const bool wg3_main = fused && wg3_main_on;
+      if (!wg3_main) {
+        TRY(side_fork(st));
+        TRY(side_run(wg3, 3, st));
+      }
       if (wgrad_early && !fused) TRY(side_run(wgo, 1, st));
       // d xn = dK.Wk + dV.Wv (+ dQ.Wq)
       float* dxn = i == 0 ? ws + w.dx : ws + w.dxn;
@@ -694,9 +706,11 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
         x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
         x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
-        if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
+        if (q_folded) { x.res.extra = ws + w.dln1; x.res.extra2 = ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; }
+        else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
       }
       TRY(run1(x, st));
+      if (wg3_main) TRY(run_wgrads(wg3, 3, st));
       if (!qall && !q_via_res) {
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
         xq.accumulate = 1;
