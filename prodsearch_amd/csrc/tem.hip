@@ -177,10 +177,14 @@ GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* 
   p.accumulate = 2;
   return p;
 }
-static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, at least one 128-row slab each
+static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, but at least ~512 reduction rows per split
+  // Every split adds a 64x64 tile of fp32 atomics onto the same weight-gradient addresses.  Measured: C2 (8,064 rows; step
+  // time by blocks per launch: 512 0.380 ms, 256 0.375, 224 0.373, 192 0.372-0.377, 128 0.392) wants ~15 splits of ~540
+  // rows; the review transformer (78k rows, 4 tiles) wants its 128 splits of ~610 rows (1.146 ms vs 1.193 with 56).
   static const int target = getenv("PS_WGRAD_BLOCKS") ? atoi(getenv("PS_WGRAD_BLOCKS")) : 512;   // tuning experiments
+  static const int min_rows = getenv("PS_WGRAD_ROWS") ? atoi(getenv("PS_WGRAD_ROWS")) : 512;
   int want = target / (tiles > 0 ? tiles : 1);
-  int cap = (rows + 127) / 128;
+  int cap = (rows + min_rows - 1) / min_rows;
   int ks = want < cap ? want : cap;
   return ks < 1 ? 1 : ks;
 }
