@@ -697,7 +697,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // holds W2 / W1 / Wo (~90 us, the step's tail): the K/V/Q weight gradients then follow the dX GEMM on the MAIN
       // stream instead — one event less, and the side stream ends before the scatter does.
       static const bool wg3_main_on = !(getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) != 0);
-      const bool wg3_main = fused && wg3_main_on;
+      const bool wg3_main = fused && wg3_main_on && ns <= 2 * M2;   // (review transformer: 78k K/V rows vs 1.5k replica rows -> side)
       if (!wg3_main) {
         TRY(side_fork(st));
         TRY(side_run(wg3, 3, st));

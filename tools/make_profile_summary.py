@@ -16,10 +16,10 @@ out.append("Workload: %s -> %d encoder replicas per row.\n" % (pj['config']['wor
 out.append("| kernel | calls | avg µs | share |\n|---|---|---|---|")
 for r in rows:
     out.append("| `%s` | %s | %.1f | %s%% |" % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
-sc = [r for r in rows if 'score_fwd_kernel' in r['Name']]
+sc = [r for r in rows if 'score_fwd' in r['Name']]
 rf = bj['roofline']
 out.append("")
-out.append("`score_fwd_kernel` is the embedding-gather+score kernel of the roofline: the trace holds the in-step launches plus the "
+out.append("`score_fwd_wide_kernel` is the embedding-gather+score kernel of the roofline: the trace holds the in-step launches plus the "
            "launches of bench.py's event-timed loop; its average here is %.2f µs, bench.py's HIP-event figure (back-to-back "
            "launches, includes the inter-launch gap) %.2f µs/launch -> %.0f GB/s algorithmic = %.3f of 8 TB/s.\n"
            % (float(sc[0]['AverageNs']) / 1e3 if sc else float('nan'), rf['us_per_launch'], rf['achieved'], rf['frac']))
