@@ -212,7 +212,7 @@ def main():
             pass
         out["roofline"] = {"bound": "hbm", "achieved": nbytes / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": nbytes / t_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "score_fwd_wide_kernel<1,2> (embedding gather + score; 16 lanes per 512-B row)",
+                           "kernel": "score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
                            "bytes_per_launch": nbytes, "us_per_launch": t_k * 1e6}
         if world == 1 and a.cpu_steps > 0 and a.workload == 'c2':
             out["cpu_baseline"] = cpu_baseline(ns, a.cpu_steps)
