@@ -34,8 +34,12 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
 // Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
 // `fold` (optional): the LayerNorm backwards park their column sums in w.lnpart and append to this list; the caller
 // must hand it to a later launch_embed_scatter (EmbedBwdArgs::fold).  nullptr: plain atomics.
+// `score_on_side` (optional, TEM with replicas): the caller has NOT launched the score backward; when the last layer's
+// backward is fused, d enc is derived from the scores inside that kernel and the score backward (table scatter only) is
+// launched on the side stream behind it, off the dependent chain; otherwise it is launched first, as usual.
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
-                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold = nullptr);
+                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold = nullptr,
+                        const ScoreArgs* score_on_side = nullptr);
 
 GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M, int N, int K);
 int run1(const GemmProblem& p, hipStream_t st);

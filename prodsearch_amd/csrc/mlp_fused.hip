@@ -307,7 +307,7 @@ __device__ inline void slab_store_kn(float* Wsb, const float4 (&r)[WRN], int tid
 }
 
 // LayerNorm backward of the 32 x 128 tile: wave w owns rows 8w..8w+7, lane the columns {lane, lane+64}.
-//   dyv(i, j)  : grad wrt the LN output at (row 8w+i, column lane + 64j)
+//   dyv(i, a, b): grad wrt the LN output at row 8w+i, columns lane (a) and lane + 64 (b); called for rows < M only
 //   x, stats, g: LN input rows (global, ld = MD), {mean, rstd} per row, gamma
 //   res        : added to dx (or null);  drop: site of the dropout applied to the result for `dropped`
 // Results: dxr[i][j] = dx (+res), dropped value written k-major to Xk and row-major to `out_drop` (global), dx to
@@ -333,7 +333,8 @@ __device__ __forceinline__ void tile_ln_bwd(DyF dyv, const float* __restrict__ x
       const bool ok = m < M;
       const float mean = ok ? stats[2 * (size_t)m] : 0.f, rstd = ok ? stats[2 * (size_t)m + 1] : 0.f;
       const float x0 = ok ? x[(size_t)m * MD + lane] : 0.f, x1 = ok ? x[(size_t)m * MD + lane + 64] : 0.f;
-      const float dy0 = ok ? dyv(i, 0) : 0.f, dy1 = ok ? dyv(i, 1) : 0.f;
+      float dy0 = 0.f, dy1 = 0.f;
+      if (ok) dyv(i, dy0, dy1);
       const float xh0 = (x0 - mean) * rstd, xh1 = (x1 - mean) * rstd;
       const float dh0 = dy0 * g0, dh1 = dy1 * g1;
       const float s1 = wave_sum(dh0 + dh1) * (1.f / MD);
@@ -397,9 +398,32 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
   // ---- final LayerNorm backward (transformer.py:86) -> d y2 (kept: residual of the FF LayerNorm), do2 -> Xs
   float dy2r[8][2];
   {
-    const float* de = a.denc;
-    auto dyv = [&](int i, int j) { return de[(size_t)(m0 + wave * 8 + i) * MD + lane + 64 * j]; };
-    tile_ln_bwd<false>(dyv, a.y2, a.stf, a.gf, dy2r, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
+    if (a.item_scores) {
+      // d enc taken straight from the score: row m = (b, j) of enc was dotted with item row idx(b, j), so
+      // d enc[m] = loss'(score[m]) * product_emb[idx]  (item_transformer.py:485,493-494,500-514) — the score backward
+      // launch then only scatters into the tables and leaves the step's dependent chain (it runs on the side stream)
+      const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+      const float wpos = a.pos_weight ? (float)a.K : 1.f;
+      const int K1 = a.K + 1;
+      auto dyv = [&](int i, float& d0, float& d1) {
+        const int m = m0 + wave * 8 + i;
+        const int b = m / K1, j = m - b * K1;
+        int64_t idx = j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1];
+        idx = idx < 0 ? a.P : (idx > a.P ? a.P : idx);
+        const float sc = a.item_scores[m];
+        const float ds = (j == 0 ? wpos * (sigmoid_f(sc) - 1.f) : sigmoid_f(sc)) * invB;
+        const float* row = a.product_emb + (size_t)idx * MD;
+        d0 = ds * row[lane]; d1 = ds * row[lane + 64];
+      };
+      tile_ln_bwd<false>(dyv, a.y2, a.stf, a.gf, dy2r, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
+    } else {
+      const float* de = a.denc;
+      auto dyv = [&](int i, float& d0, float& d1) {
+        const float* p = de + (size_t)(m0 + wave * 8 + i) * MD;
+        d0 = p[lane]; d1 = p[lane + 64];
+      };
+      tile_ln_bwd<false>(dyv, a.y2, a.stf, a.gf, dy2r, a.drop_ff2, dy2r, L.Xs, nullptr, a.do2, L.Cs, m0, M, wave, lane);
+    }
   }
   slab_store_kn(L.Ws[0], wr0, tid);
   __syncthreads();
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
       for (int r = 0; r < 16; ++r) Y[((r & 3) + 8 * (r >> 2) + 4 * h) * YLD + col] = acc_o[r];
       __syncthreads();
       float dy1r[8][2];
-      auto dyv = [&](int i, int j) { return Y[(wave * 8 + i) * YLD + lane + 64 * j]; };
+      auto dyv = [&](int i, float& d0, float& d1) { d0 = Y[(wave * 8 + i) * YLD + lane]; d1 = Y[(wave * 8 + i) * YLD + lane + 64]; };
       const bool same = a.dout == a.dy1;
       tile_ln_bwd<true>(dyv, a.y1, a.st1, a.g1, dy2r, a.drop_ctx, dy1r, L.Xs, a.dy1, same ? nullptr : a.dout, L.Cs,
                   opaque(m0), M, wave, lane);

@@ -109,7 +109,7 @@ struct ScoreArgs {
   // backward
   float scale;                   // loss_scale
   const float* scale_dev;        // optional device scalar multiplied into scale
-  float* denc;                   // [B*R,d]
+  float* denc;                   // [B*R,d]  (null: the consumer derives d enc from the scores itself, MlpBwdArgs::item_scores)
   float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
 };
 inline void score_finish(ScoreArgs& a) {
@@ -178,7 +178,10 @@ bool ps_fusion_enabled();
 // replaces 2 LayerNorm-backward + 3 dX GEMM launches; everything the weight gradients read is still written once.
 struct MlpBwdArgs {
   int M, F;
-  const float* denc;                                   // [M,128] grad wrt enc
+  const float* denc;                                   // [M,128] grad wrt enc (unused when item_scores is set)
+  // optional: d enc computed from the scores instead (TEM with replicas: row m = (b, j), M = B*(K+1))
+  const float* item_scores; const int64_t* target; const int64_t* neg_items; const float* product_emb;
+  int B, K, pos_weight; int64_t P; float scale; const float* scale_dev;
   const float* y2; const float* stf; const float* gf;  // final LN: input, {mean, rstd}, gamma
   const float* y1; const float* st1; const float* g1;  // FF LN
   const float* a1;                                     // [M,F] pre-activation of the hidden layer

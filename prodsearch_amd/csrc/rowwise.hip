@@ -838,7 +838,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
         int e = c + 32 * k;
         float rv = row[e], ev = encr[e];
         if (idx != a.P) atomicAdd(&grow[e], ds * ev);
-        if (a.R > 1) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv;
+        if (a.R > 1) { if (a.denc) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv; }
         else acc[k] += ds * rv;
       }
     }

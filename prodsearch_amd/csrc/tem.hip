@@ -514,7 +514,8 @@ extern "C" int ps_set_fuse_bwd_min(int rows) {
 }
 
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
-                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold) {
+                        const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold,
+                        const ScoreArgs* score_on_side) {
   const bool drop = D.training && D.dropout > 0.f;
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers, F = D.F;
   PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
@@ -530,6 +531,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 && d == 128 &&
                          F % 128 == 0 && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
                          mlp_bwd_fused_blocks(w.Mf) <= 256 && fold->n + 3 <= PS_MAX_COLFOLD;
+  if (score_on_side && !(fuse_last && w.R > 1)) {   // not the fused form after all: the score backward goes first
+    ScoreArgs t = *score_on_side;
+    t.denc = ws + w.denc;
+    TRY(launch_score_bwd(t, st));
+    score_on_side = nullptr;
+  }
   if (fuse_last) {
     // nothing here: launched inside the layer loop below
   } else if (NL > 0) {
@@ -568,6 +575,11 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       m.wo = Lp.wo; m.w1 = Lp.w1; m.w2 = Lp.w2;
       m.drop_ctx = make_drop(D, PS_SITE_CTX(i)); m.drop_ff1 = make_drop(D, PS_SITE_FF1(i));
       m.drop_ff2 = make_drop(D, PS_SITE_FF2(i));
+      if (score_on_side) {   // d enc from the scores (see MlpBwdArgs::item_scores)
+        const ScoreArgs& sa = *score_on_side;
+        m.item_scores = sa.item_scores; m.target = sa.target; m.neg_items = sa.neg_items; m.product_emb = sa.product_emb;
+        m.B = sa.B; m.K = sa.K; m.pos_weight = sa.pos_weight; m.P = sa.P; m.scale = sa.scale; m.scale_dev = sa.scale_dev;
+      }
       m.do2 = const_cast<float*>(do2); m.da1 = ws + w.da1; m.dy1 = ws + w.dy1;
       m.dout = drop ? ws + w.do_ : ws + w.dy1; m.dctx = ws + w.dctx;
       const int nwg = mlp_bwd_fused_blocks(M2);
@@ -593,6 +605,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
       GemmProblem wgo[1] = {gp_wgrad(m.dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
       TRY(side_fork(st));                           // fork 1: W2, W1, Wo weight gradients under the attention backward
+      if (score_on_side) {                          // ... led by the table scatter of the score backward
+        ScoreArgs t = *score_on_side;
+        t.denc = nullptr;
+        SideCtx* sc = side_ctx();
+        TRY(launch_score_bwd(t, sc ? sc->stream : st));
+      }
       TRY(side_run(wg, 1, st));
       TRY(side_run(wg1, 1, st));
       TRY(side_run(wgo, 1, st));
@@ -766,14 +784,17 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   s.scale = loss_scale; s.scale_dev = loss_scale_dev; s.denc = ws + w.denc;
   s.g_product_emb = G.product_emb; s.g_word_emb = G.word_emb; s.g_product_bias = G.product_bias;
   s.g_word_bias = G.word_bias;
-  TRY(launch_score_bwd(s, st));
+  // TEM with replicas: the encoder backward decides where the score backward runs (enc_layers_backward, score_on_side)
+  static const bool score_side_on = !(getenv("PS_SCORE_BWD_MAIN") && atoi(getenv("PS_SCORE_BWD_MAIN")) != 0);
+  const bool score_deferred = tem && NL > 0 && w.R > 1 && score_side_on;
+  if (!score_deferred) TRY(launch_score_bwd(s, st));
 
   ColFoldList fold;
   fold.n = 0;
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
   int lddqe = d;
   if (tem) {
-    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold));
+    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr));
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }
