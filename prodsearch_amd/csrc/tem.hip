@@ -183,9 +183,12 @@ static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, but at 
   // rows; the review transformer (78k rows, 4 tiles) wants its 128 splits of ~610 rows (1.146 ms vs 1.193 with 56).
   static const int target = getenv("PS_WGRAD_BLOCKS") ? atoi(getenv("PS_WGRAD_BLOCKS")) : 512;   // tuning experiments
   static const int min_rows = getenv("PS_WGRAD_ROWS") ? atoi(getenv("PS_WGRAD_ROWS")) : 512;
-  int want = target / (tiles > 0 ? tiles : 1);
-  int cap = (rows + min_rows - 1) / min_rows;
-  int ks = want < cap ? want : cap;
+  const int nt = tiles > 0 ? tiles : 1;
+  const int want = target / nt;
+  int ks = (rows + min_rows - 1) / min_rows;                 // >= ~512 rows per split ...
+  const int fill = (128 + nt - 1) / nt, cap128 = (rows + 127) / 128;
+  if (ks < fill) ks = fill < cap128 ? fill : cap128;         // ... unless that leaves fewer than ~128 workgroups (Wo: 4 tiles)
+  if (ks > want) ks = want;
   return ks < 1 ? 1 : ks;
 }
 static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
