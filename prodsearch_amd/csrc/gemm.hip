@@ -310,6 +310,15 @@ template <int FULL, int BK>
 static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGroup& g) {
   // two 32-deep slabs in flight (measured on MI355X: 1 -> 2 takes the 8064x128x512 product from 24.4 to 20.5 us and
   // 4096^3 from 104 to 112 TFLOP/s; 3 and 4 give nothing more); a 128-deep slab is a whole reduction already
+  static const int wg_pf = getenv("PS_WGRAD_PF") ? atoi(getenv("PS_WGRAD_PF")) : 2;   // tuning experiments
+  if (BK == 32 && !FULL && ta == 1 && tb == 1 && wg_pf == 4) {
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 0, 32, 4>), grid, dim3(256), 0, stream, g);
+    return;
+  }
+  if (BK == 32 && !FULL && ta == 1 && tb == 1 && wg_pf == 3) {
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 0, 32, 3>), grid, dim3(256), 0, stream, g);
+    return;
+  }
   launch_pf<FULL, BK, (BK == 32 ? 2 : 1)>(ta, tb, grid, stream, g);
 }
 

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     const int o = live ? g / d : 0, i = live ? g - o * d : 0;
     float acc = 0.f, bacc = 0.f;
     if (fsb) {
-#pragma unroll 8
+#pragma unroll 16
       for (int b = seg; b < a.B; b += 8) {
         const float y = a.fsb_qe[(size_t)b * d + o];
         const float dy = a.fsb_dqe[(size_t)b * a.fsb_lddqe + o] * (1.f - y * y);
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
       float* dst = f.dst[which];
       float sum = 0.f;
       if (live && dst) {
-#pragma unroll 4
+#pragma unroll 16
         for (int b2 = seg; b2 < f.nblk; b2 += 8) sum += f.partial[((size_t)b2 * 3 + which) * f.d + col];
       }
       fpart[seg][c] = sum;

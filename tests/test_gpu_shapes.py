@@ -53,6 +53,7 @@ def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
     (5, 33, 7, 3, 2, 64, 8, 0.3, 0.0),       # K+1 above the 32 row groups of the score kernels, pv window 2
     (130, 3, 12, 5, 1, 96, 8, 0.1, 0.1),     # ragged batch (not a multiple of any tile), d not a power of two, dropout
     (2, 5, 20, 8, 3, 128, 8, 0.0, 0.1),
+    (50, 20, 9, 4, 1, 128, 8, 0.2, 0.1),     # 1,050 replica rows: the fused per-replica kernels with a partial last tile
 ])
 def test_edge_shapes_match_oracle(B, K, L, Q, W, d, H, zero_hist, dropout):
     """Edge cases of the batch layout: tiny and ragged batches, zero-history users,
@@ -101,3 +102,15 @@ def test_edge_shapes_match_oracle(B, K, L, Q, W, d, H, zero_hist, dropout):
         s = m.test(batch.to('cuda')).cpu()
         ref_s = otem.tem_test(sd, a, batch, V, P_)
     assert rel_err(s, ref_s) < 1e-4
+
+
+@pytest.mark.parametrize('B,K,L,Q,W,zero_hist', [(7, 4, 20, 8, 1, 0.0), (2, 5, 20, 8, 3, 0.0), (33, 1, 5, 3, 1, 0.5)])
+def test_fused_backward_partial_tiles(B, K, L, Q, W, zero_hist):
+    """The fused per-replica backward (32-row tiles) forced onto tiny batches: 35, 12 and 66 replica rows."""
+    from prodsearch_amd import _lib
+    old = _lib.load().ps_set_fuse_bwd_min(1)
+    try:
+        test_edge_shapes_match_oracle(B, K, L, Q, W, 128, 8, zero_hist, 0.1)
+    finally:
+        _lib.load().ps_set_fuse_bwd_min(old)
+
