@@ -281,6 +281,8 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   {
     const int i = tid & 127, half = tid >> 7;
     float acc = 0.f;
+    if (a.fanin_src && (i >> 6) == (int)blockIdx.y)          // this group's 64 columns of the replicas' fan-in sum
+      for (int j = half; j < a.fan; j += 2) acc += a.fanin_src[((size_t)b * a.fan + j) * 128 + i];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc = fmaf(l.q[half * 32 + k], wq[k], acc);
     float* part = l.dV;                                      // free: dK / dV have been written out

@@ -208,7 +208,8 @@ __device__ inline float res_value(const ResMap& R, int row, int col) {
     else if (pos == R.qpos) i = 0;
     else return 0.f;
     float s = 0.f;
-    for (int j = 0; j < R.fan; ++j) s += R.ptr[(size_t)((nin * R.fan + j) * R.Sq + i) * R.ld + col];
+    if (R.ptr)                                   // null: the fan-in sum already sits in extra / extra2
+      for (int j = 0; j < R.fan; ++j) s += R.ptr[(size_t)((nin * R.fan + j) * R.Sq + i) * R.ld + col];
     if (R.extra) s += R.extra[(size_t)nin * R.extra_ld + col];
     if (R.extra2) s += R.extra2[(size_t)nin * R.extra_ld + col];
     return s;
@@ -238,6 +239,11 @@ struct GemmProblem {
   float* colsum_part;                   // if set (with colsum): park them instead, [4*row_tiles][3][N] slot 0 (ColFoldList layout)
   int accumulate;                       // 0: C = v ; 1: C += v (plain) ; 2: atomicAdd(C, v) (split reduction)
   int ksplit;                           // number of reduction splits (grid.z multiplier), >=1
+  // optional row list (IDX instantiations of the kernel): only the *rcount rows ridx[0..] of the operands exist as
+  // far as the product is concerned — the valid (non-pad) positions of the batch's sequences.
+  //   ta == 0:            logical row i of A / C / residual is physical row ridx[i]; M is the list length on the device
+  //   ta == 1 && tb == 1: logical reduction row k of A and B is physical row ridx[k]; K is the list length
+  const int32_t* ridx; const int32_t* rcount;
 };
 
 struct GemmGroup {

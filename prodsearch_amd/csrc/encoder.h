@@ -18,6 +18,7 @@ struct Ws {
   int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
   int64_t gcpart;           // [4 * row tiles][3][F] parked column sums of the FF2 dX GEMM (b1 gradient)
   int64_t abpart;           // per layer [n_in][3][d] parked attention bias gradients {bq, bk, bv} (sq1 backward)
+  int64_t vrows, vcount;    // int32 [B*S] valid-row list of x and its length (EmbedArgs::vrows), TEM only
   int64_t stage;            // graph replay: step word + staged copies of the call's int64 index tensors (stage_layout)
   int64_t total;
 };

@@ -47,16 +47,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // s_waitcnt vmcnt(0) ahead of the MFMA block).  So rows are clamped instead of masked — rows past the edge are
 // duplicates whose products land in output rows/columns the epilogue never stores — and only a ragged reduction
 // tail (kmask: K not a multiple of the slab, block-uniform) takes the zero-filling path.
+// pr0 / pr1 (TRANS == 0, row list; -1: none): the two physical rows this thread loads from, fetched once per workgroup.
+// kmap (TRANS == 1, row list): LDS copy of the physical reduction rows of this workgroup's range, kmap[k - kbase].
 template <int TRANS, int BK>
 __device__ inline void tile_load(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int kend,
                                  float4 (&reg)[BK / 16], int tid, bool kmask, const float* __restrict__ seg1 = nullptr,
-                                 const float* __restrict__ seg2 = nullptr, int kseg = 0) {
+                                 const float* __restrict__ seg2 = nullptr, int kseg = 0, int pr0 = -1, int pr1 = -1,
+                                 const int* kmap = nullptr, int kbase = 0) {
   constexpr int NLD = BK / 16;
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
     int r, k;
     if (TRANS == 0) {
-      r = min(row0 + (tid >> 3) + 32 * (u & 1), nrows - 1);
+      r = pr0 >= 0 ? ((u & 1) ? pr1 : pr0) : min(row0 + (tid >> 3) + 32 * (u & 1), nrows - 1);   // u is compile-time
       k = k0 + 32 * (u >> 1) + 4 * (tid & 7);
     } else {
       r = min(row0 + 4 * (tid & 15), nrows - 4);              // nrows % 4 == 0 (validated)
@@ -64,6 +67,7 @@ __device__ inline void tile_load(const float* __restrict__ src, int ld, int row0
     }
     const bool ok = !kmask || k < kend;
     int kl = ok ? k : k0;
+    if (TRANS == 1 && kmap) kl = kmap[kl - kbase];
     const float* base = src;
     if (kseg > 0) {                            // K-concatenated operand (kseg > 0): pick the segment of this k.  Plain
       const int sg = (kl >= kseg) + (kl >= 2 * kseg);   // scalars, no table: a table indexed per lane lives in scratch,
@@ -99,16 +103,20 @@ __device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16],
   }
 }
 
-template <int TA, int TB, int FULL, int BK, int PF>
+#define KIDX_MAX 2048      // reduction rows of one split a row-list weight gradient can map (LDS ints)
+template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int NLD = BK / 16;
   __shared__ float As[2][BK][LDT];
   __shared__ float Bs[2][BK][LDT];
+  __shared__ int kidx[IDX && TA == 1 ? KIDX_MAX : 1];
 
   const int prob = blockIdx.z / g.p[0].ksplit;
   const int split = blockIdx.z - prob * g.p[0].ksplit;
   const GemmProblem& P = g.p[prob];
-  const int M = P.M, N = P.N, K = P.K;
+  const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
+  const int nlist = listed ? *P.rcount : 0;
+  const int M = (listed && TA == 0) ? nlist : P.M, N = P.N, K = (listed && TA == 1) ? nlist : P.K;
   // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
   // so give every XCD whole ROW tiles: all column tiles that re-read one A row-tile share an L2.
   int tm = blockIdx.y, tn = blockIdx.x;
@@ -131,6 +139,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
 
+  int pr0 = -1, pr1 = -1;
+  const int* kmap = nullptr;
+  if (IDX && TA == 0) {                                         // the two A rows this thread loads, once (plain
+    pr0 = min(m0 + (tid >> 3), M - 1);                          // problems of a row-list launch: the natural rows)
+    pr1 = min(m0 + (tid >> 3) + 32, M - 1);
+    if (listed) { pr0 = P.ridx[pr0]; pr1 = P.ridx[pr1]; }
+  }
+  if (listed && TA == 1) {                                      // physical reduction rows of this split -> LDS
+    for (int i = tid; i < kend - kbeg; i += 256) kidx[i] = P.ridx[kbeg + i];
+    __syncthreads();
+    kmap = kidx;
+  }
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -150,8 +171,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int kl = kbeg + u * BK < kend ? kbeg + u * BK : kbeg;
-    tile_load<TA, BK>(P.A, P.lda, m0, M, kl, kend, ra[u], tid, kmask);
-    tile_load<TB, BK>(bs0, ldb, n0, N, kl, kend, rb[u], tid, kmask, bs1, bs2, bkseg);
+    tile_load<TA, BK>(P.A, P.lda, m0, M, kl, kend, ra[u], tid, kmask, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);
+    tile_load<TB, BK>(bs0, ldb, n0, N, kl, kend, rb[u], tid, kmask, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
   }
   tile_store<TA, BK>(As[0], ra[0], tid, kmask, kbeg, kend);
   tile_store<TB, BK>(Bs[0], rb[0], tid, kmask, kbeg, kend);
@@ -164,8 +185,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       const int k0 = kg + u * BK;
       if (k0 >= kend) break;                         // block-uniform
       const int kp = k0 + PF * BK < kend ? k0 + PF * BK : kbeg;   // slot u is free (its slab sits in LDS): refill it
-      tile_load<TA, BK>(P.A, P.lda, m0, M, kp, kend, ra[u], tid, kmask);            // PF slabs ahead
-      tile_load<TB, BK>(bs0, ldb, n0, N, kp, kend, rb[u], tid, kmask, bs1, bs2, bkseg);
+      tile_load<TA, BK>(P.A, P.lda, m0, M, kp, kend, ra[u], tid, kmask, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);            // PF slabs ahead
+      tile_load<TB, BK>(bs0, ldb, n0, N, kp, kend, rb[u], tid, kmask, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
       const float* a_base = &As[buf][h][wm * 32 + l31];
       const float* b_base = &Bs[buf][h][wn * 32 + l31];
 #pragma unroll
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (col_ok && row < M) {
         const float v = (acc[r] + bias) * alpha;
-        const size_t off = (size_t)row * ldc + col;
+        const size_t off = (size_t)((listed && TA == 0) ? P.ridx[row] : row) * ldc + col;
         if (accumulate == 0) C[off] = v;
         else if (accumulate == 1) C[off] += v;
         else atomicAdd(&C[off], v);
@@ -228,13 +249,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // global operands of the epilogue (activation aux, residual) for row group i; fetched one group
   // AHEAD of its use so the rolled loop does not serialise four global-latency round trips
   const bool need_aux = act == ACT_GELU_BWD || act == ACT_TANH_BWD;
-  struct Pre { float aux[4], res[4]; };
+  struct Pre { float aux[4], res[4]; int prow[4]; };
   auto preload = [&](int i, Pre& pr) {
     const int rbase = m0 + 4 * ((tid >> 6) + 4 * i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int row = rbase + q;
-      const bool ok = i < 4 && row < M;
+      const int lrow = rbase + q;
+      const bool ok = i < 4 && lrow < M;
+      const int row = (listed && TA == 0 && ok) ? P.ridx[lrow] : lrow;      // physical row of the operands
+      pr.prow[q] = row;
       pr.aux[q] = (need_aux && ok) ? P.act_aux[(size_t)row * ldc + gcol] : 0.f;
       pr.res[q] = (has_res && ok) ? res_value(P.res, row, gcol) : 0.f;
     }
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       const int row = rbase + q;
       if (row >= M) break;
       float v = (Ct[lrow + q][ccol] + cbias) * alpha;
-      const size_t off = (size_t)row * ldc + gcol;
+      const size_t off = (size_t)((IDX && TA == 0) ? cur.prow[q] : row) * ldc + gcol;
       if (P.aux_out) P.aux_out[off] = v;
       if (act == ACT_GELU) v = gelu_tanh_f(v);
       else if (act == ACT_TANH) v = tanh_fast(v);
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       }
       v += cur.res[q];
       csum += v;
-      if (P.out2) P.out2[(size_t)row * P.ld2 + gcol] = v + add2;
+      if (P.out2) P.out2[(size_t)((IDX && TA == 0) ? cur.prow[q] : row) * P.ld2 + gcol] = v + add2;
       if (accumulate == 0) C[off] = v;
       else if (accumulate == 1) C[off] += v;
       else atomicAdd(&C[off], v);
@@ -337,6 +360,27 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
   }
   dim3 grid(ps_cdiv(maxN, BN), ps_cdiv(maxM, BM), g.n * g.p[0].ksplit);
   PS_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+  bool listed = false;
+  for (int i = 0; i < g.n; ++i) {
+    const GemmProblem& p = g.p[i];
+    if (!p.ridx) continue;
+    listed = true;
+    PS_REQUIRE(p.rcount && p.drop.thr == 0u && !p.colsum && !p.aux_out && p.kseg >= p.K * (p.ta ? 1 : 0),
+               "gemm: row-list problems take no dropout / column sums / pre-activation output");
+    if (p.ta) {
+      const int nslab = ps_cdiv(p.K, 32), per = ps_cdiv(nslab, p.ksplit);
+      PS_REQUIRE(p.tb == 1 && per * 32 <= KIDX_MAX, "gemm: row-list weight gradient: %d rows per split > %d", per * 32, KIDX_MAX);
+    }
+  }
+  if (listed) {   // row-list instantiations exist for the three shapes of the step that use them (32-deep slabs)
+    const int ta = g.p[0].ta, tb = g.p[0].tb;
+    if (ta == 0 && tb == 1 && full) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 1, 32, 2, 1>), grid, dim3(256), 0, stream, g);
+    else if (ta == 1 && tb == 1 && !full) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
+    else if (ta == 0 && tb == 0 && !full) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
+    else PS_REQUIRE(false, "gemm: no row-list instantiation for ta=%d tb=%d full=%d", ta, tb, (int)full);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   static const int repeat = getenv("PS_DEBUG_REPEAT") ? atoi(getenv("PS_DEBUG_REPEAT")) : 1;   // timing experiments only
   for (int r = 0; r < repeat; ++r) {
     // few workgroups (latency-bound chain): one deep slab per round trip; many: shallow slabs, 4 wgs per CU

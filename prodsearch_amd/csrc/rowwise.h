@@ -10,6 +10,11 @@ struct EmbedArgs {
   // FS projection folded into this launch when set: query_emb = tanh(fs_w . mean + fs_b) (text_encoder.py:39) as a
   // per-row mat-vec against the L2-resident [d,d] weight (a GEMM launch of its own cost 15 us for 12.6 MFLOP at C2)
   const float* fs_w; const float* fs_b;
+  // optional (tem): the list of VALID rows of x — row b*S of every sequence (the query) and rows b*S+1+l with
+  // u_item_idxs[b][l] != P, ascending — and its length.  Padded positions (69 % of the rows at C2) carry exact zeros
+  // through the K/V backward, so the row-list GEMMs (GemmProblem::ridx) skip them.
+  int32_t* vrows; int32_t* vcount;
+  int samp_wgs;                  // filled by the launcher: sampling workgroups in the grid (the list ones follow)
   int use_pos;
   const int64_t* qw; const int64_t* ui;
   const float* word_emb; const float* hist_tab; const float* pe;
@@ -76,6 +81,9 @@ struct AttnArgs {
   // kernel's tail — each head-group workgroup multiplies its 64 dq values into Wq (rows prefetched at kernel start) and
   // writes one partial row  dxq_part[group][sequence][d];  the dX GEMM's fan-in epilogue adds both (ResMap::extra/extra2)
   const float* wq; float* dxq_part;
+  // ... together with the fan-in residual of `out = dropout(context) + inputs`: the sum over the sequence's replicas of
+  // fanin_src[(b*fan + j)*128 + i] (d y1), each head group adding its own 64 columns to its partial row
+  const float* fanin_src;
 };
 inline void attn_finish(AttnArgs& a) {
   a.fS = make_fdiv(a.S); a.fd = make_fdiv(a.d); a.fdh = make_fdiv(a.dh); a.fd4 = make_fdiv(a.d / 4);

@@ -21,7 +21,7 @@ __device__ inline int64_t clamp_idx(int64_t i, int64_t hi) { return i < 0 ? hi :
 // positional add (item_transformer.py:452,466-471, transformer.py:77-81).
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
   extern __shared__ float red[];   // [rpp][d]
-  if ((int)blockIdx.x >= a.B) {      // sampling workgroups (see EmbedArgs::samp_*): same draws as sample_kernel
+  if ((int)blockIdx.x >= a.B && (int)blockIdx.x < a.B + a.samp_wgs) {      // sampling workgroups (see EmbedArgs::samp_*): same draws as sample_kernel
     const int t = ((int)blockIdx.x - a.B) * 256 + (int)threadIdx.x;
     if (t < a.samp_nitem) {
       Philox4 r = philox4x32_10((uint32_t)t, 0u, PS_SITE_SAMPLE_ITEM, a.samp_step, a.samp_k0, a.samp_k1);
@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
       const float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
       a.samp_words[u] = f < a.samp_prob[i] ? i : (int64_t)a.samp_alias[i];
     }
+    return;
+  }
+  if ((int)blockIdx.x >= a.B + a.samp_wgs) {
+    // valid-row list (EmbedArgs::vrows), one workgroup per sequence beside the gathering ones: this sequence's rows
+    // start behind the valid rows of all earlier sequences, counted here (b*L coalesced int64 reads, L2 hits) — no
+    // scan kernel, no host round trip, nothing added to the gather's own chain
+    __shared__ int vred[4];
+    const int b = (int)blockIdx.x - a.B - a.samp_wgs, tid = threadIdx.x;
+    int cntp = 0;
+    for (int i = tid; i < b * a.L; i += 256) cntp += (a.ui[i] != a.P);
+    const bool mine = tid < a.L && a.ui[(size_t)b * a.L + tid] != a.P;       // L <= 64 (validated): wave 0 holds the row
+    const unsigned long long vm = __ballot(mine);
+    cntp = (int)wave_sum((float)cntp);                        // < 2^24: exact in fp32
+    if ((tid & 63) == 0) vred[tid >> 6] = cntp;
+    __syncthreads();
+    const int off = vred[0] + vred[1] + vred[2] + vred[3] + b;   // + one query row per earlier sequence
+    if (tid == 0) a.vrows[off] = b * a.S;
+    if (mine) a.vrows[off + 1 + __popcll(vm & ((1ull << tid) - 1ull))] = b * a.S + 1 + tid;
+    if (tid == 0 && b == a.B - 1) *a.vcount = off + 1 + __popcll(vm);
     return;
   }
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -163,7 +182,11 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0 && a.d <= 1024, "embed: d=%d unsupported", a.d);
   int rpp = 256 / (a.d / 4);
   const int nsamp = a.samp_prob ? ps_cdiv(a.samp_nitem + a.samp_nword, 256) : 0;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp), dim3(256), (size_t)(rpp + 2) * a.d * sizeof(float), st, a);
+  const int nlist = (a.vrows && a.tem && a.L <= 64) ? a.B : 0;
+  EmbedArgs b = a;
+  b.samp_wgs = nsamp;
+  if (!nlist) b.vrows = nullptr;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist), dim3(256), (size_t)(rpp + 2) * a.d * sizeof(float), st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

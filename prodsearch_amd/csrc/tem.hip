@@ -128,6 +128,8 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.stage = take(cur, 4 + 2 * ((int64_t)B * (D.Q + D.L + 1 + D.W + D.K + D.W * D.K) + 8));   // int64 = 2 floats
   w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 63) / 64 + 1) * 3 * (tem && NL > 0 ? D.F : 0));
   w.abpart = take(cur, (int64_t)NL * (NL > 0 ? w.layer[NL - 1].n_in : 0) * 3 * d);
+  w.vrows = tem ? take(cur, (int64_t)B * S + 4) : 0;
+  w.vcount = tem ? take(cur, 4) : 0;
   w.total = cur;
   return PS_OK;
 }
@@ -369,6 +371,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
   PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
   PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
+  if (tem) { e.vrows = reinterpret_cast<int32_t*>(ws + w.vrows); e.vcount = reinterpret_cast<int32_t*>(ws + w.vcount); }
   if (samp) {
     e.samp_prob = samp->prob; e.samp_alias = samp->alias; e.samp_items = samp->items; e.samp_words = samp->words;
     e.samp_nitem = D.B * D.K; e.samp_nword = D.B * D.W * D.K; e.samp_step = (uint32_t)D.step;
@@ -614,7 +617,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         SideCtx* sc = side_ctx();
         TRY(launch_score_bwd(t, sc ? sc->stream : st));
       }
-      TRY(side_run(wg, 1, st));
+      TRY(side_run(wg, 1, st));   // (a second side stream for W1 / Wo beside W2 measured 0.389 vs 0.368 ms: slower)
       TRY(side_run(wg1, 1, st));
       TRY(side_run(wgo, 1, st));
     } else {
@@ -697,7 +700,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // rows per sequence in the free d ln1 buffer) instead of a [n_in,128]x[128,128] GEMM launch of its own
       const bool q_folded = sq1 && !qall && i == 0 && d == 128 && D.H % 8 == 0 && ps_fusion_enabled() &&
                             (size_t)2 * l.n_in <= (size_t)M2;
-      if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; }
+      if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
       TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
@@ -731,8 +734,21 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       if (i == 0) {   // + residual path of `out = dropout(context) + inputs`, summed over the replicas
         x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
         x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
-        if (q_folded) { x.res.extra = ws + w.dln1; x.res.extra2 = ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; }
+        if (q_folded) {   // both partial rows already hold the replicas' fan-in sum: nothing left to walk here
+          x.res.extra = ws + w.dln1; x.res.extra2 = ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
+        }
         else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
+      }
+      // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the dX
+      // product and the K/V weight gradients run over the batch's row list (EmbedArgs::vrows) instead of all n_in*S rows
+      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      const bool listed = rows_on && ui && !valid && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
+      if (listed) {
+        const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
+        const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
+        x.ridx = vr; x.rcount = vc;
+        wg3[0].ridx = vr; wg3[0].rcount = vc;
+        wg3[1].ridx = vr; wg3[1].rcount = vc;
       }
       TRY(run1(x, st));
       if (wg3_main) TRY(run_wgrads(wg3, 3, st));
