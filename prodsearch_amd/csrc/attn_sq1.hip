@@ -118,14 +118,14 @@ __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
     l.P[h * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;               // masked_fill(mask, -1e18)
   }
   __syncthreads();
-  for (int h = tid; h < H; h += 256) {
+  for (int h = tid >> 6; h < H; h += 4) {                    // softmax: one wave per head, lane = key position (S <= 64)
     float* p = l.P + h * (S + 1);
-    float m = -INFINITY;
-    for (int s = 0; s < S; ++s) m = fmaxf(m, p[s]);
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) { float e = expf(p[s] - m); p[s] = e; sum += e; }
-    const float inv = 1.f / sum;
-    for (int s = 0; s < S; ++s) p[s] *= inv;
+    const int s = tid & 63;
+    const float v = s < S ? p[s] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = s < S ? expf(v - m) : 0.f;
+    const float inv = 1.f / wave_sum(e);
+    if (s < S) p[s] = e * inv;
   }
   __syncthreads();
   for (int i = tid; i < H * S; i += 256) {
@@ -241,21 +241,28 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int h = tid; h < H; h += 256) {                       // softmax backward
-    float* p = l.P + h * (S + 1);
+  for (int h = tid >> 6; h < H; h += 4) {                    // softmax backward: one wave per head, lane = key position
+    const float* p = l.P + h * (S + 1);
     float* g = l.dP + h * (S + 1);
-    float t = 0.f;
-    for (int s = 0; s < S; ++s) t += p[s] * g[s];
-    for (int s = 0; s < S; ++s) g[s] = p[s] * (g[s] - t);
+    const int s = tid & 63;
+    const float pv = s < S ? p[s] : 0.f, gv = s < S ? g[s] : 0.f;
+    const float t = wave_sum(pv * gv);
+    if (s < S) g[s] = pv * (gv - t);
   }
   __syncthreads();
-  for (int c = tid; c < d; c += 256) {
+  // dq / dK / dV of this group's columns: the key positions are split over nsg thread groups (all 256 threads busy
+  // instead of d of them walking S positions), partial column sums combined through LDS
+  int nsg = 256 / d;
+  if (nsg < 1 || 3 * nsg > JC) nsg = 1;                     // the partials live in the (free) dC region: [3][nsg][d]
+  float* red3 = l.dC;
+  __syncthreads();
+  for (int idx = tid; idx < nsg * d; idx += 256) {
+    const int sg = idx / d, c = idx - sg * d;
     const int h = fdiv(c, a.fdh);
     const float* g = l.dP + h * (S + 1);
     const float qc = l.q[c];
     float dq = 0.f, sk = 0.f, sv = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < S; ++s) {
+    for (int s = sg; s < S; s += nsg) {
       dq += g[s] * l.Ks[s * KLD(d) + c];
       const float dk = g[s] * qc;
       const float dv = l.dV[s * d + c];
@@ -264,9 +271,17 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
       a.dkv[off + D] = dv;
       sk += dk; sv += dv;
     }
+    red3[(0 * nsg + sg) * d + c] = dq;
+    red3[(1 * nsg + sg) * d + c] = sk;
+    red3[(2 * nsg + sg) * d + c] = sv;
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += 256) {
+    float dq = 0.f, sk = 0.f, sv = 0.f;
+    for (int g2 = 0; g2 < nsg; ++g2) { dq += red3[(0 * nsg + g2) * d + c]; sk += red3[(1 * nsg + g2) * d + c]; sv += red3[(2 * nsg + g2) * d + c]; }
     dq *= a.qscale;
     a.dq[(size_t)b * a.lddq + c0 + c] = dq;
-    if (fold_q) l.q[c] = dq;                                 // only this thread read q[c]
+    if (fold_q) l.q[c] = dq;                                 // q[c] is not read any more
     if (a.bias_part) {                                       // parked: folded by the step's last launch
       float* bp = a.bias_part + (size_t)b * 3 * D + c0 + c;
       bp[0] = dq; bp[D] = sk; bp[2 * D] = sv;
