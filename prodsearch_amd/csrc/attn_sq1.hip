@@ -49,10 +49,17 @@ static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd, int JC) {
 __device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid, int d, int c0) {
   const int S = a.S, D = a.d, nv = S * d / 4;
   const int d4 = d >> 2;
+  const int brow0 = b / a.seq_div;
   for (int i = tid; i < nv; i += 256) {
     const int sr = fdiv(i, a.fd4), c4 = (i - sr * d4) * 4;
-    const float4 kk = *reinterpret_cast<const float4*>(a.kp + ((size_t)b * S + sr) * D + c0 + c4);
-    const float4 vv = *reinterpret_cast<const float4*>(a.vp + ((size_t)b * S + sr) * D + c0 + c4);
+    // masked key positions read as zeros: their K / V rows need not exist (the row-list projection skips them), and
+    // every use of them is multiplied by an attention weight of exactly 0
+    const bool live = a.valid ? a.valid[(size_t)brow0 * S + sr] != 0.f : (sr == 0 || a.ui[(size_t)brow0 * a.L + sr - 1] != a.P);
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+    if (live) {
+      kk = *reinterpret_cast<const float4*>(a.kp + ((size_t)b * S + sr) * D + c0 + c4);
+      vv = *reinterpret_cast<const float4*>(a.vp + ((size_t)b * S + sr) * D + c0 + c4);
+    }
     float* lk = l.Ks + sr * KLD(d) + c4;
     float* lv = l.Vs + sr * KLD(d) + c4;
     lk[0] = kk.x; lk[1] = kk.y; lk[2] = kk.z; lk[3] = kk.w;

@@ -291,6 +291,20 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       if (l.Sq == S) g.p[2] = gp(xn, d, 0, Lp.wq, d, 0, ws + l.qp, d, ns, d, d);
       else g.p[2] = gp(xn + (size_t)w.qpos * d, S * d, 0, Lp.wq, d, 0, ws + l.qp, d, l.n_in, d, d);
       g.p[2].bias = Lp.bq; g.p[2].alpha = qscale;
+      // valid rows only (EmbedArgs::vrows): the K / V rows of padded positions are never read (sq1_load zero-fills them)
+      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      if (rows_on && ui && !valid && i == 0 && NL == 1 && l.Sq == 1 && w.qpos == 0 && w.vrows != 0 && l.n_in == B &&
+          S <= 64 && (D.L <= 64)) {
+        AttnArgs probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.Sq = 1; probe.S = S; probe.d = d; probe.H = D.H;
+        if (attn_sq1_fits(probe)) {
+          const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
+          const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
+          g.p[0].ridx = vr; g.p[0].rcount = vc;
+          g.p[1].ridx = vr; g.p[1].rcount = vc;
+        }
+      }
       TRY(ps_launch_gemm(g, st));
     }
     AttnArgs a;
