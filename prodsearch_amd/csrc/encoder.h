@@ -30,8 +30,10 @@ int make_ws(const PsTemDesc& D, Ws& w);
 
 // All encoder layers + the final LayerNorm on the consumed position: reads w.x, writes w.enc.
 // Key-padding mask: `valid` [n_seq, S] floats if given, else u_item_idxs != P (TEM).
+// `rows_listed`: w.vrows / w.vcount hold the list of valid (non-pad) rows of x (EmbedArgs::vrows, or the review
+// transformer's rtm_rowlist_kernel); the K/V products of a one-layer encoder then run over those rows only.
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
-                       const Ws& w, hipStream_t st);
+                       const Ws& w, hipStream_t st, bool rows_listed = false);
 // Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
 // `fold` (optional): the LayerNorm backwards park their column sums in w.lnpart and append to this list; the caller
 // must hand it to a later launch_embed_scatter (EmbedBwdArgs::fold).  nullptr: plain atomics.
@@ -40,7 +42,7 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
 // launched on the side stream behind it, off the dependent chain; otherwise it is launched first, as usual.
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
                         const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold = nullptr,
-                        const ScoreArgs* score_on_side = nullptr);
+                        const ScoreArgs* score_on_side = nullptr, bool rows_listed = false);
 
 GemmProblem gp(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* C, int ldc, int M, int N, int K);
 int run1(const GemmProblem& p, hipStream_t st);

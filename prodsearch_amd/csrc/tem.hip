@@ -265,7 +265,7 @@ int side_join(hipStream_t main_st) {
 }
 
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
-                       const Ws& w, hipStream_t st) {
+                       const Ws& w, hipStream_t st, bool rows_listed) {
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
   const float qscale = 1.f / sqrtf((float)(d / (D.H > 0 ? D.H : 1)));
   bool fused_final = false;
@@ -293,8 +293,8 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       g.p[2].bias = Lp.bq; g.p[2].alpha = qscale;
       // valid rows only (EmbedArgs::vrows): the K / V rows of padded positions are never read (sq1_load zero-fills them)
       static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
-      if (rows_on && ui && !valid && i == 0 && NL == 1 && l.Sq == 1 && w.qpos == 0 && w.vrows != 0 && l.n_in == B &&
-          S <= 64 && (D.L <= 64)) {
+      if (rows_on && rows_listed && i == 0 && NL == 1 && l.Sq == 1 && w.qpos == 0 && w.vrows != 0 && l.n_in == B &&
+          S <= 64) {
         AttnArgs probe;
         memset(&probe, 0, sizeof(probe));
         probe.Sq = 1; probe.S = S; probe.d = d; probe.H = D.H;
@@ -403,7 +403,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   }
   if (!tem) return PS_OK;
 
-  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st);
+  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st, /*rows_listed=*/D.L <= 64);
 }
 
 static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
@@ -535,7 +535,7 @@ extern "C" int ps_set_fuse_bwd_min(int rows) {
 
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
                         const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold,
-                        const ScoreArgs* score_on_side) {
+                        const ScoreArgs* score_on_side, bool rows_listed) {
   const bool drop = D.training && D.dropout > 0.f;
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers, F = D.F;
   PS_REQUIRE(G.final_ln_g && G.final_ln_b, "backward: null final LayerNorm gradient");
@@ -756,7 +756,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the dX
       // product and the K/V weight gradients run over the batch's row list (EmbedArgs::vrows) instead of all n_in*S rows
       static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
-      const bool listed = rows_on && ui && !valid && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
+      const bool listed = rows_on && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
       if (listed) {
         const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
         const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
@@ -827,7 +827,8 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
   int lddqe = d;
   if (tem) {
-    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr));
+    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr,
+                            /*rows_listed=*/D.L <= 64));
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }
