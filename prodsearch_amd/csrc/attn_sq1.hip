@@ -20,7 +20,11 @@ static inline int sq1_pick_jc(int S, int d, int H, int fan);
 
 struct Sq1Lds {
   float *Ks, *Vs, *q, *P, *valid, *Pd, *dC, *dV, *dP;
+  int* spos;      // [S] original positions of the valid keys, ascending; then 8 ints of per-sequence meta (Sq1Meta)
 };
+// The kernels work on the VALID key positions of their sequence only (the query column and the non-pad history /
+// review positions: 31 % of S at C2, 27 % on the review transformer): K / V rows k < Sv in LDS are positions spos[k].
+struct Sq1Meta { int Sv; FDiv fS, fHS, fHQS; };   // dividers of Sv, H*Sv, max(H/4,1)*Sv
 
 __device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd, int JC) {
   Sq1Lds l;
@@ -29,6 +33,7 @@ __device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd, i
   l.q = base; base += (d + 3) & ~3;
   l.P = base; base += H * (S + 1);
   l.valid = base; base += (S + 3) & ~3;
+  l.spos = reinterpret_cast<int*>(base); base += ((S + 3) & ~3) + 8;
   l.Pd = base; base += JC * H * (S + 1);
   l.dC = base; l.dV = base; l.dP = base;
   if (bwd) {
@@ -39,46 +44,62 @@ __device__ inline Sq1Lds sq1_carve(float* base, int S, int d, int H, bool bwd, i
   return l;
 }
 static inline size_t sq1_lds_bytes(int S, int d, int H, bool bwd, int JC) {
-  size_t n = (size_t)2 * S * KLD(d) + ((d + 3) & ~3) + H * (S + 1) + ((S + 3) & ~3) + (size_t)JC * H * (S + 1);
+  size_t n = (size_t)2 * S * KLD(d) + ((d + 3) & ~3) + H * (S + 1) + 2 * ((S + 3) & ~3) + 8 + (size_t)JC * H * (S + 1);
   if (bwd) n += (size_t)JC * d + (size_t)S * d + H * (S + 1);
   return n * sizeof(float);
 }
 
 // A workgroup owns the heads h0 .. h0+H-1 of one sequence = columns c0 .. c0+d-1 of its rows (heads are independent
 // in attention); `d`, `H` below are those SUB sizes, D the row stride of the global tensors.
-__device__ inline void sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid, int d, int c0) {
-  const int S = a.S, D = a.d, nv = S * d / 4;
+__device__ inline FDiv dev_fdiv(int d) {
+  FDiv f;
+  f.d = (uint32_t)(d > 0 ? d : 1);
+  f.m = f.d == 1 ? 0u : (uint32_t)((0x100000000ull + f.d - 1) / f.d);
+  return f;
+}
+// valid flags -> position list (wave 0, one ballot: S <= 64) -> K / V rows of the valid positions, q.  Ends with a
+// barrier; returns the sequence's meta.
+__device__ inline Sq1Meta sq1_load(const AttnArgs& a, const Sq1Lds& l, int b, int tid, int d, int c0, int H) {
+  const int S = a.S, D = a.d;
   const int d4 = d >> 2;
-  const int brow0 = b / a.seq_div;
-  for (int i = tid; i < nv; i += 256) {
-    const int sr = fdiv(i, a.fd4), c4 = (i - sr * d4) * 4;
-    // masked key positions read as zeros: their K / V rows need not exist (the row-list projection skips them), and
-    // every use of them is multiplied by an attention weight of exactly 0
-    const bool live = a.valid ? a.valid[(size_t)brow0 * S + sr] != 0.f : (sr == 0 || a.ui[(size_t)brow0 * a.L + sr - 1] != a.P);
-    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-    if (live) {
-      kk = *reinterpret_cast<const float4*>(a.kp + ((size_t)b * S + sr) * D + c0 + c4);
-      vv = *reinterpret_cast<const float4*>(a.vp + ((size_t)b * S + sr) * D + c0 + c4);
+  const int brow = b / a.seq_div;
+  Sq1Meta* meta = reinterpret_cast<Sq1Meta*>(l.spos + ((S + 3) & ~3));
+  if (tid < 64) {
+    const bool v = tid < S && (a.valid ? a.valid[(size_t)brow * S + tid] != 0.f
+                                       : (tid == 0 || a.ui[(size_t)brow * a.L + tid - 1] != a.P));
+    const unsigned long long vm = __ballot(v);
+    if (tid < S) l.valid[tid] = v ? 1.f : 0.f;
+    if (v) l.spos[__popcll(vm & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) {
+      const int Sv = __popcll(vm);
+      meta->Sv = Sv; meta->fS = dev_fdiv(Sv); meta->fHS = dev_fdiv(H * Sv); meta->fHQS = dev_fdiv((H / 4 > 0 ? H / 4 : 1) * Sv);
     }
-    float* lk = l.Ks + sr * KLD(d) + c4;
-    float* lv = l.Vs + sr * KLD(d) + c4;
+  }
+  for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * D + c0 + i];
+  __syncthreads();
+  const Sq1Meta m = *meta;
+  for (int i = tid; i < m.Sv * d4; i += 256) {
+    const int k = fdiv(i, a.fd4), c4 = (i - k * d4) * 4;
+    const size_t row = (size_t)b * S + l.spos[k];
+    const float4 kk = *reinterpret_cast<const float4*>(a.kp + row * D + c0 + c4);
+    const float4 vv = *reinterpret_cast<const float4*>(a.vp + row * D + c0 + c4);
+    float* lk = l.Ks + k * KLD(d) + c4;
+    float* lv = l.Vs + k * KLD(d) + c4;
     lk[0] = kk.x; lk[1] = kk.y; lk[2] = kk.z; lk[3] = kk.w;
     lv[0] = vv.x; lv[1] = vv.y; lv[2] = vv.z; lv[3] = vv.w;
   }
-  for (int i = tid; i < d; i += 256) l.q[i] = a.qp[(size_t)b * D + c0 + i];
-  const int brow = b / a.seq_div;
-  for (int s = tid; s < S; s += 256)
-    l.valid[s] = a.valid ? a.valid[(size_t)brow * S + s] : ((s == 0 || a.ui[(size_t)brow * a.L + s - 1] != a.P) ? 1.f : 0.f);
+  __syncthreads();
+  return m;
 }
 
 // dropout multipliers (or P * multipliers) of replicas j0..j0+nj-1 into Pd[jj][h][s]
-__device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int j0, int nj, int tid, bool times_p,
-                                 int H, int h0) {
-  const int S = a.S, HF = a.H, per = H * S;
+__device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, const Sq1Meta& mt, int b, int j0, int nj, int tid,
+                                 bool times_p, int H, int h0) {
+  const int S = mt.Sv, LD = a.S + 1, HF = a.H, per = H * S;
   if (a.drop.thr == 0u) {
     for (int i = tid; i < nj * per; i += 256) {
-      const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
-      l.Pd[(jj * H + h) * (S + 1) + s] = times_p ? l.P[h * (S + 1) + s] : 1.f;
+      const int jj = fdiv(i, mt.fHS), r = i - jj * per, h = fdiv(r, mt.fS), k = r - h * S;
+      l.Pd[(jj * H + h) * LD + k] = times_p ? l.P[h * LD + k] : 1.f;
     }
     return;
   }
@@ -86,70 +107,74 @@ __device__ inline void sq1_masks(const AttnArgs& a, const Sq1Lds& l, int b, int 
     // rows nout*H + 4g .. +3 share one Philox counter (col = s, row >> 2): one call serves 4 heads
     const int HQ = H >> 2, perq = HQ * S;
     for (int i = tid; i < nj * perq; i += 256) {
-      const int jj = fdiv(i, a.fHQS), r = i - jj * perq, g = fdiv(r, a.fS), s = r - g * S;
+      const int jj = fdiv(i, mt.fHQS), r = i - jj * perq, g = fdiv(r, mt.fS), k = r - g * S;
       const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * HF + h0 + 4 * g);
-      const Philox4 w = philox4x32_10((uint32_t)s, row >> 2, a.drop.site, drop_step(a.drop), a.drop.k0, a.drop.k1);
+      const Philox4 w = philox4x32_10((uint32_t)l.spos[k], row >> 2, a.drop.site, drop_step(a.drop), a.drop.k0, a.drop.k1);
       const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int h = 4 * g + q;
         float m = drop_word(a.drop, ws[q]);
-        if (times_p) m *= l.P[h * (S + 1) + s];
-        l.Pd[(jj * H + h) * (S + 1) + s] = m;
+        if (times_p) m *= l.P[h * LD + k];
+        l.Pd[(jj * H + h) * LD + k] = m;
       }
     }
     return;
   }
   for (int i = tid; i < nj * per; i += 256) {
-    const int jj = fdiv(i, a.fHS), r = i - jj * per, h = fdiv(r, a.fS), s = r - h * S;
+    const int jj = fdiv(i, mt.fHS), r = i - jj * per, h = fdiv(r, mt.fS), k = r - h * S;
     const uint32_t row = (uint32_t)((b * a.fan + j0 + jj) * HF + h0 + h);  // Sq == 1: row = nout*H + h
-    float m = drop_mult(a.drop, row, (uint32_t)s);
-    if (times_p) m *= l.P[h * (S + 1) + s];
-    l.Pd[(jj * H + h) * (S + 1) + s] = m;
+    float m = drop_mult(a.drop, row, (uint32_t)l.spos[k]);
+    if (times_p) m *= l.P[h * LD + k];
+    l.Pd[(jj * H + h) * LD + k] = m;
   }
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
-  const int S = a.S, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int SF = a.S, LD = SF + 1, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
   const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
   const int JC = a.jc;
-  Sq1Lds l = sq1_carve(lds, S, d, H, false, JC);
-  sq1_load(a, l, b, tid, d, c0);
-  __syncthreads();
+  Sq1Lds l = sq1_carve(lds, SF, d, H, false, JC);
+  const Sq1Meta mt = sq1_load(a, l, b, tid, d, c0, H);
+  const int S = mt.Sv;                                      // valid key positions of this sequence
   for (int i = tid; i < H * S; i += 256) {
-    const int h = fdiv(i, a.fS), s = i - h * S;
+    const int h = fdiv(i, mt.fS), k = i - h * S;
     float acc = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[s * KLD(d) + h * dh + c];
-    l.P[h * (S + 1) + s] = l.valid[s] != 0.f ? acc : -1e18f;               // masked_fill(mask, -1e18)
+    for (int c = 0; c < dh; ++c) acc += l.q[h * dh + c] * l.Ks[k * KLD(d) + h * dh + c];
+    l.P[h * LD + k] = acc;                                  // masked positions (masked_fill -1e18 -> weight 0) are not listed
   }
   __syncthreads();
-  for (int h = tid >> 6; h < H; h += 4) {                    // softmax: one wave per head, lane = key position (S <= 64)
-    float* p = l.P + h * (S + 1);
-    const int s = tid & 63;
-    const float v = s < S ? p[s] : -INFINITY;
+  for (int h = tid >> 6; h < H; h += 4) {                    // softmax: one wave per head, lane = key (S <= 64)
+    float* p = l.P + h * LD;
+    const int k = tid & 63;
+    const float v = k < S ? p[k] : -INFINITY;
     const float m = wave_max(v);
-    const float e = s < S ? expf(v - m) : 0.f;
+    const float e = k < S ? expf(v - m) : 0.f;
     const float inv = 1.f / wave_sum(e);
-    if (s < S) p[s] = e * inv;
+    if (k < S) p[k] = e * inv;
   }
   __syncthreads();
+  for (int i = tid; i < H * SF; i += 256) {                  // attention weights of ALL positions (0 at the masked ones)
+    const int h = fdiv(i, a.fS), s = i - h * SF;
+    if (l.valid[s] == 0.f) a.attn[((size_t)b * HF + h0 + h) * SF + s] = 0.f;
+  }
   for (int i = tid; i < H * S; i += 256) {
-    const int h = fdiv(i, a.fS), s = i - h * S;
-    a.attn[((size_t)b * HF + h0 + h) * S + s] = l.P[h * (S + 1) + s];
+    const int h = fdiv(i, mt.fS), k = i - h * S;
+    a.attn[((size_t)b * HF + h0 + h) * SF + l.spos[k]] = l.P[h * LD + k];
   }
   for (int j0 = 0; j0 < a.fan; j0 += JC) {
     const int nj = min(JC, a.fan - j0);
     __syncthreads();
-    sq1_masks(a, l, b, j0, nj, tid, true, H, h0);
+    sq1_masks(a, l, mt, b, j0, nj, tid, true, H, h0);
     __syncthreads();
     for (int i = tid; i < nj * d; i += 256) {
       const int jj = fdiv(i, a.fd), c = i - jj * d, h = fdiv(c, a.fdh);
-      const float* pd = l.Pd + (jj * H + h) * (S + 1);
+      const float* pd = l.Pd + (jj * H + h) * LD;
       float acc = 0.f;
 #pragma unroll 8
-      for (int s = 0; s < S; ++s) acc += pd[s] * l.Vs[s * KLD(d) + c];
+      for (int k = 0; k < S; ++k) acc += pd[k] * l.Vs[k * KLD(d) + c];
       a.ctx[((size_t)b * a.fan + j0 + jj) * D + c0 + c] = acc;
     }
   }
@@ -199,10 +224,10 @@ int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
 
 __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   extern __shared__ float lds[];
-  const int S = a.S, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
+  const int SF = a.S, LD = SF + 1, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
   const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
   const int JC = a.jc;
-  Sq1Lds l = sq1_carve(lds, S, d, H, true, JC);
+  Sq1Lds l = sq1_carve(lds, SF, d, H, true, JC);
   // folded dQ.Wq (AttnArgs::wq; D == 128, d == 64): thread (half, i) owns output column i and 32 of this group's 64
   // query features; its 32 weights are requested now and used after the whole backward, ~30 us later
   const bool fold_q = a.wq != nullptr;
@@ -212,17 +237,18 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
 #pragma unroll
     for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(c0 + half * 32 + k) * 128 + i];
   }
-  sq1_load(a, l, b, tid, d, c0);
+  const Sq1Meta mt = sq1_load(a, l, b, tid, d, c0, H);
+  const int S = mt.Sv;                                      // valid key positions; SF = all of them (global strides)
   for (int i = tid; i < H * S; i += 256) {
-    const int h = fdiv(i, a.fS), s = i - h * S;
-    l.P[h * (S + 1) + s] = a.attn[((size_t)b * HF + h0 + h) * S + s];
-    l.dP[h * (S + 1) + s] = 0.f;
+    const int h = fdiv(i, mt.fS), k = i - h * S;
+    l.P[h * LD + k] = a.attn[((size_t)b * HF + h0 + h) * SF + l.spos[k]];
+    l.dP[h * LD + k] = 0.f;
   }
   for (int i = tid; i < S * d; i += 256) l.dV[i] = 0.f;
   for (int j0 = 0; j0 < a.fan; j0 += JC) {
     const int nj = min(JC, a.fan - j0);
     __syncthreads();
-    sq1_masks(a, l, b, j0, nj, tid, false, H, h0);
+    sq1_masks(a, l, mt, b, j0, nj, tid, false, H, h0);
     for (int i = tid; i < nj * d; i += 256) {
       const int jj = fdiv(i, a.fd), c = i - jj * d;
       l.dC[i] = a.dctx[((size_t)b * a.fan + j0 + jj) * D + c0 + c];
@@ -230,27 +256,27 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
     __syncthreads();
     for (int i = tid; i < S * d; i += 256) {                 // dV[s][c] += sum_j P*m_j * dctx_j[c]
       const int s = fdiv(i, a.fd), c = i - s * d, h = fdiv(c, a.fdh);
-      const float p = l.P[h * (S + 1) + s];
+      const float p = l.P[h * LD + s];
       float acc = 0.f;
 #pragma unroll 8
-      for (int jj = 0; jj < nj; ++jj) acc += l.Pd[(jj * H + h) * (S + 1) + s] * l.dC[jj * d + c];
+      for (int jj = 0; jj < nj; ++jj) acc += l.Pd[(jj * H + h) * LD + s] * l.dC[jj * d + c];
       l.dV[i] += p * acc;
     }
     for (int i = tid; i < nj * H * S; i += 256) {            // dP[h][s] += m_j * (dctx_j,h . V_s,h), all (j,h,s) in parallel
-      const int jj = fdiv(i, a.fHS), r = i - jj * H * S, h = fdiv(r, a.fS), s = r - h * S;
-      const float m = l.Pd[(jj * H + h) * (S + 1) + s];
+      const int jj = fdiv(i, mt.fHS), r = i - jj * H * S, h = fdiv(r, mt.fS), s = r - h * S;
+      const float m = l.Pd[(jj * H + h) * LD + s];
       if (m != 0.f) {
         float dot = 0.f;
 #pragma unroll 8
         for (int c = 0; c < dh; ++c) dot += l.dC[jj * d + h * dh + c] * l.Vs[s * KLD(d) + h * dh + c];
-        atomicAdd(&l.dP[h * (S + 1) + s], m * dot);         // LDS atomic, <= JC adders per element
+        atomicAdd(&l.dP[h * LD + s], m * dot);              // LDS atomic, <= JC adders per element
       }
     }
   }
   __syncthreads();
   for (int h = tid >> 6; h < H; h += 4) {                    // softmax backward: one wave per head, lane = key position
-    const float* p = l.P + h * (S + 1);
-    float* g = l.dP + h * (S + 1);
+    const float* p = l.P + h * LD;
+    float* g = l.dP + h * LD;
     const int s = tid & 63;
     const float pv = s < S ? p[s] : 0.f, gv = s < S ? g[s] : 0.f;
     const float t = wave_sum(pv * gv);
@@ -266,18 +292,24 @@ __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
   for (int idx = tid; idx < nsg * d; idx += 256) {
     const int sg = idx / d, c = idx - sg * d;
     const int h = fdiv(c, a.fdh);
-    const float* g = l.dP + h * (S + 1);
+    const float* g = l.dP + h * LD;
     const float qc = l.q[c];
     float dq = 0.f, sk = 0.f, sv = 0.f;
     for (int s = sg; s < S; s += nsg) {
       dq += g[s] * l.Ks[s * KLD(d) + c];
       const float dk = g[s] * qc;
       const float dv = l.dV[s * d + c];
-      const size_t off = ((size_t)b * S + s) * a.lddkv + c0 + c;
+      const size_t off = ((size_t)b * SF + l.spos[s]) * a.lddkv + c0 + c;
       a.dkv[off] = dk;
       a.dkv[off + D] = dv;
       sk += dk; sv += dv;
     }
+    for (int s = sg; s < SF; s += nsg)                       // masked positions: exact zeros (dense consumers read them)
+      if (l.valid[s] == 0.f) {
+        const size_t off = ((size_t)b * SF + s) * a.lddkv + c0 + c;
+        a.dkv[off] = 0.f;
+        a.dkv[off + D] = 0.f;
+      }
     red3[(0 * nsg + sg) * d + c] = dq;
     red3[(1 * nsg + sg) * d + c] = sk;
     red3[(2 * nsg + sg) * d + c] = sv;
