@@ -750,6 +750,9 @@ static void to_tem_tensors(const PsRtmTensors& R, PsTemTensors& T) {
   for (int i = 0; i < PS_MAX_LAYERS; ++i) T.layer[i] = R.layer[i];
 }
 
+// the row list costs Bseq^2 / 2 count reads (rtm_rowlist_kernel): built up to 8k sequences, dense products beyond
+static bool rtm_rows_listed(const RtmWs& r, const Ws& w) { return r.S <= 64 && w.vrows != 0 && r.Bseq <= 8192; }
+
 static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& Bt, float* ws, const RtmWs& r,
                       const Ws& w, const PsTemDesc& E, bool eval, RtmK& k, hipStream_t st) {
   const int B = D.B, d = D.d;
@@ -772,7 +775,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   e.drop_fs = make_drop(dq, PS_SITE_FS);
   e.qmean_d = ws + r.qmean; e.query_emb = ws + r.query_emb;
   PS_REQUIRE(!e.fs || (P.fs_w && P.fs_b), "rtm: null FS encoder weights");
-  const bool fs_fused = e.fs && ps_fusion_enabled();
+  const bool fs_fused = e.fs && ps_fusion_enabled() && d <= 128;
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {
@@ -784,7 +787,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   const int nslots = r.Bseq * r.S;
   hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
   PS_LAUNCH_CHECK();
-  const bool listed = r.S <= 64 && w.vrows != 0;
+  const bool listed = rtm_rows_listed(r, w);
   if (listed) {
     hipLaunchKernelGGL(rtm_rowlist_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k);
     PS_LAUNCH_CHECK();
@@ -868,7 +871,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   to_tem_tensors(G, TG);
   ColFoldList fold;
   fold.n = 0;
-  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, /*rows_listed=*/r.S <= 64 && w.vrows != 0));
+  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)B * d, st));
   int eb = ps_cdiv(r.Bseq * r.S, 4); if (eb > 1024) eb = 1024;
   if (k.pvc) {
@@ -898,7 +901,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   e.qw = batch->query_word_idxs; e.drop_fs = make_drop(dq, PS_SITE_FS); e.g_word_emb = G.word_emb;
   if (D.query_encoder == PS_QENC_FS) {
     PS_REQUIRE(G.fs_w && G.fs_b, "rtm backward: null FS gradients");
-    if (ps_fusion_enabled()) {   // whole FS backward inside the scatter launch (EmbedBwdArgs::fsb_*)
+    if (ps_fusion_enabled() && d <= 128) {   // whole FS backward inside the scatter launch (EmbedBwdArgs::fsb_*)
       e.fw_x = ws + r.qmean; e.g_fs_w = G.fs_w;
       e.fsb_dqe = ws + r.dqe; e.fsb_lddqe = d; e.fsb_qe = ws + r.query_emb; e.fsb_w = params->fs_w; e.g_fs_b = G.fs_b;
     } else {

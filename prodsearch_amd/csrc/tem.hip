@@ -369,6 +369,10 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
 // -------------------------------------------------------------- encoder forward
 struct SamplerArgs { const float* prob; const int32_t* alias; int64_t* items; int64_t* words; };
 
+// The valid-row list is built by one workgroup per sequence that counts the valid positions of ALL earlier sequences
+// (B^2 L / 2 index reads in total): fine up to a few thousand sequences, dense products beyond
+static bool rows_list_ok(const PsTemDesc& D) { return D.L <= 64 && (int64_t)D.B * D.B * D.L <= ((int64_t)64 << 20); }
+
 static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
                           hipStream_t st, const SamplerArgs* samp = nullptr) {
   const bool tem = D.model == PS_MODEL_TEM;
@@ -385,14 +389,16 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   e.qmean_d = ws + w.qmean; e.query_emb = ws + w.query_emb; e.x = ws + w.x;
   PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
   PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
-  if (tem) { e.vrows = reinterpret_cast<int32_t*>(ws + w.vrows); e.vcount = reinterpret_cast<int32_t*>(ws + w.vcount); }
+  if (tem && rows_list_ok(D)) { e.vrows = reinterpret_cast<int32_t*>(ws + w.vrows); e.vcount = reinterpret_cast<int32_t*>(ws + w.vcount); }
   if (samp) {
     e.samp_prob = samp->prob; e.samp_alias = samp->alias; e.samp_items = samp->items; e.samp_words = samp->words;
     e.samp_nitem = D.B * D.K; e.samp_nword = D.B * D.W * D.K; e.samp_step = (uint32_t)D.step;
     e.samp_k0 = (uint32_t)(D.seed & 0xffffffffu); e.samp_k1 = (uint32_t)(D.seed >> 32);
   }
   PS_REQUIRE(!e.fs || (P.fs_w && P.fs_b), "forward: null FS encoder weights");
-  const bool fs_fused = e.fs && ps_fusion_enabled();   // FS projection as a per-row mat-vec inside the embed launch
+  // FS projection as a per-row mat-vec inside the embed launch — while the [d,d] weight a workgroup streams from L2 is
+  // small (64 KB at d = 128; at d = 256 the C5 step lost 60 us to it and the GEMM launch is the better deal)
+  const bool fs_fused = e.fs && ps_fusion_enabled() && d <= 128;
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
@@ -403,7 +409,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   }
   if (!tem) return PS_OK;
 
-  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st, /*rows_listed=*/D.L <= 64);
+  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st, rows_list_ok(D));
 }
 
 static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
@@ -828,7 +834,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   int lddqe = d;
   if (tem) {
     TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr,
-                            /*rows_listed=*/D.L <= 64));
+                            rows_list_ok(D)));
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }
@@ -843,7 +849,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   if (D.query_encoder == PS_QENC_FS) {
     PS_REQUIRE(G.fs_w && G.fs_b, "backward: null FS encoder gradient");
     e.fw_x = ws + w.qmean; e.g_fs_w = G.fs_w;   // f_W weight gradient rides in the scatter launch (extra workgroups)
-    if (ps_fusion_enabled()) {
+    if (ps_fusion_enabled() && d <= 128) {
       // ... and so does the rest of the FS backward: tanh', d mean = dqpre . f_W (per-row mat-vec), bias gradient
       e.fsb_dqe = dqe; e.fsb_lddqe = lddqe; e.fsb_qe = ws + w.query_emb; e.fsb_w = P.fs_w; e.g_fs_b = G.fs_b;
     } else {
