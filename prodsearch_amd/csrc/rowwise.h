@@ -118,6 +118,7 @@ struct ScoreArgs {
   float scale;                   // loss_scale
   const float* scale_dev;        // optional device scalar multiplied into scale
   float* denc;                   // [B*R,d]  (null: the consumer derives d enc from the scores itself, MlpBwdArgs::item_scores)
+  int part;                      // replicas only: 0 = everything, 1 = d enc only (no table scatter), 2 = table scatter only
   float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
 };
 inline void score_finish(ScoreArgs& a) {

@@ -860,12 +860,12 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
       if (k < epl) {
         int e = c + 32 * k;
         float rv = row[e], ev = encr[e];
-        if (idx != a.P) atomicAdd(&grow[e], ds * ev);
-        if (a.R > 1) { if (a.denc) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv; }
+        if (idx != a.P && a.part != 1) atomicAdd(&grow[e], ds * ev);
+        if (a.R > 1) { if (a.denc && a.part != 2) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv; }
         else acc[k] += ds * rv;
       }
     }
-    if (a.bias_product && c == 0) atomicAdd(&a.g_product_bias[idx], ds);
+    if (a.bias_product && c == 0 && a.part != 1) atomicAdd(&a.g_product_bias[idx], ds);
   }
   if (a.R == 1) {
 #pragma unroll
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
     }
     __syncthreads();
   }
-  if (item_wg) return;
+  if (item_wg || a.part == 1) return;
   // ---- word tasks
 #pragma unroll
   for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;

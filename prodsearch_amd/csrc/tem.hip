@@ -557,10 +557,21 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 && d == 128 &&
                          F % 128 == 0 && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
                          mlp_bwd_fused_blocks(w.Mf) <= 256 && fold->n + 3 <= PS_MAX_COLFOLD;
-  if (score_on_side && !(fuse_last && w.R > 1)) {   // not the fused form after all: the score backward goes first
+  if (score_on_side && !(fuse_last && w.R > 1)) {
+    // not the fused form: d enc is needed first, so the score backward is cut in two — its d enc half leads the main
+    // stream, its table scatter (the expensive half: 127 us of scattered atomics at C5) goes to the side stream
     ScoreArgs t = *score_on_side;
     t.denc = ws + w.denc;
-    TRY(launch_score_bwd(t, st));
+    SideCtx* sc = side_ctx();
+    if (sc && w.R > 1) {
+      t.part = 1;
+      TRY(launch_score_bwd(t, st));
+      TRY(side_fork(st));
+      t.part = 2;
+      TRY(launch_score_bwd(t, sc->stream));
+    } else {
+      TRY(launch_score_bwd(t, st));
+    }
     score_on_side = nullptr;
   }
   if (fuse_last) {
