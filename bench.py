@@ -138,6 +138,9 @@ def cpu_baseline(args_ns, n_steps):
 
 def main():
     a = parse()
+    if os.environ.get('PS_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PS_BENCH_WATCHDOG']), exit=True)
     from prodsearch_amd import dist as pdist, readme_tem_args, synth
     rank, local, world = pdist.init_from_env()
     if world != a.gpus and world > 1:
