@@ -575,7 +575,7 @@ __device__ inline Task score_task(const ScoreArgs& a, int t) {
   return k;
 }
 
-template <int SCORE_U, int NT>
+template <int SCORE_U>
 __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int ntask, int lpr) {
   const int tid = threadIdx.x;
   const int gpb = 256 / lpr;                       // row groups per block
@@ -600,13 +600,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int n
     if (tk[u].row && c < nch) {
       const float4* rp = reinterpret_cast<const float4*>(tk[u].row + 4 * c);
       const float4* vp = reinterpret_cast<const float4*>(tk[u].vec + 4 * c);
-      if (NT) {
-        typedef float nf4 __attribute__((ext_vector_type(4)));
-        nf4 a4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(rp));
-        nf4 b4 = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(vp));
-        r[u] = make_float4(a4.x, a4.y, a4.z, a4.w); v[u] = make_float4(b4.x, b4.y, b4.z, b4.w);
-      }
-      else { r[u] = *rp; v[u] = *vp; }
+      r[u] = *rp; v[u] = *vp;
     }
   }
 #pragma unroll
@@ -738,24 +732,22 @@ static int score_wide_u() {
   return env == 2 && ch != 8 ? 2 : 1;
 }
 
+// one-chunk fallback: one task per row group below 64 MB of rows per launch, two above
+static int score_one_chunk_u(const ScoreArgs& a, int ntask) {
+  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;     // tuning experiments (1 or 2)
+  if (Uenv == 1 || Uenv == 2) return Uenv;
+  return (size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2;
+}
+
 int score_fwd_blocks(const ScoreArgs& a) {
   const int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
-  const int lpr = lpr_for(a.d);
-  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;
-  const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
   if (const int ch = score_wide_ch(a, ntask)) return ps_cdiv(ps_cdiv(ntask, score_wide_u()), 256 / (a.d / 4 / ch));
-  return ps_cdiv(ps_cdiv(ntask, U), 256 / lpr);
+  return ps_cdiv(ps_cdiv(ntask, score_one_chunk_u(a, ntask)), 256 / lpr_for(a.d));
 }
 
 int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
-  int lpr = lpr_for(a.d);
-  // rows in flight per row group: measured on MI355X (profiles/r01_gather_score_tuning.txt) the latency-bound C2
-  // launch (12.8 MB) is fastest with ONE task per group (most waves), the HBM-bound C5 shape with two.
-  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;     // tuning experiments
-  static const int NT = getenv("PS_SCORE_NT") ? atoi(getenv("PS_SCORE_NT")) : 0;
-  const int U = Uenv > 0 ? Uenv : ((size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2);
   if (const int ch = score_wide_ch(a, ntask)) {
     const int wl = a.d / 4 / ch, wu = score_wide_u();
     const int wb = ps_cdiv(ps_cdiv(ntask, wu), 256 / wl);
@@ -768,17 +760,12 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
     PS_LAUNCH_CHECK();
     return PS_OK;
   }
-  int groups = ps_cdiv(ntask, U);
-  int blocks = ps_cdiv(groups, 256 / lpr);
-  dim3 g(blocks), b(256);
+  // widths the wide form does not cover (d/4 not 16 x {2,4,8}): one 16-byte chunk per lane, lpr_for(d) lanes per row
+  const int lpr = lpr_for(a.d), U = score_one_chunk_u(a, ntask);
+  const int blocks = ps_cdiv(ps_cdiv(ntask, U), 256 / lpr);
   a.loss_nblk = blocks;
-  if (U == 1) hipLaunchKernelGGL((score_fwd_kernel<1, 0>), g, b, 0, st, a, ntask, lpr);
-  else if (U == 2 && !NT) hipLaunchKernelGGL((score_fwd_kernel<2, 0>), g, b, 0, st, a, ntask, lpr);
-  else if (U == 8 && !NT) hipLaunchKernelGGL((score_fwd_kernel<8, 0>), g, b, 0, st, a, ntask, lpr);
-  else if (U == 2) hipLaunchKernelGGL((score_fwd_kernel<2, 1>), g, b, 0, st, a, ntask, lpr);
-  else if (U == 8) hipLaunchKernelGGL((score_fwd_kernel<8, 1>), g, b, 0, st, a, ntask, lpr);
-  else if (NT) hipLaunchKernelGGL((score_fwd_kernel<4, 1>), g, b, 0, st, a, ntask, lpr);
-  else hipLaunchKernelGGL((score_fwd_kernel<4, 0>), g, b, 0, st, a, ntask, lpr);
+  if (U == 1) hipLaunchKernelGGL((score_fwd_kernel<1>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
+  else hipLaunchKernelGGL((score_fwd_kernel<2>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
