@@ -376,7 +376,14 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
     const int ta = g.p[0].ta, tb = g.p[0].tb;
     if (ta == 0 && tb == 1 && full) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, 1, 32, 2, 1>), grid, dim3(256), 0, stream, g);
     else if (ta == 1 && tb == 1 && !full) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
-    else if (ta == 0 && tb == 0 && !full) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
+    else if (ta == 0 && tb == 0 && !full) {
+      // small launches whose whole reduction is one 128-deep slab (the K/V projection at C2: ~240 live workgroups):
+      // one global round trip instead of four shallow slabs (0.3615 -> 0.3564 ms/step); big grids keep 4 workgroups per CU
+      static const int deep_kv = getenv("PS_KV_DEEP") ? atoi(getenv("PS_KV_DEEP")) : 1;   // tuning experiment
+      if (deep_kv && g.p[0].K <= 128 && (size_t)grid.x * grid.y * grid.z <= 1024)
+        hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 128, 1, 1>), grid, dim3(256), 0, stream, g);
+      else hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
+    }
     else PS_REQUIRE(false, "gemm: no row-list instantiation for ta=%d tb=%d full=%d", ta, tb, (int)full);
     PS_LAUNCH_CHECK();
     return PS_OK;
