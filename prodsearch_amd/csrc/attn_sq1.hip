@@ -197,6 +197,7 @@ static inline int sq1_pick_split(const AttnArgs& a) {
   while (hy > 1 && (a.H % hy != 0 || (a.H / hy) % 4 != 0 || (a.d / hy) % 4 != 0)) hy >>= 1;
   return hy < 1 ? 1 : hy;
 }
+int attn_sq1_split(const AttnArgs& a) { return sq1_pick_split(a); }
 static inline void sq1_sub_dividers(AttnArgs& b, int hy) {
   const int Hs = b.H / hy, ds = b.d / hy;
   b.fd = make_fdiv(ds); b.fd4 = make_fdiv(ds / 4);

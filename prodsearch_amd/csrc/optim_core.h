@@ -3,7 +3,7 @@
 #include "common.h"
 #include <math.h>
 
-#define ADAM_CHUNK 8192     // elements per block
+#define ADAM_CHUNK 4096     // elements per block
 
 struct AdamPlanHeader {
   int32_t n_tensors;

@@ -95,6 +95,7 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
 bool attn_sq1_fits(const AttnArgs& a);
+int attn_sq1_split(const AttnArgs& a);   // head groups (workgroups) per sequence the sq1 kernels will use
 
 struct ScoreArgs {
   int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)

@@ -729,7 +729,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       }
       // first layer, one query row per sequence, d == 128: dQ.Wq rides in the attention backward's tail (two partial
       // rows per sequence in the free d ln1 buffer) instead of a [n_in,128]x[128,128] GEMM launch of its own
-      const bool q_folded = sq1 && !qall && i == 0 && d == 128 && D.H % 8 == 0 && ps_fusion_enabled() &&
+      const bool q_folded = sq1 && !qall && i == 0 && d == 128 && attn_sq1_split(a) == 2 && ps_fusion_enabled() &&
                             (size_t)2 * l.n_in <= (size_t)M2;
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
       TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
