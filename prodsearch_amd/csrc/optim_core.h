@@ -3,7 +3,7 @@
 #include "common.h"
 #include <math.h>
 
-#define ADAM_CHUNK 4096     // elements per block
+#define ADAM_CHUNK 4096     // elements per block (8192: 0.356 ms/step, 4096: 0.353, 2048: 0.355)
 
 struct AdamPlanHeader {
   int32_t n_tensors;
