@@ -244,6 +244,8 @@ struct GemmProblem {
   //   ta == 0:            logical row i of A / C / residual is physical row ridx[i]; M is the list length on the device
   //   ta == 1 && tb == 1: logical reduction row k of A and B is physical row ridx[k]; K is the list length
   const int32_t* ridx; const int32_t* rcount;
+  int no_deep;                          // never pick the 128-deep-slab form (133 KB of LDS per workgroup): for small products that
+                                        // run BESIDE other launches, where that footprint starves them of CUs
 };
 
 struct GemmGroup {

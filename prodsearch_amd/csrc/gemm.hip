@@ -394,7 +394,7 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
   for (int r = 0; r < repeat; ++r) {
     // few workgroups (latency-bound chain): one deep slab per round trip; many: shallow slabs, 4 wgs per CU
     static const int deep_max = getenv("PS_GEMM_DEEP_MAX") ? atoi(getenv("PS_GEMM_DEEP_MAX")) : 64;         // tuning experiments
-    const bool deep = (size_t)grid.x * grid.y * grid.z <= (size_t)deep_max;
+    const bool deep = (size_t)grid.x * grid.y * grid.z <= (size_t)deep_max && !g.p[0].no_deep;
     if (full && deep) launch<1, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);
     else if (full) launch<1, 32>(g.p[0].ta, g.p[0].tb, grid, stream, g);
     else if (deep) launch<0, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);

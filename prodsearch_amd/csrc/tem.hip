@@ -746,6 +746,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       float* dxq = ws + w.dctx;                      // free again: the attention backward has consumed it
       if (q_via_res && !q_folded) {
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxq, d, l.n_in, d, d);
+        xq.no_deep = 1;   // runs beside the side stream's weight gradients (at C5 the deep form waited 110 us for whole CUs)
         TRY(run1(xq, st));
       }
       // fork 2: they need the attention backward's dK / dV / dQ.  With the fused backward the side stream already
