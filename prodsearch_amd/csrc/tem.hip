@@ -778,7 +778,9 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       if (listed) {
         const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
         const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
-        x.ridx = vr; x.rcount = vc;
+        // (the dX product only when its fan-in residual is already folded: walking 21 replica rows per query row in
+        // a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
+        if (q_folded || l.fan == 1) { x.ridx = vr; x.rcount = vc; }
         wg3[0].ridx = vr; wg3[0].rcount = vc;
         wg3[1].ridx = vr; wg3[1].rcount = vc;
       }
