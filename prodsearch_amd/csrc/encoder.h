@@ -51,3 +51,4 @@ int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st);
 int side_fork(hipStream_t main_st);
 int side_run(GemmProblem* ps, int n, hipStream_t main_st);
 int side_join(hipStream_t main_st);
+void side_set_light(bool light);

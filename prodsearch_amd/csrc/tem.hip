@@ -219,6 +219,7 @@ struct SideCtx {
   bool used;
   uint32_t* flag;            // {fork, join} sequence words for stream write / wait-value crossings (null: event pairs)
   uint32_t fork_seq, join_seq;
+  bool light;                // use them for the current backward (side_set_light)
 };
 static SideCtx* side_ctx() {
   static SideCtx ctx;
@@ -231,10 +232,12 @@ static SideCtx* side_ctx() {
       for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ctx.ev[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&ctx.join, hipEventDisableTiming) == hipSuccess;
       ctx.next = 0; ctx.used = false;
-      ctx.flag = nullptr; ctx.fork_seq = 0; ctx.join_seq = 0;
+      ctx.flag = nullptr; ctx.fork_seq = 0; ctx.join_seq = 0; ctx.light = false;
       // forks / joins as stream write-value / wait-value operations on a device word instead of event pairs: the waiting
-      // stream loses ~3 us per crossing instead of 6-12 (0.353 -> 0.341 ms/step).  PS_SIDE_EVENTS=1 keeps the events;
-      // so does a stream that is being captured into a graph (side_fork / side_join check).
+      // stream loses ~3 us per crossing instead of 6-12 when the waits are SHORT (C2: 0.353 -> 0.341 ms/step), but a
+      // polled wait that lasts hundreds of microseconds wakes up late (review transformer 0.924 -> 0.942 ms, C5 1.64 ->
+      // 1.72 ms), so the backward picks per step (side_set_light).  PS_SIDE_EVENTS=1 keeps the events everywhere; so
+      // does a stream that is being captured into a graph (side_fork / side_join check).
       int can_wait = 0, dev = 0;
       const bool want = !(getenv("PS_SIDE_EVENTS") && atoi(getenv("PS_SIDE_EVENTS")) != 0);
       if (ok && want && hipGetDevice(&dev) == hipSuccess &&
@@ -258,7 +261,7 @@ static bool stream_capturing(hipStream_t st) {
 int side_fork(hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c) return PS_OK;
-  if (c->flag && !stream_capturing(main_st)) {
+  if (c->flag && c->light && !stream_capturing(main_st)) {
     ++c->fork_seq;
     PS_CHECK_HIP(hipStreamWriteValue32(main_st, c->flag, c->fork_seq, 0));
     PS_CHECK_HIP(hipStreamWaitValue32(c->stream, c->flag, c->fork_seq, hipStreamWaitValueGte, 0xffffffffu));
@@ -272,6 +275,11 @@ int side_fork(hipStream_t main_st) {
   c->used = true;
   return PS_OK;
 }
+// short steps cross streams with write / wait-value operations, long ones with events (see side_ctx)
+void side_set_light(bool light) {
+  SideCtx* c = side_ctx();
+  if (c) c->light = light;
+}
 // launch on the side stream (after the last fork); on the main stream when the side stream is disabled
 int side_run(GemmProblem* ps, int n, hipStream_t main_st) {
   SideCtx* c = side_ctx();
@@ -284,7 +292,7 @@ int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
 int side_join(hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c || !c->used) return PS_OK;
-  if (c->flag && !stream_capturing(main_st)) {
+  if (c->flag && c->light && !stream_capturing(main_st)) {
     ++c->join_seq;
     PS_CHECK_HIP(hipStreamWriteValue32(c->stream, c->flag + 1, c->join_seq, 0));
     PS_CHECK_HIP(hipStreamWaitValue32(main_st, c->flag + 1, c->join_seq, hipStreamWaitValueGte, 0xffffffffu));
@@ -585,6 +593,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
   // The last layer's whole per-replica backward (final LN, FFN, FF LN, Wo) as one kernel (mlp_fused.hip) when the
   // forward took the fused form too; needs parked column sums (fold) and one parked row per workgroup (<= 256).
+  side_set_light((int64_t)B * S * d <= ((int64_t)2 << 20));   // C2: 1.03 M elements of x; review transformer 10 M; C5 5.5 M
   static const bool bwd_fuse_on = !(getenv("PS_NO_FUSE_BWD") && atoi(getenv("PS_NO_FUSE_BWD")) != 0);
   const int bwd_fuse_min = fuse_bwd_min_slot();
   const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 && d == 128 &&
