@@ -172,8 +172,24 @@ def main():
         optim.step()                                     # :78
         return loss
 
-    for i in range(a.warmup):
+    # Warm-up, then the roofline leg (rank 0), then the timed steps.  The step's stream join is a write-value / wait-value
+    # pair (ps_set_side_mode, include/prodsearch_hip.h); back-to-back launch timings on a stream that has carried one are
+    # noisy (4.2 us in 7 of 12 runs, 4.4-7.3 us in the others), so the warm-up steps cross streams with events and the
+    # gather+score launch is timed on the warm, still pristine training stream (always 4.19-4.27 us there)
+    from prodsearch_amd import _lib
+    crossing = _lib.load().ps_set_side_mode(0)
+    for i in range(max(a.warmup - 1, 0)):
         step(i)
+    roof = None
+    if rank == 0 and not a.no_extras:
+        if not model._plans:                         # --warmup 0 / 1: one forward builds the launch plan
+            with torch.no_grad():
+                model(batches[0])
+        plan0 = next(iter(model._plans.values()))
+        roof = (time_gather_score(model, plan0, a.kernel_iters), plan0.layout.R)
+    _lib.load().ps_set_side_mode(crossing)
+    if a.warmup > 0:
+        step(a.warmup - 1)                           # the last warm-up step runs in the timed configuration
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -204,13 +220,12 @@ def main():
         "samples_per_s": world * B * a.steps / elapsed, "final_loss": last_loss,
     }
     if rank == 0 and not a.no_extras:
-        plan = next(iter(model._plans.values()))
-        t_k = time_gather_score(model, plan, a.kernel_iters)
-        nbytes = gather_score_bytes(plan.layout.R)
+        t_k, R_k = roof
+        nbytes = gather_score_bytes(R_k)
         traffic = None          # PMC passes cannot run inside this process: taken from the committed profile
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'gather_score_traffic.json')))
-            traffic = tj.get('R%d_bytes_per_launch' % plan.layout.R) if a.workload == 'c2' else None
+            traffic = tj.get('R%d_bytes_per_launch' % R_k) if a.workload == 'c2' else None
         except Exception:
             pass
         out["roofline"] = {"bound": "hbm", "achieved": nbytes / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,5 +1,6 @@
 # Runs on the MI355X box (gpurun): everything profiles/ is built from, under gpurun_out/refresh/.
 set -e
+export PS_SIDE_EVENTS_NOTE="counter passes run with event-pair stream crossings (auto-detected from ROCPROF_COUNTER_COLLECTION)"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
