@@ -295,8 +295,9 @@ int side_fork(hipStream_t main_st) {
 }
 // short steps cross streams with write / wait-value operations, long ones with events (see side_ctx)
 void side_set_light(bool light) {
+  static const int force = getenv("PS_SIDE_LIGHT") ? atoi(getenv("PS_SIDE_LIGHT")) : -1;   // tuning: 0 never, 1 always
   SideCtx* c = side_ctx();
-  if (c) c->light = light;
+  if (c) c->light = force >= 0 ? force != 0 : light;
 }
 // launch on the side stream (after the last fork); on the main stream when the side stream is disabled
 int side_run(GemmProblem* ps, int n, hipStream_t main_st) {
