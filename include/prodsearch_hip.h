@@ -110,7 +110,8 @@ typedef struct PsTemWsLayout {
   int32_t R;             /* encoder replicas per batch row: K+1 if dropout is drawn, else 1 */
   int32_t S;             /* L+1 */
   int64_t qmean, query_emb, x;                 /* [B,d],[B,d],[B,S,d]                 */
-  int64_t kp, vp, qp, attn, ctx;               /* last layer: [n_in*S,d] x2, [n_in,d].. */
+  int64_t kp, vp, qp, attn, ctx;               /* last layer: [n_in*S,d] x2, [n_in,d].. ; K/V rows of MASKED key positions
+                                                  are not written when the one-layer sq1 path is in use (row-list projection) */
   int64_t y1, ln1, a1, h1, y2, enc;            /* last layer replica rows              */
   int64_t item_scores, word_scores, loss_parts;/* [B,1+K],[B,W,1+K],[B,2]             */
   int64_t denc, dx;                            /* backward: [B*R,d], [B,S,d]           */
