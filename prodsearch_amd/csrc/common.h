@@ -221,6 +221,8 @@ __host__ inline void res_finish(ResMap& R) {   // call after Sq/fan/S are set
   R.dSq = make_fdiv(R.Sq); R.dfan = make_fdiv(R.fan); R.dS = make_fdiv(R.S);
 }
 
+#define PS_GEMM_KIDX_MAX 2048   // reduction rows of ONE split a row-list weight gradient can map (LDS ints)
+
 struct GemmProblem {
   const float* A; int lda; int ta;      // ta: A stored [K][M] (reduction index is the slow one)
   const float* Bseg[3]; int kseg;       // up to 3 B segments of kseg reduction rows each (nseg = ceil(K/kseg))

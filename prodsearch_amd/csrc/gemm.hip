@@ -103,7 +103,7 @@ __device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16],
   }
 }
 
-#define KIDX_MAX 2048      // reduction rows of one split a row-list weight gradient can map (LDS ints)
+#define KIDX_MAX PS_GEMM_KIDX_MAX
 template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int NLD = BK / 16;

@@ -203,6 +203,11 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
     rows = ps[i].K > rows ? ps[i].K : rows;
   }
   int ks = pick_ksplit(tiles, rows);
+  for (int i = 0; i < n; ++i)
+    if (ps[i].ridx) {   // a row-list problem maps one split's reduction rows through LDS: at most PS_GEMM_KIDX_MAX of them
+      const int need = ps_cdiv(ps_cdiv(ps[i].K, 32) * 32, PS_GEMM_KIDX_MAX - 32);
+      if (ks < need) ks = need;
+    }
   for (int i = 0; i < n; ++i) { g.p[i] = ps[i]; g.p[i].ksplit = ks; }
   return ps_launch_gemm(g, st);
 }
@@ -816,6 +821,16 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // stream instead — one event less, and the side stream ends before the scatter does.
       static const bool wg3_main_on = !(getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) != 0);
       const bool wg3_main = fused && wg3_main_on && ns <= 2 * M2;   // (review transformer: 78k K/V rows vs 1.5k replica rows -> side)
+      // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the K/V
+      // weight gradients (and the dX product below) run over the batch's row list instead of all n_in*S rows
+      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      const bool listed = rows_on && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
+      const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
+      const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
+      if (listed) {
+        wg3[0].ridx = vr; wg3[0].rcount = vc;
+        wg3[1].ridx = vr; wg3[1].rcount = vc;
+      }
       if (!wg3_main) {
         TRY(side_fork(st));
         TRY(side_run(wg3, 3, st));
@@ -833,19 +848,9 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         }
         else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
       }
-      // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the dX
-      // product and the K/V weight gradients run over the batch's row list (EmbedArgs::vrows) instead of all n_in*S rows
-      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
-      const bool listed = rows_on && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
-      if (listed) {
-        const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
-        const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
-        // (the dX product only when its fan-in residual is already folded: walking 21 replica rows per query row in
-        // a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
-        if (q_folded || l.fan == 1) { x.ridx = vr; x.rcount = vc; }
-        wg3[0].ridx = vr; wg3[0].rcount = vc;
-        wg3[1].ridx = vr; wg3[1].rcount = vc;
-      }
+      // (the dX product over the row list only when its fan-in residual is already folded: walking 21 replica rows per
+      // query row in a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
+      if (listed && (q_folded || l.fan == 1)) { x.ridx = vr; x.rcount = vc; }
       TRY(run1(x, st));
       if (wg3_main) TRY(run_wgrads(wg3, 3, st));
       if (!qall && !q_via_res) {
