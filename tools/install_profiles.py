@@ -7,7 +7,7 @@ src, dst = os.path.join(root, 'gpurun_out', 'refresh'), os.path.join(root, 'prof
 cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
 line = open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1]
 open(os.path.join(dst, rnd + '_bench.json'), 'w').write(line + '\n')
-stats = sorted(glob.glob(src + '/prof/**/*kernel_stats.csv', recursive=True))[0]
+stats = max(glob.glob(src + '/prof/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)   # newest run
 shutil.copyfile(stats, os.path.join(dst, rnd + '_bench_kernel_stats.csv'))
 cp('step_timeline.txt', rnd + '_step_timeline.txt')
 cp('gather_score_pmc.txt', rnd + '_gather_score_pmc.txt')

@@ -3,7 +3,7 @@
 import csv, glob, json, os, sys
 prof, prof_json, bench_json, rnd = sys.argv[1:5]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-stats = sorted(glob.glob(prof + '/**/*kernel_stats.csv', recursive=True))[0]
+stats = max(glob.glob(prof + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)   # newest run
 rows = list(csv.DictReader(open(stats)))
 pj = json.loads(open(prof_json).read().strip().splitlines()[-1])
 bj = json.loads(open(bench_json).read().strip().splitlines()[-1])
