@@ -139,7 +139,12 @@ class ProductRanker(nn.Module):
         plan, loss3 = self._run_forward(batch_data, bool(train_pv), neg_word_idxs)
         if not torch.is_grad_enabled():
             return loss3[0]
-        return _RtmLossFn.apply(self._anchor(), self, plan, loss3)
+        # same direct path as ItemTransformerRanker: a plain ``loss.backward()`` calls the HIP backward without the
+        # autograd engine's round trip and its ``ones_like`` fill kernel (item_transformer._LossTensor)
+        from .item_transformer import _LossTensor
+        out = _RtmLossFn.apply(self._anchor(), self, plan, loss3).as_subclass(_LossTensor)
+        out._ps_fast = (self, plan, self._fwd_step)
+        return out
 
     def test(self, batch_data):
         return self._run_score(batch_data)
@@ -421,9 +426,9 @@ class ProductRanker(nn.Module):
                 raise RuntimeError("a foreign .grad tensor is attached; call model.zero_grad() before backward")
         if fresh:
             _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(), st), 'ps_zero_floats')
-        go = grad_out.contiguous().float()
+        go = None if grad_out is None else grad_out.contiguous().float()          # None: d loss / d loss = 1
         _lib.check(lib.ps_rtm_backward(plan['desc'], ps, plan['batch'], plan['ws'].data_ptr(), gs, 1.0,
-                                       go.data_ptr(), st), 'ps_rtm_backward')
+                                       None if go is None else go.data_ptr(), st), 'ps_rtm_backward')
 
     def _run_score(self, batch):
         lib = _lib.load()
