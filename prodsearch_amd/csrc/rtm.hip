@@ -103,9 +103,9 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.nvalid = rtake(cur, 4);
   r.seqcnt = rtake(cur, (int64_t)r.Bseq + 4);
   r.dvec = rtake(cur, (int64_t)D.B * D.R * d);
-  r.dqe = rtake(cur, (int64_t)D.B * d);
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
+  r.dqe = rtake(cur, (int64_t)D.B * d);          // dqe and wcnt are adjacent: the backward zeroes both with ONE memset
   r.wcnt = r.woff = r.wcur = r.wl_slot = r.wl_word = 0;
   if (!eval && D.review_encoder == PS_RENC_PVC) {
     r.wcnt = rtake(cur, D.vocab_size);
@@ -872,13 +872,16 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   ColFoldList fold;
   fold.n = 0;
   TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
-  PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)B * d, st));
+  // d query_emb (+ the inverted index's per-word counters right behind it, rtm_make_ws): one 16-byte-aligned memset
+  {
+    const int64_t zend = k.pvc ? r.wcnt + (((int64_t)D.vocab_size + 3) & ~(int64_t)3) : r.dqe + (((int64_t)B * d + 3) & ~(int64_t)3);
+    PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)(zend - r.dqe), st));
+  }
   int eb = ps_cdiv(r.Bseq * r.S, 4); if (eb > 1024) eb = 1024;
   if (k.pvc) {
     k.gs = ws + r.enc_base + w.dx;
     k.wcnt = (int*)(ws + r.wcnt); k.woff = (int*)(ws + r.woff); k.wcur = (int*)(ws + r.wcur);
     k.wl_slot = (int*)(ws + r.wl_slot); k.wl_word = (int*)(ws + r.wl_word);
-    PS_CHECK_HIP(hipMemsetAsync(k.wcnt, 0, sizeof(int) * (size_t)D.vocab_size, st));
   }
   hipLaunchKernelGGL(rtm_embed_bwd_kernel, dim3(eb), dim3(256), (size_t)4 * d * sizeof(float), st, k);
   PS_LAUNCH_CHECK();
