@@ -48,6 +48,7 @@ struct RtmK {              // kernel-side view of one call
   // workspace
   float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *weight, *pv_scores, *pv_terms, *nvalid;
   int32_t *seqcnt, *vrows, *vcount;   // valid-row list of x (GemmProblem::ridx): per-sequence counts, rows, length
+  int count_words;                    // rtm_embed_bwd_kernel also counts the word occurrences (0: rtm_wcount_kernel did, early)
   float* loss3;
   // backward
   float scale; const float* scale_dev;
@@ -580,10 +581,11 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
         for (int k = 0; k < 16; ++k)
           if (k < epl) gw[c + 32 * k] = gk[k] * inv;
       }
-      for (int w = lane; w < a.WL; w += 64) {
-        const int64_t wi = words[w];
-        if (wi != a.V - 1 && wi >= 0 && wi < a.V) atomicAdd(&a.wcnt[wi], 1);
-      }
+      if (a.count_words)
+        for (int w = lane; w < a.WL; w += 64) {
+          const int64_t wi = words[w];
+          if (wi != a.V - 1 && wi >= 0 && wi < a.V) atomicAdd(&a.wcnt[wi], 1);
+        }
     }
   }
   __syncthreads();
@@ -626,6 +628,30 @@ __global__ __launch_bounds__(1024) void rtm_wscan_kernel(const int* cnt, int* of
     }
   }
   if (tid == 1023) off[V] = part[1023];
+}
+
+// occurrences per word (the first pass of the inverted index).  The index depends on the batch's indices only, not on
+// any gradient, so count -> scan -> fill run on the side stream from the START of the backward, under the encoder
+// backward, instead of between rtm_embed_bwd_kernel and rtm_wreduce_kernel on its tail
+__global__ __launch_bounds__(256) void rtm_wcount_kernel(const RtmK a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
+  const int64_t rpad = a.RC - 1;
+  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
+    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+    if (s == 0) continue;
+    int b, j, revrow, seg; int64_t ridx;
+    seq_decode(a, n, s, b, j, ridx, revrow, seg);
+    if (ridx == rpad) continue;
+    const bool pos = j == 0;
+    const int64_t* words;
+    if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
+    else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
+    for (int w = lane; w < a.WL; w += 64) {
+      const int64_t wi = words[w];
+      if (wi != a.V - 1 && wi >= 0 && wi < a.V) atomicAdd(&a.wcnt[wi], 1);
+    }
+  }
 }
 
 // word -> list of review slots: every non-pad word occurrence appends its slot to its word's segment
@@ -871,7 +897,6 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   to_tem_tensors(G, TG);
   ColFoldList fold;
   fold.n = 0;
-  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   // d query_emb (+ the inverted index's per-word counters right behind it, rtm_make_ws): one 16-byte-aligned memset
   {
     const int64_t zend = k.pvc ? r.wcnt + (((int64_t)D.vocab_size + 3) & ~(int64_t)3) : r.dqe + (((int64_t)B * d + 3) & ~(int64_t)3);
@@ -883,13 +908,32 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     k.wcnt = (int*)(ws + r.wcnt); k.woff = (int*)(ws + r.woff); k.wcur = (int*)(ws + r.wcur);
     k.wl_slot = (int*)(ws + r.wl_slot); k.wl_word = (int*)(ws + r.wl_word);
   }
+  // the inverted index (count, scan, fill) on the side stream, under the encoder backward (rtm_wcount_kernel)
+  static const bool early_on = !(getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0);
+  hipStream_t ss = side_stream_or(st);
+  const bool early_index = k.pvc && early_on && ss != st;
+  k.count_words = early_index ? 0 : 1;
+  if (early_index) {
+    TRY(side_fork(st));                             // behind the memset of the counters
+    hipLaunchKernelGGL(rtm_wcount_kernel, dim3(eb), dim3(256), 0, ss, k);
+    PS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rtm_wscan_kernel, dim3(1), dim3(1024), 0, ss, k.wcnt, k.woff, k.wcur, (int)D.vocab_size);
+    PS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rtm_wfill_kernel, dim3(eb), dim3(256), 0, ss, k);
+    PS_LAUNCH_CHECK();
+  }
+  TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   hipLaunchKernelGGL(rtm_embed_bwd_kernel, dim3(eb), dim3(256), (size_t)4 * d * sizeof(float), st, k);
   PS_LAUNCH_CHECK();
   if (k.pvc) {
-    hipLaunchKernelGGL(rtm_wscan_kernel, dim3(1), dim3(1024), 0, st, k.wcnt, k.woff, k.wcur, (int)D.vocab_size);
-    PS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rtm_wfill_kernel, dim3(eb), dim3(256), 0, st, k);
-    PS_LAUNCH_CHECK();
+    if (early_index) {
+      TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
+    } else {
+      hipLaunchKernelGGL(rtm_wscan_kernel, dim3(1), dim3(1024), 0, st, k.wcnt, k.woff, k.wcur, (int)D.vocab_size);
+      PS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(rtm_wfill_kernel, dim3(eb), dim3(256), 0, st, k);
+      PS_LAUNCH_CHECK();
+    }
     const int64_t max_occ = (int64_t)r.Bseq * D.R * D.WL;
     hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)((max_occ + 255) / 256)), dim3(256), 0, st, k);
     PS_LAUNCH_CHECK();

@@ -304,6 +304,10 @@ void side_set_light(bool light) {
   SideCtx* c = side_ctx();
   if (c) c->light = force >= 0 ? force != 0 : light;
 }
+hipStream_t side_stream_or(hipStream_t main_st) {
+  SideCtx* c = side_ctx();
+  return c ? c->stream : main_st;
+}
 // launch on the side stream (after the last fork); on the main stream when the side stream is disabled
 int side_run(GemmProblem* ps, int n, hipStream_t main_st) {
   SideCtx* c = side_ctx();
