@@ -255,6 +255,20 @@ int ps_scatter_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const 
                     const float* values_dev, ps_stream_t stream);
 int ps_zero_rows(float* table_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev, int64_t cap,
                  ps_stream_t stream);
+/* Device address of a coalesce workspace's status word: 0 ok, 1 an index outside [0, n_rows) was dropped, 2 more
+ * unique rows than `cap`.  Callers copy it back when they can afford a sync (the step itself never does). */
+const int32_t* ps_coalesce_bad_flag(void* ws_dev, int64_t n_rows);
+
+/* Data-parallel exchange of a table's touched rows with NO host synchronisation (new: the reference is single-process,
+ * trainer.py:64-83).  Every rank packs a fixed-capacity message — msg_rows[cap]: its sorted touched ids, then -1;
+ * msg_vals[cap,d]: their gradient rows, then zeros — the messages are all-gathered (RCCL), the union of the ids is
+ * ps_coalesce_rows over the gathered ids with pad_row = -1, and ps_merge_rows writes, for every union row, the sum of the
+ * ranks' rows IN RANK ORDER into the dense gradient: bitwise the same result on every rank.  world <= 32. */
+int ps_pack_rows(const float* grad_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev, int64_t cap,
+                 int64_t* msg_rows_dev, float* msg_vals_dev, ps_stream_t stream);
+int ps_merge_rows(const int64_t* all_rows_dev, const float* all_vals_dev, int32_t world, int64_t cap, int32_t d,
+                  float* grad_dev, const int64_t* union_rows_dev, const int32_t* union_count_dev, int64_t union_cap,
+                  ps_stream_t stream);
 
 typedef struct PsRowTable {
   float* p; float* g; float* m; float* v;   /* [n_rows, d] parameter, dense gradient, Adam moments */
@@ -339,6 +353,23 @@ typedef struct PsRtmBatch {
 } PsRtmBatch;
 
 int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int64_t* total);
+/* Offsets (in floats) of the intermediates inside the workspace, for stage-by-stage parity tests.  Sequences are
+ * n = b*J + j (J = 1+K training: j = 0 positive; J = C eval), S = R+1 positions [query, reviews]. */
+typedef struct PsRtmWsLayout {
+  int64_t total_floats;
+  int32_t Bseq, S, J, pad_;
+  int64_t query_emb;   /* [B,d]        FS(query)                                   (ps_model.py:257-258) */
+  int64_t valid;       /* [Bseq,S]     1 = unmasked position                        (:316-318)            */
+  int64_t x;           /* [Bseq,S,d]   encoder input (review vectors + seg/user/item emb, masked, + pe) (:320-334) */
+  int64_t vec;         /* [B*R,d]      review vector the PV loss predicts from (train_pv)  (PV.py:53-54, PVC.py:77-78) */
+  int64_t cnt;         /* [Bseq,R]     non-pad words per review (pvc)                */
+  int64_t enc;         /* [Bseq,d]     final-LayerNorm output at position 0          (transformer.py:90-95) */
+  int64_t scores;      /* [Bseq]       wo . enc + b                                  (transformer.py:96)    */
+  int64_t weight;      /* [Bseq]       BCE weight of each sequence                   (ps_model.py:344-345)  */
+  int64_t pv_scores;   /* [B*R,W,1+K]  PV-loss logits (train_pv)                     (PV.py:59-63)          */
+  int64_t dx;          /* [Bseq,S,d]   gradient w.r.t. x after the backward                                 */
+} PsRtmWsLayout;
+int ps_rtm_workspace_layout(const PsRtmDesc* desc, int32_t eval, PsRtmWsLayout* out);
 /* loss = model(batch, train_pv) -- ProductRanker.forward (ps_model.py:241-358); loss3 = {loss, ps_loss, pv_loss} */
 int ps_rtm_forward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* workspace,
                    float* loss3, ps_stream_t stream);

@@ -36,11 +36,15 @@ def pvc_para_vector(P, idxs, word_pad, tok_mult):
     embeddings (alias of word_embeddings, PVC.py:30), token dropout applied to the DATA
     (PVC.py:46-54: autograd never sees the mask or the 1/(1-p) scale), masked mean.
     ``tok_mult`` [N,WL] multiplier (0 or 1/(1-p)) or None."""
-    emb = P['word_embeddings.weight'][idxs]
-    if tok_mult is not None:
-        # value uses the corrupted data, gradient flows as if uncorrupted
-        emb = emb + (emb.detach() * tok_mult.unsqueeze(-1) - emb.detach())
-    return vector_mean(emb, idxs.ne(word_pad))
+    out = []
+    for lo in range(0, idxs.shape[0], 4096):          # per-review op: chunks only bound the [N,WL,d] temporaries
+        ix = idxs[lo:lo + 4096]
+        emb = P['word_embeddings.weight'][ix]
+        if tok_mult is not None:
+            # value uses the corrupted data, gradient flows as if uncorrupted
+            emb = emb + (emb.detach() * tok_mult[lo:lo + 4096].unsqueeze(-1) - emb.detach())
+        out.append(vector_mean(emb, ix.ne(word_pad)))
+    return torch.cat(out, dim=0)
 
 
 def rtm_forward(P, args, batch, neg_word_idxs, vocab_size, review_count, training=True, train_pv=True,
@@ -125,7 +129,8 @@ def rtm_forward(P, args, batch, neg_word_idxs, vocab_size, review_count, trainin
     if keep is not None:
         keep.update(k0)
         keep.update(query_emb=query_emb, pos_rev=pos_rev, neg_rev=neg_rev, scores=scores,
-                    enc_pos=top_p[:, 0, :], enc_neg=top_n[:, 0, :].view(B, K, d))
+                    enc_pos=top_p[:, 0, :], enc_neg=top_n[:, 0, :].view(B, K, d),
+                    pos_seq=pos_seq, neg_seq=neg_seq, pos_mask=pos_mask, neg_mask=neg_mask, weight=weight)
         if train_pv:
             keep.update(pv_scores=pv_scores, per_rev=per_rev)
     return loss, ps_loss, pv_loss

@@ -95,6 +95,12 @@ class PsRtmBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in RTM_BATCH_FIELDS]
 
 
+class PsRtmWsLayout(C.Structure):
+    _fields_ = [('total_floats', C.c_int64)] + [(n, C.c_int32) for n in ('Bseq', 'S', 'J', 'pad_')] + \
+               [(n, C.c_int64) for n in ('query_emb', 'valid', 'x', 'vec', 'cnt', 'enc', 'scores', 'weight',
+                                         'pv_scores', 'dx')]
+
+
 PS_RENC_PV, PS_RENC_PVC = 0, 1
 
 # every symbol include/prodsearch_hip.h declares: (restype, argtypes)
@@ -116,6 +122,7 @@ SYMBOLS = {
     'ps_tem_score': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_rtm_workspace_floats': (C.c_int, [C.POINTER(PsRtmDesc), C.c_int32, C.POINTER(C.c_int64)]),
+    'ps_rtm_workspace_layout': (C.c_int, [C.POINTER(PsRtmDesc), C.c_int32, C.POINTER(PsRtmWsLayout)]),
     'ps_rtm_forward': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_rtm_backward': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
@@ -152,6 +159,11 @@ SYMBOLS = {
     'ps_gather_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'ps_scatter_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'ps_zero_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_coalesce_bad_flag': (C.c_void_p, [C.c_void_p, C.c_int64]),
+    'ps_pack_rows': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    'ps_merge_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p]),
     'ps_adam_rowsparse_state_floats': (C.c_int64, [C.c_int32, C.POINTER(PsRowTable), C.c_int32]),
     'ps_clip_adam_rowsparse': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsRowTable), C.c_int32,
                                          C.POINTER(PsAdamHyper), C.c_void_p, C.c_void_p, C.c_void_p]),

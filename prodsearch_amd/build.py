@@ -36,30 +36,55 @@ def build_data(force=False, verbose=False):
     return DATA_LIB
 
 
-def _stale():
-    if not os.path.exists(LIB):
+OBJDIR = os.path.join(HERE, '_obj')
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def _stale():
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return _newer(LIB, deps)
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library (and the host batch builder); returns its path."""
+    """Compile every HIP source for gfx950 — one object per source, in parallel, only the stale ones — and link
+    them into one shared library (plus the host batch builder); returns its path."""
     build_data(force, verbose)
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
         hipcc = 'hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, src)] + hdrs):
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-o', obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    errs = []
+    for src, pr in jobs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            errs.append("hipcc failed on %s:\n%s" % (src, out))
+    if errs:
+        raise RuntimeError('\n'.join(errs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     return LIB
 
 

@@ -186,6 +186,92 @@ extern "C" int ps_scatter_rows(float* table_dev, int32_t d, const int64_t* rows_
   return rows_copy(1, table_dev, rows_dev, count_dev, cap, (float*)values_dev, d, stream);
 }
 
+// the `bad` word of a coalesce workspace: 0 ok, 1 an index outside [0, n_rows), 2 more unique rows than `cap`
+extern "C" const int32_t* ps_coalesce_bad_flag(void* ws_dev, int64_t n_rows) {
+  if (!ws_dev || n_rows <= 0) return nullptr;
+  unsigned long long* bitmap = (unsigned long long*)ws_dev;
+  return (const int32_t*)(bitmap + co_words(n_rows)) + co_blocks(n_rows);
+}
+
+// ---------------------------------------------------------------- data-parallel exchange of touched rows
+// One rank's wire format for one table: msg_rows[u] = row id (u < count, ascending) or -1 (u >= count), and
+// msg_vals[u, :] = its gradient row (zeros past count, so the bytes on the wire are a function of the gradient only).
+// Fixed capacity `cap` (the step's index count, a function of the batch SHAPE): no size ever crosses to the host.
+__global__ __launch_bounds__(256) void rows_pack_kernel(const float* grad, const int64_t* rows, const int32_t* count,
+                                                        int64_t cap, int64_t* msg_rows, float* msg_vals, int d) {
+  const int64_t n = (int64_t)*count;
+  const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (u >= cap) return;
+  const int lane = threadIdx.x & 31;
+  const bool live = u < n;
+  const int64_t r = live ? rows[u] : -1;
+  if (lane == 0) msg_rows[u] = r;
+  const float4* g4 = (const float4*)(grad + (live ? r : 0) * (int64_t)d);
+  float4* v4 = (float4*)(msg_vals + u * (int64_t)d);
+  for (int j = lane; j < d / 4; j += 32) v4[j] = live ? g4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int ps_pack_rows(const float* grad_dev, int32_t d, const int64_t* rows_dev, const int32_t* count_dev,
+                            int64_t cap, int64_t* msg_rows_dev, float* msg_vals_dev, ps_stream_t stream) {
+  PS_REQUIRE(grad_dev && rows_dev && count_dev && msg_rows_dev && msg_vals_dev && cap > 0 && d > 0 && d % 4 == 0,
+             "pack_rows: bad argument");
+  PS_REQUIRE(((((uintptr_t)grad_dev) | ((uintptr_t)msg_vals_dev)) & 15) == 0, "pack_rows: 16-byte alignment");
+  hipLaunchKernelGGL(rows_pack_kernel, dim3((unsigned)((cap + 7) / 8)), dim3(256), 0, (hipStream_t)stream, grad_dev,
+                     rows_dev, count_dev, cap, msg_rows_dev, msg_vals_dev, d);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// grad[u_rows[u], :] = sum over ranks r = 0 .. world-1, IN RANK ORDER, of the row rank r sent for that id (if any):
+// every rank computes bit-identical sums from the same all-gathered messages, so the replicas stay in lock step.
+// 32 lanes per union row: lane r < world binary-searches rank r's sorted id list, then all lanes add the found rows.
+#define PS_MERGE_MAX_WORLD 32
+__global__ __launch_bounds__(256) void rows_merge_kernel(const int64_t* all_rows, const float* all_vals, int world,
+                                                         int64_t cap, int d, float* grad, const int64_t* u_rows,
+                                                         const int32_t* u_count) {
+  const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 31;
+  const bool live = u < (int64_t)*u_count;          // uniform per 32-lane group
+  int64_t found = -1;
+  const int64_t row = live ? u_rows[u] : -1;
+  if (live && lane < world) {
+    const int64_t* lst = all_rows + (size_t)lane * cap;   // ascending ids, then -1 padding (= +infinity here)
+    int64_t lo = 0, hi = cap;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      const int64_t v = lst[mid];
+      if (v >= 0 && v < row) lo = mid + 1; else hi = mid;
+    }
+    if (lo < cap && lst[lo] == row) found = lo;
+  }
+  if (!live) return;
+  float4* g4 = (float4*)(grad + row * (int64_t)d);
+  for (int j = lane; j < d / 4; j += 32) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < world; ++r) {
+      const int64_t pos = __shfl(found, (threadIdx.x & 32) + r, 64);
+      if (pos >= 0) {
+        const float4 x = ((const float4*)(all_vals + ((size_t)r * cap + pos) * d))[j];
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+    }
+    g4[j] = acc;
+  }
+}
+
+extern "C" int ps_merge_rows(const int64_t* all_rows_dev, const float* all_vals_dev, int32_t world, int64_t cap,
+                             int32_t d, float* grad_dev, const int64_t* union_rows_dev, const int32_t* union_count_dev,
+                             int64_t union_cap, ps_stream_t stream) {
+  PS_REQUIRE(all_rows_dev && all_vals_dev && grad_dev && union_rows_dev && union_count_dev, "merge_rows: null argument");
+  PS_REQUIRE(world > 0 && world <= PS_MERGE_MAX_WORLD && cap > 0 && union_cap > 0 && d > 0 && d % 4 == 0,
+             "merge_rows: world %d (<= %d), cap %lld, d %d", world, PS_MERGE_MAX_WORLD, (long long)cap, d);
+  PS_REQUIRE(((((uintptr_t)grad_dev) | ((uintptr_t)all_vals_dev)) & 15) == 0, "merge_rows: 16-byte alignment");
+  hipLaunchKernelGGL(rows_merge_kernel, dim3((unsigned)((union_cap + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                     all_rows_dev, all_vals_dev, world, cap, d, grad_dev, union_rows_dev, union_count_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 // ---------------------------------------------------------------- row-sparse clip + Adam
 #define RS_MAX_TABLES 4
 #define RS_ROWS_PER_BLOCK 8

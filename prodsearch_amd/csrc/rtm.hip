@@ -129,6 +129,19 @@ extern "C" int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int6
   return PS_OK;
 }
 
+// offsets (floats) of the intermediates the parity tests compare stage by stage
+extern "C" int ps_rtm_workspace_layout(const PsRtmDesc* desc, int32_t eval, PsRtmWsLayout* out) {
+  PS_REQUIRE(desc && out, "rtm workspace layout: null argument");
+  RtmWs r; Ws w; PsTemDesc E;
+  TRY(rtm_make_ws(*desc, eval != 0, r, w, E));
+  memset(out, 0, sizeof(*out));
+  out->total_floats = r.total; out->Bseq = r.Bseq; out->S = r.S; out->J = r.J;
+  out->query_emb = r.query_emb; out->valid = r.valid; out->vec = r.vec; out->cnt = r.cnt; out->scores = r.scores;
+  out->weight = r.weight; out->pv_scores = r.pv_scores;
+  out->x = r.enc_base + w.x; out->enc = r.enc_base + w.enc; out->dx = r.enc_base + w.dx;
+  return PS_OK;
+}
+
 __device__ inline int64_t rclamp(int64_t i, int64_t hi) { return i < 0 ? hi : (i > hi ? hi : i); }
 
 // ------------------------------------------------------------------ embed forward

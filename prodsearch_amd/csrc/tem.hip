@@ -226,13 +226,49 @@ struct SideCtx {
   uint32_t fork_seq, join_seq;
   bool light;                // use them for the current backward (side_set_light)
 };
+// One context per device (a process drives one GPU in production; tests and tools may touch several), created under a
+// mutex.  A context serves ONE host thread at a time — the single-thread contract of the step (include/prodsearch_hip.h,
+// "Threading"): the loader's prefetch thread never calls into this library's device side.
+#include <mutex>
+#define PS_MAX_DEVICES 16
+static bool env_on(const char* name) { const char* e = getenv(name); return e && *e && atoi(e) != 0; }
+// Anything that lets only ONE kernel run on the device at a time deadlocks a stream wait-value (the runtime implements it
+// as a one-thread kernel spinning on the word: the producer never gets to run).  Known serialisers: counter-collecting
+// profilers (rocprofv3 / rocprof --pmc), AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING / CUDA_LAUNCH_BLOCKING, debuggers
+// (ROCgdb sets HSA_ENABLE_DEBUG), and any tool library preloaded into the process.
+static bool dispatch_may_be_serialised() {
+  static const char* const truthy[] = {"AMD_SERIALIZE_KERNEL", "AMD_SERIALIZE_COPY", "HIP_LAUNCH_BLOCKING",
+                                       "CUDA_LAUNCH_BLOCKING", "HSA_ENABLE_DEBUG"};
+  for (const char* n : truthy) if (env_on(n)) return true;
+  const char* mq = getenv("GPU_MAX_HW_QUEUES");
+  if (mq && *mq && atoi(mq) == 1) return true;          // one hardware queue: both streams share it in order
+  // a profiling / tracing tool is attached: value waits only in the one mode known to keep dispatches concurrent — a
+  // rocprofv3 kernel trace with no counter collection, PC sampling or thread trace (so that the traced timeline is the
+  // production one); every other tool, known or not, gets event pairs
+  const char* pre = getenv("LD_PRELOAD");
+  const bool tool = getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCP_METRICS") ||
+                    getenv("ROCPROFILER_METRICS_PATH") ||
+                    (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "tool")));
+  if (!tool) return false;
+  static const char* const counters[] = {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCPROF_COUNTER_GROUPS",
+                                         "ROCPROF_EXTRA_COUNTERS_CONTENTS", "ROCPROFILER_PC_SAMPLING_BETA_ENABLED",
+                                         "ROCPROF_PC_SAMPLING_METHOD", "ROCPROF_ADVANCED_THREAD_TRACE",
+                                         "ROCPROF_ATT_LIBRARY_PATH", "ROCPROF_ATTACH_PID"};
+  for (const char* n : counters) if (getenv(n)) return true;
+  return !(getenv("ROCP_TOOL_LIBRARIES") && getenv("ROCPROF_KERNEL_TRACE"));
+}
 static SideCtx* side_ctx() {
-  static SideCtx ctx;
-  static int state = 0;           // 0 = uninitialised, 1 = ready, -1 = disabled
+  static SideCtx ctxs[PS_MAX_DEVICES];
+  static int states[PS_MAX_DEVICES];           // 0 = uninitialised, 1 = ready, -1 = disabled
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PS_MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  SideCtx& ctx = ctxs[dev];
+  int& state = states[dev];
   if (state == 0) {
     state = -1;
-    const char* e = getenv("PS_NO_SIDE");
-    if (!(e && atoi(e) != 0)) {
+    if (!env_on("PS_NO_SIDE")) {
       bool ok = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ctx.ev[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&ctx.join, hipEventDisableTiming) == hipSuccess;
@@ -242,16 +278,11 @@ static SideCtx* side_ctx() {
       // stream loses ~3 us per crossing instead of 6-12 when the waits are SHORT (C2: 0.353 -> 0.341 ms/step), but a
       // polled wait that lasts hundreds of microseconds wakes up late (review transformer 0.924 -> 0.942 ms, C5 1.64 ->
       // 1.72 ms), so the backward picks per step (side_set_light).  PS_SIDE_EVENTS=1 keeps the events everywhere; so
-      // does a stream that is being captured into a graph (side_fork / side_join check).
-      int can_wait = 0, dev = 0;
-      // HAZARD: the runtime implements a wait-value as a one-thread kernel that spins on the word.  Anything that lets
-      // only ONE kernel run on the device at a time — rocprofv3 / rocprof counter collection serialises dispatches —
-      // therefore deadlocks (the spinning wait never lets the producer run; seen as a hung `rocprofv3 --pmc` pass).
-      // Counter-collecting profilers are recognised by their environment and get the event pairs.
-      const bool profiler_counters = getenv("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS") ||
-                                     getenv("HSA_TOOLS_LIB") || getenv("ROCP_METRICS") || getenv("ROCPROFILER_METRICS_PATH");
-      const bool want = !(getenv("PS_SIDE_EVENTS") && atoi(getenv("PS_SIDE_EVENTS")) != 0) && !profiler_counters;
-      if (ok && want && hipGetDevice(&dev) == hipSuccess &&
+      // does a stream that is being captured into a graph (side_fork / side_join check), and so does any environment
+      // in which dispatches may be serialised (dispatch_may_be_serialised: the value wait would never return).
+      int can_wait = 0;
+      const bool want = !env_on("PS_SIDE_EVENTS") && !dispatch_may_be_serialised();
+      if (ok && want &&
           hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can_wait) {
         if (hipMalloc((void**)&ctx.flag, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(ctx.flag, 0, 2 * sizeof(uint32_t)) != hipSuccess)
           ctx.flag = nullptr;

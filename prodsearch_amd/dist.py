@@ -59,44 +59,25 @@ class GradExchange(object):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def exchange_rows(rows, vals, group=None):
-    """Sparse all-reduce of one table's gradient: ``rows`` [u] sorted unique int64 row ids and their
-    gradient rows ``vals`` [u, d] on this rank -> (union of the ranks' rows, sorted; summed values).
-
-    all-gather of counts, then of (rows, vals) padded to the largest count — xGMI is point-to-point, so an
-    all-gather keeps all 7 links busy where a ring all-reduce of the dense table would move table-sized
-    buffers.  The merge adds the ranks' contributions in rank order (each rank's rows are unique, so every
-    index_add is collision-free): bitwise identical on every rank, which keeps the replicas in lock step."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return rows, vals
-    dev, d = rows.device, vals.shape[1]
-    cnt = torch.tensor([rows.numel()], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    cnts = [int(c) for c in cnts]
-    mx = max(max(cnts), 1)
-    prow = torch.full((mx,), -1, dtype=torch.int64, device=dev)
-    pval = torch.zeros(mx, d, dtype=vals.dtype, device=dev)
-    prow[:rows.numel()] = rows
-    pval[:rows.numel()] = vals
-    all_rows = [torch.empty_like(prow) for _ in range(world)]
-    all_vals = [torch.empty_like(pval) for _ in range(world)]
-    dist.all_gather(all_rows, prow, group=group)
-    dist.all_gather(all_vals, pval, group=group)
-    union = torch.unique(torch.cat([r[:c] for r, c in zip(all_rows, cnts)]))     # sorted
-    acc = torch.zeros(union.numel(), d, dtype=vals.dtype, device=dev)
-    for r, v, c in zip(all_rows, all_vals, cnts):
-        if c:
-            acc.index_add_(0, torch.searchsorted(union, r[:c]), v[:c])
-    return union, acc
+def _all_gather_flat(out, inp, world, group):
+    """``out`` [world, ...] <- every rank's ``inp`` [...].  One collective; backends without the flat form
+    (older gloo) get the list form over views of the same buffer."""
+    try:
+        dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather([out[r].view(-1) for r in range(world)], inp.view(-1), group=group)
 
 
 class SparseGradExchange(object):
-    """Data-parallel exchange in row-sparse mode (``args.row_sparse_adam``): one all-reduce of the dense
-    head of the flat gradient buffer (small tensors, 0.86 MB at C2) + ``exchange_rows`` per table.
-    The merged rows are written back into the dense gradient tensors and become the touched list the
-    optimizer consumes, so clip norm and Adam are computed on identical data on every rank."""
+    """Data-parallel exchange in row-sparse mode (``args.row_sparse_adam``) with NO host synchronisation.
+
+    Per step: one all-reduce of the dense head of the flat gradient buffer (small tensors, 0.86 MB at C2), and per
+    table two all-gathers of fixed-capacity messages — the rank's sorted touched row ids (then -1) and their gradient
+    rows — whose capacity is the step's index count, a function of the batch SHAPE only.  ``ps_coalesce_rows`` over
+    the gathered ids (pad -1) gives the union, ``ps_merge_rows`` writes the rank-ordered sums into the dense gradient
+    (bitwise identical on every rank), and the union becomes the touched list the optimizer walks, so clip norm and
+    Adam see identical data on every rank without another collective.  xGMI is point-to-point: an all-gather keeps
+    all 7 links busy where a ring all-reduce of a table-sized buffer would be bound by one."""
 
     def __init__(self, model, optim=None, group=None):
         self.model = model
@@ -105,19 +86,48 @@ class SparseGradExchange(object):
         if optim is not None:
             optim.grad_scale = 1.0 / self.world
 
+    def _buffers(self, info, p, cap):
+        x = info.get('xchg')
+        if x is None or x['cap'] != cap or x['world'] != self.world:
+            from . import _lib
+            lib = _lib.load()
+            dev, d, W = p.device, p.shape[1], self.world
+            ucap = max(1, min(W * cap, p.shape[0]))
+            x = dict(cap=cap, world=W, ucap=ucap,
+                     msg_rows=torch.empty(cap, device=dev, dtype=torch.int64),
+                     msg_vals=torch.empty(cap, d, device=dev, dtype=torch.float32),
+                     all_rows=torch.empty(W, cap, device=dev, dtype=torch.int64),
+                     all_vals=torch.empty(W, cap, d, device=dev, dtype=torch.float32),
+                     urows=torch.empty(ucap, device=dev, dtype=torch.int64),
+                     ucount=torch.zeros(1, device=dev, dtype=torch.int32),
+                     ws=torch.zeros(lib.ps_coalesce_ws_bytes(p.shape[0]), device=dev, dtype=torch.uint8))
+            info['xchg'] = x
+        return x
+
     def __call__(self):
         if self.world == 1:
             return None
+        from . import _lib
+        lib = _lib.load()
         m = self.model
         dist.all_reduce(m._grad_flat[:m._n_dense_grad], op=dist.ReduceOp.SUM, group=self.group)
         for _, p, gview in m._sparse_tabs:
             info = p._ps_rows
-            rows = info['rows'][:int(info['count'][0])]
-            union, acc = exchange_rows(rows, gview[rows], self.group)
-            gview[union] = acc
-            info['rows'] = union
-            info['count'] = torch.tensor([union.numel()], dtype=torch.int32, device=union.device)
-            info['cap'] = max(1, union.numel())
+            cap, d = int(info['cap']), p.shape[1]
+            x = self._buffers(info, p, cap)
+            st = torch.cuda.current_stream(p.device).cuda_stream
+            _lib.check(lib.ps_pack_rows(gview.data_ptr(), d, info['rows'].data_ptr(), info['count'].data_ptr(), cap,
+                                        x['msg_rows'].data_ptr(), x['msg_vals'].data_ptr(), st), 'ps_pack_rows')
+            _all_gather_flat(x['all_rows'], x['msg_rows'], self.world, self.group)
+            _all_gather_flat(x['all_vals'], x['msg_vals'], self.world, self.group)
+            lst = (_lib.PsIdxList * 1)()
+            lst[0].idx, lst[0].n = x['all_rows'].data_ptr(), self.world * cap
+            _lib.check(lib.ps_coalesce_rows(lst, 1, p.shape[0], -1, x['ws'].data_ptr(), x['urows'].data_ptr(),
+                                            x['ucap'], x['ucount'].data_ptr(), st), 'ps_coalesce_rows')
+            _lib.check(lib.ps_merge_rows(x['all_rows'].data_ptr(), x['all_vals'].data_ptr(), self.world, cap, d,
+                                         gview.data_ptr(), x['urows'].data_ptr(), x['ucount'].data_ptr(), x['ucap'],
+                                         st), 'ps_merge_rows')
+            info['active'] = (x['urows'], x['ucount'], x['ucap'])     # what the optimizer / zero_grad walk this step
         return None
 
 

@@ -103,17 +103,28 @@ def _init_like_reference(module):
 
 
 # -------------------------------------------------------------------- autograd
+def _check_same_forward(model, step):
+    """Each batch shape owns ONE workspace (activations, sampled negatives, batch pointers) that the next forward
+    overwrites, so only the most recent forward can be differentiated — unlike autograd, which would keep both graphs
+    alive.  Anything else must fail loudly rather than return the other forward's gradients."""
+    if model._fwd_step != step:
+        raise RuntimeError("backward() of a loss whose forward is no longer the model's latest one (forward #%d, now #%d): "
+                           "the HIP workspace holds one forward at a time; call backward() before the next forward()"
+                           % (step, model._fwd_step))
+
+
 class _RankLossFn(torch.autograd.Function):
     """One node: forward launched the HIP forward; backward launches the HIP backward,
     which writes the dense ``.grad`` of every reachable parameter directly."""
 
     @staticmethod
     def forward(ctx, anchor, model, plan, loss3):
-        ctx.model, ctx.plan = model, plan
+        ctx.model, ctx.plan, ctx.step = model, plan, model._fwd_step
         return loss3[0]
 
     @staticmethod
     def backward(ctx, grad_out):
+        _check_same_forward(ctx.model, ctx.step)
         ctx.model._run_backward(ctx.plan, grad_out)
         return None, None, None, None
 
@@ -129,9 +140,9 @@ class _LossTensor(torch.Tensor):
         fast = self.__dict__.pop('_ps_fast', None)
         if fast is not None and gradient is None and not create_graph and inputs is None and not retain_graph:
             model, plan, step = fast
-            if model._fwd_step == step:              # the workspace still holds this forward's activations
-                model._run_backward(plan, None)
-                return None
+            _check_same_forward(model, step)         # the workspace must still hold this forward's activations
+            model._run_backward(plan, None)
+            return None
         return super().backward(gradient, retain_graph, create_graph, inputs)
 
 
@@ -527,6 +538,7 @@ class ItemTransformerRanker(nn.Module):
                             grad_ptr=gview.data_ptr(), dirty=False)
                 p._ps_rows = info
             info['cap'] = cap
+            info['active'] = None          # a data-parallel exchange installs the ranks' union here (dist.SparseGradExchange)
             if not lists:
                 info['count'].zero_()
                 continue
@@ -538,14 +550,42 @@ class ItemTransformerRanker(nn.Module):
                                             info['count'].data_ptr(), st), 'ps_coalesce_rows')
             info['dirty'] = True
 
+    @staticmethod
+    def _rows_view(info):
+        """(rows, count, cap) the optimizer and zero_grad walk: the ranks' union after an exchange, else this rank's."""
+        return info.get('active') or (info['rows'], info['count'], info['cap'])
+
     def touched_rows(self):
         """{state_dict key: sorted unique row ids} of the last backward (row-sparse mode; host sync)."""
+        self.check_index_errors()
         out = {}
         for name, p in self.named_parameters():
             info = getattr(p, '_ps_rows', None)
             if info is not None:
-                out[name] = info['rows'][:int(info['count'][0])].clone()
+                rows, count, _ = self._rows_view(info)
+                out[name] = rows[:int(count[0])].clone()
         return out
+
+    def check_index_errors(self):
+        """Row-sparse mode: raise if a step's index lists held a row outside its table or overflowed a touched list
+        (the kernels drop such rows and set a status word; reading it is a host sync, so the step itself never does —
+        the trainer calls this where it reads the loss)."""
+        import ctypes
+        lib = _lib.load()
+        for name, p in self.named_parameters():
+            info = getattr(p, '_ps_rows', None)
+            if info is None:
+                continue
+            for ws in (info['ws'], (info.get('xchg') or {}).get('ws')):
+                if ws is None:
+                    continue
+                addr = lib.ps_coalesce_bad_flag(ws.data_ptr(), p.shape[0])
+                off = addr - ws.data_ptr()
+                flag = int(ws[off:off + 4].view(torch.int32)[0])
+                if flag:
+                    ws[off:off + 4].zero_()
+                    raise RuntimeError("row-sparse step: %s" % ("an index outside [0, %d) addressed %s" % (p.shape[0], name)
+                                       if flag == 1 else "touched-row list of %s overflowed its capacity" % name))
 
     def _zero_for_backward(self):
         lib = _lib.load()
@@ -557,8 +597,9 @@ class ItemTransformerRanker(nn.Module):
         for path, p, gview in self._sparse_tabs:
             info = getattr(p, '_ps_rows', None)
             if info is not None and info['dirty']:       # touched by a backward no optimizer step consumed
-                _lib.check(lib.ps_zero_rows(gview.data_ptr(), p.shape[1], info['rows'].data_ptr(),
-                                            info['count'].data_ptr(), info['cap'], st), 'ps_zero_rows')
+                rows, count, cap = self._rows_view(info)
+                _lib.check(lib.ps_zero_rows(gview.data_ptr(), p.shape[1], rows.data_ptr(), count.data_ptr(), cap, st),
+                           'ps_zero_rows')
                 info['dirty'] = False
 
     def zero_grad(self, set_to_none=True):

@@ -153,7 +153,8 @@ class Optimizer(object):
             info = p._ps_rows
             t = tabs[i]
             t.p, t.g, t.m, t.v = p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()
-            t.rows, t.count, t.cap, t.d = info['rows'].data_ptr(), info['count'].data_ptr(), info['cap'], p.shape[1]
+            rows, count, cap = info.get('active') or (info['rows'], info['count'], info['cap'])
+            t.rows, t.count, t.cap, t.d = rows.data_ptr(), count.data_ptr(), cap, p.shape[1]
         need = lib.ps_adam_rowsparse_state_floats(plan['n_chunks'], tabs, len(tabs))
         if need < 0:
             _lib.check(1, 'ps_adam_rowsparse_state_floats')

@@ -38,11 +38,13 @@ class _ReviewEncoder(_Holder):
 class _RtmLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, plan, loss3):
-        ctx.model, ctx.plan = model, plan
+        ctx.model, ctx.plan, ctx.step = model, plan, model._fwd_step
         return loss3[0]
 
     @staticmethod
     def backward(ctx, grad_out):
+        from .item_transformer import _check_same_forward
+        _check_same_forward(ctx.model, ctx.step)
         ctx.model._run_backward(ctx.plan, grad_out)
         return None, None, None, None
 
@@ -294,8 +296,10 @@ class ProductRanker(nn.Module):
             import ctypes as C
             tot = C.c_int64(0)
             _lib.check(lib.ps_rtm_workspace_floats(desc, int(eval_mode), C.byref(tot)), 'ps_rtm_workspace_floats')
+            lay = _lib.PsRtmWsLayout()
+            _lib.check(lib.ps_rtm_workspace_layout(desc, int(eval_mode), lay), 'ps_rtm_workspace_layout')
             plan = dict(desc=desc, batch=_lib.PsRtmBatch(), ws=torch.empty(tot.value, device=self._dev(), dtype=torch.float32),
-                        neg_words=None, keep=None)
+                        neg_words=None, keep=None, layout=lay)
             self._plans[key] = plan
         return plan
 
@@ -454,3 +458,12 @@ class ProductRanker(nn.Module):
         _lib.check(lib.ps_rtm_score(plan['desc'], ps, bt, plan['ws'].data_ptr(), scores.data_ptr(), self._stream()),
                    'ps_rtm_score')
         return scores
+
+    # --------------------------------------------------------------- test support
+    def workspace_view(self, plan, name, shape):
+        """View of one intermediate inside the workspace (parity tests compare every stage; PsRtmWsLayout)."""
+        off = getattr(plan['layout'], name)
+        n = 1
+        for s in shape:
+            n *= s
+        return plan['ws'][off:off + n].view(*shape)

@@ -71,28 +71,44 @@ def test_gloo_world2_gradient_exchange():
 
 
 def _sparse_worker(rank, world, port, q):
+    """The wire protocol of dist.SparseGradExchange on CPU tensors: fixed-capacity messages (sorted ids then -1; rows
+    then zeros) through dist._all_gather_flat, then the union / rank-ordered merge the HIP kernels perform
+    (ps_coalesce_rows + ps_merge_rows; restated here in numpy as the checker) against a dense all-reduce."""
+    import numpy as np
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     pdist.init_from_env(backend='gloo')
-    n_rows, d = 500, 16
+    n_rows, d, cap = 500, 16, 96
     gen = torch.Generator().manual_seed(7 + rank)
-    # ragged: rank 0 touches 37 rows, rank 1 touches 90 (some shared), plus an empty-list round
     out = []
+    # ragged: rank 0 touches 37 rows, rank 1 touches 90 (some shared), plus an empty-list round
     for n_touch in ((37, 90)[rank], 0 if rank == 0 else 5):
         rows = torch.sort(torch.randperm(n_rows, generator=gen)[:n_touch]).values
         vals = torch.randn(n_touch, d, generator=gen)
         dense = torch.zeros(n_rows, d)
         dense[rows] = vals
-        union, acc = pdist.exchange_rows(rows, vals)
-        dist.all_reduce(dense)                               # what a dense exchange would have produced
-        merged = torch.zeros(n_rows, d)
-        merged[union] = acc
+        msg_rows = torch.full((cap,), -1, dtype=torch.int64)
+        msg_vals = torch.zeros(cap, d)
+        msg_rows[:n_touch] = rows
+        msg_vals[:n_touch] = vals
+        all_rows = torch.empty(world, cap, dtype=torch.int64)
+        all_vals = torch.empty(world, cap, d)
+        pdist._all_gather_flat(all_rows, msg_rows, world, None)
+        pdist._all_gather_flat(all_vals, msg_vals, world, None)
+        ar, av = all_rows.numpy(), all_vals.numpy()
+        union = np.unique(ar[ar >= 0])
+        merged = np.zeros((n_rows, d), np.float32)
+        for r in range(world):                                 # rank order: identical sums on every rank
+            live = ar[r] >= 0
+            merged[ar[r][live]] += av[r][live]
+        dist.all_reduce(dense)                                 # what a dense exchange would have produced
         rows_all = [None] * world
         dist.all_gather_object(rows_all, rows.tolist())
         want_union = sorted(set(sum(rows_all, [])))
-        gathered = [torch.zeros_like(merged) for _ in range(world)]
-        dist.all_gather(gathered, merged)
-        out.append((union.tolist() == want_union, bool(torch.allclose(merged, dense, atol=1e-6)),
+        mt = torch.from_numpy(merged)
+        gathered = [torch.zeros_like(mt) for _ in range(world)]
+        dist.all_gather(gathered, mt)
+        out.append((union.tolist() == want_union, bool(torch.allclose(mt, dense, atol=1e-6)),
                     all(torch.equal(gathered[0], x) for x in gathered)))      # bitwise identical replicas
     q.put((rank, out))
     dist.barrier()

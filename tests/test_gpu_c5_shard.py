@@ -1,0 +1,158 @@
+"""One GPU's shard of BASELINE.json configs[4] as a parity test: item_transformer d=256, ff=1024, bs=1024, K=20,
+row-sparse Adam (``args.row_sparse_adam``), and an item table PAST 2^31 bytes (8,000,001 rows x 1 KiB = 8.2 GB), so every
+row offset of the gather / scatter / optimizer kernels needs its 64-bit form.  Reference semantics: ``forward_dotproduct``
+(models/item_transformer.py:440-520), ``trainer.py:74-79``.
+
+The full table never goes to the host: the oracle runs on the COMPACTED table (the rows the batch addresses, remapped),
+which is the same arithmetic — an embedding lookup only ever sees the rows it indexes."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+P_, V, B, K, L, Q, W, D, FF = 8_000_000, 32387, 1024, 20, 20, 8, 1, 256, 1024
+
+
+def _setup(dropout):
+    from prodsearch_amd import ItemTransformerRanker, build_optim, readme_tem_args, synth
+    a = readme_tem_args(dropout=dropout, embedding_size=D, ff_size=FF, row_sparse_adam=True, lr=0.002)
+    wd = synth.make_word_dists(V)
+    torch.manual_seed(5)
+    m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    assert m.product_emb.weight.numel() * 4 > 2 ** 31
+    optim = build_optim(a, m, None)
+    batch = synth.make_tem_batch(77, B, P_, V, Q=Q, L=L, W=W, word_dists=wd)
+    # make sure rows at both ends of the table (offsets beyond 2^31 bytes) are addressed
+    batch.target_prod_idxs[:3] = torch.tensor([P_ - 1, P_ - 2, 0])
+    batch.u_item_idxs[5, 0] = P_ - 3
+    ni, nw = synth.sample_negatives(78, B, K, W, P_, wd)
+    ni[0, 0] = P_ - 4
+    m.train()
+    return a, wd, m, optim, batch, ni, nw
+
+
+def _compact(m, batch, ni):
+    """(compact state dict on the host, remapped batch / negatives, sorted unique item rows)."""
+    import copy
+    items = torch.unique(torch.cat([batch.target_prod_idxs.reshape(-1), ni.reshape(-1), batch.u_item_idxs.reshape(-1)]))
+    items = items[items != P_]
+    U = items.numel()
+    remap = lambda t: torch.where(t == P_, torch.full_like(t, U), torch.searchsorted(items, t.clamp(max=P_ - 1)))
+    sd = {}
+    for k, v in m.state_dict().items():
+        if k == 'product_emb.weight':
+            sd[k] = torch.cat([v[items.cuda()].cpu(), torch.zeros(1, D)], 0)
+        elif k == 'product_bias':
+            sd[k] = torch.cat([v[items.cuda()].cpu(), torch.zeros(1)], 0)
+        else:
+            sd[k] = v.detach().cpu().clone()
+    b2 = copy.copy(batch)
+    b2.target_prod_idxs = remap(batch.target_prod_idxs)
+    b2.u_item_idxs = remap(batch.u_item_idxs)
+    return sd, b2, remap(ni), items
+
+
+def test_c5_shard_step_matches_the_oracle_on_the_gathered_rows():
+    from oracle import tem as otem
+    a, wd, m, optim, batch, ni, nw = _setup(0.0)
+    sd, b2, ni2, items = _compact(m, batch, ni)
+    U = items.numel()
+    before_rows = m.product_emb.weight.detach()[items.cuda()].clone()
+    probe = torch.tensor([1, 12345, P_ // 2, P_ - 5], device='cuda')          # rows no index of the step addresses
+    probe = probe[~torch.isin(probe, items.cuda())]
+    before_probe = m.product_emb.weight.detach()[probe].clone()
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    # oracle on the compact table (dropout 0: one encode per row is exact)
+    Pm = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith('pos_emb.pe')) for k, v in sd.items()}
+    oloss, ops, oil = otem.tem_forward(Pm, a, b2, ni2, nw, V, U, training=True)
+    assert rel_err(loss.detach().cpu(), oloss.detach()) < 1e-4
+    grads = otem.grads_of(oloss, Pm, otem.tem_pad_rows(a, V, U))
+    # bit-exact index work: the touched lists are the batch's index sets
+    touched = m.touched_rows()
+    assert torch.equal(touched['product_emb.weight'].cpu(), items)
+    words = np.setdiff1d(np.unique(np.concatenate([batch.query_word_idxs.numpy().ravel(), nw.numpy().ravel(),
+                                                   batch.pos_iword_idxs.numpy().ravel()])), [V - 1])
+    assert np.array_equal(touched['word_embeddings.weight'].cpu().numpy(), words)
+    # gradients: table rows on the touched list vs the oracle's compact-table gradient; dense tensors whole
+    g_items = m.product_emb.weight.grad[items.cuda()].cpu()
+    assert rel_err(g_items, grads['product_emb.weight'][:U]) < 5e-4
+    assert rel_err(m.word_embeddings.weight.grad.cpu(), grads['word_embeddings.weight']) < 5e-4
+    for n, p in m.named_parameters():
+        if p.grad is None or n in ('product_emb.weight', 'word_embeddings.weight') or n.endswith('linear_keys.bias'):
+            continue
+        assert rel_err(p.grad.cpu(), grads[n]) < 5e-4, n
+    # nothing outside the touched rows received a gradient (checked on the device: the table is 8 GB)
+    nz = m.product_emb.weight.grad.ne(0).any(1)
+    assert int(nz.sum()) == int(nz[items.cuda()].sum())
+    optim.step()
+    torch.cuda.synchronize()
+    after_rows = m.product_emb.weight.detach()[items.cuda()]
+    assert bool((after_rows != before_rows).any(1).all())                       # every touched row moved ...
+    assert torch.equal(m.product_emb.weight.detach()[probe], before_probe)       # ... untouched rows did not
+    assert float(m.product_emb.weight.grad[items.cuda()].abs().max()) == 0       # touched gradient rows come back zeroed
+    m.check_index_errors()
+
+
+def test_c5_shard_dropout_step_is_deterministic_and_moves_exactly_the_touched_rows():
+    """reference default dropout 0.1: the K+1 replicas are really computed (R = 21, 21,504 replica rows)."""
+    res = []
+    for rep in range(2):
+        a, wd, m, optim, batch, ni, nw = _setup(0.1)
+        before = m.product_emb.weight.detach().clone()
+        losses = []
+        for _ in range(2):
+            loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+            m.zero_grad()
+            loss.backward()
+            optim.step()
+            losses.append(float(loss.detach()))
+        assert all(np.isfinite(losses))
+        moved = torch.nonzero((m.product_emb.weight.detach() != before).any(1)).flatten().cpu()
+        items = torch.unique(torch.cat([batch.target_prod_idxs.reshape(-1), ni.reshape(-1), batch.u_item_idxs.reshape(-1)]))
+        assert torch.equal(moved, items[items != P_])                            # moved rows = touched rows, exactly
+        res.append(losses)
+        del m, optim, before
+        torch.cuda.empty_cache()
+    assert res[0][0] == res[1][0]          # forward of step 1: same seed, same Philox step -> identical bits
+
+
+def test_gather_score_launch_in_its_8_lane_form_matches_a_host_dot_product():
+    """B = 8192: 344k tasks x 1 KiB = 352 MB of rows per launch selects the 8-lanes-per-row form of
+    score_fwd_wide_kernel (rowwise.hip: `huge`); logits against a host fp32 dot product of the same rows."""
+    from prodsearch_amd import ItemTransformerRanker, _lib, readme_tem_args, synth
+    Bh, Ph = 8192, 3_000_000                                                     # 3.07 GB table: past 2^31 bytes too
+    a = readme_tem_args(dropout=0.0, embedding_size=D, ff_size=FF)
+    wd = synth.make_word_dists(V)
+    torch.manual_seed(9)
+    m = ItemTransformerRanker(a, 'cuda', V, Ph, None, word_dists=wd)
+    m.train()
+    batch = synth.make_tem_batch(3, Bh, Ph, V, Q=Q, L=L, W=W, word_dists=wd)
+    batch.target_prod_idxs[0] = Ph - 1
+    ni, nw = synth.sample_negatives(4, Bh, K, W, Ph, wd)
+    with torch.no_grad():
+        m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    plan = next(iter(m._plans.values()))
+    lay = plan.layout
+    enc = torch.randn(Bh, D, device='cuda')
+    m.workspace_view(plan, 'enc', (Bh, D)).copy_(enc)
+    ps, _ = m._structs()
+    _lib.check(_lib.load().ps_gather_score(plan.desc, ps, plan.batch, plan.ws.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), 'ps_gather_score')
+    torch.cuda.synchronize()
+    got = m.workspace_view(plan, 'item_scores', (Bh, K + 1)).cpu()
+    idx = torch.cat([batch.target_prod_idxs[:, None], ni], 1)
+    rows = m.product_emb.weight.detach()[idx.cuda()].cpu()                      # [Bh, K+1, D]
+    want = (rows * enc.cpu()[:, None, :]).sum(-1)
+    assert rel_err(got, want) < 1e-4
+    gw = m.workspace_view(plan, 'word_scores', (Bh, W, K + 1)).cpu()
+    widx = torch.cat([batch.pos_iword_idxs[:, :, None], nw.view(Bh, W, K)], 2)
+    tgt_rows = m.product_emb.weight.detach()[batch.target_prod_idxs.cuda()].cpu()
+    wrows = m.word_embeddings.weight.detach().cpu()[widx]
+    wb = m.word_bias.detach().cpu()[widx]
+    wantw = (wrows * tgt_rows[:, None, None, :]).sum(-1) + wb
+    assert rel_err(gw, wantw) < 1e-4

@@ -347,3 +347,23 @@ def test_folded_sampling_draws_equal_the_standalone_sampler():
     m.zero_grad()
     loss.backward()                                         # and the backward reads them from the plan
     assert m.product_emb.weight.grad[got_i.flatten().unique()].abs().sum() > 0
+
+
+def test_backward_of_a_superseded_forward_is_refused():
+    """One workspace per batch shape: forward A, forward B, then A.backward() would silently differentiate B's
+    activations and negatives — every backward path (the direct one, autograd with a scaled loss) must raise instead."""
+    g = Golden('tem_c1')
+    m = _model(g)
+    b = g.batch().to('cuda')
+    ni, nw = g.negs(0)
+    loss_a = m(b, neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    scaled_a = loss_a * 2.0
+    loss_b = m(b, neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    with pytest.raises(RuntimeError, match='no longer'):
+        scaled_a.backward()                                  # autograd path (_RankLossFn.backward)
+    with pytest.raises(RuntimeError, match='no longer'):
+        loss_a.backward()                                    # direct path (_LossTensor.backward)
+    loss_b.backward()                                        # the latest forward is fine
+    torch.cuda.synchronize()
+    assert m.word_embeddings.weight.grad is not None

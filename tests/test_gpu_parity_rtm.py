@@ -47,8 +47,18 @@ def test_rtm_forward_matches_reference(case):
     with torch.no_grad():
         loss = m(g.batch().to('cuda'), train_pv=g.train_pv, neg_word_idxs=_neg(g, 0))
     assert rel_err(loss.cpu(), g.tensor('loss_0')) < LOSS_TOL
-    # stage check against the oracle: product logits and PV logits straight from the workspace
+    # the HIP path's own logits against the REFERENCE's (golden), straight from the workspace
     plan = next(iter(m._plans.values()))
+    B, K, R, d = g.B, g.K, g.R, g.args.embedding_size
+    S, J = R + 1, K + 1
+    torch.cuda.synchronize()
+    scores = m.workspace_view(plan, 'scores', (B, J)).cpu()
+    assert rel_err(scores, g.tensor('prod_scores')) < LOSS_TOL
+    real = g.batch().pos_prod_ridxs.reshape(-1).ne(g.RC - 1)
+    if g.train_pv:
+        pv = m.workspace_view(plan, 'pv_scores', (B * R, g.W, J)).cpu()
+        assert rel_err(pv[real], g.tensor('pv_scores')[real]) < LOSS_TOL          # padded reviews carry no PV loss
+    # every stage against the oracle run with the same Philox masks
     gen = g.dropout(0)
     drop = gen if (gen is not None and g.args.dropout > 0) else None
     tok = gen.tok if (gen is not None and gen.corrupt_rate > 0) else None
@@ -56,7 +66,17 @@ def test_rtm_forward_matches_reference(case):
     with torch.no_grad():
         ortm.rtm_forward(g.params(), g.args, g.batch(), g.neg_words(0), g.V, g.RC, training=True,
                          train_pv=g.train_pv, drop=drop, tok_drop=tok, keep=keep)
-    assert rel_err(keep['scores'], g.tensor('prod_scores')) < 1e-4
+    assert rel_err(keep['scores'], g.tensor('prod_scores')) < 1e-4                # the oracle itself is pinned
+    assert rel_err(m.workspace_view(plan, 'query_emb', (B, d)).cpu(), keep['query_emb']) < 2e-4
+    mask = torch.cat([keep['pos_mask'].unsqueeze(1), keep['neg_mask']], dim=1)                    # [B,J,S]
+    assert torch.equal(m.workspace_view(plan, 'valid', (B, J, S)).cpu().ne(0), mask)               # bit-exact
+    seq = torch.cat([keep['pos_seq'].unsqueeze(1), keep['neg_seq']], dim=1) * mask.unsqueeze(-1).float()
+    if g.args.use_pos_emb:
+        seq = seq + ortm.positional_encoding(5000, d)[:S]
+    assert rel_err(m.workspace_view(plan, 'x', (B, J, S, d)).cpu(), seq) < 2e-4
+    enc = torch.cat([keep['enc_pos'].unsqueeze(1), keep['enc_neg']], dim=1)
+    assert rel_err(m.workspace_view(plan, 'enc', (B, J, d)).cpu(), enc) < 2e-4
+    assert torch.equal(m.workspace_view(plan, 'weight', (B, J)).cpu(), keep['weight'])
 
 
 @pytest.mark.parametrize('case', RTM_CASES)

@@ -175,3 +175,81 @@ def test_rowsparse_zero_grad_without_step_cleans_touched_rows():
     loss = m(b, neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
     with pytest.raises(NotImplementedError):
         loss.backward()                                     # accumulation over dirty rows is refused
+
+
+@pytest.mark.parametrize('world,d', [(2, 128), (3, 96), (8, 256)])
+def test_pack_and_merge_rows_sum_the_ranks_in_rank_order(world, d):
+    """Wire format + merge of the data-parallel row exchange (dist.SparseGradExchange) with the ranks simulated in one
+    process: ps_pack_rows per rank, union by ps_coalesce_rows(pad -1), ps_merge_rows -> bitwise the rank-ordered sum."""
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n_rows, cap = 70_000, 500
+    rng = np.random.default_rng(world * 1000 + d)
+    all_rows = torch.empty(world, cap, dtype=torch.int64, device='cuda')
+    all_vals = torch.empty(world, cap, d, device='cuda')
+    ref = torch.zeros(n_rows, d)
+    union = set()
+    for r in range(world):
+        n = [0, 1, cap, 137, 333][r % 5] if r else 321
+        rows = np.sort(rng.choice(n_rows, n, replace=False))
+        rows[: min(n, 3)] = np.sort(np.array([0, 64, n_rows - 1])[: min(n, 3)])      # shared by every non-empty rank
+        rows = np.unique(rows)
+        n = len(rows)
+        grad = torch.zeros(n_rows, d, device='cuda')
+        vals = torch.randn(n, d)
+        grad[torch.from_numpy(rows).cuda()] = vals.cuda()
+        rows_dev = torch.full((cap,), 12345, dtype=torch.int64, device='cuda')       # garbage past count must not leak
+        rows_dev[:n] = torch.from_numpy(rows).cuda()
+        cnt = torch.tensor([n], dtype=torch.int32, device='cuda')
+        _lib.check(lib.ps_pack_rows(grad.data_ptr(), d, rows_dev.data_ptr(), cnt.data_ptr(), cap,
+                                    all_rows[r].data_ptr(), all_vals[r].data_ptr(), st), 'ps_pack_rows')
+        ref.index_add_(0, torch.from_numpy(rows), vals)                              # (0 + r0) + r1 + ...: rank order
+        union |= set(rows.tolist())
+    torch.cuda.synchronize()
+    assert all(int((all_rows[r] >= 0).sum()) == int((all_rows[r] != -1).sum()) for r in range(world))
+    ucap = min(world * cap, n_rows)
+    ws = torch.zeros(lib.ps_coalesce_ws_bytes(n_rows), dtype=torch.uint8, device='cuda')
+    urows = torch.empty(ucap, dtype=torch.int64, device='cuda')
+    ucount = torch.zeros(1, dtype=torch.int32, device='cuda')
+    lst = (_lib.PsIdxList * 1)()
+    lst[0].idx, lst[0].n = all_rows.data_ptr(), world * cap
+    _lib.check(lib.ps_coalesce_rows(lst, 1, n_rows, -1, ws.data_ptr(), urows.data_ptr(), ucap, ucount.data_ptr(), st), 'co')
+    grad = torch.full((n_rows, d), 7.0, device='cuda')                # merged rows are OVERWRITTEN, others untouched
+    _lib.check(lib.ps_merge_rows(all_rows.data_ptr(), all_vals.data_ptr(), world, cap, d, grad.data_ptr(),
+                                 urows.data_ptr(), ucount.data_ptr(), ucap, st), 'ps_merge_rows')
+    torch.cuda.synchronize()
+    want_union = np.array(sorted(union))
+    assert np.array_equal(urows[:int(ucount[0])].cpu().numpy(), want_union)
+    got = grad.cpu()
+    assert torch.equal(got[torch.from_numpy(want_union)], ref[torch.from_numpy(want_union)])      # bitwise
+    mask = torch.ones(n_rows, dtype=torch.bool)
+    mask[torch.from_numpy(want_union)] = False
+    assert bool((got[mask] == 7.0).all())
+    addr = lib.ps_coalesce_bad_flag(ws.data_ptr(), n_rows)
+    off = addr - ws.data_ptr()
+    assert int(ws[off:off + 4].view(torch.int32)[0]) == 0
+
+
+def test_index_errors_are_reported_when_asked():
+    import copy
+    from prodsearch_amd import ItemTransformerRanker
+    g = Golden('tem_c1')
+    a = copy.copy(g.args)
+    a.row_sparse_adam = True
+    m = ItemTransformerRanker(a, 'cuda', g.V, g.P, None, word_dists=g.word_dists)
+    m.load_state_dict(g.params(), strict=False)
+    m.train()
+    b = g.batch().to('cuda')
+    ni, nw = g.negs(0)
+    loss = m(b, neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    m.check_index_errors()                                   # clean step: silent
+    info = m.product_emb.weight._ps_rows
+    lib = __import__('prodsearch_amd._lib', fromlist=['x']).load()
+    off = lib.ps_coalesce_bad_flag(info['ws'].data_ptr(), m.product_emb.weight.shape[0]) - info['ws'].data_ptr()
+    info['ws'][off:off + 4].view(torch.int32)[0] = 1         # what co_mark_kernel sets for an out-of-range index
+    with pytest.raises(RuntimeError, match='outside'):
+        m.check_index_errors()
+    m.check_index_errors()                                   # the flag is cleared once reported
