@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
           const bool va = wa64 != a.V - 1 && wa64 >= 0 && wa64 < a.V, vb = wb64 != a.V - 1 && wb64 >= 0 && wb64 < a.V;
           const int wa = va ? (int)wa64 : 0, wb = vb ? (int)wb64 : 0;
           unsigned long long ma = __ballot(va && (need_unc || tm0 != 0.f)), mb = __ballot(vb && (need_unc || tm1 != 0.f));
-          nw = half == 0 ? __popcll(__ballot(va)) + __popcll(__ballot(vb)) : 0;   // the halves are summed below
+          // (the ballots are taken by the WHOLE wave, outside the half-wave select: inside it only lanes 0-31 would vote
+          // and a review would never count more than 32 words)
+          const int nvalid = __popcll(__ballot(va)) + __popcll(__ballot(vb));
+          nw = half == 0 ? nvalid : 0;                                            // the halves are summed below
           while (ma | mb) {                                               // 8 word rows in flight per wave
             float4 rowv[4]; float mt[4];
 #pragma unroll

@@ -135,22 +135,22 @@ def test_rtm_full_size_token_corruption_follows_the_philox_stream():
 
 
 def test_rtm_full_size_training_step_with_reference_defaults_is_finite_and_learns():
-    """dropout 0.1 + corrupt 0.9 (reference defaults), 6 steps of the trainer's call order: finite losses, parameters
+    """dropout 0.1 + corrupt 0.9 (reference defaults), 12 steps of the trainer's call order: finite losses, parameters
     move, and the loss on the fixed batch goes down (the fused backward, side-stream index and 512-workgroup walkers are
     all on this path)."""
     from prodsearch_amd import build_optim
     a, sd, m, batch = _setup('pvc', dropout=0.1, corrupt=0.9)
-    a.lr = 0.002
-    optim = build_optim(a, m, None)
+    optim = build_optim(a, m, None)              # lr 0.0005 (README.md:13-25)
     b = batch.to('cuda')
     losses = []
-    for _ in range(6):
+    for _ in range(12):
         loss = m(b, train_pv=False)
         m.zero_grad()
         loss.backward()
         optim.step()
         losses.append(float(loss.detach()))
+    print("losses", losses)
     assert all(np.isfinite(losses))
-    assert losses[-1] < losses[0]
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])          # (every step draws new dropout / corruption masks)
     moved = (m.transformer_encoder.wo.weight.detach().cpu() - sd['transformer_encoder.wo.weight']).abs().max()
     assert float(moved) > 0
