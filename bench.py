@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — train (u,q,i,neg) tuples/sec of the TEM ranking-loss step on MI355X.
+"""bench.py — train (u,q,i,neg) tuples/sec of the ranking-loss step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], the config the metric is quoted on): item_transformer,
-d=128, 1 layer, 8 heads, ff 512, uprev 20, B=384 per GPU, 20 negatives, Q=8, W=1,
-P=18,357 items, V=32,387 words, README training flags (README.md:13-25)
-incl. the reference's default dropout 0.1 (main.py:60) => the K+1 encoder replicas are
-really computed.  One step = trainer.py:74-78: loss = model(batch); model.zero_grad();
-loss.backward(); optim.step()  — sampling, forward, backward, grad exchange (N>1), clip+Adam.
-Inputs are synthetic and already resident in HBM.
+Workloads (BASELINE.json `configs`):
+  c2 (default, configs[1], the config the metric is quoted on): item_transformer, d=128, 1 layer, 8 heads, ff 512,
+     uprev 20, B=384 per GPU, 20 negatives, Q=8, W=1, P=18,357 items, V=32,387 words, README training
+     flags (README.md:13-25) incl. the reference's default dropout 0.1 (main.py:60) => the K+1 encoder replicas are
+     really computed.
+  c4 (configs[3]): review_transformer (RTM) d=128, bs=256, K=5, 20+30 reviews of 100 words, pvc review encoder,
+     dropout 0.1, corrupt_rate 0.9 (reference defaults).
+  c5 (one GPU's shard of configs[4]): item_transformer d=256, ff 1024, bs=1024, 50 M-item table, row-sparse Adam.
+One step = trainer.py:74-78: loss = model(batch); model.zero_grad(); loss.backward(); optim.step() — sampling,
+forward, backward, gradient exchange (N>1), clip+Adam.  Inputs are synthetic and already resident in HBM.
 
-The JSON line also carries
-  roofline     — the embedding-gather+score kernel: algorithmic bytes / HIP-event time
-  cpu_baseline — the oracle (op-for-op CPU restatement incl. the B*(K+1) replicated
-                 encoder) timed on this box's host cores on a bounded sample (rank 0, N=1)
+Timing: `value` / `ms_per_step` = EXACTLY --steps steps between barrier + synchronize on both sides (max over ranks).
+Then, outside that region (rank 0): `median_ms_per_step` over --reps steps timed one by one with HIP events, and
+  roofline     — the workload's dominant gather kernel: algorithmic bytes per launch / its average IN-STEP duration,
+                 measured live with one HIP event pair around every launch of it, on the stream it is launched on, over a
+                 second pass of --steps steps (ps_ktimer_arm / ps_ktimer_read, include/prodsearch_hip.h)
+  cpu_baseline — the oracle (op-for-op CPU restatement; for c2 incl. the B*(K+1) replicated encoder) timed on this box's
+                 host cores on a bounded sample (rank 0, N=1)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -35,6 +42,8 @@ FF = 512
 # --workload c5: one GPU's shard of BASELINE configs[4] (50 M-item table, d=256, bs=1024/GPU);
 # 51 GB table + dense gradient + Adam moments = 205 GB of HBM, row-sparse optimizer (dense Adam would stream 1.4 TB)
 C5 = dict(P_ITEMS=50_000_000, B=1024, D=256, FF=1024)
+# --workload c4: BASELINE configs[3]
+C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)
 
 
 def parse():
@@ -42,58 +51,148 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--reps', type=int, default=200, help='steps timed one by one with HIP events for the median (0 = skip)')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--cpu-steps', type=int, default=3, help='CPU-baseline sample (0 = skip)')
-    ap.add_argument('--kernel-iters', type=int, default=300)
-    ap.add_argument('--no-extras', action='store_true', help='skip roofline / cpu_baseline legs')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c5'],
-                    help='c2 = BASELINE configs[1] (the metric); c5 = per-GPU shard of configs[4]')
+    ap.add_argument('--no-extras', action='store_true', help='skip median / roofline / cpu_baseline legs')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
+                    help='c2 = BASELINE configs[1] (the metric); c4 = configs[3] (RTM); c5 = per-GPU shard of configs[4]')
+    ap.add_argument('--encoder', default='pvc', choices=['pvc', 'pv'], help='c4: review encoder')
     ap.add_argument('--items', type=int, default=0, help='override the catalogue size (c5 dry runs)')
     ap.add_argument('--row-sparse', action='store_true',
                     help='touched-rows-only zero/clip/Adam/exchange (args.row_sparse_adam); always on for c5')
     return ap.parse_args()
 
 
-def make_model(args_ns, device, seed):
-    from prodsearch_amd import ItemTransformerRanker, build_optim, synth
-    wd = synth.make_word_dists(V_WORDS)
-    torch.manual_seed(seed)                     # identical init on every rank
-    model = ItemTransformerRanker(args_ns, device, V_WORDS, P_ITEMS, None, word_dists=wd)
-    optim = build_optim(args_ns, model, None)
-    return model, optim, wd
+# ------------------------------------------------------------------------------------------ workloads
+class TemWorkload(object):
+    """item_transformer (c2 / c5)."""
+
+    def __init__(self, a, rank, dev):
+        from prodsearch_amd import ItemTransformerRanker, build_optim, readme_tem_args, synth
+        self.a = a
+        self.ns = readme_tem_args(dropout=a.dropout, embedding_size=D, ff_size=FF, row_sparse_adam=a.row_sparse)
+        self.wd = synth.make_word_dists(V_WORDS)
+        torch.manual_seed(1234)                     # identical init on every rank
+        self.model = ItemTransformerRanker(self.ns, 'cuda', V_WORDS, P_ITEMS, None, word_dists=self.wd)
+        self.optim = build_optim(self.ns, self.model, None)
+        self.batches = [synth.make_tem_batch(1000 + 97 * rank + i, B, P_ITEMS, V_WORDS, Q=Q, L=L, W=W,
+                                             word_dists=self.wd).to(dev) for i in range(8)]
+        self.B, self.K = B, K
+        self.ktag = 'gather_score'
+
+    def forward(self, i):
+        return self.model(self.batches[i % len(self.batches)])      # trainer.py:74 (negatives sampled on device)
+
+    def describe(self):
+        R = next(iter(self.model._plans.values())).layout.R
+        return ("item_transformer d=%d 1 layer 8 heads ff=%d uprev=20 bs=%d/GPU 20 neg Q=8 W=1 P=%d V=32387 dropout=%.2f%s "
+                "(BASELINE configs[%d])" % (D, FF, B, P_ITEMS, self.a.dropout, " row-sparse Adam" if self.a.row_sparse else "",
+                                            4 if self.a.workload == 'c5' else 1)), {"replicas_per_row": R}
+
+    def metric(self):
+        return "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (B, D)
+
+    def roofline_spec(self):
+        """Algorithmic bytes of ONE gather+score launch: every table row once (4d B) + its int64 index,
+        every distinct vector it is dotted with, every score written."""
+        R = next(iter(self.model._plans.values())).layout.R
+        rows = B * (1 + K) * (1 + W)
+        vecs = B * R + B                            # encoder outputs + target-item rows
+        nbytes = rows * (4 * D + 8) + vecs * 4 * D + rows * 4
+        return dict(tag='gather_score', bytes=nbytes,
+                    kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
+                    traffic_key='R%d_bytes_per_launch' % R if self.a.workload == 'c2' else None)
+
+    def cpu_baseline(self, n_steps):
+        return cpu_baseline_tem(self.ns, n_steps)
 
 
-def gather_score_bytes(R):
-    """Algorithmic bytes of ONE gather+score launch: every table row once
-    (4d B) + its int64 index, every distinct vector it is dotted with, every score written."""
-    rows = B * (1 + K) * (1 + W)
-    vecs = B * R + B                            # encoder outputs + target-item rows
-    return rows * (4 * D + 8) + vecs * 4 * D + rows * 4
+class RtmWorkload(object):
+    """review_transformer (c4)."""
+
+    def __init__(self, a, rank, dev):
+        from prodsearch_amd import ProductRanker, build_optim, default_args, synth, rtm_data
+        self.a = a
+        c = C4
+        self.ns = default_args(model_name='review_transformer', review_encoder_name=a.encoder, embedding_size=128,
+                               heads=8, ff_size=512, inter_layers=1, neg_per_pos=c['K'], dropout=a.dropout,
+                               corrupt_rate=0.9, lr=0.0005, review_word_limit=c['WL'], uprev_review_limit=c['U'],
+                               iprev_review_limit=c['I'])
+        self.wd = synth.make_word_dists(V_WORDS)
+        rng = synth.rng_for(5)
+        rw = torch.from_numpy(rng.integers(0, V_WORDS - 1, size=(c['RC'], c['WL'])))
+        lens = torch.from_numpy(rng.integers(c['WL'] // 4, c['WL'] + 1, size=c['RC']))
+        rw[torch.arange(c['WL'])[None, :] >= lens[:, None]] = V_WORDS - 1
+        rw[-1] = V_WORDS - 1
+        self.rw = rw
+        torch.manual_seed(1234)
+        self.model = ProductRanker(self.ns, 'cuda', V_WORDS, c['RC'], 1000, 1000, rw, None, word_dists=self.wd)
+        self.optim = build_optim(self.ns, self.model, None)
+        self.cpu_batches = [rtm_data.make_rtm_batch(100 + 97 * rank + s, c['B'], c['K'], c['RC'], V_WORDS, rw, Q=8,
+                                                    u_lim=c['U'], i_lim=c['I'], W=1, train_pv=False, encoder=a.encoder,
+                                                    word_dists=self.wd) for s in range(4)]
+        self.batches = [b.to(dev) for b in self.cpu_batches]
+        self.B, self.K = c['B'], c['K']
+        self.ktag = 'rtm_embed'
+
+    def forward(self, i):
+        return self.model(self.batches[i % len(self.batches)], train_pv=False)
+
+    def describe(self):
+        c = C4
+        return ("review_transformer (RTM) d=128 1 layer 8 heads ff=512 bs=%d/GPU K=%d R=%d+%d WL=%d %s review encoder "
+                "dropout=%.2f corrupt_rate=0.90 %dk reviews V=32387 (BASELINE configs[3])"
+                % (c['B'], c['K'], c['U'], c['I'], c['WL'], self.a.encoder, self.a.dropout, c['RC'] // 1000)), {}
+
+    def metric(self):
+        return "train (u,q,i,neg) tuples/sec at bs=%d, %d neg, d=128 (review_transformer)" % (C4['B'], C4['K'])
+
+    def roofline_spec(self):
+        """rtm_embed_kernel (review vectors, PVC.py:46-61): per valid review slot its WL int64 word ids, per word that is
+        neither padding nor dropped by the token corruption one 4d-byte row (expected count: the Philox masks are drawn
+        on the device), and the [Bseq, S, d] encoder input it writes."""
+        c, d = C4, 128
+        b0 = self.cpu_batches[0]
+        pad_r = c['RC'] - 1
+        slots = int((b0.pos_prod_ridxs != pad_r).sum() + (b0.neg_prod_ridxs != pad_r).sum())
+        S = c['U'] + c['I'] + 1
+        out_bytes = c['B'] * (c['K'] + 1) * S * d * 4
+        if self.a.encoder == 'pvc':
+            words = int((b0.pos_prod_rword_idxs != V_WORDS - 1).sum() + (b0.neg_prod_rword_idxs != V_WORDS - 1).sum())
+            rows = words * (1.0 - 0.9)
+            nbytes = slots * c['WL'] * 8 + rows * 4 * d + out_bytes
+            note = "%d review slots x %d ids + %.0f surviving word rows (%.0f non-pad words x 0.1) + %d B of x" % (
+                slots, c['WL'], rows, words, out_bytes)
+        else:
+            nbytes = slots * (8 + 4 * d) + out_bytes
+            note = "%d review rows + %d B of x" % (slots, out_bytes)
+        return dict(tag='rtm_embed', bytes=int(nbytes), kernel="rtm_embed_kernel (review-vector gather + mean-pool; %s)" % note,
+                    traffic_key=None)
+
+    def cpu_baseline(self, n_steps):
+        return cpu_baseline_rtm(self, n_steps)
 
 
-def time_gather_score(model, plan, iters):
-    """Average duration of the gather+score launch, HIP events on the launch stream."""
-    from prodsearch_amd import _lib
-    lib = _lib.load()
-    ps, _ = model._structs()
-    st = torch.cuda.current_stream()
-    for _ in range(20):
-        _lib.check(lib.ps_gather_score(plan.desc, ps, plan.batch, plan.ws.data_ptr(), st.cuda_stream), 'gather_score')
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record(st)
-    for _ in range(iters):
-        lib.ps_gather_score(plan.desc, ps, plan.batch, plan.ws.data_ptr(), st.cuda_stream)
-    e1.record(st)
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+# ------------------------------------------------------------------------------------------ CPU baselines
+def _best_pool(one_step, ncpu, cands=(8, 16, 32, 64)):
+    """torch's intra-op pool does not scale to every hardware thread of a 2-socket host on these small ops: a short
+    calibration picks the fastest of a few pool sizes; `cores` reports the pool that was timed."""
+    cands = sorted({min(ncpu, c) for c in cands})
+    torch.set_num_threads(cands[0])
+    one_step()                                   # warm-up (allocator, first-touch)
+    trial = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        trial[c] = one_step()
+    best = min(trial, key=trial.get)
+    torch.set_num_threads(best)
+    return best, trial, cands
 
 
-def cpu_baseline(args_ns, n_steps):
+def cpu_baseline_tem(args_ns, n_steps):
     """The oracle as the CPU path: same shapes/flags, reference structure (replicated encoder,
-    torch RNG dropout), fwd + bwd + clip/Adam on the host cores.  torch's intra-op pool does not
-    scale to every hardware thread of a 2-socket host on these small ops, so a short calibration
-    picks the fastest of a few pool sizes first; ``cores`` reports the pool that was timed."""
+    torch RNG dropout), fwd + bwd + clip/Adam on the host cores."""
     from oracle import tem as otem, optim as ooptim
     from prodsearch_amd import synth
     ncpu = os.cpu_count() or 1
@@ -118,15 +217,7 @@ def cpu_baseline(args_ns, n_steps):
             opt.step(Pm, grads)
         return time.perf_counter() - t0
 
-    cands = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})
-    torch.set_num_threads(cands[0])
-    one_step()                                   # warm-up (allocator, first-touch)
-    trial = {}
-    for c in cands:
-        torch.set_num_threads(c)
-        trial[c] = one_step()
-    best = min(trial, key=trial.get)
-    torch.set_num_threads(best)
+    best, trial, cands = _best_pool(one_step, ncpu)
     times = [one_step() for _ in range(n_steps)]
     t = sum(times) / len(times)
     return {"value": B * K / t, "unit": "tuples/s", "cores": best, "kind": "port",
@@ -136,12 +227,54 @@ def cpu_baseline(args_ns, n_steps):
                          ", ".join("%d: %.1fs" % (c, trial[c]) for c in cands))}
 
 
+def cpu_baseline_rtm(wl, n_steps):
+    """oracle/rtm.py as the CPU path of configs[3]: the same batches and flags, torch RNG dropout and token corruption,
+    fwd + autograd bwd + clip/Adam on the host cores."""
+    from oracle import rtm as ortm, tem as otem, optim as ooptim
+    ncpu = os.cpu_count() or 1
+    ns, c = wl.ns, C4
+    Pm = {}
+    for k, v in wl.model.state_dict().items():
+        if k.endswith('pos_emb.pe') or k.startswith('review_encoder.'):      # aliases of word_embeddings / buffers
+            if k != 'review_encoder.review_embeddings.weight':
+                continue
+        Pm[k] = v.detach().cpu().clone().requires_grad_(True)
+    opt = ooptim.ClipAdam(ns.lr, ns.max_grad_norm, ns.beta1, ns.beta2, 1e-9, ns.l2_lambda)
+    drop = otem.TorchDropout(ns.dropout) if ns.dropout > 0 else None
+    p = float(ns.corrupt_rate)
+    tok = (lambda shape, which: (torch.rand(shape) >= p).float() / (1.0 - p)) if wl.a.encoder == 'pvc' else None
+    counter = [0]
+
+    def one_step():
+        s = counter[0]
+        counter[0] += 1
+        batch = wl.cpu_batches[s % len(wl.cpu_batches)]
+        t0 = time.perf_counter()
+        loss, _, _ = ortm.rtm_forward(Pm, ns, batch, None, V_WORDS, c['RC'], training=True, train_pv=False, drop=drop,
+                                      tok_drop=tok)
+        names = [n for n in Pm]
+        gs = torch.autograd.grad(loss, [Pm[n] for n in names], allow_unused=True)
+        with torch.no_grad():
+            opt.step(Pm, dict(zip(names, gs)))
+        return time.perf_counter() - t0
+
+    best, trial, cands = _best_pool(one_step, ncpu, cands=(8, 16, 32))
+    times = [one_step() for _ in range(n_steps)]
+    t = sum(times) / len(times)
+    return {"value": c['B'] * c['K'] / t, "unit": "tuples/s", "cores": best, "kind": "port",
+            "sample": "%d steps of the same B=%d,K=%d RTM step (oracle/rtm.py: fwd + autograd bwd + clip/Adam, dropout %.2f, "
+                      "token corruption 0.9), %.2f s/step on %d of %d host threads (fastest of pools %s after 1 warm-up step)"
+                      % (len(times), c['B'], c['K'], ns.dropout, t, best, ncpu,
+                         ", ".join("%d: %.1fs" % (cc, trial[cc]) for cc in cands))}
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
     if os.environ.get('PS_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['PS_BENCH_WATCHDOG']), exit=True)
-    from prodsearch_amd import dist as pdist, readme_tem_args, synth
+    from prodsearch_amd import _lib, dist as pdist
     rank, local, world = pdist.init_from_env()
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
@@ -155,41 +288,23 @@ def main():
         a.row_sparse = True
     if a.items:
         globals().update(P_ITEMS=a.items)
-    ns = readme_tem_args(dropout=a.dropout, embedding_size=D, ff_size=FF, row_sparse_adam=a.row_sparse)
-    model, optim, wd = make_model(ns, 'cuda', seed=1234)
-    model._seed = pdist.rank_seed(ns.seed, rank)
+    wl = RtmWorkload(a, rank, dev) if a.workload == 'c4' else TemWorkload(a, rank, dev)
+    model, optim = wl.model, wl.optim
+    model._seed = pdist.rank_seed(wl.ns.seed, rank)
     pdist.broadcast_parameters(model)
     exchange = pdist.make_exchange(model, optim)
     model.train()
-    batches = [synth.make_tem_batch(1000 + 97 * rank + i, B, P_ITEMS, V_WORDS, Q=Q, L=L, W=W, word_dists=wd).to(dev)
-               for i in range(8)]
 
     def step(i):
-        loss = model(batches[i % len(batches)])          # trainer.py:74 (negatives sampled on device)
+        loss = wl.forward(i)                             # trainer.py:74
         model.zero_grad()                                # :76
         loss.backward()                                  # :77
         exchange()                                       # RCCL all-reduce of the flat gradient (N>1)
         optim.step()                                     # :78
         return loss
 
-    # Warm-up, then the roofline leg (rank 0), then the timed steps.  The step's stream join is a write-value / wait-value
-    # pair (ps_set_side_mode, include/prodsearch_hip.h); back-to-back launch timings on a stream that has carried one are
-    # noisy (4.2 us in 7 of 12 runs, 4.4-7.3 us in the others), so the warm-up steps cross streams with events and the
-    # gather+score launch is timed on the warm, still pristine training stream (always 4.19-4.27 us there)
-    from prodsearch_amd import _lib
-    crossing = _lib.load().ps_set_side_mode(0)
-    for i in range(max(a.warmup - 1, 0)):
+    for i in range(a.warmup):
         step(i)
-    roof = None
-    if rank == 0 and not a.no_extras:
-        if not model._plans:                         # --warmup 0 / 1: one forward builds the launch plan
-            with torch.no_grad():
-                model(batches[0])
-        plan0 = next(iter(model._plans.values()))
-        roof = (time_gather_score(model, plan0, a.kernel_iters), plan0.layout.R)
-    _lib.load().ps_set_side_mode(crossing)
-    if a.warmup > 0:
-        step(a.warmup - 1)                           # the last warm-up step runs in the timed configuration
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -203,37 +318,58 @@ def main():
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
     last_loss = float(loss.detach())
 
+    desc, extra_cfg = wl.describe()
+    Bw, Kw = wl.B, wl.K
     out = {
-        "metric": "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (B, D),
-        "value": world * B * K * a.steps / elapsed, "unit": "tuples/s",
+        "metric": wl.metric(),
+        "value": world * Bw * Kw * a.steps / elapsed, "unit": "tuples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "item_transformer d=%d 1 layer 8 heads ff=%d uprev=20 bs=%d/GPU 20 neg "
-                               "Q=8 W=1 P=%d V=32387 dropout=%.2f%s (BASELINE configs[%d])"
-                               % (D, FF, B, P_ITEMS, a.dropout, " row-sparse Adam" if a.row_sparse else "",
-                                  4 if a.workload == 'c5' else 1),
-                   "global_batch": world * B, "parallelism": "dp%d" % world,
-                   "step": "sample+fwd+bwd+%sclip/Adam via nn.Module API (trainer.py:74-78)"
-                           % ("allreduce+" if world > 1 else ""),
-                   "replicas_per_row": next(iter(model._plans.values())).layout.R},
-        "samples_per_s": world * B * a.steps / elapsed, "final_loss": last_loss,
+        "config": dict({"workload": desc, "global_batch": world * Bw, "parallelism": "dp%d" % world,
+                        "step": "sample+fwd+bwd+%sclip/Adam via nn.Module API (trainer.py:74-78)"
+                                % ("allreduce+" if world > 1 else "")}, **extra_cfg),
+        "samples_per_s": world * Bw * a.steps / elapsed, "final_loss": last_loss,
     }
     if rank == 0 and not a.no_extras:
-        t_k, R_k = roof
-        nbytes = gather_score_bytes(R_k)
-        traffic = None          # PMC passes cannot run inside this process: taken from the committed profile
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'gather_score_traffic.json')))
-            traffic = tj.get('R%d_bytes_per_launch' % R_k) if a.workload == 'c2' else None
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "hbm", "achieved": nbytes / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": nbytes / t_k / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
-                           "bytes_per_launch": nbytes, "us_per_launch": t_k * 1e6}
-        if world == 1 and a.cpu_steps > 0 and a.workload == 'c2':
-            out["cpu_baseline"] = cpu_baseline(ns, a.cpu_steps)
+        lib = _lib.load()
+        # (1) median of single steps, each between two HIP events on the step's stream
+        if a.reps > 0:
+            st = torch.cuda.current_stream()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+            for i, (e0, e1) in enumerate(ev):
+                e0.record(st)
+                step(i)
+                e1.record(st)
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+            out["median_ms_per_step"] = ts[len(ts) // 2]
+            out["reps"] = a.reps
+            out["p10_p90_ms_per_step"] = [ts[len(ts) // 10], ts[(9 * len(ts)) // 10]]
+        # (2) roofline: in-step duration of the workload's gather kernel, one event pair per launch on its own stream
+        spec = wl.roofline_spec()
+        _lib.check(lib.ps_ktimer_arm(spec['tag'].encode(), a.steps), 'ps_ktimer_arm')
+        for i in range(a.steps):
+            step(i)
+        avg, mn, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
+        _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
+        traffic = traffic_src = None                # PMC passes cannot run inside this process
+        if spec['traffic_key']:
+            try:
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'gather_score_traffic.json')))
+                traffic, traffic_src = tj.get(spec['traffic_key']), "committed profile: " + tj.get('source', '')
+            except Exception:
+                pass
+        t_k = avg.value * 1e-6
+        out["roofline"] = {"bound": "hbm", "achieved": spec['bytes'] / t_k / 1e9 if t_k > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": spec['bytes'] / t_k / 1e9 / HBM_PEAK_GBS if t_k > 0 else 0.0,
+                           "traffic": traffic, "traffic_source": traffic_src, "kernel": spec['kernel'],
+                           "bytes_per_launch": spec['bytes'], "us_per_launch": avg.value, "us_per_launch_min": mn.value,
+                           "launches_timed": cnt.value,
+                           "timing": "HIP event pair around every in-step launch, on the launch stream, over a second pass "
+                                     "of %d steps (ps_ktimer)" % a.steps}
+        if world == 1 and a.cpu_steps > 0 and a.workload in ('c2', 'c4'):
+            out["cpu_baseline"] = wl.cpu_baseline(a.cpu_steps)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -387,6 +387,12 @@ int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensors* params, 
  * (0 or 1/(1-p)) of element (row, col) of dropout site `site` at desc->seed/step/dropout. */
 float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint32_t row, uint32_t col);
 
+/* Measurement hook (bench.py's roofline): while armed, the launch sites of ONE tagged kernel ("gather_score", "mlp_fwd",
+ * "mlp_bwd", "rtm_embed") bracket every launch with a HIP event pair recorded on the launch stream, up to max_samples;
+ * ps_ktimer_read synchronises, returns the average / minimum duration in microseconds and disarms.  tag NULL: disarm. */
+int ps_ktimer_arm(const char* tag, int32_t max_samples);
+int ps_ktimer_read(double* avg_us, double* min_us, int32_t* count);
+
 /* Unit-test hook of the fp32 MFMA GEMM: C[M,N] = alpha * op(A) op(B) (+bias) (+C if accumulate).
  * ta: A stored [K,M];  tb==0: B stored [N,K] (nn.Linear), tb==1: B stored [K,N]. */
 int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int ldb, int tb,

@@ -27,6 +27,21 @@ void ps_set_error(const char* fmt, ...);
 
 static inline int ps_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------ kernel timer (measurement only)
+// ps_ktimer_arm("tag", n) makes the launch sites of ONE tagged kernel bracket their launch with a HIP event pair recorded
+// on the launch stream (bench.py's roofline: the kernel's in-step duration, measured live on its own stream);
+// ps_ktimer_read averages the pairs.  Unarmed (the default) the two calls are one pointer compare.
+const char* ps_ktimer_tag();                       // armed tag or nullptr
+void ps_ktimer_mark(const char* tag, hipStream_t st, int end);
+struct KTimeScope {
+  const char* tag; hipStream_t st; bool on;
+  KTimeScope(const char* t, hipStream_t s) : tag(t), st(s), on(false) {
+    const char* armed = ps_ktimer_tag();
+    if (armed && __builtin_strcmp(armed, t) == 0) { on = true; ps_ktimer_mark(tag, st, 0); }
+  }
+  ~KTimeScope() { if (on) ps_ktimer_mark(tag, st, 1); }
+};
+
 // ------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al., SC'11), the generator torch/curand use; 10 rounds.
 // Dropout element (row, col) of site s at step t:  ctr = (col, row>>2, s, t), word = row&3,

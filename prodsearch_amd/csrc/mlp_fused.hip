@@ -275,6 +275,7 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  KTimeScope kt("mlp_fwd", st);
   hipLaunchKernelGGL(mlp_fwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;
@@ -542,6 +543,7 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  KTimeScope kt("mlp_bwd", st);
   hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;

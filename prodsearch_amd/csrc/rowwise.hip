@@ -747,6 +747,7 @@ int score_fwd_blocks(const ScoreArgs& a) {
 
 int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
+  KTimeScope kt("gather_score", st);
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
   if (const int ch = score_wide_ch(a, ntask)) {
     const int wl = a.d / 4 / ch, wu = score_wide_u();

@@ -855,7 +855,10 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   }
   PS_REQUIRE(!D.use_pos_emb || P.pe, "rtm: null positional table");
   const int nslots = r.Bseq * r.S;
-  hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+  {
+    KTimeScope kt("rtm_embed", st);
+    hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+  }
   PS_LAUNCH_CHECK();
   const bool listed = rtm_rows_listed(r, w);
   if (listed) {

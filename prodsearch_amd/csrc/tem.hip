@@ -33,6 +33,55 @@ void ps_set_error(const char* fmt, ...) {
 extern "C" const char* ps_last_error(void) { return g_err; }
 extern "C" const char* ps_version(void) { return "prodsearch_hip 0.1 (gfx950, fp32 MFMA)"; }
 
+// ------------------------------------------------------------------ kernel timer (common.h)
+#include <vector>
+static struct KTimer {
+  char tag[32];
+  bool armed;
+  std::vector<hipEvent_t> e0, e1;
+  int n, cap;
+} g_kt = {"", false, {}, {}, 0, 0};
+const char* ps_ktimer_tag() { return g_kt.armed ? g_kt.tag : nullptr; }
+void ps_ktimer_mark(const char* tag, hipStream_t st, int end) {
+  (void)tag;
+  if (!g_kt.armed) return;
+  if (!end) { if (g_kt.n < g_kt.cap) (void)hipEventRecord(g_kt.e0[g_kt.n], st); }
+  else if (g_kt.n < g_kt.cap) { (void)hipEventRecord(g_kt.e1[g_kt.n], st); ++g_kt.n; }
+}
+extern "C" int ps_ktimer_arm(const char* tag, int32_t max_samples) {
+  g_kt.armed = false;
+  g_kt.n = 0;
+  if (!tag || !*tag || max_samples <= 0) return PS_OK;            // disarm
+  PS_REQUIRE(strlen(tag) < sizeof(g_kt.tag), "ktimer: tag too long");
+  while ((int)g_kt.e0.size() < max_samples) {
+    hipEvent_t a, b;
+    PS_CHECK_HIP(hipEventCreate(&a));
+    PS_CHECK_HIP(hipEventCreate(&b));
+    g_kt.e0.push_back(a); g_kt.e1.push_back(b);
+  }
+  g_kt.cap = max_samples;
+  strcpy(g_kt.tag, tag);
+  g_kt.armed = true;
+  return PS_OK;
+}
+// average / min duration (us) of the launches bracketed since ps_ktimer_arm; synchronises the device; disarms
+extern "C" int ps_ktimer_read(double* avg_us, double* min_us, int32_t* count) {
+  PS_REQUIRE(avg_us && count, "ktimer: null argument");
+  g_kt.armed = false;
+  PS_CHECK_HIP(hipDeviceSynchronize());
+  double sum = 0, mn = 1e30;
+  for (int i = 0; i < g_kt.n; ++i) {
+    float ms = 0.f;
+    PS_CHECK_HIP(hipEventElapsedTime(&ms, g_kt.e0[i], g_kt.e1[i]));
+    sum += ms * 1e3; mn = ms * 1e3 < mn ? ms * 1e3 : mn;
+  }
+  *count = g_kt.n;
+  *avg_us = g_kt.n ? sum / g_kt.n : 0.0;
+  if (min_us) *min_us = g_kt.n ? mn : 0.0;
+  g_kt.n = 0;
+  return PS_OK;
+}
+
 static int check_desc(const PsTemDesc& D) {
   PS_REQUIRE(D.B > 0 && D.K >= 0 && D.Q > 0 && D.W >= 0 && D.d > 0, "desc: bad sizes B=%d K=%d Q=%d W=%d d=%d",
              D.B, D.K, D.Q, D.W, D.d);

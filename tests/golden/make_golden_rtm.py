@@ -91,6 +91,16 @@ CASES = {
                                   heads=4, ff_size=64, inter_layers=1, neg_per_pos=2, dropout=0.0, lr=0.002,
                                   use_user_emb=True, pos_weight=True),
                         V=400, RC=300, B=6, Q=6, u=2, i=3, WL=10, C=5, steps=1, train_pv=False),
+    # long reviews (up to 80 words: more than 32 and more than 64 per review — the word slots a wave holds in its second
+    # register and the counts a half wave cannot vote), token corruption + dropout drawn, with and without the PV loss
+    'rtm_pvc_wl80': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=64,
+                                   heads=4, ff_size=128, inter_layers=1, neg_per_pos=3, dropout=0.1, lr=0.002,
+                                   corrupt_rate=0.5, seed=23),
+                         V=500, RC=300, B=8, Q=6, u=3, i=4, WL=80, C=6, steps=1, train_pv=False),
+    'rtm_pvc_wl80_pv': dict(args=dict(model_name='review_transformer', review_encoder_name='pvc', embedding_size=64,
+                                      heads=4, ff_size=128, inter_layers=1, neg_per_pos=3, dropout=0.0, lr=0.002,
+                                      corrupt_rate=0.9, seed=29, pv_window_size=2),
+                            V=500, RC=300, B=8, Q=6, u=3, i=4, WL=80, C=6, steps=2, train_pv=True),
 }
 USER_SIZE, PRODUCT_SIZE = 40, 50
 
