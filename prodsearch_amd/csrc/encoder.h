@@ -14,6 +14,7 @@ struct Ws {
   LayerWs layer[PS_MAX_LAYERS];
   int64_t fin_stats, enc;
   int64_t item_scores, word_scores, loss_parts, item_terms, word_terms, loss_blk;
+  int64_t word_blk, item_blk, ticket;   // folded scoring (ScoreArgs): word / item loss partials, arrival counter
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
   int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
   int64_t gcpart;           // [4 * row tiles][3][F] parked column sums of the FF2 dX GEMM (b1 gradient)
@@ -32,8 +33,9 @@ int make_ws(const PsTemDesc& D, Ws& w);
 // Key-padding mask: `valid` [n_seq, S] floats if given, else u_item_idxs != P (TEM).
 // `rows_listed`: w.vrows / w.vcount hold the list of valid (non-pad) rows of x (EmbedArgs::vrows, or the review
 // transformer's rtm_rowlist_kernel); the K/V products of a one-layer encoder then run over those rows only.
+// `fold_sc` (optional, TEM with replicas): item scoring + loss run in the epilogue of the last layer's fused kernel.
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
-                       const Ws& w, hipStream_t st, bool rows_listed = false);
+                       const Ws& w, hipStream_t st, bool rows_listed = false, const ScoreArgs* fold_sc = nullptr);
 // Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
 // `fold` (optional): the LayerNorm backwards park their column sums in w.lnpart and append to this list; the caller
 // must hand it to a later launch_embed_scatter (EmbedBwdArgs::fold).  nullptr: plain atomics.

@@ -266,6 +266,387 @@ __global__ __launch_bounds__(256, 1) void mlp_fwd_fused_kernel(const MlpFwdArgs 
   }
 }
 
+// ====================================================================== forward, wave-specialised form
+// PMC profile of the kernel above (profiles/r02_mlp_counters.md): per wave 36.9k cycles of MFMA, ~33k cycles of OTHER
+// vector instructions (Philox, GELU, LayerNorm, addresses) and ~33k cycles of waiting — one wave per SIMD does them one
+// after the other, so the matrix pipe is busy 27 % of the time.  The matrix and vector pipes of a SIMD run concurrently
+// when the instructions come from DIFFERENT waves, hence this form: 8 waves per workgroup, two per SIMD,
+//   waves 0-3 (matrix waves)  only read operands from LDS and issue MFMAs — 32 per 64-deep weight slab;
+//   waves 4-7 (helper waves)  stream the weight slabs (global -> registers -> LDS ring) and run the GELU/dropout
+//                             epilogue of W1 chunk c out of an LDS copy of its accumulators WHILE the matrix waves
+//                             multiply the next product (W1 chunk c+1 or W2 chunk c-1): the products are ordered
+//                             Wo, W1c0, W1c1, W2c0, W1c2, W2c1, ..., W2c(n-1) so nobody waits for that epilogue.
+// Only the two LayerNorm stages (after Wo, after the last W2 chunk) are on the critical path; all 8 waves share them,
+// 4 rows each, keeping their y1 elements in registers from the first to the second.  Same k order of every
+// accumulation and the same element-wise arithmetic as the kernel above: bitwise the same outputs.
+#define WS_THREADS 512
+struct MlpWsLds {
+  float Xs[MD * XLD];           // A operand of Wo / W1: ctx, then ln1                      (k-major)
+  float Hs[2][MD * XLD];        // A operand of W2: h1 chunk c in Hs[c & 1]                 (k-major)
+  float Ws[2][MBK * WLD];       // weight slab ring
+  float Cs[2][MBM * YLD];       // accumulator tiles handed to the epilogues (row-major): Wo / final in [0], W1 chunk c in [c & 1]
+  float red[16];                // folded score: per-wave loss partials, the `last arriver` flag
+};
+static_assert(sizeof(MlpWsLds) <= 160 * 1024, "wave-specialised MLP: LDS budget");
+static_assert(SPP == 2, "the helper waves split a chunk epilogue over the two slabs of the following product");
+
+// STAMP: diagnostic build only (tools/dbg/ws_stamps.py) — workgroup 0's wave 0 (matrix) and wave 4 (helper) record
+// s_memtime when they start a slab's work and when they reach its closing barrier
+static unsigned long long* g_ws_stamp = nullptr;
+extern "C" void ps_debug_set_stamp_buffer(void* p) { g_ws_stamp = (unsigned long long*)p; }
+#define WS_STAMP(slot)                                                                                         \
+  do {                                                                                                         \
+    if (STAMP && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {                                   \
+      unsigned long long t_;                                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                               \
+      stamp[((wave >> 2) * 64 + (slot)) ] = t_;                                                                \
+    }                                                                                                          \
+  } while (0)
+template <bool STAMP>
+__global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdArgs a, unsigned long long* stamp) {
+  extern __shared__ float lds_raw[];
+  MlpWsLds& L = *reinterpret_cast<MlpWsLds*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const bool is_m = wave < 4;
+  const int htid = tid & 255, hw = wave & 3;          // helper-wave local thread / wave ids
+  const int m0 = blockIdx.x * MBM, M = a.M;
+  const int mcol = wave * 32 + l31;                   // matrix waves: this lane's output column of every 128-wide product
+  const int nchunk = a.F / 128;
+  const int NP = 1 + 2 * nchunk, NS = SPP * NP;
+
+  // product p: kind 0 = Wo, 1 = W1 chunk c, 2 = W2 chunk c
+  auto prod = [&](int p, int& kind, int& c) {
+    if (p == 0) { kind = 0; c = 0; }
+    else if (p == 1) { kind = 1; c = 0; }
+    else if (p == 2 * nchunk) { kind = 2; c = nchunk - 1; }
+    else if (p & 1) { kind = 2; c = (p - 3) >> 1; }
+    else { kind = 1; c = p >> 1; }
+  };
+  auto slab_src = [&](int s, const float*& W, int& ldw, int& n0, int& k0) {
+    int kind, c;
+    prod(s / SPP, kind, c);
+    const int r = s % SPP;
+    if (kind == 0) { W = a.wo; ldw = MD; n0 = 0; k0 = MBK * r; }
+    else if (kind == 1) { W = a.w1; ldw = MD; n0 = 128 * c; k0 = MBK * r; }
+    else { W = a.w2; ldw = a.F; n0 = 0; k0 = 128 * c + MBK * r; }
+  };
+
+  // the Philox step of the three dropout sites, read once (graph replay keeps it in device memory: DropSpec::step_ptr)
+  const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+
+  // ---- prologue
+  float4 wr0[WRN], wr1[WRN];
+  if (!is_m) {
+    const float* W; int ldw, n0, k0;
+    slab_src(0, W, ldw, n0, k0);
+    slab_load(W, ldw, n0, k0, wr0, htid);
+    slab_src(1, W, ldw, n0, k0);
+    slab_load(W, ldw, n0, k0, wr1, htid);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                       // ctx tile -> Xs (k-major)
+    const int f = tid + WS_THREADS * u, row = f >> 5, kq = f & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + row < M) v = *reinterpret_cast<const float4*>(a.ctx + (size_t)(m0 + row) * MD + 4 * kq);
+    L.Xs[(4 * kq + 0) * XLD + row] = v.x;
+    L.Xs[(4 * kq + 1) * XLD + row] = v.y;
+    L.Xs[(4 * kq + 2) * XLD + row] = v.z;
+    L.Xs[(4 * kq + 3) * XLD + row] = v.w;
+  }
+  // rows 4*wave .. 4*wave+3, columns lane and lane + 64: this lane's elements in both LayerNorm stages
+  float y1r[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + 4 * wave + q;
+    const float* src = a.xin + ((size_t)((m < M ? m : 0) / a.fan) * a.S + a.qpos) * MD;
+    y1r[q][0] = m < M ? src[lane] : 0.f;
+    y1r[q][1] = m < M ? src[lane + 64] : 0.f;
+  }
+  // folded scoring (MlpFwdArgs::fold_score): the item row each of this lane's 4 enc rows will be dotted with — requested
+  // now, consumed after the last LayerNorm
+  float itr[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  float ibias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.fold_score) {
+    const ScoreArgs& S = a.sc;
+    const int K1 = S.K + 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + 4 * wave + q;
+      if (m < M) {
+        const int b = fdiv(m, S.fK1), j = m - b * K1;
+        int64_t idx = j == 0 ? S.target[b] : S.neg_items[(size_t)b * S.K + j - 1];
+        idx = idx < 0 ? S.P : (idx > S.P ? S.P : idx);
+        const float* row = S.product_emb + (size_t)idx * MD;
+        itr[q][0] = row[lane]; itr[q][1] = row[lane + 64];
+        if (S.bias_product) ibias[q] = S.product_bias[idx];
+      }
+    }
+  }
+  if (!is_m) {
+    slab_store(L.Ws[0], wr0, htid);
+    const float* W; int ldw, n0, k0;
+    slab_src(2 < NS ? 2 : NS - 1, W, ldw, n0, k0);
+    slab_load(W, ldw, n0, k0, wr0, htid);
+  }
+  __syncthreads();
+
+  f32x16 acc, acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
+
+  // one LayerNorm stage, all 8 waves: v = dropout(C + bias) + residual -> (out_pre) ; LayerNorm -> out_ln, stats, Xk
+  // (the global stores are a separate step, ln_store: the last stage scores and takes its ticket first, so that the
+  // signalling lane has no store of this stage to wait for)
+  auto ln_stage = [&](const float* Cst, const float* __restrict__ bias, const DropSpec& drop, const uint32_t dstep, const float* __restrict__ g,
+                      const float* __restrict__ bta, float* Xk, float (&res)[4][2], float (&o)[4][2], float (&mr)[4][2]) {
+    const int rb = opaque(m0) + 4 * wave;
+    const float b0 = bias[lane], b1 = bias[lane + 64];
+    const float g0 = g[lane], g1 = g[lane + 64], e0 = bta[lane], e1 = bta[lane + 64];
+    Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (drop.thr) {
+      r0 = philox4x32_10((uint32_t)lane, (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+      r1 = philox4x32_10((uint32_t)lane + 64u, (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * wave + q, m = rb + q;
+      float v0 = Cst[row * YLD + lane] + b0, v1 = Cst[row * YLD + lane + 64] + b1;
+      if (drop.thr) {
+        v0 *= drop_word(drop, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+        v1 *= drop_word(drop, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+      }
+      v0 += res[q][0]; v1 += res[q][1];
+      res[q][0] = v0; res[q][1] = v1;
+      const float mean = wave_sum(v0 + v1) * (1.f / MD);
+      const float d0 = v0 - mean, d1 = v1 - mean;
+      const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / MD) + 1e-6f);
+      const float o0 = d0 * rstd * g0 + e0, o1 = d1 * rstd * g1 + e1;
+      o[q][0] = o0; o[q][1] = o1;
+      mr[q][0] = mean; mr[q][1] = rstd;
+      if (Xk) { Xk[lane * XLD + row] = o0; Xk[(lane + 64) * XLD + row] = o1; }
+      (void)m;
+    }
+  };
+  auto ln_store = [&](float* out_pre, float* out_ln, float* stats, const float (&res)[4][2], const float (&o)[4][2],
+                      const float (&mr)[4][2]) {
+    const int rb = opaque(m0) + 4 * wave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = rb + q;
+      if (m < M) {
+        out_pre[(size_t)m * MD + lane] = res[q][0]; out_pre[(size_t)m * MD + lane + 64] = res[q][1];
+        out_ln[(size_t)m * MD + lane] = o[q][0]; out_ln[(size_t)m * MD + lane + 64] = o[q][1];
+        if (lane == 0) { stats[2 * (size_t)m] = mr[q][0]; stats[2 * (size_t)m + 1] = mr[q][1]; }
+      }
+    }
+  };
+
+  // folded scoring, all 8 waves, after the final LayerNorm: o = this lane's enc elements.  score, loss term, one loss
+  // partial per workgroup, handed over by agent-scope atomics alone (below); the workgroup that arrives last adds the
+  // word tasks' partials (left by the embed launch, an earlier kernel) and writes the loss.
+  auto score_stage = [&](const float (&o)[4][2], auto&& stores) {
+    const ScoreArgs& S = a.sc;
+    const int K1 = S.K + 1;
+    WS_STAMP(40);
+    // lane q (< 4) ends up with row q's score and computes its loss term: one softplus per wave instead of four
+    float scq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float sdot = wave_sum(o[q][0] * itr[q][0] + o[q][1] * itr[q][1]) + ibias[q];
+      scq = lane == q ? sdot : scq;
+    }
+    const int mq = m0 + 4 * wave + (lane & 3);
+    const bool rowq = lane < 4 && mq < M;
+    const int bq = fdiv(rowq ? mq : 0, S.fK1), jq = (rowq ? mq : 0) - bq * K1;
+    const float twq = jq == 0 ? -(S.pos_weight ? (float)S.K : 1.f) : 1.f;
+    const float termq = fabsf(twq) * softplus_f(twq < 0.f ? -scq : scq);
+    const float cps = wave_sum(rowq ? termq : 0.f);
+    if (lane == 0) L.red[wave] = cps;
+    WS_STAMP(41);
+    __syncthreads();
+    WS_STAMP(42);
+    unsigned long long mine = 0ull, old = 0ull;
+    const unsigned long long one = 1ull << 48, mask = one - 1ull;
+    if (tid == 0) {
+      // one returning 64-bit atomic per workgroup carries BOTH its partial (fixed point, 2^-20 units: integer adds
+      // commute, so the total is exact and independent of the arrival order) and its arrival (bits 48+): nothing to
+      // store, drain or re-read.  (Eight shard words + a top word, so that at most 32 + 8 workgroups meet on one address,
+      // measured no faster: the workgroup that ends the kernel then pays two round trips.)
+      const float p = ((L.red[0] + L.red[1]) + (L.red[2] + L.red[3])) + ((L.red[4] + L.red[5]) + (L.red[6] + L.red[7]));
+      unsigned long long* tk = reinterpret_cast<unsigned long long*>(S.ticket);
+      mine = (unsigned long long)(long long)__float2ll_rn(p * 1048576.f) | one;
+      old = __hip_atomic_fetch_add(tk, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the stage's stores are issued under the atomic's round trip (2-2.5 us while the chip streams this kernel's writes)
+    if (rowq) { S.item_scores[mq] = scq; S.item_terms[mq] = termq; }
+    stores();
+    if (tid == 0) {
+      float last = 0.f;
+      if ((old >> 48) == gridDim.x - 1u) {
+        last = 1.f;
+        L.red[9] = (float)((double)((old & mask) + (mine & mask)) * (1.0 / 1048576.0));
+      }
+      L.red[8] = last;
+    }
+    WS_STAMP(43);
+    __syncthreads();
+    WS_STAMP(44);
+    if (L.red[8] == 0.f) return;
+    // last arriver: add the word tasks' partials (left by the embed launch) in a fixed order => bitwise reproducible
+    if (wave == 0) {
+      float il = 0.f;
+      for (int i = lane; i < S.word_nblk; i += 64) il += S.word_blk[i];
+      il = wave_sum(il);
+      if (lane == 0) {
+        const float ps = L.red[9] / (float)S.B;
+        il /= (float)S.B;
+        S.loss3[0] = ps + il; S.loss3[1] = ps; S.loss3[2] = il;
+        if (S.loss_acc) { S.loss_acc[0] += ps; S.loss_acc[1] += il; }
+      }
+    }
+  };
+
+  // matrix waves: accumulator tile -> Cs (row-major)
+  auto dump = [&](float* Cst, f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Cst[((r & 3) + 8 * (r >> 2) + 4 * h) * YLD + mcol] = v[r];
+      v[r] = 0.f;
+    }
+  };
+
+  // ---- the two roles run their own loops (every barrier below is reached by all 8 waves: one per slab, one more in
+  // front of each LayerNorm stage).  Separate loops rather than one loop with a role branch inside: registers loaded
+  // under a branch become phis at the join and the compiler then waits for the prefetch right where it was issued.
+  if (is_m) {
+    for (int s = 0; s < NS; ++s) {
+      int kind, c;
+      prod(s / SPP, kind, c);
+      const int r = s % SPP;
+      const float* A = kind == 2 ? L.Hs[c & 1] : L.Xs;
+      const float* Wb = L.Ws[s & 1];
+      WS_STAMP(2 * s);
+#pragma unroll
+      for (int half = 0; half < MBK / 32; ++half) {                               // 16 MFMAs (32 k) at a time
+        const float* ab = A + (MBK * r + 32 * half + h) * XLD + l31;
+        const float* bb = Wb + (32 * half + h) * WLD + mcol;
+        float av[16], bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLD]; }
+        if (kind == 2) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+      }
+      if (r == SPP - 1) {
+        if (kind == 1) dump(L.Cs[c & 1], acc);
+        else if (kind == 0) {
+          dump(L.Cs[0], acc);
+          __syncthreads();                            // Wo accumulators in Cs; every matrix wave is done reading ctx from Xs
+          float o[4][2], mr[4][2];
+          ln_stage(L.Cs[0], a.bo, a.drop_ctx, step_ctx, a.g1, a.be1, L.Xs, y1r, o, mr);
+          ln_store(a.y1, a.ln1, a.st1, y1r, o, mr);
+        } else if (s == NS - 1) {
+          dump(L.Cs[0], acc_o);
+          __syncthreads();
+          float o[4][2], mr[4][2];
+          ln_stage(L.Cs[0], a.b2, a.drop_ff2, step_ff2, a.gf, a.bef, nullptr, y1r, o, mr);
+          if (a.fold_score) score_stage(o, [&]() { ln_store(a.y2, a.enc, a.stf, y1r, o, mr); });
+          else ln_store(a.y2, a.enc, a.stf, y1r, o, mr);
+        }
+      }
+      WS_STAMP(2 * s + 1);
+      __syncthreads();
+    }
+    WS_STAMP(2 * NS);
+    return;
+  }
+
+  // helper waves.  wnext holds slab s + 1 on entry of step s (loaded two steps earlier)
+  auto helper_step = [&](const int s, float4 (&wnext)[WRN]) __attribute__((always_inline)) {
+    int kind, c;
+    prod(s / SPP, kind, c);
+    const int r = s % SPP;
+    // epilogue of the W1 chunk whose product ended just before this one: rows 8*hw + 4*r .. +3, columns 2*lane, 2*lane+1
+    int pk = -1, pc = 0;
+    if (s >= SPP) prod(s / SPP - 1, pk, pc);
+    const bool epi = pk == 1;
+    const int f0 = 128 * pc + 2 * lane;
+    WS_STAMP(2 * s);
+    // its two bias values are requested FIRST: behind the slab loads below they would make the compiler wait for
+    // every load in flight (vmcnt(0)) — the whole L2 round trip of the prefetch, once per slab
+    float2 bia = make_float2(0.f, 0.f);
+    if (epi) bia = *reinterpret_cast<const float2*>(a.b1 + f0);
+    // publish slab s + 1 to the other ring buffer (the matrix waves finished reading it a barrier ago), refill its
+    // registers two slabs ahead (unconditional: past the end a cache hit that is dropped)
+    if (s + 1 < NS) slab_store(L.Ws[(s + 1) & 1], wnext, htid);
+    {
+      const float* W; int ldw, n0, k0;
+      slab_src(s + 3 < NS ? s + 3 : NS - 1, W, ldw, n0, k0);
+      slab_load(W, ldw, n0, k0, wnext, htid);
+    }
+    if (epi) {
+      const float* Cst = L.Cs[pc & 1];
+      float* Hk = L.Hs[pc & 1];
+      const int rl0 = 8 * hw + 4 * r, rb = opaque(m0) + rl0;
+      Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+      if (a.drop_ff1.thr) {
+        r0 = philox4x32_10((uint32_t)f0, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+        r1 = philox4x32_10((uint32_t)f0 + 1u, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = rl0 + q, m = rb + q;
+        const float p0 = Cst[rl * YLD + 2 * lane] + bia.x, p1 = Cst[rl * YLD + 2 * lane + 1] + bia.y;
+        float h0 = gelu_tanh_f(p0), h1v = gelu_tanh_f(p1);
+        if (a.drop_ff1.thr) {
+          h0 *= drop_word(a.drop_ff1, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+          h1v *= drop_word(a.drop_ff1, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+        }
+        Hk[(2 * lane) * XLD + rl] = h0; Hk[(2 * lane + 1) * XLD + rl] = h1v;
+        if (m < M) {
+          *reinterpret_cast<float2*>(a.a1 + (size_t)m * a.F + f0) = make_float2(p0, p1);
+          *reinterpret_cast<float2*>(a.h1 + (size_t)m * a.F + f0) = make_float2(h0, h1v);
+        }
+      }
+    }
+    if (r == SPP - 1) {
+      if (kind == 0) {
+        __syncthreads();
+        float o[4][2], mr[4][2];
+        ln_stage(L.Cs[0], a.bo, a.drop_ctx, step_ctx, a.g1, a.be1, L.Xs, y1r, o, mr);
+        ln_store(a.y1, a.ln1, a.st1, y1r, o, mr);
+      } else if (s == NS - 1) {
+        __syncthreads();
+        float o[4][2], mr[4][2];
+        ln_stage(L.Cs[0], a.b2, a.drop_ff2, step_ff2, a.gf, a.bef, nullptr, y1r, o, mr);
+        if (a.fold_score) score_stage(o, [&]() { ln_store(a.y2, a.enc, a.stf, y1r, o, mr); });
+        else ln_store(a.y2, a.enc, a.stf, y1r, o, mr);
+      }
+    }
+    WS_STAMP(2 * s + 1);
+    __syncthreads();
+  };
+  for (int s = 0; s < NS; s += 2) {                   // NS = 2 * NP is even; wr1 holds slab s + 1, wr0 slab s + 2
+    helper_step(s, wr1);
+    helper_step(s + 1, wr0);
+  }
+  WS_STAMP(2 * NS);
+}
+
+static bool mlp_ws_enabled() {
+  static const bool on = !(getenv("PS_MLP_WS") && atoi(getenv("PS_MLP_WS")) == 0);
+  return on;
+}
+bool mlp_fwd_can_fold_score(int M, int F, int d) {
+  static const bool fold_on = !(getenv("PS_NO_FOLD_SCORE") && atoi(getenv("PS_NO_FOLD_SCORE")) != 0);
+  return fold_on && ps_fusion_enabled() && mlp_ws_enabled() && d == MD && F % 128 == 0 && F >= 256 && M > 0 &&
+         ps_cdiv(M, MBM) <= 256;               // one workgroup per CU, all resident: the ticket hand-off's measured regime
+}
+
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.F % 128 == 0 && a.M > 0, "fused mlp: F=%d M=%d", a.F, a.M);
   static bool attr_set = false;
@@ -276,6 +657,24 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
     attr_set = true;
   }
   KTimeScope kt("mlp_fwd", st);
+  PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs the wave-specialised form");
+  if (mlp_ws_enabled() && a.F >= 256) {
+    static bool ws_attr = false;
+    if (!ws_attr) {
+      PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_ws_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpWsLds)));
+      PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_ws_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpWsLds)));
+      ws_attr = true;
+    }
+    if (g_ws_stamp)
+      hipLaunchKernelGGL(mlp_fwd_ws_kernel<true>, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpWsLds), st, a, g_ws_stamp);
+    else
+      hipLaunchKernelGGL(mlp_fwd_ws_kernel<false>, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpWsLds), st, a,
+                         (unsigned long long*)nullptr);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   hipLaunchKernelGGL(mlp_fwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -2,6 +2,51 @@
 #pragma once
 #include "common.h"
 
+struct ScoreArgs {
+  int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)
+  FDiv fK1, fWK1, fC;            // fast dividers of K+1, W*(K+1), C (filled by score_finish)
+  int64_t P, V;
+  int bias_product, pos_weight;
+  const int64_t* target; const int64_t* neg_items; const int64_t* pos_words; const int64_t* neg_words;
+  const int64_t* candi;
+  const float* product_emb; const float* word_emb; const float* product_bias; const float* word_bias;
+  const float* enc;              // [B*R, d]
+  float* item_scores;            // [B,1+K]   (eval: [B,C])
+  float* word_scores;            // [B,W,1+K]
+  float* loss_parts;             // [B,2]
+  float* item_terms;             // [B,1+K]   per-task loss terms (softplus), written by the gather+score kernel
+  float* word_terms;             // [B,W,1+K]
+  float* loss3;                  // {total, ps, item}
+  float* loss_acc;               // optional running sums {ps, item} (item_transformer.py:516-517)
+  float* loss_blk;               // [2*blocks] per-workgroup loss partials written by the gather+score kernel
+  int loss_nblk;                 // filled by launch_score_fwd
+  // backward
+  float scale;                   // loss_scale
+  const float* scale_dev;        // optional device scalar multiplied into scale
+  float* denc;                   // [B*R,d]  (null: the consumer derives d enc from the scores itself, MlpBwdArgs::item_scores)
+  int part;                      // replicas only: 0 = everything, 1 = d enc only (no table scatter), 2 = table scatter only
+  float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
+  // ---- folded form (TEM with replicas, the wave-specialised fused MLP forward): no gather+score / loss launches.
+  //  * the word tasks (item_to_words, item_transformer.py:260-283: encoder-independent) run as extra workgroups of the
+  //    embed launch, PS_WORD_TASKS_PER_WG each, leaving one loss partial per workgroup in word_blk;
+  //  * the item tasks run in the epilogue of the fused MLP forward (row m = (b, j) of enc is dotted with item row
+  //    idx(b, j) right where it is produced), one loss partial per workgroup in item_blk (write-through stores);
+  //    idx(b, j) right where it is produced); each workgroup hands its loss partial over in fixed point with one
+  //    returning 64-bit atomic (`ticket`: 8 shard words + 1 top word, zeroed by the embed launch);
+  //  * the workgroup of the fused kernel that arrives last adds the word partials in a fixed order and writes the loss.
+  float* word_blk; int word_nblk; float* item_blk; uint32_t* ticket;
+  // negative words drawn inside the launch that consumes them (the sampling workgroups of the same launch have not
+  // necessarily run yet): same Philox stream and alias table as sample_kernel, so the values equal neg_words[]
+  const float* samp_prob; const int32_t* samp_alias; uint32_t samp_step, samp_k0, samp_k1; int samp_inline;
+};
+#define PS_WORD_TASKS_PER_WG 16
+inline void score_finish(ScoreArgs& a) {
+  a.fK1 = make_fdiv(a.K + 1); a.fWK1 = make_fdiv(a.W * (a.K + 1)); a.fC = make_fdiv(a.C > 0 ? a.C : 1);
+}
+int launch_score_fwd(ScoreArgs& a, hipStream_t st);           // gather + dot ("gather+score kernel")
+int launch_loss(const ScoreArgs& a, hipStream_t st);
+int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
+
 struct EmbedArgs {
   int B, Q, L, S, d;
   int64_t P, V;
@@ -26,6 +71,9 @@ struct EmbedArgs {
   // score kernel that reads them runs much later) instead of a launch of their own in front of it
   const float* samp_prob; const int32_t* samp_alias; int64_t* samp_items; int64_t* samp_words;
   int samp_nitem, samp_nword; uint32_t samp_step, samp_k0, samp_k1;
+  // optional: the word tasks of the loss ride in this launch too (ScoreArgs, folded form); word_wgs / list_wgs are
+  // filled by the launcher (grid = B gather + samp_wgs + list_wgs + word_wgs workgroups)
+  int fold_words; ScoreArgs sc; int word_wgs, list_wgs;
 };
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);
 
@@ -97,38 +145,6 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
 bool attn_sq1_fits(const AttnArgs& a);
 int attn_sq1_split(const AttnArgs& a);   // head groups (workgroups) per sequence the sq1 kernels will use
 
-struct ScoreArgs {
-  int B, K, W, C, R, d;          // C > 0: eval mode (B*C candidate tasks only)
-  FDiv fK1, fWK1, fC;            // fast dividers of K+1, W*(K+1), C (filled by score_finish)
-  int64_t P, V;
-  int bias_product, pos_weight;
-  const int64_t* target; const int64_t* neg_items; const int64_t* pos_words; const int64_t* neg_words;
-  const int64_t* candi;
-  const float* product_emb; const float* word_emb; const float* product_bias; const float* word_bias;
-  const float* enc;              // [B*R, d]
-  float* item_scores;            // [B,1+K]   (eval: [B,C])
-  float* word_scores;            // [B,W,1+K]
-  float* loss_parts;             // [B,2]
-  float* item_terms;             // [B,1+K]   per-task loss terms (softplus), written by the gather+score kernel
-  float* word_terms;             // [B,W,1+K]
-  float* loss3;                  // {total, ps, item}
-  float* loss_acc;               // optional running sums {ps, item} (item_transformer.py:516-517)
-  float* loss_blk;               // [2*blocks] per-workgroup loss partials written by the gather+score kernel
-  int loss_nblk;                 // filled by launch_score_fwd
-  // backward
-  float scale;                   // loss_scale
-  const float* scale_dev;        // optional device scalar multiplied into scale
-  float* denc;                   // [B*R,d]  (null: the consumer derives d enc from the scores itself, MlpBwdArgs::item_scores)
-  int part;                      // replicas only: 0 = everything, 1 = d enc only (no table scatter), 2 = table scatter only
-  float* g_product_emb; float* g_word_emb; float* g_product_bias; float* g_word_bias;
-};
-inline void score_finish(ScoreArgs& a) {
-  a.fK1 = make_fdiv(a.K + 1); a.fWK1 = make_fdiv(a.W * (a.K + 1)); a.fC = make_fdiv(a.C > 0 ? a.C : 1);
-}
-int launch_score_fwd(ScoreArgs& a, hipStream_t st);           // gather + dot ("gather+score kernel")
-int launch_loss(const ScoreArgs& a, hipStream_t st);
-int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
-
 struct EmbedBwdArgs {
   int B, Q, L, S, d;
   int64_t P, V;
@@ -179,8 +195,10 @@ struct MlpFwdArgs {
   const float *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *gf, *bef;
   DropSpec drop_ctx, drop_ff1, drop_ff2;
   float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
+  int fold_score; ScoreArgs sc;   // item scoring + loss in the epilogue (ScoreArgs, folded form); M = B*(K+1)
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
+bool mlp_fwd_can_fold_score(int M, int F, int d);   // the wave-specialised kernel will serve this shape
 bool ps_fusion_enabled();
 
 // ---- backward of the same tail as ONE kernel (mlp_fused.hip; d == 128, parked column sums):

@@ -15,6 +15,106 @@ static inline int lpr_for(int d) {   // lanes per row for float4 lanes: pow2 >= 
 
 __device__ inline int64_t clamp_idx(int64_t i, int64_t hi) { return i < 0 ? hi : (i > hi ? hi : i); }
 
+struct Task {
+  const float* row; const float* vec; float bias; float* out;
+  float* term; float tw;     // loss term = |tw| * softplus(sign(tw) * score): tw < 0 for the positive
+  float lw;                  // weight of the term in the batch loss: item tasks +1; word tasks -(valid / #valid windows)
+};
+__device__ inline Task score_task(const ScoreArgs& a, int t) {
+  Task k;
+  const int K1 = a.K + 1;
+  if (a.C > 0) {                                   // eval: candidates
+    int b = fdiv(t, a.fC);
+    int64_t idx = clamp_idx(a.candi[t], a.P);
+    k.row = a.product_emb + (size_t)idx * a.d;
+    k.vec = a.enc + (size_t)b * a.R * a.d;
+    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
+    k.out = a.item_scores + t;
+    k.term = nullptr; k.tw = 0.f; k.lw = 0.f;
+    return k;
+  }
+  const int nitem = a.B * K1;
+  if (t < nitem) {
+    int b = fdiv(t, a.fK1), j = t - b * K1;
+    int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+    k.row = a.product_emb + (size_t)idx * a.d;
+    k.vec = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * a.d;
+    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
+    k.out = a.item_scores + t;
+    k.term = a.item_terms + t;
+    k.tw = j == 0 ? -(a.pos_weight ? (float)a.K : 1.f) : 1.f;
+    k.lw = 1.f;
+  } else {
+    int u = t - nitem;
+    int b = fdiv(u, a.fWK1), r = u - b * (a.W * K1);
+    int w = fdiv(r, a.fK1), j = r - w * K1;
+    int64_t widx;
+    if (j == 0) widx = a.pos_words[(size_t)b * a.W + w];
+    else if (a.samp_inline) {                      // the draw sample_kernel makes for this slot (same stream, same table)
+      const uint32_t su = (uint32_t)(b * a.W * a.K + w * a.K + j - 1);
+      Philox4 rr = philox4x32_10(su, 0u, PS_SITE_SAMPLE_WORD, a.samp_step, a.samp_k0, a.samp_k1);
+      const int64_t i = (int64_t)(((uint64_t)rr.x * (uint64_t)a.V) >> 32);
+      const float f = (float)(rr.y >> 8) * (1.0f / 16777216.0f);
+      widx = f < a.samp_prob[i] ? i : (int64_t)a.samp_alias[i];
+    } else widx = a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1];
+    int64_t idx = clamp_idx(widx, a.V - 1);
+    int64_t tb = clamp_idx(a.target[b], a.P);
+    k.row = a.word_emb + (size_t)idx * a.d;
+    k.vec = a.product_emb + (size_t)tb * a.d;
+    k.bias = a.word_bias[idx];
+    k.out = a.word_scores + u;
+    k.term = a.word_terms + u;
+    k.tw = j == 0 ? -1.f : 1.f;
+    // masked mean over the window (get_vector_mean, item_transformer.py:281): padded slots drop out
+    int cnt = 0;
+    for (int ww = 0; ww < a.W; ++ww) cnt += a.pos_words[(size_t)b * a.W + ww] != a.V - 1;
+    const bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
+    k.lw = valid ? -1.f / (float)cnt : -0.f;
+  }
+  return k;
+}
+
+
+// Word tasks of the loss as workgroups of the embed launch (ScoreArgs, folded form): 16 lanes per task (rows of d <= 512
+// floats in 16-byte chunks), 16 tasks per pass, PS_WORD_TASKS_PER_WG tasks per workgroup; one {il} partial per workgroup.
+__device__ inline void word_tasks_wg(const ScoreArgs& a, int wg) {
+  __shared__ float wred[16];
+  const int tid = threadIdx.x, grp = tid >> 4, c = tid & 15;
+  const int nitem = a.B * (a.K + 1), nword = a.B * a.W * (a.K + 1);
+  const int nch = a.d >> 2;
+  float cil = 0.f;
+  if (wg == 0 && tid < 18) a.ticket[tid] = 0u;         // the fused kernel's 9 arrival / partial-sum words, reset once per step
+  for (int pass = 0; pass < PS_WORD_TASKS_PER_WG / 16; ++pass) {
+    const int u = wg * PS_WORD_TASKS_PER_WG + pass * 16 + grp;
+    float s = 0.f;
+    Task k;
+    k.out = nullptr;
+    if (u < nword) {
+      k = score_task(a, nitem + u);
+      for (int cc = c; cc < nch; cc += 16) {
+        const float4 r = *reinterpret_cast<const float4*>(k.row + 4 * cc);
+        const float4 v = *reinterpret_cast<const float4*>(k.vec + 4 * cc);
+        s += r.x * v.x + r.y * v.y + r.z * v.z + r.w * v.w;
+      }
+    }
+    s = group_sum(s, 16);
+    if (c == 0 && k.out) {
+      const float sc = s + k.bias;
+      *k.out = sc;
+      const float term = fabsf(k.tw) * softplus_f(k.tw < 0.f ? -sc : sc);
+      *k.term = term;
+      cil -= term * k.lw;
+    }
+  }
+  if (c == 0) wred[grp] = cil;
+  __syncthreads();
+  if (tid == 0) {
+    float q = 0.f;
+    for (int g2 = 0; g2 < 16; ++g2) q += wred[g2];
+    a.word_blk[wg] = q;
+  }
+}
+
 // =============================================================== embed forward
 // Reference: word_embeddings(query_word_idxs) + get_vector_mean (item_transformer.py:449-450,
 // text_encoder.py:6-16) + FS dropout (text_encoder.py:34-35); history gather, mask and
@@ -33,6 +133,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
       const float f = (float)(r.y >> 8) * (1.0f / 16777216.0f);
       a.samp_words[u] = f < a.samp_prob[i] ? i : (int64_t)a.samp_alias[i];
     }
+    return;
+  }
+  if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs) {       // word tasks of the loss (EmbedArgs::fold_words)
+    word_tasks_wg(a.sc, (int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs);
     return;
   }
   if ((int)blockIdx.x >= a.B + a.samp_wgs) {
@@ -185,8 +289,12 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   const int nlist = (a.vrows && a.tem && a.L <= 64) ? a.B : 0;
   EmbedArgs b = a;
   b.samp_wgs = nsamp;
+  b.list_wgs = nlist;
   if (!nlist) b.vrows = nullptr;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist), dim3(256), (size_t)(rpp + 2) * a.d * sizeof(float), st, b);
+  b.word_wgs = a.fold_words ? a.sc.word_nblk : 0;
+  PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist + b.word_wgs), dim3(256),
+                     (size_t)(rpp + 2) * a.d * sizeof(float), st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -524,57 +632,6 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
 //   item_to_words   item_transformer.py:262-275
 // A row group of LPR lanes (16 B per lane) owns 4 tasks at a time: 4 index loads, then
 // 4 row + 4 vector loads in flight, then shuffle reductions.
-struct Task {
-  const float* row; const float* vec; float bias; float* out;
-  float* term; float tw;     // loss term = |tw| * softplus(sign(tw) * score): tw < 0 for the positive
-  float lw;                  // weight of the term in the batch loss: item tasks +1; word tasks -(valid / #valid windows)
-};
-__device__ inline Task score_task(const ScoreArgs& a, int t) {
-  Task k;
-  const int K1 = a.K + 1;
-  if (a.C > 0) {                                   // eval: candidates
-    int b = fdiv(t, a.fC);
-    int64_t idx = clamp_idx(a.candi[t], a.P);
-    k.row = a.product_emb + (size_t)idx * a.d;
-    k.vec = a.enc + (size_t)b * a.R * a.d;
-    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
-    k.out = a.item_scores + t;
-    k.term = nullptr; k.tw = 0.f; k.lw = 0.f;
-    return k;
-  }
-  const int nitem = a.B * K1;
-  if (t < nitem) {
-    int b = fdiv(t, a.fK1), j = t - b * K1;
-    int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
-    k.row = a.product_emb + (size_t)idx * a.d;
-    k.vec = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * a.d;
-    k.bias = a.bias_product ? a.product_bias[idx] : 0.f;
-    k.out = a.item_scores + t;
-    k.term = a.item_terms + t;
-    k.tw = j == 0 ? -(a.pos_weight ? (float)a.K : 1.f) : 1.f;
-    k.lw = 1.f;
-  } else {
-    int u = t - nitem;
-    int b = fdiv(u, a.fWK1), r = u - b * (a.W * K1);
-    int w = fdiv(r, a.fK1), j = r - w * K1;
-    int64_t idx = clamp_idx(j == 0 ? a.pos_words[(size_t)b * a.W + w]
-                                   : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
-    int64_t tb = clamp_idx(a.target[b], a.P);
-    k.row = a.word_emb + (size_t)idx * a.d;
-    k.vec = a.product_emb + (size_t)tb * a.d;
-    k.bias = a.word_bias[idx];
-    k.out = a.word_scores + u;
-    k.term = a.word_terms + u;
-    k.tw = j == 0 ? -1.f : 1.f;
-    // masked mean over the window (get_vector_mean, item_transformer.py:281): padded slots drop out
-    int cnt = 0;
-    for (int ww = 0; ww < a.W; ++ww) cnt += a.pos_words[(size_t)b * a.W + ww] != a.V - 1;
-    const bool valid = a.pos_words[(size_t)b * a.W + w] != a.V - 1;
-    k.lw = valid ? -1.f / (float)cnt : -0.f;
-  }
-  return k;
-}
-
 template <int SCORE_U>
 __global__ __launch_bounds__(256) void score_fwd_kernel(const ScoreArgs a, int ntask, int lpr) {
   const int tid = threadIdx.x;

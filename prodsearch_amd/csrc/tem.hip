@@ -155,6 +155,9 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.item_terms = take(cur, (int64_t)B * (D.K + 1));
   w.word_terms = take(cur, (int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1));
   w.loss_blk = take(cur, 2 * ((int64_t)B * (D.K + 1) * (1 + D.W) / 4 + 2));     // >= 2 floats per score workgroup
+  w.word_blk = take(cur, ps_cdiv((int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1), PS_WORD_TASKS_PER_WG) + 4);
+  w.item_blk = take(cur, ps_cdiv((int64_t)B * w.R, 32) + 4);
+  w.ticket = take(cur, 20);      // 9 x 64-bit words (8 shards + top), 16-byte aligned
   // backward scratch (sized for the widest layer)
   w.denc = take(cur, (int64_t)w.Mf * d);
   if (tem) {
@@ -415,7 +418,7 @@ int side_join(hipStream_t main_st) {
 }
 
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
-                       const Ws& w, hipStream_t st, bool rows_listed) {
+                       const Ws& w, hipStream_t st, bool rows_listed, const ScoreArgs* fold_sc) {
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
   const float qscale = 1.f / sqrtf((float)(d / (D.H > 0 ? D.H : 1)));
   bool fused_final = false;
@@ -467,6 +470,7 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
     TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
                       P.final_ln_g && P.final_ln_b;
+    PS_REQUIRE(!fold_sc || fuse, "forward: folded scoring without the fused last layer");
     if (fuse) {   // Wo + LN + W1 + GELU + W2 + final LN of the last layer in one kernel (mlp_fused.hip)
       MlpFwdArgs m;
       memset(&m, 0, sizeof(m));
@@ -478,6 +482,7 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       m.drop_ff2 = make_drop(D, PS_SITE_FF2(i));
       m.y1 = ws + l.y1; m.ln1 = ws + l.ln1; m.st1 = ws + l.ff_stats; m.a1 = ws + l.a1; m.h1 = ws + l.h1;
       m.y2 = ws + l.y2; m.stf = ws + w.fin_stats; m.enc = ws + w.enc;
+      if (fold_sc) { m.fold_score = 1; m.sc = *fold_sc; }
       TRY(launch_mlp_fwd_fused(m, st));
       fused_final = true;
       continue;
@@ -524,7 +529,7 @@ struct SamplerArgs { const float* prob; const int32_t* alias; int64_t* items; in
 static bool rows_list_ok(const PsTemDesc& D) { return D.L <= 64 && (int64_t)D.B * D.B * D.L <= ((int64_t)64 << 20); }
 
 static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
-                          hipStream_t st, const SamplerArgs* samp = nullptr) {
+                          hipStream_t st, const SamplerArgs* samp = nullptr, const ScoreArgs* fold_sc = nullptr) {
   const bool tem = D.model == PS_MODEL_TEM;
   const int B = D.B, d = D.d, S = w.S, NL = tem ? D.n_layers : 0;
   const float* hist = D.sep_prod_emb ? P.hist_product_emb : P.product_emb;
@@ -550,6 +555,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   // small (64 KB at d = 128; at d = 256 the C5 step lost 60 us to it and the GEMM launch is the better deal)
   const bool fs_fused = e.fs && ps_fusion_enabled() && d <= 128;
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
+  if (fold_sc) { e.fold_words = 1; e.sc = *fold_sc; }
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
     GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
@@ -559,7 +565,24 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   }
   if (!tem) return PS_OK;
 
-  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st, rows_list_ok(D));
+  return enc_layers_forward(D, P, Bt.u_item_idxs, nullptr, ws, w, st, rows_list_ok(D), fold_sc);
+}
+
+// Folded scoring (ScoreArgs): TEM training forward with replicas whose last layer takes the wave-specialised fused form
+static bool can_fold_score(const PsTemDesc& D, const PsTemTensors& P, const Ws& w, hipStream_t st) {
+  if (D.model != PS_MODEL_TEM || D.n_layers < 1 || D.C != 0 || w.R != D.K + 1 || w.R < 2 || D.W < 1) return false;
+  const LayerWs& l = w.layer[D.n_layers - 1];
+  if (l.Sq != 1 || l.M2 != w.Mf || !P.final_ln_g || !P.final_ln_b) return false;
+  if (stream_capturing(st)) return false;            // graph replay patches the loss kernel's arguments: unfolded form
+  return mlp_fwd_can_fold_score(w.Mf, D.F, D.d);
+}
+static void fold_finish(const PsTemDesc& D, float* ws, const Ws& w, ScoreArgs& s, const SamplerArgs* samp) {
+  s.word_blk = ws + w.word_blk; s.item_blk = ws + w.item_blk; s.ticket = reinterpret_cast<uint32_t*>(ws + w.ticket);
+  s.word_nblk = ps_cdiv((int64_t)D.B * D.W * (D.K + 1), PS_WORD_TASKS_PER_WG);
+  if (samp) {
+    s.samp_inline = 1; s.samp_prob = samp->prob; s.samp_alias = samp->alias;
+    s.samp_step = (uint32_t)D.step; s.samp_k0 = (uint32_t)(D.seed & 0xffffffffu); s.samp_k1 = (uint32_t)(D.seed >> 32);
+  }
 }
 
 static void fill_score(const PsTemDesc& D, const PsTemTensors& P, const PsTemBatch& Bt, float* ws, const Ws& w,
@@ -588,10 +611,14 @@ extern "C" int ps_tem_forward(const PsTemDesc* desc, const PsTemTensors* params,
   PS_REQUIRE(batch->target_prod_idxs && batch->neg_item_idxs && (D.W == 0 || (batch->pos_iword_idxs &&
              batch->neg_word_idxs)), "forward: null batch tensors");
   PS_REQUIRE(params->word_bias && (!D.bias_product || params->product_bias), "forward: null bias tensors");
-  TRY(encode_forward(D, *params, *batch, workspace, w, st));
   ScoreArgs s;
   fill_score(D, *params, *batch, workspace, w, s);
   s.loss3 = loss3; s.loss_acc = loss_acc;
+  if (can_fold_score(D, *params, w, st)) {             // no gather+score / loss launches: see ScoreArgs, folded form
+    fold_finish(D, workspace, w, s, nullptr);
+    return encode_forward(D, *params, *batch, workspace, w, st, nullptr, &s);
+  }
+  TRY(encode_forward(D, *params, *batch, workspace, w, st));
   TRY(launch_score_fwd(s, st));
   TRY(launch_loss(s, st));
   return PS_OK;
@@ -615,10 +642,14 @@ extern "C" int ps_tem_forward_sampled(const PsTemDesc* desc, const PsTemTensors*
   PsTemBatch Bt = *batch;
   Bt.neg_item_idxs = neg_item_out; Bt.neg_word_idxs = neg_word_out;
   const SamplerArgs samp = {alias_prob, alias_idx, neg_item_out, neg_word_out};
-  TRY(encode_forward(D, *params, Bt, workspace, w, st, &samp));
   ScoreArgs s;
   fill_score(D, *params, Bt, workspace, w, s);
   s.loss3 = loss3; s.loss_acc = loss_acc;
+  if (can_fold_score(D, *params, w, st)) {
+    fold_finish(D, workspace, w, s, &samp);
+    return encode_forward(D, *params, Bt, workspace, w, st, &samp, &s);
+  }
+  TRY(encode_forward(D, *params, Bt, workspace, w, st, &samp));
   TRY(launch_score_fwd(s, st));
   TRY(launch_loss(s, st));
   return PS_OK;
