@@ -930,7 +930,289 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs 
   }
 }
 
+// ====================================================================== backward, wave-specialised form
+// Same roles as mlp_fwd_ws_kernel: waves 0-3 multiply, waves 4-7 stream the weight slabs and run the GELU' / dropout
+// epilogue of W2 chunk c (its pre-activations requested a step ahead) while the matrix waves multiply the next product.
+// Product order  W2c0, W2c1, W1c0, W2c2, W1c1, ..., W2c(n-1), W1c(n-2), W1c(n-1), Wo ;  the two LayerNorm backwards
+// (before the first product, before Wo) are shared by all 8 waves, 4 rows each.
+struct MlpBwdWsLds {
+  float Xs[MD * XLD];           // A operand of the W2 / Wo products: do2, then dout       (k-major)
+  float Hs[2][MD * XLD];        // A operand of the W1 product: d a1 chunk c in Hs[c & 1]  (k-major)
+  float Ws[2][MBK * WLB];       // weight slab ring
+  float Cs[2][MBM * YLD];       // accumulator tiles handed to the epilogues (row-major); [1] doubles as the LayerNorm
+                                // stages' column-sum scratch [3][8 waves][128]
+};
+static_assert(sizeof(MlpBwdWsLds) <= 160 * 1024, "wave-specialised MLP backward: LDS budget");
+static_assert(3 * 8 * MD <= MBM * YLD, "column-sum scratch must fit an accumulator tile");
+
+__global__ __launch_bounds__(WS_THREADS, 2) void mlp_bwd_ws_kernel(const MlpBwdArgs a) {
+  extern __shared__ float lds_raw[];
+  MlpBwdWsLds& L = *reinterpret_cast<MlpBwdWsLds*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const bool is_m = wave < 4;
+  const int htid = tid & 255, hw = wave & 3;
+  const int m0 = blockIdx.x * MBM, M = a.M;
+  const int mcol = wave * 32 + l31;
+  const int nchunk = a.F / 128;
+  const int NP = 2 * nchunk + 1, NS = SPP * NP;
+  float (*Csum)[8][MD] = reinterpret_cast<float (*)[8][MD]>(L.Cs[1]);
+  const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+
+  // product p: kind 0 = W2 chunk c (d h1), 1 = W1 chunk c (d ln1 +=), 2 = Wo (d ctx)
+  auto prod = [&](int p, int& kind, int& c) {
+    if (p == 2 * nchunk) { kind = 2; c = 0; }
+    else if (p < 2) { kind = 0; c = p; }
+    else if (p == 2 * nchunk - 1) { kind = 1; c = nchunk - 1; }
+    else if (p & 1) { kind = 0; c = (p + 1) >> 1; }
+    else { kind = 1; c = (p >> 1) - 1; }
+  };
+  auto slab_src = [&](int s, const float*& W, int& ldw, int& k0, int& n0) {
+    int kind, c;
+    prod(s / SPP, kind, c);
+    const int r = s % SPP;
+    if (kind == 0) { W = a.w2; ldw = a.F; k0 = MBK * r; n0 = 128 * c; }            // d h1[:, chunk] = do2 . W2[:, chunk]
+    else if (kind == 1) { W = a.w1; ldw = MD; k0 = 128 * c + MBK * r; n0 = 0; }    // d ln1 += d a1[:, chunk] . W1[chunk, :]
+    else { W = a.wo; ldw = MD; k0 = MBK * r; n0 = 0; }                              // d ctx = dout . Wo
+  };
+
+  float4 wr0[WRN], wr1[WRN];
+  if (!is_m) {
+    const float* W; int ldw, k0, n0;
+    slab_src(0, W, ldw, k0, n0);
+    slab_load_kn(W, ldw, k0, n0, wr0, htid);
+    slab_src(1, W, ldw, k0, n0);
+    slab_load_kn(W, ldw, k0, n0, wr1, htid);
+  }
+
+  // LayerNorm backward of rows 4*wave .. 4*wave+3 (columns lane, lane + 64), all 8 waves:
+  //   dy(q, d0, d1): grad wrt the LN output; x / stats / g: LN input rows, {mean, rstd}, gamma;  res: added to dx
+  // dx (+res) -> dxr (and out_dx); dropout(dx) -> Xs (k-major) and out_drop; column sums {dy*xhat, dy, dropped} -> Csum
+  auto ln_bwd_stage = [&](auto&& dy, const float* __restrict__ x, const float* __restrict__ stats,
+                          const float* __restrict__ g, const bool has_res, const float (&res)[4][2], const DropSpec& drop,
+                          const uint32_t dstep, float (&dxr)[4][2], float* out_dx, float* out_drop) {
+    const int rb = opaque(m0) + 4 * wave;
+    const float g0 = g[lane], g1 = g[lane + 64];
+    float ag[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f}, ac[2] = {0.f, 0.f};
+    Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (drop.thr) {
+      r0 = philox4x32_10((uint32_t)lane, (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+      r1 = philox4x32_10((uint32_t)lane + 64u, (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * wave + q, m = rb + q;
+      const bool ok = m < M;
+      const float mean = ok ? stats[2 * (size_t)m] : 0.f, rstd = ok ? stats[2 * (size_t)m + 1] : 0.f;
+      const float x0 = ok ? x[(size_t)m * MD + lane] : 0.f, x1 = ok ? x[(size_t)m * MD + lane + 64] : 0.f;
+      float dy0 = 0.f, dy1 = 0.f;
+      if (ok) dy(q, dy0, dy1);
+      const float xh0 = (x0 - mean) * rstd, xh1 = (x1 - mean) * rstd;
+      const float dh0 = dy0 * g0, dh1 = dy1 * g1;
+      const float s1 = wave_sum(dh0 + dh1) * (1.f / MD);
+      const float s2 = wave_sum(dh0 * xh0 + dh1 * xh1) * (1.f / MD);
+      float d0 = rstd * (dh0 - s1 - xh0 * s2), d1 = rstd * (dh1 - s1 - xh1 * s2);
+      if (has_res) { d0 += res[q][0]; d1 += res[q][1]; }
+      dxr[q][0] = d0; dxr[q][1] = d1;
+      float v0 = d0, v1 = d1;
+      if (drop.thr) {
+        v0 *= drop_word(drop, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+        v1 *= drop_word(drop, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+      }
+      L.Xs[lane * XLD + row] = v0; L.Xs[(lane + 64) * XLD + row] = v1;
+      if (ok) {
+        if (out_dx) { out_dx[(size_t)m * MD + lane] = d0; out_dx[(size_t)m * MD + lane + 64] = d1; }
+        if (out_drop) { out_drop[(size_t)m * MD + lane] = v0; out_drop[(size_t)m * MD + lane + 64] = v1; }
+      }
+      ag[0] += dy0 * xh0; ag[1] += dy1 * xh1;
+      ab[0] += dy0; ab[1] += dy1;
+      ac[0] += v0; ac[1] += v1;
+    }
+    Csum[0][wave][lane] = ag[0]; Csum[0][wave][lane + 64] = ag[1];
+    Csum[1][wave][lane] = ab[0]; Csum[1][wave][lane + 64] = ab[1];
+    Csum[2][wave][lane] = ac[0]; Csum[2][wave][lane + 64] = ac[1];
+  };
+  // after a barrier: park the workgroup's three column sums  part[blk][3][128]  (fixed order over the 8 waves)
+  auto park = [&](float* part) {
+    for (int t = tid; t < 3 * MD; t += WS_THREADS) {
+      const int which = t >> 7, colx = t & 127;
+      part[((size_t)blockIdx.x * 3 + which) * MD + colx] =
+          ((Csum[which][0][colx] + Csum[which][1][colx]) + (Csum[which][2][colx] + Csum[which][3][colx])) +
+          ((Csum[which][4][colx] + Csum[which][5][colx]) + (Csum[which][6][colx] + Csum[which][7][colx]));
+    }
+  };
+
+  // ---- final LayerNorm backward (transformer.py:86) -> d y2 (kept: residual of the FF LayerNorm), do2 -> Xs
+  float dy2r[4][2];
+  {
+    const float zero[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if (a.item_scores) {
+      // d enc straight from the score (MlpBwdArgs::item_scores): d enc[m] = loss'(score[m]) * product_emb[idx(b, j)]
+      const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+      const float wpos = a.pos_weight ? (float)a.K : 1.f;
+      const int K1 = a.K + 1;
+      auto dyv = [&](int q, float& d0, float& d1) {
+        const int m = m0 + 4 * wave + q;
+        const int b = m / K1, j = m - b * K1;
+        int64_t idx = j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1];
+        idx = idx < 0 ? a.P : (idx > a.P ? a.P : idx);
+        const float sc = a.item_scores[m];
+        const float ds = (j == 0 ? wpos * (sigmoid_f(sc) - 1.f) : sigmoid_f(sc)) * invB;
+        const float* row = a.product_emb + (size_t)idx * MD;
+        d0 = ds * row[lane]; d1 = ds * row[lane + 64];
+      };
+      ln_bwd_stage(dyv, a.y2, a.stf, a.gf, false, zero, a.drop_ff2, step_ff2, dy2r, nullptr, a.do2);
+    } else {
+      const float* de = a.denc;
+      auto dyv = [&](int q, float& d0, float& d1) {
+        const float* pq = de + (size_t)(m0 + 4 * wave + q) * MD;
+        d0 = pq[lane]; d1 = pq[lane + 64];
+      };
+      ln_bwd_stage(dyv, a.y2, a.stf, a.gf, false, zero, a.drop_ff2, step_ff2, dy2r, nullptr, a.do2);
+    }
+  }
+  if (!is_m) {
+    slab_store_kn(L.Ws[0], wr0, htid);
+    const float* W; int ldw, k0, n0;
+    slab_src(2 < NS ? 2 : NS - 1, W, ldw, k0, n0);
+    slab_load_kn(W, ldw, k0, n0, wr0, htid);
+  }
+  __syncthreads();
+  park(a.part_f);
+  __syncthreads();                                    // Csum (= Cs[1]) is free again before W2 chunk 1 is dumped into it
+
+  f32x16 acc, acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
+  auto dump = [&](float* Cst, f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Cst[((r & 3) + 8 * (r >> 2) + 4 * h) * YLD + mcol] = v[r];
+      v[r] = 0.f;
+    }
+  };
+  // FF LayerNorm backward, all 8 waves: d ln1 tile in Cs[0] -> dy1 (+ d y2 residual), dout = dropout(dy1) -> Xs
+  auto ff_ln_stage = [&]() {
+    const float* Y = L.Cs[0];
+    float dy1r[4][2];
+    auto dyv = [&](int q, float& d0, float& d1) { d0 = Y[(4 * wave + q) * YLD + lane]; d1 = Y[(4 * wave + q) * YLD + lane + 64]; };
+    const bool same = a.dout == a.dy1;
+    ln_bwd_stage(dyv, a.y1, a.st1, a.g1, true, dy2r, a.drop_ctx, step_ctx, dy1r, a.dy1, same ? nullptr : a.dout);
+    __syncthreads();
+    park(a.part_1);
+  };
+
+  if (is_m) {
+    for (int s = 0; s < NS; ++s) {
+      int kind, c;
+      prod(s / SPP, kind, c);
+      const int r = s % SPP;
+      const float* A = kind == 1 ? L.Hs[c & 1] : L.Xs;
+      const float* Wb = L.Ws[s & 1];
+#pragma unroll
+      for (int half = 0; half < MBK / 32; ++half) {
+        const float* ab = A + (MBK * r + 32 * half + h) * XLD + l31;
+        const float* bb = Wb + (32 * half + h) * WLB + mcol;
+        float av[16], bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { av[i] = ab[2 * i * XLD]; bv[i] = bb[2 * i * WLB]; }
+        if (kind == 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc_o, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        }
+      }
+      if (r == SPP - 1) {
+        if (kind == 0) dump(L.Cs[c & 1], acc);
+        else if (kind == 1 && c == nchunk - 1) {
+          dump(L.Cs[0], acc_o);
+          __syncthreads();                            // d ln1 in Cs[0]; every d a1 chunk has been consumed
+          ff_ln_stage();
+        } else if (kind == 2) {
+          const int mm0 = opaque(m0);
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) {
+            const int m = mm0 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+            if (m < M) a.dctx[(size_t)m * MD + mcol] = acc[rr];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  float csb[2] = {0.f, 0.f};                          // b1 column sums of this wave's 8 rows (two half steps)
+  auto helper_step = [&](const int s, float4 (&wnext)[WRN]) __attribute__((always_inline)) {
+    int kind, c;
+    prod(s / SPP, kind, c);
+    const int r = s % SPP;
+    // epilogue of the W2 chunk whose product ended just before this one: rows 8*hw + 4*r .. +3, columns 2*lane, 2*lane+1
+    int pk = -1, pc = 0;
+    if (s >= SPP) prod(s / SPP - 1, pk, pc);
+    const bool epi = pk == 0;
+    const int f0 = 128 * pc + 2 * lane;
+    const int rl0 = 8 * hw + 4 * r, rb = opaque(m0) + rl0;
+    // its pre-activations are requested FIRST (see mlp_fwd_ws_kernel)
+    float2 a1v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a1v[q] = make_float2(0.f, 0.f);
+      if (epi && rb + q < M) a1v[q] = *reinterpret_cast<const float2*>(a.a1 + (size_t)(rb + q) * a.F + f0);
+    }
+    if (s + 1 < NS) slab_store_kn(L.Ws[(s + 1) & 1], wnext, htid);
+    {
+      const float* W; int ldw, k0, n0;
+      slab_src(s + 3 < NS ? s + 3 : NS - 1, W, ldw, k0, n0);
+      slab_load_kn(W, ldw, k0, n0, wnext, htid);
+    }
+    if (epi) {
+      // d a1 = (do2 . W2) * gelu'(a1) * dropout  (neural.py:30-33 backwards) -> Hs (k-major) + global; b1 column sums
+      const float* Cst = L.Cs[pc & 1];
+      float* Hk = L.Hs[pc & 1];
+      Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+      if (a.drop_ff1.thr) {
+        r0 = philox4x32_10((uint32_t)f0, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+        r1 = philox4x32_10((uint32_t)f0 + 1u, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+      }
+      if (r == 0) { csb[0] = 0.f; csb[1] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rl = rl0 + q, m = rb + q;
+        float v0 = Cst[rl * YLD + 2 * lane] * gelu_tanh_grad(a1v[q].x);
+        float v1 = Cst[rl * YLD + 2 * lane + 1] * gelu_tanh_grad(a1v[q].y);
+        if (a.drop_ff1.thr) {
+          v0 *= drop_word(a.drop_ff1, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+          v1 *= drop_word(a.drop_ff1, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+        }
+        Hk[(2 * lane) * XLD + rl] = v0; Hk[(2 * lane + 1) * XLD + rl] = v1;
+        if (m < M) *reinterpret_cast<float2*>(a.da1 + (size_t)m * a.F + f0) = make_float2(v0, v1);
+        csb[0] += v0; csb[1] += v1;
+      }
+      // one parked row per (workgroup, helper wave): part_b1[(4*wg + hw)][slot 0][F]
+      if (r == SPP - 1)
+        *reinterpret_cast<float2*>(a.part_b1 + ((size_t)(blockIdx.x * 4 + hw) * 3) * a.F + f0) = make_float2(csb[0], csb[1]);
+    }
+    if (r == SPP - 1 && kind == 1 && c == nchunk - 1) {
+      __syncthreads();
+      ff_ln_stage();
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < NS; s += 2) {
+    helper_step(s, wr1);
+    if (s + 1 < NS) helper_step(s + 1, wr0);
+  }
+}
+
+bool mlp_bwd_ws_enabled() {
+  static const bool on = !(getenv("PS_MLP_BWD_WS") && atoi(getenv("PS_MLP_BWD_WS")) == 0) && mlp_ws_enabled();
+  return on;
+}
 int mlp_bwd_fused_blocks(int M) { return ps_cdiv(M, MBM); }
+// parked rows of the b1 column sums: one per workgroup, or one per (workgroup, helper wave) in the wave-specialised form
+int mlp_bwd_b1_rows(int M, int F) { return (mlp_bwd_ws_enabled() && F >= 256 ? 4 : 1) * ps_cdiv(M, MBM); }
 
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.F % 128 == 0 && a.M > 0, "fused mlp backward: F=%d M=%d", a.F, a.M);
@@ -943,6 +1225,17 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
     attr_set = true;
   }
   KTimeScope kt("mlp_bwd", st);
+  if (mlp_bwd_ws_enabled() && a.F >= 256) {
+    static bool ws_attr = false;
+    if (!ws_attr) {
+      PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_ws_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdWsLds)));
+      ws_attr = true;
+    }
+    hipLaunchKernelGGL(mlp_bwd_ws_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpBwdWsLds), st, a);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -222,7 +222,8 @@ struct MlpBwdArgs {
   float* dctx;                                         // [M,128]
   float* part_f;                                       // [workgroups][3][128] {dgamma_f, dbeta_f, colsum -> b2}
   float* part_1;                                       // [workgroups][3][128] {dgamma_1, dbeta_1, colsum -> bo}
-  float* part_b1;                                      // [workgroups][3][F] slot 0: colsum -> b1
+  float* part_b1;                                      // [mlp_bwd_b1_rows()][3][F] slot 0: colsum -> b1
 };
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);
 int mlp_bwd_fused_blocks(int M);
+int mlp_bwd_b1_rows(int M, int F);   // rows of MlpBwdArgs::part_b1 the kernel parks (ColFold::nblk)

@@ -178,7 +178,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.dqmean = take(cur, (int64_t)B * d);
   w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
   w.stage = take(cur, 4 + 2 * ((int64_t)B * (D.Q + D.L + 1 + D.W + D.K + D.W * D.K) + 8));   // int64 = 2 floats
-  w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 63) / 64 + 1) * 3 * (tem && NL > 0 ? D.F : 0));
+  w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 31) / 32 + 1) * 3 * (tem && NL > 0 ? D.F : 0));   // >= mlp_bwd_b1_rows()
   w.abpart = take(cur, (int64_t)NL * (NL > 0 ? w.layer[NL - 1].n_in : 0) * 3 * d);
   w.vrows = tem ? take(cur, (int64_t)B * S + 4) : 0;
   w.vcount = tem ? take(cur, 4) : 0;
@@ -815,7 +815,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         ++fold->n;
         ColFold& c2 = fold->e[fold->n];
         m.part_b1 = ws + w.gcpart;
-        c2.partial = m.part_b1; c2.nblk = nwg; c2.d = F;
+        c2.partial = m.part_b1; c2.nblk = mlp_bwd_b1_rows(M2, F); c2.d = F;
         c2.dst[0] = Lg.b1; c2.dst[1] = nullptr; c2.dst[2] = nullptr;
         ++fold->n;
       }
