@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32), = the fp32 vector peak
 P_ITEMS, V_WORDS = 18357, 32387
 B, K, L, Q, W, D = 384, 20, 20, 8, 1, 128
 FF = 512
@@ -94,15 +95,25 @@ class TemWorkload(object):
         return "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (B, D)
 
     def roofline_spec(self):
-        """Algorithmic bytes of ONE gather+score launch: every table row once (4d B) + its int64 index,
-        every distinct vector it is dotted with, every score written."""
+        """The step's dominant kernel.  With replicas at d = 128 (c2) that is the fused per-replica forward
+        (mlp_fwd_ws_kernel: Wo -> LN -> W1 -> GELU -> W2 -> LN for every one of the B*(K+1) replica rows, with the item
+        gather + score + loss in its epilogue): MFMA-bound, 2*d*d + 4*d*F flops per row.  Otherwise (c5: d = 256) the
+        stand-alone gather+score launch: HBM-bound, every table row once (4d B) + its int64 index, every distinct vector
+        it is dotted with, every score written."""
         R = next(iter(self.model._plans.values())).layout.R
         rows = B * (1 + K) * (1 + W)
         vecs = B * R + B                            # encoder outputs + target-item rows
-        nbytes = rows * (4 * D + 8) + vecs * 4 * D + rows * 4
-        return dict(tag='gather_score', bytes=nbytes,
+        gather_bytes = rows * (4 * D + 8) + vecs * 4 * D + rows * 4
+        if D == 128 and R > 1 and (B * R + 31) // 32 <= 256:
+            flops = B * R * (2 * D * D + 4 * D * FF)
+            return dict(tag='mlp_fwd', bound='mfma', work=flops, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', scale=1e12,
+                        kernel="mlp_fwd_ws_kernel (fused per-replica encoder tail, %d rows x (2*%d*%d + 4*%d*%d) flop, fp32 MFMA; "
+                               "item gather + score + loss folded into its epilogue: %d B of gathered rows and scores)"
+                               % (B * R, D, D, D, FF, B * (1 + K) * (4 * D + 8 + 4)),
+                        traffic_key=None, extra={"gather_score_bytes_all_tasks": gather_bytes})
+        return dict(tag='gather_score', bound='hbm', work=gather_bytes, peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
-                    traffic_key='R%d_bytes_per_launch' % R if self.a.workload == 'c2' else None)
+                    traffic_key=None, extra={})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_tem(self.ns, n_steps)
@@ -167,8 +178,8 @@ class RtmWorkload(object):
         else:
             nbytes = slots * (8 + 4 * d) + out_bytes
             note = "%d review rows + %d B of x" % (slots, out_bytes)
-        return dict(tag='rtm_embed', bytes=int(nbytes), kernel="rtm_embed_kernel (review-vector gather + mean-pool; %s)" % note,
-                    traffic_key=None)
+        return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
+                    kernel="rtm_embed_kernel (review-vector gather + mean-pool; %s)" % note, traffic_key=None, extra={})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_rtm(self, n_steps)
@@ -361,13 +372,14 @@ def main():
             except Exception:
                 pass
         t_k = avg.value * 1e-6
-        out["roofline"] = {"bound": "hbm", "achieved": spec['bytes'] / t_k / 1e9 if t_k > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": spec['bytes'] / t_k / 1e9 / HBM_PEAK_GBS if t_k > 0 else 0.0,
-                           "traffic": traffic, "traffic_source": traffic_src, "kernel": spec['kernel'],
-                           "bytes_per_launch": spec['bytes'], "us_per_launch": avg.value, "us_per_launch_min": mn.value,
-                           "launches_timed": cnt.value,
-                           "timing": "HIP event pair around every in-step launch, on the launch stream, over a second pass "
-                                     "of %d steps (ps_ktimer)" % a.steps}
+        ach = spec['work'] / t_k / spec['scale'] if t_k > 0 else 0.0
+        out["roofline"] = dict({"bound": spec['bound'], "achieved": ach, "peak": spec['peak'], "unit": spec['unit'],
+                                "frac": ach / spec['peak'], "traffic": traffic, "traffic_source": traffic_src,
+                                "kernel": spec['kernel'],
+                                ("flops_per_launch" if spec['bound'] == 'mfma' else "bytes_per_launch"): spec['work'],
+                                "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
+                                "timing": "HIP event pair around every in-step launch, on the launch stream, over a second "
+                                          "pass of %d steps (ps_ktimer)" % a.steps}, **spec['extra'])
         if world == 1 and a.cpu_steps > 0 and a.workload in ('c2', 'c4'):
             out["cpu_baseline"] = wl.cpu_baseline(a.cpu_steps)
     if world > 1:

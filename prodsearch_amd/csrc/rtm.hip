@@ -348,6 +348,199 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
       *reinterpret_cast<float4*>(a.vec + (size_t)revrow * d + 4 * cc) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ------------------------------------------------------------------ embed forward, pvc encoder: four reviews per wave
+// The per-slot kernel above spends most of its time in Philox: a wave (one review) evaluates the token masks of its word
+// slots and the dropout words of its output columns, and every evaluation yields four words of which it uses ONE — the
+// other three belong to the three neighbouring review rows (counter (col, row >> 2), word row & 3).  Here a wave owns
+// the four review rows  4g .. 4g+3  of one side (positive: row b*R + r; negative: row (b*K + k)*R + r), so each
+// evaluation serves four reviews (6x fewer Philox instructions), and the gather runs in four 16-lane groups, one review
+// each (rows of d <= 256 floats in 16-byte chunks, c and c + 16, ...), four word rows in flight per group:
+//   1. lane l reads word slots l and l + 64 of the four reviews (coalesced) and evaluates their token masks;
+//   2. the surviving (word id, multiplier) pairs are compacted into one LDS list per review (ballot + prefix popcount);
+//   3. group q walks list q, accumulating the corrupted (and, positive under train_pv, the uncorrupted) sum;
+//   4. mean, dropout (the wave's 128 dropout evaluations shared through LDS), segment / user / item rows, key mask,
+//      positional row -> x.   Query positions (s = 0) and the per-sequence counts ride as extra waves of the launch.
+#define E4_LIST 128
+struct E4Lds {
+  int wid[4][4][E4_LIST];          // [wave][review][entry]
+  float tm[4][4][E4_LIST];
+  uint32_t dw[4][256][4];          // [wave][column][review]: dropout words of the output row
+};
+template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
+__global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK) {
+  __shared__ E4Lds L;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = blockIdx.x * 4 + wv;
+  const int d = a.d;
+  const int64_t rpad = a.RC - 1;
+  if (g >= npos_grp + nneg_grp) {
+    // ---- query position of sequence n (one wave): x[n][0], valid[n][0], the sequence's valid-position count
+    const int n = g - npos_grp - nneg_grp;
+    if (n >= a.B * a.J) return;
+    const int b = fdiv(n, a.fJ), j = n - b * a.J;
+    const bool pos = j == 0;
+    const size_t base = pos ? (size_t)b : (size_t)b * a.K + (j - 1);
+    const int64_t* rid = (pos ? a.pos_r : a.neg_r) + base * a.R;
+    bool okl = lane == 0;
+    if (lane > 0 && lane < a.S) okl = rid[lane - 1] != rpad;
+    const int cntv = __popcll(__ballot(okl));
+    if (lane == 0) { a.seqcnt[n] = cntv; a.valid[(size_t)n * a.S] = 1.f; }
+    const size_t spos = base * a.S;
+    const int seg = (int)(pos ? a.pos_seg : a.neg_seg)[spos];
+    int64_t uid = -1, iid = -1;
+    if (a.user_emb) { uid = (pos ? a.pos_u : a.neg_u)[spos]; if (uid < 0 || uid > a.U) uid = -1; }
+    if (a.item_emb) { iid = (pos ? a.pos_i : a.neg_i)[spos]; if (iid < 0 || iid > a.PI) iid = -1; }
+    for (int col = lane; col < d; col += 64) {
+      float val = a.query_emb[(size_t)b * d + col];
+      if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
+      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
+      if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
+      if (a.use_pos) val += a.pe[col];
+      a.x[(size_t)n * a.S * d + col] = val;
+    }
+    return;
+  }
+  const bool pos = g < npos_grp;
+  const int gg = pos ? g : g - npos_grp;            // = review row >> 2 on its side: the Philox row counter
+  const int nrev = pos ? a.B * a.R : a.B * a.K * a.R;
+  const bool need_unc = pos && a.train_pv;
+  const int64_t* wsrc = pos ? (a.train_pv ? a.pos_pvc : a.pos_words) : (a.train_pv ? a.neg_pvc : a.neg_words_rev);
+  const DropSpec& ts = pos ? a.t_pos : a.t_neg;
+  const DropSpec& ds = pos ? a.d_pos : a.d_neg;
+
+  // ---- 1. the four reviews: where they sit
+  int nq[4], sq[4], segq[4], nwq[4], nlq[4], rrq[4];
+  bool okq[4], liveq[4];
+  int64_t uidq[4], iidq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rr = 4 * gg + q;
+    liveq[q] = rr < nrev;
+    const int rrc = liveq[q] ? rr : 0;
+    rrq[q] = rrc;
+    const int base = fdiv(rrc, fR), r = rrc - base * a.R;
+    int b, n;
+    if (pos) { b = base; n = b * a.J; }
+    else { b = fdiv(base, fK); n = b * a.J + 1 + (base - b * a.K); }
+    nq[q] = n; sq[q] = r + 1;
+    const int64_t ridx = (pos ? a.pos_r : a.neg_r)[rrc];
+    okq[q] = liveq[q] && ridx != rpad;
+    const size_t spos = (size_t)base * a.S + r + 1;
+    segq[q] = (int)(pos ? a.pos_seg : a.neg_seg)[spos];
+    uidq[q] = -1; iidq[q] = -1;
+    if (a.user_emb) { uidq[q] = (pos ? a.pos_u : a.neg_u)[spos]; if (uidq[q] < 0 || uidq[q] > a.U) uidq[q] = -1; }
+    if (a.item_emb) { iidq[q] = (pos ? a.pos_i : a.neg_i)[spos]; if (iidq[q] < 0 || iidq[q] > a.PI) iidq[q] = -1; }
+    nwq[q] = 0; nlq[q] = 0;
+  }
+  // 73 % of the review slots of a C4 batch are padding: a group without a real review skips the Philox evaluations, the
+  // lists and the gather (wave-uniform branch) and only writes its masked rows
+  const bool any_ok = okq[0] || okq[1] || okq[2] || okq[3];
+  if (any_ok) {
+    // ---- the word slots and their token masks
+    Philox4 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
+    if (ts.thr) {
+      t0 = philox4x32_10((uint32_t)lane, (uint32_t)gg, ts.site, drop_step(ts), ts.k0, ts.k1);
+      if (a.WL > 64) t1 = philox4x32_10((uint32_t)lane + 64u, (uint32_t)gg, ts.site, drop_step(ts), ts.k0, ts.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // word slots lane and lane + 64 of review q
+      const int64_t* words = wsrc + (size_t)rrq[q] * a.WL;
+      const int64_t wa64 = (okq[q] && lane < a.WL) ? words[lane] : a.V - 1;
+      const int64_t wb64 = (okq[q] && lane + 64 < a.WL) ? words[lane + 64] : a.V - 1;
+      const bool va = wa64 != a.V - 1 && wa64 >= 0 && wa64 < a.V, vb = wb64 != a.V - 1 && wb64 >= 0 && wb64 < a.V;
+      const uint32_t w0 = q == 0 ? t0.x : (q == 1 ? t0.y : (q == 2 ? t0.z : t0.w));
+      const uint32_t w1 = q == 0 ? t1.x : (q == 1 ? t1.y : (q == 2 ? t1.z : t1.w));
+      const float tm0 = ts.thr ? drop_word(ts, w0) : 1.f, tm1 = ts.thr ? drop_word(ts, w1) : 1.f;
+      // ---- 2. compaction: entries of slots < 64 first, then slots >= 64 (ascending slot order, like the per-slot kernel)
+      const bool ka = va && (need_unc || tm0 != 0.f), kb = vb && (need_unc || tm1 != 0.f);
+      const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      nwq[q] = __popcll(__ballot(va)) + __popcll(__ballot(vb));
+      nlq[q] = __popcll(ma) + __popcll(mb);
+      if (ka) { const int p = __popcll(ma & lt); L.wid[wv][q][p] = (int)wa64; L.tm[wv][q][p] = tm0; }
+      if (kb) { const int p = __popcll(ma) + __popcll(mb & lt); L.wid[wv][q][p] = (int)wb64; L.tm[wv][q][p] = tm1; }
+    }
+  }
+  // dropout words of the output row: lane evaluates columns lane, lane + 64, ... for the four reviews at once
+  if (ds.thr && any_ok)
+    for (int col = lane; col < d; col += 64) {
+      const Philox4 r = philox4x32_10((uint32_t)col, (uint32_t)gg, ds.site, drop_step(ds), ds.k0, ds.k1);
+      L.dw[wv][col][0] = r.x; L.dw[wv][col][1] = r.y; L.dw[wv][col][2] = r.z; L.dw[wv][col][3] = r.w;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the lists are read back by other lanes of this wave only
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- 3. gather: group q = lane >> 4 walks list q
+  const int q = lane >> 4, c = lane & 15;
+  const int myn = q == 0 ? nlq[0] : (q == 1 ? nlq[1] : (q == 2 ? nlq[2] : nlq[3]));
+  const int maxn = max(max(nlq[0], nlq[1]), max(nlq[2], nlq[3]));
+  float4 v[NCHL], vc[NCHL];
+#pragma unroll
+  for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
+  const int* wl = L.wid[wv][q];
+  const float* tl = L.tm[wv][q];
+  for (int i0 = 0; i0 < maxn; i0 += 4) {
+    float4 rowv[4][NCHL]; float mt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool on = i0 + u < myn;
+      const int wi = on ? wl[i0 + u] : 0;
+      mt[u] = on ? tl[i0 + u] : 0.f;
+      const float* row = a.word_emb + (size_t)wi * d + 4 * c;
+#pragma unroll
+      for (int k = 0; k < NCHL; ++k)
+        rowv[u][k] = on ? *reinterpret_cast<const float4*>(row + 64 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < NCHL; ++k) {
+        v[k].x += rowv[u][k].x; v[k].y += rowv[u][k].y; v[k].z += rowv[u][k].z; v[k].w += rowv[u][k].w;
+        vc[k].x += rowv[u][k].x * mt[u]; vc[k].y += rowv[u][k].y * mt[u];
+        vc[k].z += rowv[u][k].z * mt[u]; vc[k].w += rowv[u][k].w * mt[u];
+      }
+  }
+
+  // ---- 4. this group's review: mean, dropout, segment / user / item rows, mask, positional row
+  const bool live = q == 0 ? liveq[0] : (q == 1 ? liveq[1] : (q == 2 ? liveq[2] : liveq[3]));
+  if (!live) return;
+  const bool ok = q == 0 ? okq[0] : (q == 1 ? okq[1] : (q == 2 ? okq[2] : okq[3]));
+  const int n = q == 0 ? nq[0] : (q == 1 ? nq[1] : (q == 2 ? nq[2] : nq[3]));
+  const int s = q == 0 ? sq[0] : (q == 1 ? sq[1] : (q == 2 ? sq[2] : sq[3]));
+  const int seg = q == 0 ? segq[0] : (q == 1 ? segq[1] : (q == 2 ? segq[2] : segq[3]));
+  const int nw = q == 0 ? nwq[0] : (q == 1 ? nwq[1] : (q == 2 ? nwq[2] : nwq[3]));
+  const int64_t uid = q == 0 ? uidq[0] : (q == 1 ? uidq[1] : (q == 2 ? uidq[2] : uidq[3]));
+  const int64_t iid = q == 0 ? iidq[0] : (q == 1 ? iidq[1] : (q == 2 ? iidq[2] : iidq[3]));
+  const int rr = 4 * gg + q;
+  const float cntf = (float)(nw > 0 ? nw : 1), inv = 1.f / cntf;
+  if (c == 0) { a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f; a.cnt[(size_t)n * a.R + s - 1] = cntf; }
+#pragma unroll
+  for (int k = 0; k < NCHL; ++k) {
+    const int col0 = 4 * c + 64 * k;
+    const float unc[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
+    const float cor[4] = {vc[k].x * inv, vc[k].y * inv, vc[k].z * inv, vc[k].w * inv};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = col0 + e;
+      float val = need_unc ? unc[e] : cor[e];        // the sequence gets the UNcorrupted mean under train_pv (PVC.py:76,95)
+      if (ds.thr && ok) val *= drop_word(ds, L.dw[wv][col][q]);                   // dropout_layer (ps_model.py:303-304)
+      if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
+      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
+      if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
+      val = ok ? val : 0.f;
+      if (a.use_pos) val += a.pe[(size_t)s * d + col];
+      o[e] = val;
+    }
+    *reinterpret_cast<float4*>(a.x + ((size_t)n * a.S + s) * d + col0) = make_float4(o[0], o[1], o[2], o[3]);
+    if (need_unc)                                   // the PV loss predicts from the corrupted mean (PVC.py:78)
+      *reinterpret_cast<float4*>(a.vec + (size_t)rr * d + col0) =
+          ok ? make_float4(cor[0], cor[1], cor[2], cor[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------ scores
 // also writes the loss weight of the sequence (ps_model.py:344-345): pos_weight for the positive, and for a
 // negative 1 iff it has at least one real review
@@ -857,7 +1050,17 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   const int nslots = r.Bseq * r.S;
   {
     KTimeScope kt("rtm_embed", st);
-    hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+    static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
+    if (e4_on && k.pvc && !eval && D.WL <= 128 && (d == 64 || d == 128 || d == 256) && r.S <= 64) {
+      const int npos = ps_cdiv((int64_t)B * D.R, 4), nneg = ps_cdiv((int64_t)B * D.K * D.R, 4);
+      const dim3 grid(ps_cdiv(npos + nneg + r.Bseq, 4));
+      const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
+      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
+      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
+      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
+    } else {
+      hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+    }
   }
   PS_LAUNCH_CHECK();
   const bool listed = rtm_rows_listed(r, w);
