@@ -289,7 +289,9 @@ int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTa
 /* ------------------------------------------------------------------ RTM (review_transformer)
  * ProductRanker (models/ps_model.py:53-370) with the pv (models/PV.py) / pvc (models/PVC.py) review
  * encoders.  Sequences are [query, R reviews]; K negatives per row (training) or C candidates (eval). */
-enum { PS_RENC_PV = 0, PS_RENC_PVC = 1 };
+enum { PS_RENC_PV = 0, PS_RENC_PVC = 1,
+       PS_RENC_FS = 2,    /* review vector = tanh(f_W . dropout(masked mean of its words) + b)  (ps_model.py:148-149, 301-305;   */
+       PS_RENC_AVG = 3 }; /*                 dropout(masked mean)                                text_encoder.py:19-40, 62-83)  */
 
 typedef struct PsRtmDesc {
   int32_t B, K;          /* batch rows, --neg_per_pos                                             */
@@ -301,7 +303,7 @@ typedef struct PsRtmDesc {
   int32_t d, H, F, n_layers;
   int64_t vocab_size;    /* V, pad = V-1                                                          */
   int64_t review_count;  /* pad review = review_count-1 (ps_model.py:70)                          */
-  int32_t review_encoder;/* PS_RENC_PV / PS_RENC_PVC (--review_encoder_name)                      */
+  int32_t review_encoder;/* PS_RENC_PV / PVC / FS / AVG (--review_encoder_name)                   */
   int32_t query_encoder; /* PS_QENC_FS / PS_QENC_AVG                                              */
   int32_t use_pos_emb, use_seg_emb, pos_weight;
   int32_t train_pv;      /* forward(batch, train_pv): add the PV word-prediction loss (ps_model.py:265-280) */
@@ -325,6 +327,7 @@ typedef struct PsRtmTensors {
   float *wo_w, *wo_b;    /* transformer_encoder.wo [1,d],[1] (transformer.py:69,96)                */
   float *user_emb;       /* user_emb.weight [user_size+1,d]       (use_user_emb) or NULL           */
   float *product_emb;    /* product_emb.weight [product_size+1,d] (use_item_emb) or NULL           */
+  float *rev_fs_w, *rev_fs_b; /* review_encoder.f_W [d,d],[d] (fs review encoder) or NULL          */
   PsLayerTensors layer[PS_MAX_LAYERS];
 } PsRtmTensors;
 
@@ -350,6 +353,7 @@ typedef struct PsRtmBatch {
   const int64_t *neg_item_idxs;           /* [B,K,R+1]                               */
   const int64_t *candi_seq_user_idxs;     /* [B,C,R+1] eval                          */
   const int64_t *candi_seq_item_idxs;     /* [B,C,R+1] eval                          */
+  const uint8_t *neg_prod_rword_masks;    /* [B,K,R,WL] uint8: fs / avg review encoders (with pos_prod_rword_masks [B,R,WL]) */
 } PsRtmBatch;
 
 int ps_rtm_workspace_floats(const PsRtmDesc* desc, int32_t eval, int64_t* total);
@@ -379,9 +383,11 @@ int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsR
 /* scores = model.test(batch) [B,C] -- ProductRanker.test (ps_model.py:205-239) */
 int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* workspace,
                  float* scores, ps_stream_t stream);
-/* model.get_review_embeddings() for the pvc encoder (ps_model.py:186-203): uncorrupted mean per review, last row 0 */
+/* model.get_review_embeddings() for the pvc / fs / avg encoders (ps_model.py:186-203): per review the (uncorrupted,
+ * undropped) mean of its non-pad words — fs: projected, tanh(f_W . mean + b) — last row 0.
+ * scratch: [review_count, d] floats, fs only (else NULL). */
 int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensors* params, const int64_t* review_words,
-                             float* out, ps_stream_t stream);
+                             float* scratch, float* out, ps_stream_t stream);
 
 /* Host evaluation of the dropout stream (tests pin oracle/philox.py to it): multiplier
  * (0 or 1/(1-p)) of element (row, col) of dropout site `site` at desc->seed/step/dropout. */

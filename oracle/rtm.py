@@ -1,8 +1,8 @@
 """Oracle (TEST INFRASTRUCTURE): CPU restatement of the RTM training/eval step.
 
 Plain PyTorch fp32 CPU ops restating kepingbi/ProdSearch's ``ProductRanker``
-(models/ps_model.py:53-370) with the ``pv`` (models/PV.py) and ``pvc``
-(models/PVC.py) review encoders; parameters are a dict keyed by the reference's
+(models/ps_model.py:53-370) with the ``pv`` (models/PV.py), ``pvc``
+(models/PVC.py), ``fs`` and ``avg`` (models/text_encoder.py) review encoders; parameters are a dict keyed by the reference's
 ``state_dict`` names.  Pinned by tests/golden/rtm_*.npz (outputs of the reference
 itself); see oracle/__init__.py for who may import this.
 
@@ -92,13 +92,33 @@ def rtm_forward(P, args, batch, neg_word_idxs, vocab_size, review_count, trainin
             pos_rev = pvc_para_vector(P, pidx, word_pad, tm(tuple(pidx.shape), 'pos'))
             neg_idx = batch.neg_prod_rword_idxs.view(B * K * R, -1)
         neg_rev = pvc_para_vector(P, neg_idx, word_pad, tm(tuple(neg_idx.shape), 'neg')).view(B, K, R, d)
+    elif enc_name in ('fs', 'avg'):
+        # FSEncoder / AVGEncoder over the review words with the BATCH's word masks (ps_model.py:301-305,
+        # text_encoder.py:32-40 / :76-83): masked mean -> dropout (-> tanh(f_W . + b)); no further dropout_layer, no PV loss
+        def enc(idx, mask, which):
+            n = idx.shape[0] * idx.shape[1] if idx.dim() == 3 else idx.shape[0]
+            idx2, m2 = idx.reshape(-1, idx.shape[-1]), mask.reshape(-1, mask.shape[-1]).bool()
+            out = []
+            for lo in range(0, idx2.shape[0], 4096):
+                out.append(vector_mean(P['word_embeddings.weight'][idx2[lo:lo + 4096]], m2[lo:lo + 4096]))
+            mean = drop(torch.cat(out, 0), which, 0)
+            if enc_name == 'fs':
+                mean = torch.tanh(F.linear(mean, P['review_encoder.f_W.weight'], P['review_encoder.f_W.bias']))
+            return mean
+        pos_rev = enc(batch.pos_prod_rword_idxs, batch.pos_prod_rword_masks, 'rev_pos').view(B * R, d)
+        neg_rev = enc(batch.neg_prod_rword_idxs.view(B * K * R, -1), batch.neg_prod_rword_masks.view(B * K * R, -1),
+                      'rev_neg').view(B, K, R, d)
+        train_pv = False
     else:
         raise NotImplementedError(enc_name)
     if train_pv:
         sample_count = pos_r.ne(rev_pad).float().sum(-1)                             # :277
         pv_loss = per_rev.sum() / sample_count.sum()                                 # :280
-    pos_rev = drop(pos_rev, 'rev_pos', 0).view(B, R, d)                              # :303
-    neg_rev = drop(neg_rev.reshape(B, K, R, d), 'rev_neg', 0)                        # :304
+    if enc_name in ('pv', 'pvc'):
+        pos_rev = drop(pos_rev, 'rev_pos', 0)                                        # :303
+        neg_rev = drop(neg_rev.reshape(B, K, R, d), 'rev_neg', 0)                    # :304
+    pos_rev = pos_rev.view(B, R, d)
+    neg_rev = neg_rev.reshape(B, K, R, d)
 
     pos_mask = torch.cat([torch.ones(B, 1, dtype=torch.bool), pos_r.ne(rev_pad)], dim=1)        # :316
     neg_ridx_mask = neg_r.ne(rev_pad)
@@ -141,8 +161,16 @@ def rtm_review_embeddings(P, args, review_words, vocab_size):
     the pv table itself, or the UNcorrupted pvc mean of each review's words with the last row 0."""
     if args.review_encoder_name == 'pv':
         return P['review_encoder.review_embeddings.weight']
-    emb = pvc_para_vector(P, review_words[:-1], vocab_size - 1, None)
-    return torch.cat([emb, torch.zeros(1, emb.shape[1])], dim=0)
+    emb = pvc_para_vector(P, review_words[:-1], vocab_size - 1, None)       # masked mean of the non-pad words
+    last = torch.zeros(1, emb.shape[1])
+    if args.review_encoder_name == 'fs':                                     # :198-200: review_encoder(words, words != pad), eval mode
+        w, bias = P['review_encoder.f_W.weight'], P['review_encoder.f_W.bias']
+        emb = torch.tanh(F.linear(emb, w, bias))
+        # the reference walks review_words in slices of 128 up to row ceil((RC-1)/128)*128: unless RC-1 is a multiple of
+        # 128 that includes the padding review, whose (empty) mean goes through the projection too: tanh(bias), not 0
+        if (review_words.shape[0] - 1) % 128 != 0:
+            last = torch.tanh(bias).unsqueeze(0)
+    return torch.cat([emb, last], dim=0)
 
 
 def rtm_test(P, args, batch, review_embeddings, vocab_size, review_count):

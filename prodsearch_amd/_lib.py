@@ -79,12 +79,12 @@ class PsRtmDesc(C.Structure):
 
 
 RTM_TOP_FIELDS = ('word_emb', 'review_emb', 'seg_emb', 'fs_w', 'fs_b', 'pe', 'final_ln_g', 'final_ln_b',
-                  'wo_w', 'wo_b', 'user_emb', 'product_emb')
+                  'wo_w', 'wo_b', 'user_emb', 'product_emb', 'rev_fs_w', 'rev_fs_b')
 RTM_BATCH_FIELDS = ('query_word_idxs', 'pos_prod_ridxs', 'pos_seg_idxs', 'pos_prod_rword_idxs',
                     'pos_prod_rword_masks', 'neg_prod_ridxs', 'neg_seg_idxs', 'neg_prod_rword_idxs',
                     'pos_prod_rword_idxs_pvc', 'neg_prod_rword_idxs_pvc', 'neg_word_idxs',
                     'candi_prod_ridxs', 'candi_seg_idxs', 'review_embeddings', 'pos_user_idxs', 'neg_user_idxs',
-                    'pos_item_idxs', 'neg_item_idxs', 'candi_seq_user_idxs', 'candi_seq_item_idxs')
+                    'pos_item_idxs', 'neg_item_idxs', 'candi_seq_user_idxs', 'candi_seq_item_idxs', 'neg_prod_rword_masks')
 
 
 class PsRtmTensors(C.Structure):
@@ -101,7 +101,7 @@ class PsRtmWsLayout(C.Structure):
                                          'pv_scores', 'dx')]
 
 
-PS_RENC_PV, PS_RENC_PVC = 0, 1
+PS_RENC_PV, PS_RENC_PVC, PS_RENC_FS, PS_RENC_AVG = 0, 1, 2, 3
 
 # every symbol include/prodsearch_hip.h declares: (restype, argtypes)
 SYMBOLS = {
@@ -130,7 +130,7 @@ SYMBOLS = {
     'ps_rtm_score': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.POINTER(PsRtmBatch),
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_rtm_review_embeddings': (C.c_int, [C.POINTER(PsRtmDesc), C.POINTER(PsRtmTensors), C.c_void_p,
-                                           C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_sample_negatives': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     'ps_build_alias_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

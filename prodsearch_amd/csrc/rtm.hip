@@ -27,6 +27,7 @@ struct RtmWs {
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
   int64_t wcnt, woff, wcur, wl_slot, wl_word;   // pvc backward: inverted index word -> review slots (int32 arrays)
+  int64_t raw, yfs, dpre, dmean;                // fs review encoder: [Bseq*R, d] dropped means, projections, their gradients
   int64_t enc_base;         // the shared encoder workspace (Ws) starts here
   int64_t total;
 };
@@ -43,6 +44,12 @@ struct RtmK {              // kernel-side view of one call
   int64_t U, PI;                                  // their pad ids (user_size, product_size)
   const float *user_emb, *item_emb; float *g_user_emb, *g_item_emb;
   const uint8_t* pos_masks;
+  // fs / avg review encoders (ps_model.py:301-305): the word-mean path of pvc with the BATCH's word masks deciding which
+  // words count (text_encoder.py:6-16; pvc uses idx != pad, PVC.py:58) and no token corruption.  fs additionally
+  // projects the mean: tanh(f_W . dropout(mean) + b) (text_encoder.py:32-40) — the embed kernels then leave the
+  // dropped means in `raw` [B*R + B*K*R, d] (positive rows first), a GEMM writes `yfs`, rtm_fs_finish builds x.
+  const uint8_t *wmask_pos, *wmask_neg;
+  float *raw; const float* yfs; const float* dmean;   // dmean: backward, grad wrt raw (same layout)
   // tensors
   const float *word_emb, *table, *seg_emb, *pe, *wo_w, *wo_b;
   // workspace
@@ -65,8 +72,10 @@ static int rtm_check(const PsRtmDesc& D) {
   PS_REQUIRE(D.B > 0 && D.K >= 0 && D.R > 0 && D.Q > 0 && D.d > 0, "rtm desc: bad sizes");
   PS_REQUIRE(D.d % 32 == 0 && D.d <= 512 && D.d / 4 <= 64 * 2, "rtm desc: embedding_size %d", D.d);
   PS_REQUIRE(D.R + 1 <= 64, "rtm desc: %d reviews per sequence (S <= 64)", D.R);
-  PS_REQUIRE(D.review_encoder == PS_RENC_PV || D.review_encoder == PS_RENC_PVC, "rtm desc: review encoder %d", D.review_encoder);
-  PS_REQUIRE(D.review_encoder != PS_RENC_PVC || D.WL > 0, "rtm desc: pvc needs WL");
+  PS_REQUIRE(D.review_encoder >= PS_RENC_PV && D.review_encoder <= PS_RENC_AVG, "rtm desc: review encoder %d", D.review_encoder);
+  PS_REQUIRE(D.review_encoder == PS_RENC_PV || D.WL > 0, "rtm desc: word-mean review encoders need WL");
+  PS_REQUIRE(D.review_encoder == PS_RENC_PV || D.review_encoder == PS_RENC_PVC || !D.train_pv,
+             "rtm desc: the fs / avg review encoders have no PV loss (ps_model.py:264: train_pv only applies to pv / pvc)");
   PS_REQUIRE(D.dropout >= 0.f && D.dropout < 1.f && D.corrupt_rate >= 0.f && D.corrupt_rate < 1.f, "rtm desc: rates");
   return PS_OK;
 }
@@ -108,12 +117,17 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.dqmean = rtake(cur, (int64_t)D.B * d);
   r.dqe = rtake(cur, (int64_t)D.B * d);          // dqe and wcnt are adjacent: the backward zeroes both with ONE memset
   r.wcnt = r.woff = r.wcur = r.wl_slot = r.wl_word = 0;
-  if (!eval && D.review_encoder == PS_RENC_PVC) {
+  r.raw = r.yfs = r.dpre = r.dmean = 0;
+  if (!eval && D.review_encoder != PS_RENC_PV) {
     r.wcnt = rtake(cur, D.vocab_size);
     r.woff = rtake(cur, D.vocab_size + 1);
     r.wcur = rtake(cur, D.vocab_size);
     r.wl_slot = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
     r.wl_word = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
+  }
+  if (!eval && D.review_encoder == PS_RENC_FS) {     // (behind the index arrays: dqe .. wcnt must stay one contiguous memset)
+    const int64_t nr = (int64_t)r.Bseq * D.R * d;
+    r.raw = rtake(cur, nr); r.yfs = rtake(cur, nr); r.dpre = rtake(cur, nr); r.dmean = rtake(cur, nr);
   }
   r.enc_base = cur;
   TRY(make_ws(E, w));
@@ -143,6 +157,10 @@ extern "C" int ps_rtm_workspace_layout(const PsRtmDesc* desc, int32_t eval, PsRt
 }
 
 __device__ inline int64_t rclamp(int64_t i, int64_t hi) { return i < 0 ? hi : (i > hi ? hi : i); }
+// does word slot `off` (= review row * WL + slot) count in its review's mean?
+__device__ inline bool word_ok(const RtmK& a, const uint8_t* wm, size_t off, int64_t wi) {
+  return (wm ? wm[off] != 0 : wi != a.V - 1) && wi >= 0 && wi < a.V;
+}
 
 // ------------------------------------------------------------------ embed forward
 // one wave per (sequence, position); lanes: half = lane>>5 picks every other word row, c = lane&31 the float4
@@ -227,6 +245,8 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
         const int64_t* words;
         if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + r) * a.WL;
         else words = ((a.train_pv || a.eval) ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
+        const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
+        const size_t woff = (size_t)revrow * a.WL;
         const DropSpec& ts = pos ? a.t_pos : a.t_neg;
         // one Philox evaluation per (review, word slot): lane l owns slots l and l+64, the loop reads them by shuffle
         const float tm0 = drop_mult(ts, (uint32_t)revrow, (uint32_t)lane);
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
           // lane l holds word slots l and l+64 (two coalesced loads); the slots that survive the token mask are
           // compacted with ballots, so the row loop runs over ~10 % of the review at the reference's corrupt_rate
           const int64_t wa64 = lane < a.WL ? words[lane] : a.V - 1, wb64 = lane + 64 < a.WL ? words[lane + 64] : a.V - 1;
-          const bool va = wa64 != a.V - 1 && wa64 >= 0 && wa64 < a.V, vb = wb64 != a.V - 1 && wb64 >= 0 && wb64 < a.V;
+          const bool va = lane < a.WL && word_ok(a, wm, woff + lane, wa64), vb = lane + 64 < a.WL && word_ok(a, wm, woff + lane + 64, wb64);
           const int wa = va ? (int)wa64 : 0, wb = vb ? (int)wb64 : 0;
           unsigned long long ma = __ballot(va && (need_unc || tm0 != 0.f)), mb = __ballot(vb && (need_unc || tm1 != 0.f));
           // (the ballots are taken by the WHOLE wave, outside the half-wave select: inside it only lanes 0-31 would vote
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
             rowv[u] = make_float4(0.f, 0.f, 0.f, 0.f); mt[u] = 0.f;
             const float tmw = w < 64 ? __shfl(tm0, w & 63, 64) : (w < 128 ? __shfl(tm1, (w - 64) & 63, 64)
                                                                           : drop_mult(ts, (uint32_t)revrow, (uint32_t)w));
-            if (wi != a.V - 1 && wi >= 0 && wi < a.V) {
+            if (w < a.WL && word_ok(a, wm, woff + w, wi)) {
               if (act && (need_unc || tmw != 0.f))
                 rowv[u] = *reinterpret_cast<const float4*>(a.word_emb + (size_t)wi * d + 4 * cc);
               mt[u] = tmw;
@@ -327,6 +347,11 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
         }
         val *= drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);     // dropout_layer (ps_model.py:303-304)
         o[e] = val;
+      }
+      if (a.raw) {                                   // fs: the projection and the rest of x follow (rtm_fs_finish_kernel)
+        const size_t rg = pos ? (size_t)revrow : (size_t)a.B * a.R + revrow;
+        *reinterpret_cast<float4*>(a.raw + rg * d + 4 * cc) = ok ? make_float4(o[0], o[1], o[2], o[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
       }
     }
 #pragma unroll
@@ -446,9 +471,12 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     for (int q = 0; q < 4; ++q) {
       // word slots lane and lane + 64 of review q
       const int64_t* words = wsrc + (size_t)rrq[q] * a.WL;
+      const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
+      const size_t woff = (size_t)rrq[q] * a.WL;
       const int64_t wa64 = (okq[q] && lane < a.WL) ? words[lane] : a.V - 1;
       const int64_t wb64 = (okq[q] && lane + 64 < a.WL) ? words[lane + 64] : a.V - 1;
-      const bool va = wa64 != a.V - 1 && wa64 >= 0 && wa64 < a.V, vb = wb64 != a.V - 1 && wb64 >= 0 && wb64 < a.V;
+      const bool va = okq[q] && lane < a.WL && word_ok(a, wm, woff + lane, wa64);
+      const bool vb = okq[q] && lane + 64 < a.WL && word_ok(a, wm, woff + lane + 64, wb64);
       const uint32_t w0 = q == 0 ? t0.x : (q == 1 ? t0.y : (q == 2 ? t0.z : t0.w));
       const uint32_t w1 = q == 0 ? t1.x : (q == 1 ? t1.y : (q == 2 ? t1.z : t1.w));
       const float tm0 = ts.thr ? drop_word(ts, w0) : 1.f, tm1 = ts.thr ? drop_word(ts, w1) : 1.f;
@@ -527,12 +555,18 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       const int col = col0 + e;
       float val = need_unc ? unc[e] : cor[e];        // the sequence gets the UNcorrupted mean under train_pv (PVC.py:76,95)
       if (ds.thr && ok) val *= drop_word(ds, L.dw[wv][col][q]);                   // dropout_layer (ps_model.py:303-304)
+      if (a.raw) { o[e] = ok ? val : 0.f; continue; }                             // fs: rtm_fs_finish_kernel does the rest
       if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
       if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
       if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
       val = ok ? val : 0.f;
       if (a.use_pos) val += a.pe[(size_t)s * d + col];
       o[e] = val;
+    }
+    if (a.raw) {
+      const size_t rg = pos ? (size_t)rr : (size_t)a.B * a.R + rr;
+      *reinterpret_cast<float4*>(a.raw + rg * d + col0) = make_float4(o[0], o[1], o[2], o[3]);
+      continue;
     }
     *reinterpret_cast<float4*>(a.x + ((size_t)n * a.S + s) * d + col0) = make_float4(o[0], o[1], o[2], o[3]);
     if (need_unc)                                   // the PV loss predicts from the corrupted mean (PVC.py:78)
@@ -762,7 +796,9 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
     for (int k = 0; k < 16; ++k)
       if (k < epl) {
         const uint32_t col = (uint32_t)(c + 32 * k);
-        float t = gk[k] * drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);
+        // fs: the review vector reached x through tanh(f_W . raw + b); its input gradient d raw was left in a.dmean
+        const float gsrc = a.dmean ? a.dmean[((pos ? (size_t)revrow : (size_t)a.B * a.R + revrow)) * d + col] : gk[k];
+        float t = gsrc * drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);
         if (pos && a.train_pv) {
           t += a.dvec[(size_t)revrow * d + col];
           if (!a.pvc) t *= drop_mult(a.d_pv, (uint32_t)revrow, col);
@@ -790,11 +826,13 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
         for (int k = 0; k < 16; ++k)
           if (k < epl) gw[c + 32 * k] = gk[k] * inv;
       }
-      if (a.count_words)
+      if (a.count_words) {
+        const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
         for (int w = lane; w < a.WL; w += 64) {
           const int64_t wi = words[w];
-          if (wi != a.V - 1 && wi >= 0 && wi < a.V) atomicAdd(&a.wcnt[wi], 1);
+          if (word_ok(a, wm, (size_t)revrow * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
         }
+      }
     }
   }
   __syncthreads();
@@ -856,9 +894,10 @@ __global__ __launch_bounds__(256) void rtm_wcount_kernel(const RtmK a) {
     const int64_t* words;
     if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
     else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
+    const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
     for (int w = lane; w < a.WL; w += 64) {
       const int64_t wi = words[w];
-      if (wi != a.V - 1 && wi >= 0 && wi < a.V) atomicAdd(&a.wcnt[wi], 1);
+      if (word_ok(a, wm, (size_t)revrow * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
     }
   }
 }
@@ -880,7 +919,7 @@ __global__ __launch_bounds__(256) void rtm_wfill_kernel(const RtmK a) {
     else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
     for (int w = lane; w < a.WL; w += 64) {
       const int64_t wi = words[w];
-      if (wi == a.V - 1 || wi < 0 || wi >= a.V) continue;
+      if (!word_ok(a, pos ? a.wmask_pos : a.wmask_neg, (size_t)revrow * a.WL + w, wi)) continue;
       const int e = a.woff[wi] + atomicAdd(&a.wcur[wi], 1);
       a.wl_slot[e] = slot;
       a.wl_word[e] = (int)wi;
@@ -969,20 +1008,81 @@ __global__ __launch_bounds__(256) void rtm_review_table_kernel(const float* word
   }
 }
 
+// ------------------------------------------------------------------ fs review encoder (text_encoder.py:32-40)
+// forward tail: x[n][s] = (valid ? tanh-projection + segment / user / item rows : 0) + pe[s]; one wave per review slot
+__global__ __launch_bounds__(256) void rtm_fs_finish_kernel(const RtmK a) {
+  const int lane = threadIdx.x & 63;
+  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (slot >= a.B * a.J * a.S) return;
+  const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+  if (s == 0) return;                                   // query rows were written by the embed kernel
+  int b, j, revrow, seg; int64_t ridx; size_t spos;
+  seq_decode(a, n, s, b, j, ridx, revrow, seg, &spos);
+  const bool pos = j == 0, ok = ridx != a.RC - 1;
+  const size_t rg = pos ? (size_t)revrow : (size_t)a.B * a.R + revrow;
+  int64_t uid = -1, iid = -1;
+  if (a.user_emb) { uid = (pos ? a.pos_u : a.neg_u)[spos]; if (uid < 0 || uid > a.U) uid = -1; }
+  if (a.item_emb) { iid = (pos ? a.pos_i : a.neg_i)[spos]; if (iid < 0 || iid > a.PI) iid = -1; }
+  const int d = a.d;
+  for (int col = lane; col < d; col += 64) {
+    float val = 0.f;
+    if (ok) {
+      val = a.yfs[rg * d + col];
+      if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
+      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
+      if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
+    }
+    if (a.use_pos) val += a.pe[(size_t)s * d + col];
+    a.x[((size_t)n * a.S + s) * d + col] = val;
+  }
+}
+// backward head: d pre[row] = valid ? dx[n][s] * (1 - y^2) : 0 for every review slot; bias gradient = its column sums
+__global__ __launch_bounds__(256) void rtm_fs_bwd_kernel(const RtmK a, float* dpre, float* g_bias) {
+  extern __shared__ float bsum[];                  // [d]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int d = a.d;
+  for (int e = threadIdx.x; e < d; e += 256) bsum[e] = 0.f;
+  __syncthreads();
+  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
+  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
+    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+    if (s == 0) continue;
+    int b, j, revrow, seg; int64_t ridx;
+    seq_decode(a, n, s, b, j, ridx, revrow, seg);
+    const bool ok = ridx != a.RC - 1;
+    const size_t rg = j == 0 ? (size_t)revrow : (size_t)a.B * a.R + revrow;
+    for (int col = lane; col < d; col += 64) {
+      float v = 0.f;
+      if (ok) {
+        const float y = a.yfs[rg * d + col];
+        v = a.dx[((size_t)n * a.S + s) * d + col] * (1.f - y * y);
+        atomicAdd(&bsum[col], v);
+      }
+      dpre[rg * d + col] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < d; e += 256) atomicAdd(&g_bias[e], bsum[e]);
+}
+
 // ------------------------------------------------------------------ host side
 static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& Bt, float* ws, const RtmWs& r, const Ws& w,
                    bool eval, RtmK& k) {
   memset(&k, 0, sizeof(k));
   k.B = D.B; k.J = r.J; k.K = D.K; k.R = D.R; k.S = r.S; k.Q = D.Q; k.W = D.W > 0 ? D.W : 1; k.WL = D.WL; k.d = D.d;
   k.V = D.vocab_size; k.RC = D.review_count;
-  k.pvc = D.review_encoder == PS_RENC_PVC && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
+  // `pvc` = every word-mean review encoder in training (pvc, fs, avg); only pvc corrupts tokens and ignores the word masks
+  k.pvc = D.review_encoder != PS_RENC_PV && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
+  const bool masked_mean = !eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG);
+  if (masked_mean) { k.wmask_pos = Bt.pos_prod_rword_masks; k.wmask_neg = Bt.neg_prod_rword_masks; }
+  if (!eval && D.review_encoder == PS_RENC_FS) { k.raw = ws + r.raw; k.yfs = ws + r.yfs; }
   k.pos_weight = D.pos_weight; k.train_pv = eval ? 0 : D.train_pv; k.training = eval ? 0 : D.training; k.eval = eval;
   k.fJ = make_fdiv(r.J); k.fS = make_fdiv(r.S); k.fK1 = make_fdiv(D.K + 1);
   PsTemDesc dd;
   memset(&dd, 0, sizeof(dd));
   dd.training = k.training; dd.dropout = D.dropout; dd.seed = D.seed; dd.step = D.step;
   k.d_pv = make_drop(dd, SITE_REV_PV); k.d_pos = make_drop(dd, SITE_REV_POS); k.d_neg = make_drop(dd, SITE_REV_NEG);
-  dd.dropout = D.corrupt_rate;
+  dd.dropout = D.review_encoder == PS_RENC_PVC ? D.corrupt_rate : 0.f;
   k.t_pos = make_drop(dd, SITE_TOK_POS); k.t_neg = make_drop(dd, SITE_TOK_NEG);
   k.U = D.user_size; k.PI = D.product_size;
   if (D.use_user_emb) { k.user_emb = P.user_emb; k.pos_u = Bt.pos_user_idxs; k.neg_u = eval ? Bt.candi_seq_user_idxs : Bt.neg_user_idxs; }
@@ -1026,6 +1126,8 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   PS_REQUIRE(!D.use_user_emb || (k.user_emb && k.neg_u && (eval || k.pos_u)), "rtm: use_user_emb needs user_emb and the user index tensors");
   PS_REQUIRE(!D.use_item_emb || (k.item_emb && k.neg_i && (eval || k.pos_i)), "rtm: use_item_emb needs product_emb and the item index tensors");
   if (k.pvc) PS_REQUIRE(k.train_pv ? (k.pos_pvc && k.neg_pvc) : (k.pos_words && k.neg_words_rev), "rtm: null review word tensors");
+  if (!eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG))
+    PS_REQUIRE(k.wmask_pos && k.wmask_neg, "rtm: the fs / avg review encoders need the batch's word masks");
   if (k.train_pv) PS_REQUIRE(k.pos_words && k.pos_masks && k.neg_word_idxs, "rtm: null PV-loss tensors");
   // query encoder (shared kernels): masked mean (+FS dropout) then tanh(f_W . + b)
   PsTemDesc dq;
@@ -1063,6 +1165,14 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
     }
   }
   PS_LAUNCH_CHECK();
+  if (k.raw) {   // fs review encoder: y = tanh(f_W . raw + b) for every review slot, then the rest of x
+    PS_REQUIRE(P.rev_fs_w && P.rev_fs_b, "rtm: null review-encoder f_W");
+    GemmProblem p = gp(ws + r.raw, d, 0, P.rev_fs_w, d, 0, ws + r.yfs, d, r.Bseq * D.R, d, d);
+    p.bias = P.rev_fs_b; p.act = ACT_TANH;
+    TRY(run1(p, st));
+    hipLaunchKernelGGL(rtm_fs_finish_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+    PS_LAUNCH_CHECK();
+  }
   const bool listed = rtm_rows_listed(r, w);
   if (listed) {
     hipLaunchKernelGGL(rtm_rowlist_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k);
@@ -1110,11 +1220,30 @@ extern "C" int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, c
 }
 
 extern "C" int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensors* params, const int64_t* review_words,
-                                        float* out, ps_stream_t stream) {
+                                        float* scratch, float* out, ps_stream_t stream) {
   PS_REQUIRE(desc && params && review_words && out && params->word_emb && desc->WL > 0, "rtm review table: bad argument");
-  hipLaunchKernelGGL(rtm_review_table_kernel, dim3(ps_cdiv(desc->review_count, 4)), dim3(256), 0, (hipStream_t)stream,
-                     params->word_emb, review_words, out, desc->review_count, desc->WL, desc->d, desc->vocab_size);
+  const bool fs = desc->review_encoder == PS_RENC_FS;
+  PS_REQUIRE(!fs || (scratch && params->rev_fs_w && params->rev_fs_b), "rtm review table: fs needs scratch and f_W");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rtm_review_table_kernel, dim3(ps_cdiv(desc->review_count, 4)), dim3(256), 0, st,
+                     params->word_emb, review_words, fs ? scratch : out, desc->review_count, desc->WL, desc->d, desc->vocab_size);
   PS_LAUNCH_CHECK();
+  if (fs) {
+    const int d = desc->d;
+    // The reference fills the table in slices of 128 reviews up to row ceil((RC-1)/128)*128 (ps_model.py:190-203): unless
+    // RC-1 is a multiple of 128 that takes in the padding review, whose empty mean is projected like any other —
+    // its row is tanh(bias), not 0 (its positions are masked in every sequence, so only the table itself shows it)
+    const int64_t rc = desc->review_count;
+    const bool pad_projected = (rc - 1) % 128 != 0;
+    const int64_t n = pad_projected ? rc : rc - 1;
+    PS_REQUIRE(n < ((int64_t)1 << 31), "rtm review table: too many reviews");
+    if (n > 0) {
+      GemmProblem p = gp(scratch, d, 0, params->rev_fs_w, d, 0, out, d, (int)n, d, d);
+      p.bias = params->rev_fs_b; p.act = ACT_TANH;
+      TRY(run1(p, st));
+    }
+    if (!pad_projected) PS_CHECK_HIP(hipMemsetAsync(out + (size_t)n * d, 0, sizeof(float) * d, st));
+  }
   return PS_OK;
 }
 
@@ -1176,6 +1305,19 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     PS_LAUNCH_CHECK();
   }
   TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
+  if (D.review_encoder == PS_RENC_FS) {
+    // through the review projection: d pre = dx * tanh', bias gradient, weight gradient, d raw = d pre . f_W
+    PS_REQUIRE(G.rev_fs_w && G.rev_fs_b && params->rev_fs_w, "rtm backward: null review-encoder f_W gradient");
+    const int NR = r.Bseq * D.R;
+    k.dx = ws + r.enc_base + w.dx;
+    hipLaunchKernelGGL(rtm_fs_bwd_kernel, dim3(eb), dim3(256), (size_t)d * sizeof(float), st, k, ws + r.dpre, G.rev_fs_b);
+    PS_LAUNCH_CHECK();
+    GemmProblem wg[1] = {gp_wgrad(ws + r.dpre, d, ws + r.raw, d, G.rev_fs_w, d, d, NR)};
+    TRY(side_wgrads(wg, 1, st));
+    GemmProblem px = gp(ws + r.dpre, d, 0, params->rev_fs_w, d, 1, ws + r.dmean, d, NR, d, d);
+    TRY(run1(px, st));
+    k.dmean = ws + r.dmean;
+  }
   hipLaunchKernelGGL(rtm_embed_bwd_kernel, dim3(eb), dim3(256), (size_t)4 * d * sizeof(float), st, k);
   PS_LAUNCH_CHECK();
   if (k.pvc) {

@@ -10,10 +10,10 @@ Mirrors the reference's ``nn.Module`` contract (``models/ps_model.py:53-370``; c
     model.get_review_embeddings(); scores = model.test(batch); model.clear_review_embbeddings()
 
 Same ``state_dict`` keys as the reference (incl. the aliases ``review_encoder.word_embeddings.weight``
-and, for pvc, ``review_encoder.context_embeddings.weight``).  Supported review encoders: ``pv`` and
-``pvc`` (the reference default), with or without the per-position user / item embeddings
-(``use_user_emb`` / ``use_item_emb``); ``fs`` / ``avg`` review encoders and ``fix_emb`` are outside
-the built path and raise ``NotImplementedError``.  All numerics run in
+and, for pvc, ``review_encoder.context_embeddings.weight``).  Supported review encoders: ``pv``, ``pvc`` (the reference
+default), ``fs`` and ``avg`` (``ps_model.py:148-151``, ``:301-305``; ``models/text_encoder.py``), with or without the
+per-position user / item embeddings (``use_user_emb`` / ``use_item_emb``); ``fix_emb`` is outside the built path and
+raises ``NotImplementedError``.  All numerics run in
 ``libprodsearch_hip.so`` (``ps_rtm_*`` entry points); the torch modules are parameter holders.
 """
 import numpy as np
@@ -53,8 +53,8 @@ class ProductRanker(nn.Module):
     def __init__(self, args, device, vocab_size, review_count, product_size, user_size,
                  review_words, vocab_words, word_dists=None):
         super(ProductRanker, self).__init__()
-        if args.review_encoder_name not in ('pv', 'pvc'):
-            raise NotImplementedError("review_encoder_name %r: only pv / pvc are built" % args.review_encoder_name)
+        if args.review_encoder_name not in ('pv', 'pvc', 'fs', 'avg'):
+            raise NotImplementedError("review_encoder_name %r: pv / pvc / fs / avg are built" % args.review_encoder_name)
         if getattr(args, 'fix_emb', False):
             raise NotImplementedError("fix_emb is outside the built path")
         if getattr(args, 'pretrain_emb_dir', '') or getattr(args, 'pretrain_up_emb_dir', ''):
@@ -91,7 +91,12 @@ class ProductRanker(nn.Module):
             self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx)
         self.word_embeddings = nn.Embedding(vocab_size, d, padding_idx=self.word_pad_idx)
         self.transformer_encoder = _TransformerEncoder(d, args.ff_size, args.inter_layers)
-        self.review_encoder = _ReviewEncoder(self.word_embeddings, self.review_encoder_name, review_count, d)
+        if self.review_encoder_name == 'fs':
+            self.review_encoder = _FSEncoder(d)              # review_encoder.f_W (ps_model.py:148-149)
+        elif self.review_encoder_name == 'avg':
+            self.review_encoder = _Holder()                  # AVGEncoder has no parameters (:150-151)
+        else:
+            self.review_encoder = _ReviewEncoder(self.word_embeddings, self.review_encoder_name, review_count, d)
         self.query_encoder = _FSEncoder(d) if args.query_encoder_name == 'fs' else _Holder()
         self.seg_embeddings = nn.Embedding(4, d, padding_idx=self.seg_pad_idx)
         self.review_embeddings = None
@@ -108,6 +113,8 @@ class ProductRanker(nn.Module):
         nn.init.normal_(self.seg_embeddings.weight)
         if self.review_encoder_name == 'pv':
             nn.init.normal_(self.review_encoder.review_embeddings.weight)
+        elif self.review_encoder_name == 'fs':
+            _init_like_reference(self.review_encoder)
         if self.args.query_encoder_name == 'fs':
             _init_like_reference(self.query_encoder)
         _init_like_reference(self.transformer_encoder)
@@ -133,8 +140,9 @@ class ProductRanker(nn.Module):
         self.review_words = rw.contiguous()
         d.WL = rw.shape[1]
         out = torch.empty(self.review_count, self.embedding_size, device=self._dev(), dtype=torch.float32)
-        _lib.check(lib.ps_rtm_review_embeddings(d, ps, self.review_words.data_ptr(), out.data_ptr(), self._stream()),
-                   'ps_rtm_review_embeddings')
+        scratch = torch.empty_like(out) if self.review_encoder_name == 'fs' else None
+        _lib.check(lib.ps_rtm_review_embeddings(d, ps, self.review_words.data_ptr(), _lib.ptr(scratch), out.data_ptr(),
+                                                self._stream()), 'ps_rtm_review_embeddings')
         self.review_embeddings = out
 
     def forward(self, batch_data, train_pv=True, neg_word_idxs=None):
@@ -187,6 +195,8 @@ class ProductRanker(nn.Module):
                (('wo_w',), te.wo.weight), (('wo_b',), te.wo.bias)]
         if self.review_encoder_name == 'pv':
             out.append((('review_emb',), self.review_encoder.review_embeddings.weight))
+        if self.review_encoder_name == 'fs':
+            out += [(('rev_fs_w',), self.review_encoder.f_W.weight), (('rev_fs_b',), self.review_encoder.f_W.bias)]
         if self.use_user_emb:
             out.append((('user_emb',), self.user_emb.weight))
         if self.use_item_emb:
@@ -251,7 +261,7 @@ class ProductRanker(nn.Module):
         d.B, d.K, d.R, d.Q, d.W, d.WL, d.C = B, K, R, Q, W, WL, C
         d.d, d.H, d.F, d.n_layers = a.embedding_size, a.heads, a.ff_size, a.inter_layers
         d.vocab_size, d.review_count = self.vocab_size, self.review_count
-        d.review_encoder = _lib.PS_RENC_PV if self.review_encoder_name == 'pv' else _lib.PS_RENC_PVC
+        d.review_encoder = dict(pv=_lib.PS_RENC_PV, pvc=_lib.PS_RENC_PVC, fs=_lib.PS_RENC_FS, avg=_lib.PS_RENC_AVG)[self.review_encoder_name]
         d.query_encoder = _lib.PS_QENC_FS if a.query_encoder_name == 'fs' else _lib.PS_QENC_AVG
         d.use_pos_emb, d.use_seg_emb, d.pos_weight = int(a.use_pos_emb), int(a.use_seg_emb), int(a.pos_weight)
         d.train_pv = int(train_pv)
@@ -373,7 +383,9 @@ class ProductRanker(nn.Module):
         R, K = pr.shape[1], nr.shape[1]
         if tuple(nr.shape) != (B, K, R):
             raise RuntimeError("neg_prod_ridxs has shape %s, expected %s" % (tuple(nr.shape), (B, K, R)))
-        pvc = self.review_encoder_name == 'pvc'
+        pvc = self.review_encoder_name in ('pvc', 'fs', 'avg')      # the word-mean encoders: review vectors from review words
+        if self.review_encoder_name in ('fs', 'avg'):
+            train_pv = False                                         # "pv" not in the name: no PV loss (ps_model.py:264)
         pw = self._idx(b.pos_prod_rword_idxs, 'pos_prod_rword_idxs')
         W = pw.shape[2] if train_pv else max(1, self.args.pv_window_size)
         WL = 0
@@ -392,7 +404,8 @@ class ProductRanker(nn.Module):
         bt.query_word_idxs, bt.pos_prod_ridxs, bt.neg_prod_ridxs = qw.data_ptr(), pr.data_ptr(), nr.data_ptr()
         bt.pos_prod_rword_idxs = pw.data_ptr()
         for name, dtype in (('pos_seg_idxs', torch.int64), ('neg_seg_idxs', torch.int64),
-                            ('pos_prod_rword_masks', torch.uint8), ('neg_prod_rword_idxs', torch.int64),
+                            ('pos_prod_rword_masks', torch.uint8), ('neg_prod_rword_masks', torch.uint8),
+                            ('neg_prod_rword_idxs', torch.int64),
                             ('pos_prod_rword_idxs_pvc', torch.int64), ('neg_prod_rword_idxs_pvc', torch.int64)):
             t = self._idx(getattr(b, name, None), name, dtype)
             lead = {'pos_seg_idxs': (B, R + 1), 'neg_seg_idxs': (B, K, R + 1)}.get(

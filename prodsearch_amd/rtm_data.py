@@ -157,9 +157,9 @@ def make_rtm_batch(seed, B, K, review_count, vocab_size, review_words, Q=8, u_li
             kw['pos_prod_rword_idxs_pvc'] = rw[pos_r]
             kw['neg_prod_rword_idxs_pvc'] = rw[neg_r]
     else:
-        pos_words = rw[pos_r] if encoder == 'pvc' else np.full((B, R, W), V - 1, dtype=np.int64)
+        pos_words = rw[pos_r] if encoder in ('pvc', 'fs', 'avg') else np.full((B, R, W), V - 1, dtype=np.int64)
         pos_masks = (pos_words != V - 1).astype(np.uint8)
-        if encoder == 'pvc':
+        if encoder in ('pvc', 'fs', 'avg'):
             kw['neg_prod_rword_idxs'] = rw[neg_r]
             kw['neg_prod_rword_masks'] = (rw[neg_r] != V - 1).astype(np.uint8)
     pos_u = neg_u = pos_i = neg_i = None

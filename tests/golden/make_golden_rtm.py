@@ -101,6 +101,13 @@ CASES = {
                                       heads=4, ff_size=128, inter_layers=1, neg_per_pos=3, dropout=0.0, lr=0.002,
                                       corrupt_rate=0.9, seed=29, pv_window_size=2),
                             V=500, RC=300, B=8, Q=6, u=3, i=4, WL=80, C=6, steps=2, train_pv=True),
+    # fs / avg review encoders (ps_model.py:148-151, 301-305): masked mean of the review words (-> f_W, tanh), dropout drawn
+    'rtm_fs': dict(args=dict(model_name='review_transformer', review_encoder_name='fs', embedding_size=64, heads=4,
+                             ff_size=128, inter_layers=1, neg_per_pos=3, dropout=0.1, lr=0.002, seed=41),
+                   V=500, RC=300, B=8, Q=6, u=3, i=4, WL=70, C=6, steps=2, train_pv=False),
+    'rtm_avg': dict(args=dict(model_name='review_transformer', review_encoder_name='avg', embedding_size=32, heads=4,
+                              ff_size=64, inter_layers=2, neg_per_pos=3, dropout=0.2, lr=0.002, seed=43, use_user_emb=True),
+                    V=400, RC=300, B=8, Q=6, u=3, i=4, WL=40, C=6, steps=1, train_pv=False),
 }
 USER_SIZE, PRODUCT_SIZE = 40, 50
 
