@@ -15,6 +15,7 @@ struct Ws {
   int64_t fin_stats, enc;
   int64_t item_scores, word_scores, loss_parts, item_terms, word_terms, loss_blk;
   int64_t word_blk, item_blk, ticket;   // folded scoring (ScoreArgs): word / item loss partials, arrival counter
+  int64_t wsplit;           // bf16x3 planes of the last layer's wo / w1 / w2 (WSplit), 0: not allocated
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
   int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
   int64_t gcpart;           // [4 * row tiles][3][F] parked column sums of the FF2 dX GEMM (b1 gradient)
@@ -28,6 +29,8 @@ struct Ws {
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 int make_ws(const PsTemDesc& D, Ws& w);
+// the last layer's weights as the fused kernels' bf16x3 planes inside the workspace (on = 0 when the x3 form is not taken)
+WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const Ws& w);
 
 // All encoder layers + the final LayerNorm on the consumed position: reads w.x, writes w.enc.
 // Key-padding mask: `valid` [n_seq, S] floats if given, else u_item_idxs != P (TEM).

@@ -299,7 +299,7 @@ extern "C" void ps_debug_set_stamp_buffer(void* p) { g_ws_stamp = (unsigned long
     if (STAMP && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {                                   \
       unsigned long long t_;                                                                                   \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                               \
-      stamp[((wave >> 2) * 64 + (slot)) ] = t_;                                                                \
+      stamp[((wave >> 2) * 128 + (slot)) ] = t_;                                                                \
     }                                                                                                          \
   } while (0)
 template <bool STAMP>
@@ -333,6 +333,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdA
 
   // the Philox step of the three dropout sites, read once (graph replay keeps it in device memory: DropSpec::step_ptr)
   const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+
+  // the six small vectors of the two LayerNorm stages, requested now: at the stages themselves their L2 round trip would
+  // sit on the critical path of all 8 waves
+  const float pv_bo[2] = {a.bo[lane], a.bo[lane + 64]}, pv_g1[2] = {a.g1[lane], a.g1[lane + 64]},
+              pv_be1[2] = {a.be1[lane], a.be1[lane + 64]}, pv_b2[2] = {a.b2[lane], a.b2[lane + 64]},
+              pv_gf[2] = {a.gf[lane], a.gf[lane + 64]}, pv_bef[2] = {a.bef[lane], a.bef[lane + 64]};
 
   // ---- prologue
   float4 wr0[WRN], wr1[WRN];
@@ -397,11 +403,11 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdA
   // one LayerNorm stage, all 8 waves: v = dropout(C + bias) + residual -> (out_pre) ; LayerNorm -> out_ln, stats, Xk
   // (the global stores are a separate step, ln_store: the last stage scores and takes its ticket first, so that the
   // signalling lane has no store of this stage to wait for)
-  auto ln_stage = [&](const float* Cst, const float* __restrict__ bias, const DropSpec& drop, const uint32_t dstep, const float* __restrict__ g,
-                      const float* __restrict__ bta, float* Xk, float (&res)[4][2], float (&o)[4][2], float (&mr)[4][2]) {
+  auto ln_stage = [&](const float* Cst, const float (&bias)[2], const DropSpec& drop, const uint32_t dstep, const float (&g)[2],
+                      const float (&bta)[2], float* Xk, float (&res)[4][2], float (&o)[4][2], float (&mr)[4][2]) {
     const int rb = opaque(m0) + 4 * wave;
-    const float b0 = bias[lane], b1 = bias[lane + 64];
-    const float g0 = g[lane], g1 = g[lane + 64], e0 = bta[lane], e1 = bta[lane + 64];
+    const float b0 = bias[0], b1 = bias[1];
+    const float g0 = g[0], g1 = g[1], e0 = bta[0], e1 = bta[1];
     Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
     if (drop.thr) {
       r0 = philox4x32_10((uint32_t)lane, (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
@@ -547,13 +553,13 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdA
           dump(L.Cs[0], acc);
           __syncthreads();                            // Wo accumulators in Cs; every matrix wave is done reading ctx from Xs
           float o[4][2], mr[4][2];
-          ln_stage(L.Cs[0], a.bo, a.drop_ctx, step_ctx, a.g1, a.be1, L.Xs, y1r, o, mr);
+          ln_stage(L.Cs[0], pv_bo, a.drop_ctx, step_ctx, pv_g1, pv_be1, L.Xs, y1r, o, mr);
           ln_store(a.y1, a.ln1, a.st1, y1r, o, mr);
         } else if (s == NS - 1) {
           dump(L.Cs[0], acc_o);
           __syncthreads();
           float o[4][2], mr[4][2];
-          ln_stage(L.Cs[0], a.b2, a.drop_ff2, step_ff2, a.gf, a.bef, nullptr, y1r, o, mr);
+          ln_stage(L.Cs[0], pv_b2, a.drop_ff2, step_ff2, pv_gf, pv_bef, nullptr, y1r, o, mr);
           if (a.fold_score) score_stage(o, [&]() { ln_store(a.y2, a.enc, a.stf, y1r, o, mr); });
           else ln_store(a.y2, a.enc, a.stf, y1r, o, mr);
         }
@@ -617,12 +623,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdA
       if (kind == 0) {
         __syncthreads();
         float o[4][2], mr[4][2];
-        ln_stage(L.Cs[0], a.bo, a.drop_ctx, step_ctx, a.g1, a.be1, L.Xs, y1r, o, mr);
+        ln_stage(L.Cs[0], pv_bo, a.drop_ctx, step_ctx, pv_g1, pv_be1, L.Xs, y1r, o, mr);
         ln_store(a.y1, a.ln1, a.st1, y1r, o, mr);
       } else if (s == NS - 1) {
         __syncthreads();
         float o[4][2], mr[4][2];
-        ln_stage(L.Cs[0], a.b2, a.drop_ff2, step_ff2, a.gf, a.bef, nullptr, y1r, o, mr);
+        ln_stage(L.Cs[0], pv_b2, a.drop_ff2, step_ff2, pv_gf, pv_bef, nullptr, y1r, o, mr);
         if (a.fold_score) score_stage(o, [&]() { ln_store(a.y2, a.enc, a.stf, y1r, o, mr); });
         else ln_store(a.y2, a.enc, a.stf, y1r, o, mr);
       }
@@ -637,13 +643,351 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_ws_kernel(const MlpFwdA
   WS_STAMP(2 * NS);
 }
 
+// ====================================================================== forward, bf16x3 form
+// Measured (tools/micro/coexec.hip, bf16x3.hip; profiles/r02_mfma_notes.md): v_mfma_f32_32x32x2_f32 runs on the SIMD's
+// vector ALUs — it does NOT overlap the other wave's VALU work (120 us + 277 us -> 385 us) and costs 4,445 cycles per
+// 32x32x128 product.  The same product as SIX v_mfma_f32_32x32x16_bf16 over a three-way bf16 split of both operands
+// (x = hi + mid + lo, 3 x 8 = 24 mantissa bits, exact;  hh + hm + mh + mm + hl + lh, fp32 accumulation) costs 1,457
+// cycles and is as accurate (max error / sum|a b|: 1.10e-7 against 1.13e-7 for the fp32 MFMA, fp64 reference).
+// This kernel is mlp_fwd_ws_kernel with that product: same roles, same product order, same epilogue arithmetic; the
+// A operands (ctx, ln1, h1 chunks) are split where they are produced, the weights arrive pre-split (WSplit).
+// LDS images are [row][k] bf16 with their 16-byte chunks XOR-swizzled so that ds_read_b128 of 16 rows is conflict-free
+// without padding (155 KB in all): A tiles [32][128]: chunk ^ (row & 15);  weight slabs [128 n][32 k]: chunk ^ ((n >> 2) & 3).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define X3_BK 64          // reduction depth of one weight slab
+#define X3_SPP 2          // slabs per 128-deep product
+#define X3_CH 6           // 16-byte chunks of a slab per thread: 3 planes x 128 n x (X3_BK / 8) chunks / 512 threads
+struct MlpX3Lds {         // exactly the 160 KiB a workgroup may own
+  uint16_t Xa[3][MBM * MD];          // A planes of Wo / W1: ctx, then ln1
+  uint16_t Ha[3][MBM * MD];          // A planes of W2: the current h1 chunk
+  uint16_t Wb[2][3][MD * X3_BK];     // weight slab ring (its first floats double as the last stage's scratch `red`)
+  float Cs[MBM * MD];                // accumulator tile handed to the element-wise stages (row-major, unpadded)
+};
+static_assert(sizeof(MlpX3Lds) <= 160 * 1024, "bf16x3 MLP: LDS budget");
+__device__ inline int x3_a_off(int row, int k) { return row * MD + ((((k >> 3) ^ (row & 15)) << 3) | (k & 7)); }
+// weight slab rows are X3_BK * 2 = 128 bytes: 8 chunks; 16 rows read the same logical chunk -> XOR with (n >> 1) & 7
+__device__ inline int x3_b_off(int n, int k) { return n * X3_BK + ((((k >> 3) ^ ((n >> 1) & 7)) << 3) | (k & 7)); }
+__device__ inline void x3_split(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  const __bf16 bh = (__bf16)x;
+  float r = x - (float)bh;
+  const __bf16 bm = (__bf16)r;
+  r -= (float)bm;
+  const __bf16 bl = (__bf16)r;
+  h = __builtin_bit_cast(uint16_t, bh); m = __builtin_bit_cast(uint16_t, bm); l = __builtin_bit_cast(uint16_t, bl);
+}
+// two adjacent k of one row -> the three planes (4-byte stores)
+__device__ inline void x3_put2(uint16_t (*planes)[MBM * MD], int row, int k, float v0, float v1) {
+  uint16_t h0, m0, l0, h1, m1, l1;
+  x3_split(v0, h0, m0, l0); x3_split(v1, h1, m1, l1);
+  const int off = x3_a_off(row, k);
+  *reinterpret_cast<uint32_t*>(&planes[0][off]) = (uint32_t)h0 | ((uint32_t)h1 << 16);
+  *reinterpret_cast<uint32_t*>(&planes[1][off]) = (uint32_t)m0 | ((uint32_t)m1 << 16);
+  *reinterpret_cast<uint32_t*>(&planes[2][off]) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+}
+// six bf16 MFMAs = one exact-fp32-grade 32x32x16 product step (small terms first)
+__device__ inline void x3_mma(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// Structure (per-slab stamps of the role-split form showed the helper waves, not the matrix pipe, on the critical path
+// once the products were bf16): all 8 waves stream the weight slabs (6 chunks of 16 bytes per thread and slab, prefetched
+// two slabs ahead); waves 0-3 multiply (24 MFMAs per slab); every element-wise stage — the two LayerNorms and the
+// GELU / dropout between W1 chunk c and W2 chunk c — is shared by all 8 waves, 4 rows each, behind one barrier.
+// Products run in their natural order  Wo, (W1c, W2c) for c = 0 .. n-1.
+template <bool STAMP>
+__global__ __launch_bounds__(WS_THREADS, 2) void mlp_fwd_x3_kernel(const MlpFwdArgs a, unsigned long long* stamp) {
+  extern __shared__ float lds_raw[];
+  MlpX3Lds& L = *reinterpret_cast<MlpX3Lds*>(lds_raw);
+  float* red = reinterpret_cast<float*>(&L.Wb[0][0][0]);          // free once the last slab has been multiplied
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const bool is_m = wave < 4;
+  const int m0 = blockIdx.x * MBM, M = a.M;
+  const int mcol = (wave & 3) * 32 + l31;
+  const int nchunk = a.F / 128;
+  const int NP = 1 + 2 * nchunk, NS = X3_SPP * NP;
+  const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+
+  // product p: 0 = Wo; 1 + 2c = W1 chunk c; 2 + 2c = W2 chunk c
+  auto slab_src = [&](int s, const uint16_t*& base, size_t& psz, int& ld, int& n0, int& k0) {
+    const int p = s / X3_SPP, r = s % X3_SPP;
+    if (p == 0) { base = a.x3.nat[0]; psz = (size_t)MD * MD; ld = MD; n0 = 0; k0 = X3_BK * r; }
+    else if (p & 1) { base = a.x3.nat[1]; psz = (size_t)a.F * MD; ld = MD; n0 = 128 * ((p - 1) >> 1); k0 = X3_BK * r; }
+    else { base = a.x3.nat[2]; psz = (size_t)MD * a.F; ld = a.F; n0 = 0; k0 = 128 * ((p - 2) >> 1) + X3_BK * r; }
+  };
+  // chunk q = tid + 512 u of a slab: plane q / 1024, row (q % 1024) / 8, chunk q % 8
+  auto slab_load = [&](int s, uint4 (&r)[X3_CH]) {
+    const uint16_t* base; size_t psz; int ld, n0, k0;
+    slab_src(s, base, psz, ld, n0, k0);
+#pragma unroll
+    for (int u = 0; u < X3_CH; ++u) {
+      const int q = tid + WS_THREADS * u, pl = q >> 10, rem = q & 1023, n = rem >> 3, j = rem & 7;
+      r[u] = *reinterpret_cast<const uint4*>(base + pl * psz + (size_t)(n0 + n) * ld + k0 + 8 * j);
+    }
+  };
+  auto slab_store = [&](uint16_t (*Wbuf)[MD * X3_BK], const uint4 (&r)[X3_CH]) {
+#pragma unroll
+    for (int u = 0; u < X3_CH; ++u) {
+      const int q = tid + WS_THREADS * u, pl = q >> 10, rem = q & 1023, n = rem >> 3, j = rem & 7;
+      *reinterpret_cast<uint4*>(&Wbuf[pl][x3_b_off(n, 8 * j)]) = make_uint4(r[u].x, r[u].y, r[u].z, r[u].w);
+    }
+  };
+
+  // ---- prologue
+  uint4 wr0[X3_CH], wr1[X3_CH];
+  slab_load(0, wr0);
+  slab_load(1, wr1);
+  {                                                   // ctx tile -> Xa planes: thread = (row, one 8-element chunk)
+    const int row = tid >> 4, kc = tid & 15;
+    float v[8];
+    if (m0 + row < M) {
+      const float4 v0 = *reinterpret_cast<const float4*>(a.ctx + (size_t)(m0 + row) * MD + 8 * kc);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.ctx + (size_t)(m0 + row) * MD + 8 * kc + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) x3_put2(L.Xa, row, 8 * kc + e, v[e], v[e + 1]);
+  }
+  // rows 4*wave .. 4*wave+3, columns 2*lane and 2*lane + 1: this lane's elements in every element-wise stage
+  float y1r[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = m0 + 4 * wave + q;
+    const float* src = a.xin + ((size_t)((m < M ? m : 0) / a.fan) * a.S + a.qpos) * MD;
+    const float2 v = m < M ? *reinterpret_cast<const float2*>(src + 2 * lane) : make_float2(0.f, 0.f);
+    y1r[q][0] = v.x; y1r[q][1] = v.y;
+  }
+  float itr[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  float ibias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.fold_score) {
+    const ScoreArgs& S = a.sc;
+    const int K1 = S.K + 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + 4 * wave + q;
+      if (m < M) {
+        const int b = fdiv(m, S.fK1), j = m - b * K1;
+        int64_t idx = j == 0 ? S.target[b] : S.neg_items[(size_t)b * S.K + j - 1];
+        idx = idx < 0 ? S.P : (idx > S.P ? S.P : idx);
+        const float2 v = *reinterpret_cast<const float2*>(S.product_emb + (size_t)idx * MD + 2 * lane);
+        itr[q][0] = v.x; itr[q][1] = v.y;
+        if (S.bias_product) ibias[q] = S.product_bias[idx];
+      }
+    }
+  }
+  slab_store(L.Wb[0], wr0);
+  slab_load(2 < NS ? 2 : NS - 1, wr0);
+  __syncthreads();
+
+  f32x16 acc, acc_o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc_o[r] = 0.f; }
+
+  // one LayerNorm stage, all 8 waves (see mlp_fwd_ws_kernel); the normalised rows go to Xa as bf16x3 planes
+  auto ln_stage = [&](const float* __restrict__ bias, const DropSpec& drop, const uint32_t dstep,
+                      const float* __restrict__ g, const float* __restrict__ bta, bool to_xa, float (&res)[4][2],
+                      float (&o)[4][2], float (&mr)[4][2]) {
+    const int rb = opaque(m0) + 4 * wave;
+    const float2 bb = *reinterpret_cast<const float2*>(bias + 2 * lane);
+    const float2 gg = *reinterpret_cast<const float2*>(g + 2 * lane), ee = *reinterpret_cast<const float2*>(bta + 2 * lane);
+    Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (drop.thr) {
+      r0 = philox4x32_10((uint32_t)(2 * lane), (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+      r1 = philox4x32_10((uint32_t)(2 * lane + 1), (uint32_t)rb >> 2, drop.site, dstep, drop.k0, drop.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 4 * wave + q;
+      const float2 cv = *reinterpret_cast<const float2*>(L.Cs + row * MD + 2 * lane);
+      float v0 = cv.x + bb.x, v1 = cv.y + bb.y;
+      if (drop.thr) {
+        v0 *= drop_word(drop, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+        v1 *= drop_word(drop, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+      }
+      v0 += res[q][0]; v1 += res[q][1];
+      res[q][0] = v0; res[q][1] = v1;
+      const float mean = wave_sum(v0 + v1) * (1.f / MD);
+      const float d0 = v0 - mean, d1 = v1 - mean;
+      const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.f / MD) + 1e-6f);
+      const float o0 = d0 * rstd * gg.x + ee.x, o1 = d1 * rstd * gg.y + ee.y;
+      o[q][0] = o0; o[q][1] = o1;
+      mr[q][0] = mean; mr[q][1] = rstd;
+      if (to_xa) x3_put2(L.Xa, row, 2 * lane, o0, o1);
+    }
+  };
+  auto ln_store = [&](float* out_pre, float* out_ln, float* stats, const float (&res)[4][2], const float (&o)[4][2],
+                      const float (&mr)[4][2]) {
+    const int rb = opaque(m0) + 4 * wave;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = rb + q;
+      if (m < M) {
+        *reinterpret_cast<float2*>(out_pre + (size_t)m * MD + 2 * lane) = make_float2(res[q][0], res[q][1]);
+        *reinterpret_cast<float2*>(out_ln + (size_t)m * MD + 2 * lane) = make_float2(o[q][0], o[q][1]);
+        if (lane == 0) { stats[2 * (size_t)m] = mr[q][0]; stats[2 * (size_t)m + 1] = mr[q][1]; }
+      }
+    }
+  };
+  // GELU / dropout stage between W1 chunk c and W2 chunk c, all 8 waves: a1 chunk in Cs -> h1 chunk planes in Ha
+  auto gelu_stage = [&](const int c) {
+    const int f0 = 128 * c + 2 * lane, rb = opaque(m0) + 4 * wave;
+    const float2 bia = *reinterpret_cast<const float2*>(a.b1 + f0);
+    Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (a.drop_ff1.thr) {
+      r0 = philox4x32_10((uint32_t)f0, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+      r1 = philox4x32_10((uint32_t)f0 + 1u, (uint32_t)rb >> 2, a.drop_ff1.site, step_ff1, a.drop_ff1.k0, a.drop_ff1.k1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rl = 4 * wave + q, m = rb + q;
+      const float2 cv = *reinterpret_cast<const float2*>(L.Cs + rl * MD + 2 * lane);
+      const float p0 = cv.x + bia.x, p1 = cv.y + bia.y;
+      float h0 = gelu_tanh_f(p0), h1v = gelu_tanh_f(p1);
+      if (a.drop_ff1.thr) {
+        h0 *= drop_word(a.drop_ff1, q == 0 ? r0.x : (q == 1 ? r0.y : (q == 2 ? r0.z : r0.w)));
+        h1v *= drop_word(a.drop_ff1, q == 0 ? r1.x : (q == 1 ? r1.y : (q == 2 ? r1.z : r1.w)));
+      }
+      x3_put2(L.Ha, rl, 2 * lane, h0, h1v);
+      if (m < M) {
+        *reinterpret_cast<float2*>(a.a1 + (size_t)m * a.F + f0) = make_float2(p0, p1);
+        *reinterpret_cast<float2*>(a.h1 + (size_t)m * a.F + f0) = make_float2(h0, h1v);
+      }
+    }
+  };
+  // folded scoring (see mlp_fwd_ws_kernel)
+  auto score_stage = [&](const float (&o)[4][2], auto&& stores) {
+    const ScoreArgs& S = a.sc;
+    const int K1 = S.K + 1;
+    float scq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float sdot = wave_sum(o[q][0] * itr[q][0] + o[q][1] * itr[q][1]) + ibias[q];
+      scq = lane == q ? sdot : scq;
+    }
+    const int mq = m0 + 4 * wave + (lane & 3);
+    const bool rowq = lane < 4 && mq < M;
+    const int bq = fdiv(rowq ? mq : 0, S.fK1), jq = (rowq ? mq : 0) - bq * K1;
+    const float twq = jq == 0 ? -(S.pos_weight ? (float)S.K : 1.f) : 1.f;
+    const float termq = fabsf(twq) * softplus_f(twq < 0.f ? -scq : scq);
+    const float cps = wave_sum(rowq ? termq : 0.f);
+    if (lane == 0) red[wave] = cps;
+    __syncthreads();
+    unsigned long long mine = 0ull, old = 0ull;
+    const unsigned long long one = 1ull << 48, mask = one - 1ull;
+    if (tid == 0) {
+      const float p = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+      unsigned long long* tk = reinterpret_cast<unsigned long long*>(S.ticket);
+      mine = (unsigned long long)(long long)__float2ll_rn(p * 1048576.f) | one;
+      old = __hip_atomic_fetch_add(tk, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (rowq) { S.item_scores[mq] = scq; S.item_terms[mq] = termq; }
+    stores();
+    if (tid == 0) {
+      float last = 0.f;
+      if ((old >> 48) == gridDim.x - 1u) {
+        last = 1.f;
+        red[9] = (float)((double)((old & mask) + (mine & mask)) * (1.0 / 1048576.0));
+      }
+      red[8] = last;
+    }
+    __syncthreads();
+    if (red[8] == 0.f) return;
+    if (wave == 0) {
+      float il = 0.f;
+      for (int i = lane; i < S.word_nblk; i += 64) il += S.word_blk[i];
+      il = wave_sum(il);
+      if (lane == 0) {
+        const float ps = red[9] / (float)S.B;
+        il /= (float)S.B;
+        S.loss3[0] = ps + il; S.loss3[1] = ps; S.loss3[2] = il;
+        if (S.loss_acc) { S.loss_acc[0] += ps; S.loss_acc[1] += il; }
+      }
+    }
+  };
+  auto dump = [&](f32x16& v) {                         // matrix waves: accumulator tile -> Cs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      L.Cs[((r & 3) + 8 * (r >> 2) + 4 * h) * MD + mcol] = v[r];
+      v[r] = 0.f;
+    }
+  };
+
+  auto slab_step = [&](const int s, uint4 (&wnext)[X3_CH]) __attribute__((always_inline)) {
+    const int p = s / X3_SPP, r = s % X3_SPP;
+    const bool is_w2 = p >= 2 && (p & 1) == 0;
+    WS_STAMP(2 * s);
+    if (is_m) {
+      const uint16_t (*A)[MBM * MD] = is_w2 ? L.Ha : L.Xa;
+      const uint16_t (*Wb)[MD * X3_BK] = L.Wb[s & 1];
+#pragma unroll
+      for (int ks = 0; ks < X3_BK / 16; ++ks) {
+        bf16x8 av[3], bv[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          av[pl] = *reinterpret_cast<const bf16x8*>(&A[pl][x3_a_off(l31, X3_BK * r + 16 * ks + 8 * h)]);
+          bv[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl][x3_b_off(mcol, 16 * ks + 8 * h)]);
+        }
+        if (is_w2) x3_mma(acc_o, av, bv); else x3_mma(acc, av, bv);
+      }
+    }
+    // every wave: publish slab s + 1 (its ring buffer was multiplied a barrier ago), refill the registers two slabs ahead
+    if (s + 1 < NS) slab_store(L.Wb[(s + 1) & 1], wnext);
+    slab_load(s + 3 < NS ? s + 3 : NS - 1, wnext);
+    if (r == X3_SPP - 1) {
+      if (p == 0) {                                   // Wo done: y1 = dropout(. + bo) + x ; LayerNorm_ff -> ln1
+        if (is_m) dump(acc);
+        __syncthreads();
+        float o[4][2], mr[4][2];
+        ln_stage(a.bo, a.drop_ctx, step_ctx, a.g1, a.be1, true, y1r, o, mr);
+        ln_store(a.y1, a.ln1, a.st1, y1r, o, mr);
+      } else if (p & 1) {                             // W1 chunk done: GELU / dropout -> h1 chunk
+        if (is_m) dump(acc);
+        __syncthreads();
+        gelu_stage((p - 1) >> 1);
+      } else if (s == NS - 1) {                       // last W2 chunk: y2 = dropout(. + b2) + y1 ; final LayerNorm -> enc
+        if (is_m) dump(acc_o);
+        __syncthreads();
+        float o[4][2], mr[4][2];
+        ln_stage(a.b2, a.drop_ff2, step_ff2, a.gf, a.bef, false, y1r, o, mr);
+        if (a.fold_score) score_stage(o, [&]() { ln_store(a.y2, a.enc, a.stf, y1r, o, mr); });
+        else ln_store(a.y2, a.enc, a.stf, y1r, o, mr);
+      }
+    }
+    WS_STAMP(2 * s + 1);
+    __syncthreads();
+  };
+  for (int s = 0; s < NS; s += 2) {                   // NS = 2 * NP is even; wr1 holds slab s + 1, wr0 slab s + 2
+    slab_step(s, wr1);
+    slab_step(s + 1, wr0);
+  }
+  WS_STAMP(2 * NS);
+}
+
+// Opt-in (PS_MLP_X3=1): validated by the whole parity suite, but at C2 it does not pay — the fused forward goes 59.4 ->
+// 54.7 us while the embed launch grows by the re-split, 0.3186 against 0.3178 ms/step (profiles/r02_mlp_notes.md): once the
+// products are cheap the kernel is bound by its element-wise VALU work (Philox, GELU, LayerNorm, the splits) and barriers.
+bool mlp_x3_enabled(int F) {
+  static const bool on = getenv("PS_MLP_X3") && atoi(getenv("PS_MLP_X3")) != 0;
+  return on && ps_fusion_enabled() && F % 128 == 0 && F >= 256;
+}
+int64_t mlp_x3_floats(int d, int F) {      // 2 layouts x 3 planes x (d*d + 2*d*F) bf16
+  return ((int64_t)2 * 3 * ((int64_t)d * d + 2 * (int64_t)d * F) * 2 + 3) / 4 + 16;
+}
+
 static bool mlp_ws_enabled() {
   static const bool on = !(getenv("PS_MLP_WS") && atoi(getenv("PS_MLP_WS")) == 0);
   return on;
 }
 bool mlp_fwd_can_fold_score(int M, int F, int d) {
   static const bool fold_on = !(getenv("PS_NO_FOLD_SCORE") && atoi(getenv("PS_NO_FOLD_SCORE")) != 0);
-  return fold_on && ps_fusion_enabled() && mlp_ws_enabled() && d == MD && F % 128 == 0 && F >= 256 && M > 0 &&
+  return fold_on && ps_fusion_enabled() && (mlp_ws_enabled() || mlp_x3_enabled(F)) && d == MD && F % 128 == 0 && F >= 256 && M > 0 &&
          ps_cdiv(M, MBM) <= 256;               // one workgroup per CU, all resident: the ticket hand-off's measured regime
 }
 
@@ -658,6 +1002,24 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   }
   KTimeScope kt("mlp_fwd", st);
   PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs the wave-specialised form");
+  PS_REQUIRE(!a.fold_score || a.x3.on || mlp_ws_enabled(), "fused mlp: folded scoring needs an 8-wave form");
+  if (a.x3.on) {
+    static bool x3_attr = false;
+    if (!x3_attr) {
+      PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_x3_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpX3Lds)));
+      PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_x3_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpX3Lds)));
+      x3_attr = true;
+    }
+    if (g_ws_stamp)
+      hipLaunchKernelGGL(mlp_fwd_x3_kernel<true>, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpX3Lds), st, a, g_ws_stamp);
+    else
+      hipLaunchKernelGGL(mlp_fwd_x3_kernel<false>, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpX3Lds), st, a,
+                         (unsigned long long*)nullptr);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   if (mlp_ws_enabled() && a.F >= 256) {
     static bool ws_attr = false;
     if (!ws_attr) {

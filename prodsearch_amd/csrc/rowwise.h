@@ -47,6 +47,15 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st);           // gather + dot ("
 int launch_loss(const ScoreArgs& a, hipStream_t st);
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
 
+// bf16x3 weight planes of the fused per-replica kernels (mlp_fused.hip, "x3" forms): every fp32 weight is split into
+// three bf16 values w = hi + mid + lo (3 x 8 = 24 mantissa bits: exact), kept as three bf16 planes in the matrix's own
+// [rows][cols] layout (`nat`, the forward's B operands) and transposed (`tr`, the backward's).  Re-split at the start of
+// every forward (extra workgroups of the embed launch): whoever changed the weights in between is picked up.
+struct WSplit {
+  const float* w[3]; int rows[3], cols[3];     // final_linear [d][d], w_1 [F][d], w_2 [d][F]  (nn.Linear [out][in])
+  uint16_t* nat[3]; uint16_t* tr[3];           // plane p of matrix m: nat[m] + p*rows*cols ([rows][cols]);  tr[m] + p*rows*cols ([cols][rows])
+  int on;
+};
 struct EmbedArgs {
   int B, Q, L, S, d;
   int64_t P, V;
@@ -74,6 +83,7 @@ struct EmbedArgs {
   // optional: the word tasks of the loss ride in this launch too (ScoreArgs, folded form); word_wgs / list_wgs are
   // filled by the launcher (grid = B gather + samp_wgs + list_wgs + word_wgs workgroups)
   int fold_words; ScoreArgs sc; int word_wgs, list_wgs;
+  WSplit split; int split_wgs;   // optional: re-split the fused kernels' weights (WSplit); split_wgs filled by the launcher
 };
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);
 
@@ -196,9 +206,12 @@ struct MlpFwdArgs {
   DropSpec drop_ctx, drop_ff1, drop_ff2;
   float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
   int fold_score; ScoreArgs sc;   // item scoring + loss in the epilogue (ScoreArgs, folded form); M = B*(K+1)
+  WSplit x3;                      // bf16x3 planes of wo / w1 / w2 (x3.on: take the bf16-MFMA form)
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool mlp_fwd_can_fold_score(int M, int F, int d);   // the wave-specialised kernel will serve this shape
+bool mlp_x3_enabled(int F);                          // the fused kernels will take their bf16x3 form (they then need WSplit)
+int64_t mlp_x3_floats(int d, int F);                 // workspace floats of the planes (natural + transposed)
 bool ps_fusion_enabled();
 
 // ---- backward of the same tail as ONE kernel (mlp_fused.hip; d == 128, parked column sums):
@@ -223,6 +236,7 @@ struct MlpBwdArgs {
   float* part_f;                                       // [workgroups][3][128] {dgamma_f, dbeta_f, colsum -> b2}
   float* part_1;                                       // [workgroups][3][128] {dgamma_1, dbeta_1, colsum -> bo}
   float* part_b1;                                      // [mlp_bwd_b1_rows()][3][F] slot 0: colsum -> b1
+  WSplit x3;                                           // bf16x3 planes (transposed ones are read here)
 };
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);
 int mlp_bwd_fused_blocks(int M);

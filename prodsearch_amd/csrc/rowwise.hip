@@ -135,6 +135,38 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     }
     return;
   }
+  if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs) {   // weight re-split (EmbedArgs::split)
+    const WSplit& W = a.split;
+    int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;   // float4 index
+    for (int m = 0; m < 3; ++m) {
+      const int n4 = W.rows[m] * W.cols[m] / 4;
+      if (q >= n4) { q -= n4; continue; }
+      const float4 v = reinterpret_cast<const float4*>(W.w[m])[q];
+      const float x[4] = {v.x, v.y, v.z, v.w};
+      const int e0 = 4 * q, row = e0 / W.cols[m], col = e0 - row * W.cols[m];
+      const size_t plane = (size_t)W.rows[m] * W.cols[m];
+      uint16_t hb[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        float r = x[e] - (float)h;
+        const __bf16 md = (__bf16)r;
+        r -= (float)md;
+        const __bf16 lo = (__bf16)r;
+        hb[0][e] = __builtin_bit_cast(uint16_t, h); hb[1][e] = __builtin_bit_cast(uint16_t, md); hb[2][e] = __builtin_bit_cast(uint16_t, lo);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        uint16_t* nat = W.nat[m] + pl * plane + e0;
+        *reinterpret_cast<uint2*>(nat) = make_uint2((uint32_t)hb[pl][0] | ((uint32_t)hb[pl][1] << 16),
+                                                    (uint32_t)hb[pl][2] | ((uint32_t)hb[pl][3] << 16));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) W.tr[m][pl * plane + (size_t)(col + e) * W.rows[m] + row] = hb[pl][e];
+      }
+      return;
+    }
+    return;
+  }
   if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs) {       // word tasks of the loss (EmbedArgs::fold_words)
     word_tasks_wg(a.sc, (int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs);
     return;
@@ -292,8 +324,17 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   b.list_wgs = nlist;
   if (!nlist) b.vrows = nullptr;
   b.word_wgs = a.fold_words ? a.sc.word_nblk : 0;
+  b.split_wgs = 0;
+  if (a.split.on) {
+    int n4 = 0;
+    for (int m = 0; m < 3; ++m) {
+      PS_REQUIRE(a.split.w[m] && a.split.nat[m] && a.split.tr[m] && a.split.cols[m] % 4 == 0, "embed: weight split: bad matrix %d", m);
+      n4 += a.split.rows[m] * a.split.cols[m] / 4;
+    }
+    b.split_wgs = ps_cdiv(n4, 256);
+  }
   PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist + b.word_wgs), dim3(256),
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist + b.word_wgs + b.split_wgs), dim3(256),
                      (size_t)(rpp + 2) * a.d * sizeof(float), st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;

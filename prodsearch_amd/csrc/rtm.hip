@@ -1142,6 +1142,11 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   PS_REQUIRE(!e.fs || (P.fs_w && P.fs_b), "rtm: null FS encoder weights");
   const bool fs_fused = e.fs && ps_fusion_enabled() && d <= 128;
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
+  {
+    PsTemTensors Ts;
+    to_tem_tensors(P, Ts);
+    e.split = make_wsplit(E, Ts, ws + r.enc_base, w);      // the fused kernels' bf16x3 weight planes ride in this launch
+  }
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {
     GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);

@@ -158,6 +158,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   w.word_blk = take(cur, ps_cdiv((int64_t)B * (D.W > 0 ? D.W : 1) * (D.K + 1), PS_WORD_TASKS_PER_WG) + 4);
   w.item_blk = take(cur, ps_cdiv((int64_t)B * w.R, 32) + 4);
   w.ticket = take(cur, 20);      // 9 x 64-bit words (8 shards + top), 16-byte aligned
+  w.wsplit = (tem && NL > 0 && d == 128 && mlp_x3_enabled(D.F)) ? take(cur, mlp_x3_floats(d, D.F)) : 0;
   // backward scratch (sized for the widest layer)
   w.denc = take(cur, (int64_t)w.Mf * d);
   if (tem) {
@@ -205,6 +206,25 @@ extern "C" int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out
   out->item_scores = w.item_scores; out->word_scores = w.word_scores; out->loss_parts = w.loss_parts;
   out->denc = w.denc; out->dx = w.dx;
   return PS_OK;
+}
+
+WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const Ws& w) {
+  WSplit s;
+  memset(&s, 0, sizeof(s));
+  const int NL = D.model == PS_MODEL_TEM ? D.n_layers : 0;
+  if (NL < 1 || !w.wsplit || D.d != 128 || !mlp_x3_enabled(D.F) || w.layer[NL - 1].Sq != 1) return s;
+  const PsLayerTensors& L = P.layer[NL - 1];
+  if (!L.wo || !L.w1 || !L.w2) return s;
+  const int d = D.d, F = D.F;
+  s.w[0] = L.wo; s.rows[0] = d; s.cols[0] = d;
+  s.w[1] = L.w1; s.rows[1] = F; s.cols[1] = d;
+  s.w[2] = L.w2; s.rows[2] = d; s.cols[2] = F;
+  uint16_t* base = reinterpret_cast<uint16_t*>(ws + w.wsplit);
+  size_t off = 0;
+  for (int m = 0; m < 3; ++m) { s.nat[m] = base + off; off += (size_t)3 * s.rows[m] * s.cols[m]; }
+  for (int m = 0; m < 3; ++m) { s.tr[m] = base + off; off += (size_t)3 * s.rows[m] * s.cols[m]; }
+  s.on = 1;
+  return s;
 }
 
 // ----------------------------------------------------------------- GEMM helpers
@@ -483,6 +503,7 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       m.y1 = ws + l.y1; m.ln1 = ws + l.ln1; m.st1 = ws + l.ff_stats; m.a1 = ws + l.a1; m.h1 = ws + l.h1;
       m.y2 = ws + l.y2; m.stf = ws + w.fin_stats; m.enc = ws + w.enc;
       if (fold_sc) { m.fold_score = 1; m.sc = *fold_sc; }
+      m.x3 = make_wsplit(D, P, ws, w);
       TRY(launch_mlp_fwd_fused(m, st));
       fused_final = true;
       continue;
@@ -556,6 +577,7 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   const bool fs_fused = e.fs && ps_fusion_enabled() && d <= 128;
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   if (fold_sc) { e.fold_words = 1; e.sc = *fold_sc; }
+  e.split = make_wsplit(D, P, ws, w);
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
     GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);

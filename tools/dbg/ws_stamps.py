@@ -12,14 +12,14 @@ b = synth.make_tem_batch(1, B, P_, V, word_dists=wd).to('cuda')
 lib = ctypes.CDLL(_lib.lib_path())
 for _ in range(5):
     m(b)
-buf = torch.zeros(128, dtype=torch.int64, device='cuda')
+buf = torch.zeros(256, dtype=torch.int64, device='cuda')
 lib.ps_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 with torch.no_grad():
     m(b)
 torch.cuda.synchronize()
 lib.ps_debug_set_stamp_buffer(ctypes.c_void_p(0))
 t = buf.cpu().tolist()
-M, H = t[:64], t[64:]
+M, H = t[:128], t[128:]
 t0 = min(M[0], H[0])
 NS = 18
 print("slab  M:start  M:work  M:wait | H:start  H:work  H:wait   (cycles; work = start->barrier arrival, wait = arrival->next start)")
@@ -28,4 +28,4 @@ for s in range(NS):
     hs, he, hn = H[2 * s], H[2 * s + 1], H[2 * s + 2]
     print("%3d  %8d %7d %7d | %8d %7d %7d" % (s, ms - t0, me - ms, mn - me, hs - t0, he - hs, hn - he))
 print("total M %d  H %d cycles" % (M[2 * NS] - t0, H[2 * NS] - t0))
-print("final stage (rel. to slab 17 start): M", [M[i] - M[34] for i in range(40, 45)], " H", [H[i] - H[34] for i in range(40, 45)])
+
