@@ -367,3 +367,162 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
+
+// ================================================================== one wave per sequence (fan == 1)
+// Without dropout replicas (the review transformer: 1,536 sequences of 51 positions, 27 % of them real; TEM without
+// dropout) a sequence's attention is ~14 keys x 128 columns of work: the workgroup form above spends its time in barriers
+// and LDS staging (71 us for the C4 backward, 4 rounds of 3 workgroups per CU).  Here a WAVE owns a sequence, all heads:
+// a K / V row is read as one float4 per lane (LPR = d/4 lanes per row, 64/LPR keys per step), a head's dot product is a
+// reduction over its dh/4 neighbouring lanes, the per-(key, head) softmax terms wait in 4 KB of LDS between the two passes,
+// and nothing synchronises until the workgroup's four sequences multiply their dq rows into Wq together (AttnArgs::wq).
+#define W1_MAXH 8
+__device__ inline float4 f4_ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void f4_st(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline float f4_dot(const float4& x, const float4& y) { return (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w); }
+__device__ inline void f4_fma(float4& acc, float s, const float4& v) { acc.x = fmaf(s, v.x, acc.x); acc.y = fmaf(s, v.y, acc.y); acc.z = fmaf(s, v.z, acc.z); acc.w = fmaf(s, v.w, acc.w); }
+__device__ inline float4 f4_scale(float s, const float4& v) { return make_float4(s * v.x, s * v.y, s * v.z, s * v.w); }
+__device__ inline float4 f4_xor_add(const float4& v, int o) {
+  return make_float4(v.x + __shfl_xor(v.x, o, 64), v.y + __shfl_xor(v.y, o, 64), v.z + __shfl_xor(v.z, o, 64), v.w + __shfl_xor(v.w, o, 64));
+}
+// valid key positions of sequence b: lane s holds the flag; returns the mask, writes the ascending position list
+__device__ inline unsigned long long w1_valid(const AttnArgs& a, int b, int lane, int* sp) {
+  const int brow = b / a.seq_div;
+  const bool v = lane < a.S && (a.valid ? a.valid[(size_t)brow * a.S + lane] != 0.f
+                                        : (lane == 0 || a.ui[(size_t)brow * a.L + lane - 1] != a.P));
+  const unsigned long long vm = __ballot(v);
+  if (v) sp[__popcll(vm & ((1ull << lane) - 1ull))] = lane;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return vm;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int pads_unread) {
+  constexpr int D = 4 * LPR, KPS = 64 / LPR;
+  __shared__ int sp[4][64];
+  __shared__ float pl[4][64][W1_MAXH], dpl[4][64][W1_MAXH];
+  __shared__ float dqs[4][D];
+  __shared__ float part[256 / D][4][D];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = (int)blockIdx.x * 4 + wv;
+  const int S = a.S, HF = a.H, lph = a.dh >> 2;
+  const int sub = lane / LPR, cl = lane % LPR, c = 4 * cl, h = cl / lph;
+  if (b < a.n_in) {
+    const unsigned long long vm = w1_valid(a, b, lane, sp[wv]);
+    const int Sv = __popcll(vm);
+    const float4 dc4 = f4_ld(a.dctx + (size_t)b * D + c);
+    const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
+    float th = 0.f;
+    const uint32_t drow = (uint32_t)(b * HF + h);
+    for (int k0 = 0; k0 < Sv; k0 += KPS) {
+      const int k = k0 + sub;
+      const bool on = k < Sv;
+      const int p = on ? sp[wv][k] : 0;
+      const size_t row = (size_t)b * S + p;
+      const float4 v4 = on ? f4_ld(a.vp + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float P = on ? a.attn[((size_t)b * HF + h) * S + p] : 0.f;
+      const float m = !on ? 0.f : (a.drop.thr ? drop_mult(a.drop, drow, (uint32_t)p) : 1.f);
+      float dot = f4_dot(dc4, v4);
+      for (int o = 1; o < lph; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      const float dP = m * dot;
+      th = fmaf(P, dP, th);
+      if (on) {
+        const float4 dv4 = f4_scale(P * m, dc4);
+        f4_st(a.dkv + row * a.lddkv + D + c, dv4);
+        sv4.x += dv4.x; sv4.y += dv4.y; sv4.z += dv4.z; sv4.w += dv4.w;
+        if ((cl & (lph - 1)) == 0) { pl[wv][k][h] = P; dpl[wv][k][h] = dP; }
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) th += __shfl_xor(th, o, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k0 = 0; k0 < Sv; k0 += KPS) {
+      const int k = k0 + sub;
+      const bool on = k < Sv;
+      const int p = on ? sp[wv][k] : 0;
+      const size_t row = (size_t)b * S + p;
+      const float4 k4 = on ? f4_ld(a.kp + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float g = on ? pl[wv][k][h] * (dpl[wv][k][h] - th) : 0.f;        // softmax backward
+      f4_fma(dq4, g, k4);
+      if (on) {
+        const float4 dk4 = f4_scale(g, q4);
+        f4_st(a.dkv + row * a.lddkv + c, dk4);
+        sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { dq4 = f4_xor_add(dq4, o); sk4 = f4_xor_add(sk4, o); sv4 = f4_xor_add(sv4, o); }
+    if (!pads_unread) {                                      // masked positions: exact zeros (dense consumers read them)
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < S; s0 += KPS) {
+        const int s = s0 + sub;
+        if (s < S && !((vm >> s) & 1ull)) {
+          float* o = a.dkv + ((size_t)b * S + s) * a.lddkv;
+          f4_st(o + c, z); f4_st(o + D + c, z);
+        }
+      }
+    }
+    dq4 = f4_scale(a.qscale, dq4);
+    if (sub == 0) {
+      f4_st(a.dq + (size_t)b * a.lddq + c, dq4);
+      f4_st(&dqs[wv][c], dq4);
+      if (a.bias_part) {                                     // parked: folded by the step's last launch
+        float* bp = a.bias_part + (size_t)b * 3 * D + c;
+        f4_st(bp, dq4); f4_st(bp + D, sk4); f4_st(bp + 2 * D, sv4);
+      } else {
+        const float dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w}, skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w}, svv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&a.dbq[c + e], dqv[e]); atomicAdd(&a.dbk[c + e], skv[e]); atomicAdd(&a.dbv[c + e], svv[e]);
+        }
+      }
+    }
+  } else if (sub == 0) {
+    f4_st(&dqs[wv][c], make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  if (!a.wq) return;
+  // d x[query row] += dq . Wq (+ the fan-in residual row): thread (part, i) owns output column i and D/NP of the D features
+  __syncthreads();
+  constexpr int NP = 256 / D, KP = D / NP;
+  const int i = tid % D, pt = tid / D;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* wcol = a.wq + (size_t)(pt * KP) * D + i;
+#pragma unroll 16
+  for (int k = 0; k < KP; ++k) {
+    const float wv2 = wcol[(size_t)k * D];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = fmaf(dqs[s][pt * KP + k], wv2, acc[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) part[pt][s][i] = acc[s];
+  __syncthreads();
+  for (int e = tid; e < 4 * D; e += 256) {
+    const int s = e / D, col = e - s * D, bb = (int)blockIdx.x * 4 + s;
+    if (bb >= a.n_in) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v += part[q][s][col];
+    if (a.fanin_src) v += a.fanin_src[(size_t)bb * D + col];
+    a.dxq_part[(size_t)bb * D + col] = v;
+  }
+}
+
+bool attn_w1_fits(const AttnArgs& a) {
+  static const bool on = !(getenv("PS_ATTN_W1") && atoi(getenv("PS_ATTN_W1")) == 0);
+  const int lph = a.dh / 4;
+  return on && a.Sq == 1 && a.fan == 1 && a.S <= 64 && (a.d == 128 || a.d == 64) && a.H <= W1_MAXH && a.dh % 4 == 0 &&
+         lph >= 1 && (lph & (lph - 1)) == 0 && a.dh * a.H == a.d;
+}
+int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st) {
+  PS_REQUIRE(attn_w1_fits(a), "attention bwd(w1): unsupported shape");
+  PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(w1): folded dQ.Wq needs its output row buffer");
+  const dim3 grid(ps_cdiv(a.n_in, 4));
+  if (a.d == 128) hipLaunchKernelGGL(attn_bwd_w1_kernel<32>, grid, dim3(256), 0, st, a, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL(attn_bwd_w1_kernel<16>, grid, dim3(256), 0, st, a, pads_unread ? 1 : 0);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}

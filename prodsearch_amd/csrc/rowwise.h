@@ -84,6 +84,7 @@ struct EmbedArgs {
   // filled by the launcher (grid = B gather + samp_wgs + list_wgs + word_wgs workgroups)
   int fold_words; ScoreArgs sc; int word_wgs, list_wgs;
   WSplit split; int split_wgs;   // optional: re-split the fused kernels' weights (WSplit); split_wgs filled by the launcher
+  int32_t* zero_i32; int zero_n, zero_wgs;   // optional: int32 words to clear (the review transformer's word counters); zero_wgs filled by the launcher
 };
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);
 
@@ -153,6 +154,8 @@ int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
 bool attn_sq1_fits(const AttnArgs& a);
+bool attn_w1_fits(const AttnArgs& a);      // one wave per sequence (fan == 1, d 64 / 128)
+int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st);
 int attn_sq1_split(const AttnArgs& a);   // head groups (workgroups) per sequence the sq1 kernels will use
 
 struct EmbedBwdArgs {

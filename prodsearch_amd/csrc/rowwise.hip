@@ -135,6 +135,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     }
     return;
   }
+  if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs + a.split_wgs) {   // EmbedArgs::zero_i32
+    const int i = (((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs - a.split_wgs) * 256 + (int)threadIdx.x) * 4;
+    if (i + 3 < a.zero_n) *reinterpret_cast<int4*>(a.zero_i32 + i) = make_int4(0, 0, 0, 0);
+    else for (int j = i; j < a.zero_n; ++j) a.zero_i32[j] = 0;
+    return;
+  }
   if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs) {   // weight re-split (EmbedArgs::split)
     const WSplit& W = a.split;
     int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;   // float4 index
@@ -334,7 +340,9 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
     b.split_wgs = ps_cdiv(n4, 256);
   }
   PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist + b.word_wgs + b.split_wgs), dim3(256),
+  b.zero_wgs = a.zero_i32 && a.zero_n > 0 ? ps_cdiv(a.zero_n, 1024) : 0;
+  PS_REQUIRE(!b.zero_wgs || ((uintptr_t)a.zero_i32 & 15) == 0, "embed: zero_i32 must be 16-byte aligned");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(a.B + nsamp + nlist + b.word_wgs + b.split_wgs + b.zero_wgs), dim3(256),
                      (size_t)(rpp + 2) * a.d * sizeof(float), st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -26,7 +26,9 @@ struct RtmWs {
   int Bseq, S, J;
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
-  int64_t wcnt, woff, wcur, wl_slot, wl_word;   // pvc backward: inverted index word -> review slots (int32 arrays)
+  int64_t wrank;
+  int64_t wcnt, woff, wcur, wl;   // pvc backward: inverted index word -> review slots (int32 arrays; wl: int2 {slot, word})
+  int64_t segpart;          // [ceil(Bseq*S / 64)][3][d] parked segment-embedding gradient partials (rtm_embed_bwd_kernel)
   int64_t raw, yfs, dpre, dmean;                // fs review encoder: [Bseq*R, d] dropped means, projections, their gradients
   int64_t enc_base;         // the shared encoder workspace (Ws) starts here
   int64_t total;
@@ -55,7 +57,8 @@ struct RtmK {              // kernel-side view of one call
   // workspace
   float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *weight, *pv_scores, *pv_terms, *nvalid;
   int32_t *seqcnt, *vrows, *vcount;   // valid-row list of x (GemmProblem::ridx): per-sequence counts, rows, length
-  int count_words;                    // rtm_embed_bwd_kernel also counts the word occurrences (0: rtm_wcount_kernel did, early)
+  int count_words;                    // rtm_embed_bwd_kernel also counts the word occurrences (0: the forward did)
+  int count_fwd;                      // rtm_embed4_kernel counts them (the counters were cleared by the query-encoder launch)
   float* loss3;
   // backward
   float scale; const float* scale_dev;
@@ -63,7 +66,9 @@ struct RtmK {              // kernel-side view of one call
   float *g_word_emb, *g_table, *g_seg_emb, *g_wo_w, *g_wo_b;
   // pvc backward through an inverted index (word -> review slots) instead of one atomic row per word occurrence
   float* gs;                  // = dx, rewritten in place: row (n, s) becomes the gradient each of its words receives
-  int *wcnt, *woff, *wcur, *wl_slot, *wl_word;
+  int *wcnt, *woff, *wcur;
+  int2* wl;                   // the occurrence list: {slot, word}, one 8-byte store per occurrence
+  int* wrank;                 // [B*R + B*K*R][WL] rank of a counted word among its word's occurrences, -1: not counted (count_fwd)
 };
 
 static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
@@ -116,19 +121,20 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
   r.dqe = rtake(cur, (int64_t)D.B * d);          // dqe and wcnt are adjacent: the backward zeroes both with ONE memset
-  r.wcnt = r.woff = r.wcur = r.wl_slot = r.wl_word = 0;
+  r.wcnt = r.woff = r.wcur = r.wl = r.wrank = 0;
   r.raw = r.yfs = r.dpre = r.dmean = 0;
   if (!eval && D.review_encoder != PS_RENC_PV) {
-    r.wcnt = rtake(cur, D.vocab_size);
+    r.wcnt = rtake(cur, D.vocab_size + 1);        // [V] occurrence counts + the segment allocator's running total
     r.woff = rtake(cur, D.vocab_size + 1);
     r.wcur = rtake(cur, D.vocab_size);
-    r.wl_slot = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
-    r.wl_word = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
+    r.wl = rtake(cur, 2 * (int64_t)r.Bseq * D.R * D.WL);
+    r.wrank = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
   }
   if (!eval && D.review_encoder == PS_RENC_FS) {     // (behind the index arrays: dqe .. wcnt must stay one contiguous memset)
     const int64_t nr = (int64_t)r.Bseq * D.R * d;
     r.raw = rtake(cur, nr); r.yfs = rtake(cur, nr); r.dpre = rtake(cur, nr); r.dmean = rtake(cur, nr);
   }
+  r.segpart = eval ? 0 : rtake(cur, (int64_t)ps_cdiv((int64_t)r.Bseq * r.S, 4 * 16) * 3 * d);
   r.enc_base = cur;
   TRY(make_ws(E, w));
   r.total = cur + w.total;
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   // 73 % of the review slots of a C4 batch are padding: a group without a real review skips the Philox evaluations, the
   // lists and the gather (wave-uniform branch) and only writes its masked rows
   const bool any_ok = okq[0] || okq[1] || okq[2] || okq[3];
+  int cwa[4] = {-1, -1, -1, -1}, cwb[4] = {-1, -1, -1, -1};     // the counted words of slots lane / lane + 64 (-1: none)
   if (any_ok) {
     // ---- the word slots and their token masks
     Philox4 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
@@ -486,6 +493,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       const unsigned long long lt = (1ull << lane) - 1ull;
       nwq[q] = __popcll(__ballot(va)) + __popcll(__ballot(vb));
       nlq[q] = __popcll(ma) + __popcll(mb);
+      cwa[q] = va ? (int)wa64 : -1; cwb[q] = vb ? (int)wb64 : -1;
       if (ka) { const int p = __popcll(ma & lt); L.wid[wv][q][p] = (int)wa64; L.tm[wv][q][p] = tm0; }
       if (kb) { const int p = __popcll(ma) + __popcll(mb & lt); L.wid[wv][q][p] = (int)wb64; L.tm[wv][q][p] = tm1; }
     }
@@ -531,9 +539,20 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       }
   }
 
+  // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
+  // occurrences of that word (a returning atomic on the word's counter, in flight under the rest of the kernel); the fill
+  // then places the occurrence at  segment start + rank  without another atomic
+  int rka[4], rkb[4];
+  if (a.count_fwd && any_ok) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      rka[qq] = cwa[qq] >= 0 ? atomicAdd(&a.wcnt[cwa[qq]], 1) : -1;
+      rkb[qq] = cwb[qq] >= 0 ? atomicAdd(&a.wcnt[cwb[qq]], 1) : -1;
+    }
+  }
   // ---- 4. this group's review: mean, dropout, segment / user / item rows, mask, positional row
   const bool live = q == 0 ? liveq[0] : (q == 1 ? liveq[1] : (q == 2 ? liveq[2] : liveq[3]));
-  if (!live) return;
+  if (live) {
   const bool ok = q == 0 ? okq[0] : (q == 1 ? okq[1] : (q == 2 ? okq[2] : okq[3]));
   const int n = q == 0 ? nq[0] : (q == 1 ? nq[1] : (q == 2 ? nq[2] : nq[3]));
   const int s = q == 0 ? sq[0] : (q == 1 ? sq[1] : (q == 2 ? sq[2] : sq[3]));
@@ -572,6 +591,16 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     if (need_unc)                                   // the PV loss predicts from the corrupted mean (PVC.py:78)
       *reinterpret_cast<float4*>(a.vec + (size_t)rr * d + col0) =
           ok ? make_float4(cor[0], cor[1], cor[2], cor[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  }
+  if (a.count_fwd && any_ok) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+      if (okq[qq]) {
+        int* rk = a.wrank + ((size_t)(pos ? 0 : a.B * a.R) + rrq[qq]) * a.WL;
+        if (lane < a.WL) rk[lane] = rka[qq];
+        if (lane + 64 < a.WL) rk[lane + 64] = rkb[qq];
+      }
   }
 }
 
@@ -747,182 +776,244 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
     }
 }
 
-// Backward of rtm_embed: one wave per (sequence, position), grid-strided so that the 4 segment-embedding rows
-// are reduced in LDS before touching the (very contended) global atomics.
-__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a) {
-  extern __shared__ float segacc[];               // [4][d]
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, c = lane & 31;
-  const int d = a.d, epl = d >> 5;
-  for (int e = threadIdx.x; e < 4 * d; e += 256) segacc[e] = 0.f;
-  __syncthreads();
-  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
+// Backward of rtm_embed.  A wave owns EB_SPW consecutive (sequence, position) slots: lane i decodes slot i (one
+// coalesced read of the indices), a ballot keeps the real ones (27 % on a C4 batch) and the wave walks them two at a
+// time, so the dependent chain per wave is ~3 pairs instead of the 38 slots of the round-1 grid-stride loop (69 us,
+// latency-bound).  Lane l owns columns l, l + 64, ...  The segment-embedding gradient (3 rows fed by EVERY slot) is
+// summed in registers, combined over the workgroup's waves in LDS and PARKED as one [3][d] partial per workgroup
+// (`seg_part`, folded by the step's last launch, ColFoldList) instead of 3d same-address atomics per workgroup.
+#define EB_SPW 16
+template <int NK>      // columns per lane: d <= 64 * NK
+__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part) {
+  __shared__ float segs[4][3][64 * NK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int d = a.d;
+  const int nslots = a.B * a.J * a.S;
   const int64_t rpad = a.RC - 1;
-  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
-    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
-    int b, j, revrow, seg; int64_t ridx; size_t spos;
-    seq_decode(a, n, s, b, j, ridx, revrow, seg, &spos);
-    const bool pos = j == 0;
-    const bool ok = s == 0 || ridx != rpad;
-    if (!ok) continue;
-    const float* g = a.dx + ((size_t)n * a.S + s) * d;
-    float gk[16];
+  const int base = ((int)blockIdx.x * 4 + wv) * EB_SPW;
+  // ---- lane i < EB_SPW: where slot base + i sits
+  int my_n = 0, my_s = 0, my_b = 0, my_rev = 0, my_seg = 3, my_pos = 0;
+  int64_t my_ridx = rpad; size_t my_spos = 0;
+  bool okl = false;
+  if (lane < EB_SPW && base + lane < nslots) {
+    const int slot = base + lane;
+    my_n = fdiv(slot, a.fS); my_s = slot - my_n * a.S;
+    int j;
+    seq_decode(a, my_n, my_s, my_b, j, my_ridx, my_rev, my_seg, &my_spos);
+    my_pos = j == 0;
+    okl = my_s == 0 || my_ridx != rpad;
+  }
+  unsigned long long todo = __ballot(okl);
+  float sacc[3][NK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) gk[k] = k < epl ? g[c + 32 * k] : 0.f;
-    if (half == 0 && (a.g_user_emb || a.g_item_emb)) {      // user / item embedding rows of this position
-      const int64_t uid = a.g_user_emb ? (pos ? a.pos_u : a.neg_u)[spos] : -1;
-      const int64_t iid = a.g_item_emb ? (pos ? a.pos_i : a.neg_i)[spos] : -1;
+  for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k < epl) {
-          if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + c + 32 * k], gk[k]);
-          if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + c + 32 * k], gk[k]);
-        }
-    }
-    if (a.use_seg && half == 0) {
+    for (int k = 0; k < NK; ++k) sacc[q][k] = 0.f;
+  while (todo) {
+    int li[2]; bool on[2];
+    li[0] = __ffsll((long long)todo) - 1; todo &= todo - 1; on[0] = true;
+    on[1] = todo != 0;
+    li[1] = on[1] ? __ffsll((long long)todo) - 1 : li[0];
+    if (on[1]) todo &= todo - 1;
+    int n[2], sx[2], bb[2], rev[2], seg[2]; bool pos[2];
+    float gk[2][NK], src[2][NK], dv[2][NK], cntv[2];
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k < epl) atomicAdd(&segacc[seg * d + c + 32 * k], gk[k]);
-    }
-    if (s == 0) {
-      if (half == 0) {
+    for (int u = 0; u < 2; ++u) {
+      n[u] = __shfl(my_n, li[u], 64); sx[u] = __shfl(my_s, li[u], 64); bb[u] = __shfl(my_b, li[u], 64);
+      rev[u] = __shfl(my_rev, li[u], 64); seg[u] = __shfl(my_seg, li[u], 64); pos[u] = __shfl(my_pos, li[u], 64) != 0;
+      const float* g = a.dx + ((size_t)n[u] * a.S + sx[u]) * d;
+      const bool rv = on[u] && sx[u] > 0;
+      const float* gm = a.dmean ? a.dmean + ((pos[u] ? (size_t)rev[u] : (size_t)a.B * a.R + rev[u])) * d : g;
+      const bool wantdv = rv && pos[u] && a.train_pv;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < epl) atomicAdd(&a.dqe[(size_t)b * d + c + 32 * k], gk[k]);
-      }
-      continue;
-    }
-    // through dropout_layer (and, pv positive with train_pv, the PV drop_layer + the PV-loss gradient)
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (k < epl) {
-        const uint32_t col = (uint32_t)(c + 32 * k);
+      for (int k = 0; k < NK; ++k) {
+        const int col = lane + 64 * k;
+        const bool in = on[u] && col < d;
+        gk[u][k] = in ? g[col] : 0.f;
         // fs: the review vector reached x through tanh(f_W . raw + b); its input gradient d raw was left in a.dmean
-        const float gsrc = a.dmean ? a.dmean[((pos ? (size_t)revrow : (size_t)a.B * a.R + revrow)) * d + col] : gk[k];
-        float t = gsrc * drop_mult(pos ? a.d_pos : a.d_neg, (uint32_t)revrow, col);
-        if (pos && a.train_pv) {
-          t += a.dvec[(size_t)revrow * d + col];
-          if (!a.pvc) t *= drop_mult(a.d_pv, (uint32_t)revrow, col);
-        }
-        gk[k] = t;
+        src[u][k] = (in && rv && a.dmean) ? gm[col] : gk[u][k];
+        dv[u][k] = (wantdv && col < d) ? a.dvec[(size_t)rev[u] * d + col] : 0.f;
       }
-    if (!a.pvc) {
-      if (half == 0) {
+      cntv[u] = (rv && a.pvc) ? a.cnt[(size_t)n[u] * a.R + sx[u] - 1] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;                            // wave-uniform
+      if (a.g_user_emb || a.g_item_emb) {              // user / item embedding rows of this position
+        const size_t spos = __shfl((unsigned long long)my_spos, li[u], 64);
+        const int64_t uid = a.g_user_emb ? (pos[u] ? a.pos_u : a.neg_u)[spos] : -1;
+        const int64_t iid = a.g_item_emb ? (pos[u] ? a.pos_i : a.neg_i)[spos] : -1;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int col = lane + 64 * k;
+          if (col < d) {
+            if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + col], gk[u][k]);
+            if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + col], gk[u][k]);
+          }
+        }
+      }
+      if (a.use_seg && seg[u] < 3) {                   // row 3 is the padding_idx of seg_embeddings: no gradient
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (seg[u] == 0) sacc[0][k] += gk[u][k];
+          else if (seg[u] == 1) sacc[1][k] += gk[u][k];
+          else sacc[2][k] += gk[u][k];
+        }
+      }
+      if (sx[u] == 0) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+          if (lane + 64 * k < d) atomicAdd(&a.dqe[(size_t)bb[u] * d + lane + 64 * k], gk[u][k]);
+        continue;
+      }
+      // through dropout_layer (and, pv positive with train_pv, the PV drop_layer + the PV-loss gradient)
+      float t[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const uint32_t col = (uint32_t)(lane + 64 * k);
+        t[k] = 0.f;
+        if ((int)col < d) {
+          float v = src[u][k] * drop_mult(pos[u] ? a.d_pos : a.d_neg, (uint32_t)rev[u], col);
+          if (pos[u] && a.train_pv) {
+            v += dv[u][k];
+            if (!a.pvc) v *= drop_mult(a.d_pv, (uint32_t)rev[u], col);
+          }
+          t[k] = v;
+        }
+      }
+      if (!a.pvc) {
+        const int64_t ridx = __shfl((long long)my_ridx, li[u], 64);
         float* grow = a.g_table + (size_t)rclamp(ridx, rpad) * d;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < epl) atomicAdd(&grow[c + 32 * k], gk[k]);
-      }
-    } else {
-      // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
-      const float inv = 1.f / a.cnt[(size_t)n * a.R + s - 1];
-      const int64_t* words;
-      if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
-      else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
-      // 1.2 M word occurrences x 512 B of fp32 atomics per step ran at 0.7 TB/s; instead the row is rewritten in
-      // place as the per-word gradient and the words are only COUNTED here (rtm_wfill / rtm_wreduce do the rest)
-      float* gw = a.gs + ((size_t)n * a.S + s) * d;
-      if (half == 0) {
+        for (int k = 0; k < NK; ++k)
+          if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], t[k]);
+      } else {
+        // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
+        // 1.2 M word occurrences x 512 B of fp32 atomics per step ran at 0.7 TB/s; instead the row is rewritten in
+        // place as the per-word gradient (rtm_wreduce_kernel sums the rows of a word's occurrences through the index)
+        const float inv = 1.f / cntv[u];
+        float* gw = a.gs + ((size_t)n[u] * a.S + sx[u]) * d;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < epl) gw[c + 32 * k] = gk[k] * inv;
-      }
-      if (a.count_words) {
-        const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
-        for (int w = lane; w < a.WL; w += 64) {
-          const int64_t wi = words[w];
-          if (word_ok(a, wm, (size_t)revrow * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
+        for (int k = 0; k < NK; ++k)
+          if (lane + 64 * k < d) gw[lane + 64 * k] = t[k] * inv;
+        if (a.count_words) {                           // the index is built behind this kernel (no side stream)
+          const int64_t* words;
+          if (pos[u]) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)bb[u] * a.R + sx[u] - 1) * a.WL;
+          else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)rev[u] * a.WL;
+          const uint8_t* wm = pos[u] ? a.wmask_pos : a.wmask_neg;
+          for (int w = lane; w < a.WL; w += 64) {
+            const int64_t wi = words[w];
+            if (word_ok(a, wm, (size_t)rev[u] * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
+          }
         }
       }
     }
   }
+  if (!a.use_seg) return;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (lane + 64 * k < d) segs[wv][q][lane + 64 * k] = sacc[q][k];
   __syncthreads();
-  if (a.use_seg)
-    for (int e = threadIdx.x; e < 3 * d; e += 256)      // row 3 is the padding_idx of seg_embeddings: no gradient
-      atomicAdd(&a.g_seg_emb[e], segacc[e]);
+  for (int e = threadIdx.x; e < 3 * d; e += 256) {
+    const int q = e / d, col = e - q * d;
+    seg_part[(size_t)blockIdx.x * 3 * d + e] = (segs[0][q][col] + segs[1][q][col]) + (segs[2][q][col] + segs[3][q][col]);
+  }
 }
 
-// exclusive scan of the per-word counts (V <= a few 10k: one workgroup), cursor reset.  Each lane owns a run of
-// `per` (multiple of 4) consecutive words and moves them as 16-byte vectors; the runs meet in one LDS scan.
-__global__ __launch_bounds__(1024) void rtm_wscan_kernel(const int* cnt, int* off, int* cur, int V) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (((V + 1023) / 1024) + 3) & ~3;
-  const int beg = tid * per, end = min(V, beg + per);
-  int s = 0;
-  for (int i = beg; i < end; i += 4) {
-    if (i + 3 < V) { const int4 v = *reinterpret_cast<const int4*>(cnt + i); s += (v.x + v.y) + (v.z + v.w); }
-    else for (int j = i; j < end; ++j) s += cnt[j];
+// segment of every word in the occurrence list, cursor reset.  wreduce needs a word's occurrences CONTIGUOUS, not the
+// segments in word order, so instead of a scan (one workgroup, 27 us for 32k words) every wave sums its 64 counts and
+// bumps one running total (`tot`, zeroed with the counts) by the sum; the total ends as the list length.
+__global__ __launch_bounds__(256) void rtm_walloc_kernel(const int* cnt, int* off, int* cur, int* tot, int V) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = w < V ? cnt[w] : 0;
+  int incl = c;                                            // inclusive prefix over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  part[tid] = s;
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd(tot, total);
+  base = __shfl(base, 63, 64);
+  if (w < V) { off[w] = base + incl - c; cur[w] = 0; }
+}
+
+// ---- the inverted index word -> review slots: count, allocate (rtm_walloc_kernel), fill.
+// The index depends on the batch's indices only, not on any gradient (rtm_index_in_forward).  Round 1 walked the slots one
+// wave per slot, 38 slots in a row per wave: each step of that walk is a chain of dependent reads (review id -> word ids ->
+// atomic), 56 us to count and 70 us to fill.  (Aggregating a workgroup's words in an LDS hash table first was measured and
+// is slower: a chunk's words are mostly distinct, the popular ones are not what costs.)  Now
+//   * the count rides in rtm_embed4_kernel, which has every word id in registers anyway (RtmK::count_fwd);
+//   * the fill (and the count, when it does not ride) flattens a chunk of slots: the workgroup lists its real reviews, then
+//     its threads stride over (review, word slot) pairs, four independent reads / atomics in flight per lane.
+#define WI_CHUNK_MAX 256
+template <int FILL>     // 0: count, 1: fill (a returning atomic on the word's cursor per occurrence), 2: fill from the ranks
+__global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk, FDiv fWL) {
+  __shared__ int l_rev[WI_CHUNK_MAX], l_slot[WI_CHUNK_MAX];     // rev: review row on its side, ~row for a positive
+  __shared__ int l_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nslots = a.B * a.J * a.S;
+  const int64_t rpad = a.RC - 1;
+  if (tid == 0) l_n = 0;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int add = tid >= o ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += add;
-    __syncthreads();
+  {
+    const int slot = (int)blockIdx.x * chunk + tid;
+    bool real = false; int enc = 0;
+    if (tid < chunk && slot < nslots) {
+      const int n = fdiv(slot, a.fS), s = slot - n * a.S;
+      if (s > 0) {
+        int b, j, seg, rev; int64_t ridx;
+        seq_decode(a, n, s, b, j, ridx, rev, seg);
+        real = ridx != rpad;
+        enc = j == 0 ? ~rev : rev;
+      }
+    }
+    const unsigned long long m = __ballot(real);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&l_n, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (real) { const int at = base + __popcll(m & ((1ull << lane) - 1ull)); l_rev[at] = enc; l_slot[at] = slot; }
   }
-  int run = part[tid] - s;
-  const int4 zero = make_int4(0, 0, 0, 0);
-  for (int i = beg; i < end; i += 4) {
-    if (i + 3 < V) {
-      const int4 v = *reinterpret_cast<const int4*>(cnt + i);
-      int4 o;
-      o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z; run = o.w + v.w;
-      *reinterpret_cast<int4*>(off + i) = o;
-      *reinterpret_cast<int4*>(cur + i) = zero;
+  __syncthreads();
+  const int total = l_n * a.WL;
+  for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+    int64_t wi[4]; int sl[4], rk[4]; bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      const bool in = i < total;
+      const int r = in ? fdiv(i, fWL) : 0, w = i - r * a.WL;
+      const int enc = l_rev[r];
+      const bool pos = enc < 0;
+      const int rev = pos ? ~enc : enc;
+      const int64_t* words = (pos ? (a.train_pv ? a.pos_pvc : a.pos_words) : (a.train_pv ? a.neg_pvc : a.neg_words_rev));
+      const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
+      const size_t off = (size_t)rev * a.WL + (in ? w : 0);
+      wi[u] = in ? words[off] : -1;
+      if (FILL == 2) {
+        rk[u] = in ? a.wrank[((size_t)(pos ? 0 : a.B * a.R) + rev) * a.WL + w] : -1;
+        ok[u] = rk[u] >= 0;
+      } else {
+        ok[u] = in && word_ok(a, wm, off, wi[u]);
+      }
+      sl[u] = l_slot[r];
+    }
+    if (FILL == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) atomicAdd(&a.wcnt[wi[u]], 1);
     } else {
-      for (int j = i; j < end; ++j) { off[j] = run; run += cnt[j]; cur[j] = 0; }
-    }
-  }
-  if (tid == 1023) off[V] = part[1023];
-}
-
-// occurrences per word (the first pass of the inverted index).  The index depends on the batch's indices only, not on
-// any gradient, so count -> scan -> fill run on the side stream from the START of the backward, under the encoder
-// backward, instead of between rtm_embed_bwd_kernel and rtm_wreduce_kernel on its tail
-__global__ __launch_bounds__(256) void rtm_wcount_kernel(const RtmK a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
-  const int64_t rpad = a.RC - 1;
-  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
-    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
-    if (s == 0) continue;
-    int b, j, revrow, seg; int64_t ridx;
-    seq_decode(a, n, s, b, j, ridx, revrow, seg);
-    if (ridx == rpad) continue;
-    const bool pos = j == 0;
-    const int64_t* words;
-    if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
-    else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
-    const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
-    for (int w = lane; w < a.WL; w += 64) {
-      const int64_t wi = words[w];
-      if (word_ok(a, wm, (size_t)revrow * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
-    }
-  }
-}
-
-// word -> list of review slots: every non-pad word occurrence appends its slot to its word's segment
-__global__ __launch_bounds__(256) void rtm_wfill_kernel(const RtmK a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nslots = a.B * a.J * a.S, nw = gridDim.x * 4;
-  const int64_t rpad = a.RC - 1;
-  for (int slot = blockIdx.x * 4 + wv; slot < nslots; slot += nw) {
-    const int n = fdiv(slot, a.fS), s = slot - n * a.S;
-    if (s == 0) continue;
-    int b, j, revrow, seg; int64_t ridx;
-    seq_decode(a, n, s, b, j, ridx, revrow, seg);
-    if (ridx == rpad) continue;
-    const bool pos = j == 0;
-    const int64_t* words;
-    if (pos) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)b * a.R + s - 1) * a.WL;
-    else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)revrow * a.WL;
-    for (int w = lane; w < a.WL; w += 64) {
-      const int64_t wi = words[w];
-      if (!word_ok(a, pos ? a.wmask_pos : a.wmask_neg, (size_t)revrow * a.WL + w, wi)) continue;
-      const int e = a.woff[wi] + atomicAdd(&a.wcur[wi], 1);
-      a.wl_slot[e] = slot;
-      a.wl_word[e] = (int)wi;
+      int at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        at[u] = !ok[u] ? 0 : a.woff[wi[u]] + (FILL == 2 ? rk[u] : atomicAdd(&a.wcur[wi[u]], 1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) a.wl[at[u]] = make_int2(sl[u], (int)wi[u]);
     }
   }
 }
@@ -932,12 +1023,13 @@ __global__ __launch_bounds__(256) void rtm_wfill_kernel(const RtmK a) {
 __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int T = a.woff[a.V];
+  const int T = a.wcnt[a.V];                         // the allocator's total (rtm_walloc_kernel)
   const int base = wave * 64;
   if (base >= T) return;
   const int d = a.d;                                 // lane l owns columns l, l+64, ... (< d <= 512)
   const int e = base + lane;
-  const int my_slot = e < T ? a.wl_slot[e] : -1, my_word = e < T ? a.wl_word[e] : -1;
+  const int2 mine = e < T ? a.wl[e] : make_int2(-1, -1);
+  const int my_slot = mine.x, my_word = mine.y;
   const int n = min(64, T - base);
   float acc[8];
 #pragma unroll
@@ -1104,6 +1196,47 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   k.nvalid = ws + r.nvalid;
   k.seqcnt = reinterpret_cast<int32_t*>(ws + r.seqcnt);
   k.dx = we + w.dx; k.denc = we + w.denc; k.dvec = ws + r.dvec; k.dqe = ws + r.dqe;
+  if (r.wcnt) {
+    k.wcnt = (int*)(ws + r.wcnt); k.woff = (int*)(ws + r.woff); k.wcur = (int*)(ws + r.wcur);
+    k.wl = (int2*)(ws + r.wl); k.wrank = (int*)(ws + r.wrank);
+  }
+}
+
+// The inverted index word -> review slots of the pvc / fs / avg backward depends on the batch's indices only.  Its first
+// pass (per-word counts, and with them every occurrence's rank inside its word) rides in the training forward when that
+// embeds through rtm_embed4_kernel, which holds every word id in registers; the backward then only allocates and fills,
+// on the side stream under its first kernels.
+static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
+  static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
+  return e4_on && k.pvc && !k.eval && D.WL <= 128 && (D.d == 64 || D.d == 128 || D.d == 256) && r.S <= 64;
+}
+static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
+  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
+  return !late && rtm_embed4_taken(D, k, r);
+}
+// count (unless a kernel that reads the words anyway did), allocate, fill
+static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hipStream_t st) {
+  static const int env_chunk = getenv("PS_RTM_IDX_CHUNK") ? atoi(getenv("PS_RTM_IDX_CHUNK")) : 64;
+  const int nslots = r.Bseq * r.S;
+  const int chunk = env_chunk < 1 ? 1 : (env_chunk > WI_CHUNK_MAX ? WI_CHUNK_MAX : env_chunk), nwg = ps_cdiv(nslots, chunk);
+  const FDiv fWL = make_fdiv(k.WL > 0 ? k.WL : 1);
+  if (count) {
+    hipLaunchKernelGGL(rtm_windex_kernel<0>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
+    PS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(rtm_walloc_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.wcnt, k.woff, k.wcur, k.wcnt + V, V);
+  PS_LAUNCH_CHECK();
+  if (k.count_fwd) hipLaunchKernelGGL(rtm_windex_kernel<2>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
+  else hipLaunchKernelGGL(rtm_windex_kernel<1>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+// workgroups of the slot-walking kernels (measured, ms/step: 128 0.850, 256 0.764, 384 0.762, 512 0.734, 1024 0.749,
+// 2048 0.784, 4096 0.837)
+static int rtm_slot_blocks(const RtmWs& r) {
+  static const int eb_cap = getenv("PS_RTM_EB") ? atoi(getenv("PS_RTM_EB")) : 512;
+  int eb = ps_cdiv(r.Bseq * r.S, 4);
+  return eb > eb_cap ? eb_cap : eb;
 }
 
 static void to_tem_tensors(const PsRtmTensors& R, PsTemTensors& T) {
@@ -1147,6 +1280,10 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
     to_tem_tensors(P, Ts);
     e.split = make_wsplit(E, Ts, ws + r.enc_base, w);      // the fused kernels' bf16x3 weight planes ride in this launch
   }
+  // the backward's inverted index (rtm_counts_in_forward): its counters are cleared by this launch, filled by the next
+  const bool use_e4 = rtm_embed4_taken(D, k, r);
+  k.count_fwd = rtm_counts_in_forward(D, k, r);
+  if (k.count_fwd) { e.zero_i32 = k.wcnt; e.zero_n = (int)D.vocab_size + 1; }
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {
     GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);
@@ -1157,8 +1294,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   const int nslots = r.Bseq * r.S;
   {
     KTimeScope kt("rtm_embed", st);
-    static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
-    if (e4_on && k.pvc && !eval && D.WL <= 128 && (d == 64 || d == 128 || d == 256) && r.S <= 64) {
+    if (use_e4) {
       const int npos = ps_cdiv((int64_t)B * D.R, 4), nneg = ps_cdiv((int64_t)B * D.K * D.R, 4);
       const dim3 grid(ps_cdiv(npos + nneg + r.Bseq, 4));
       const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
@@ -1269,6 +1405,13 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   if (D.use_user_emb) { PS_REQUIRE(G.user_emb, "rtm backward: null user_emb gradient"); k.g_user_emb = G.user_emb; }
   if (D.use_item_emb) { PS_REQUIRE(G.product_emb, "rtm backward: null product_emb gradient"); k.g_item_emb = G.product_emb; }
   const int B = D.B, d = D.d;
+  const bool fwd_index = rtm_counts_in_forward(D, k, r);
+  k.count_fwd = fwd_index;
+  if (fwd_index) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
+    hipStream_t ss = side_stream_or(st);
+    if (ss != st) { side_set_light(false); TRY(side_fork(st)); }
+    TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));
+  }
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k);
   PS_LAUNCH_CHECK();
@@ -1281,34 +1424,14 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   to_tem_tensors(G, TG);
   ColFoldList fold;
   fold.n = 0;
-  // d query_emb (+ the inverted index's per-word counters right behind it, rtm_make_ws): one 16-byte-aligned memset
+  // d query_emb (+, when the index is built here, the per-word counters right behind it, rtm_make_ws): one memset
   {
-    const int64_t zend = k.pvc ? r.wcnt + (((int64_t)D.vocab_size + 3) & ~(int64_t)3) : r.dqe + (((int64_t)B * d + 3) & ~(int64_t)3);
+    const int64_t zend = k.pvc && !fwd_index ? r.wcnt + (((int64_t)D.vocab_size + 1 + 3) & ~(int64_t)3) : r.dqe + (((int64_t)B * d + 3) & ~(int64_t)3);
     PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)(zend - r.dqe), st));
   }
-  // workgroups of the slot-walking backward kernels (measured, ms/step: 128 0.850, 256 0.764, 384 0.762, 512 0.734, 1024 0.749,
-  // 2048 0.784, 4096 0.837: every workgroup ends with 3d same-address atomics for the segment embeddings)
-  static const int eb_cap = getenv("PS_RTM_EB") ? atoi(getenv("PS_RTM_EB")) : 512;
-  int eb = ps_cdiv(r.Bseq * r.S, 4); if (eb > eb_cap) eb = eb_cap;
-  if (k.pvc) {
-    k.gs = ws + r.enc_base + w.dx;
-    k.wcnt = (int*)(ws + r.wcnt); k.woff = (int*)(ws + r.woff); k.wcur = (int*)(ws + r.wcur);
-    k.wl_slot = (int*)(ws + r.wl_slot); k.wl_word = (int*)(ws + r.wl_word);
-  }
-  // the inverted index (count, scan, fill) on the side stream, under the encoder backward (rtm_wcount_kernel)
-  static const bool early_on = !(getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0);
-  hipStream_t ss = side_stream_or(st);
-  const bool early_index = k.pvc && early_on && ss != st;
-  k.count_words = early_index ? 0 : 1;
-  if (early_index) {
-    TRY(side_fork(st));                             // behind the memset of the counters
-    hipLaunchKernelGGL(rtm_wcount_kernel, dim3(eb), dim3(256), 0, ss, k);
-    PS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rtm_wscan_kernel, dim3(1), dim3(1024), 0, ss, k.wcnt, k.woff, k.wcur, (int)D.vocab_size);
-    PS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rtm_wfill_kernel, dim3(eb), dim3(256), 0, ss, k);
-    PS_LAUNCH_CHECK();
-  }
+  const int eb = rtm_slot_blocks(r);
+  if (k.pvc) k.gs = ws + r.enc_base + w.dx;
+  k.count_words = fwd_index ? 0 : 1;
   TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   if (D.review_encoder == PS_RENC_FS) {
     // through the review projection: d pre = dx * tanh', bias gradient, weight gradient, d raw = d pre . f_W
@@ -1323,16 +1446,26 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     TRY(run1(px, st));
     k.dmean = ws + r.dmean;
   }
-  hipLaunchKernelGGL(rtm_embed_bwd_kernel, dim3(eb), dim3(256), (size_t)4 * d * sizeof(float), st, k);
-  PS_LAUNCH_CHECK();
+  {
+    const int nwg = ps_cdiv(r.Bseq * r.S, 4 * EB_SPW);
+    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
+    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
+    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
+    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
+    PS_LAUNCH_CHECK();
+    if (D.use_seg_emb) {
+      PS_REQUIRE(fold.n < PS_MAX_COLFOLD, "rtm backward: too many parked column sums");
+      ColFold& f = fold.e[fold.n++];
+      f.partial = ws + r.segpart; f.nblk = nwg; f.d = d;
+      f.dst[0] = G.seg_emb; f.dst[1] = G.seg_emb + d; f.dst[2] = G.seg_emb + 2 * (size_t)d;
+    }
+  }
   if (k.pvc) {
-    if (early_index) {
-      TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
+    if (!fwd_index) {
+      const int V = (int)D.vocab_size;
+      TRY(rtm_build_index(k, r, V, false, st));
     } else {
-      hipLaunchKernelGGL(rtm_wscan_kernel, dim3(1), dim3(1024), 0, st, k.wcnt, k.woff, k.wcur, (int)D.vocab_size);
-      PS_LAUNCH_CHECK();
-      hipLaunchKernelGGL(rtm_wfill_kernel, dim3(eb), dim3(256), 0, st, k);
-      PS_LAUNCH_CHECK();
+      TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
     }
     const int64_t max_occ = (int64_t)r.Bseq * D.R * D.WL;
     hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)((max_occ + 255) / 256)), dim3(256), 0, st, k);

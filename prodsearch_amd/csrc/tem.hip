@@ -933,10 +933,16 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       }
       // first layer, one query row per sequence, d == 128: dQ.Wq rides in the attention backward's tail (two partial
       // rows per sequence in the free d ln1 buffer) instead of a [n_in,128]x[128,128] GEMM launch of its own
-      const bool q_folded = sq1 && !qall && i == 0 && d == 128 && attn_sq1_split(a) == 2 && ps_fusion_enabled() &&
-                            (size_t)2 * l.n_in <= (size_t)M2;
+      const bool w1 = sq1 && attn_w1_fits(a);           // one wave per sequence (no replicas)
+      const bool q_folded = sq1 && !qall && i == 0 && ps_fusion_enabled() &&
+                            (w1 ? (size_t)l.n_in <= (size_t)M2
+                                : d == 128 && attn_sq1_split(a) == 2 && (size_t)2 * l.n_in <= (size_t)M2);
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
-      TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
+      // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
+      static const bool rows_on0 = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      const bool listed0 = rows_on0 && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
+      if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1), st));
+      else TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
       wg3[0] = gp_wgrad(ws + w.dkv, a.lddkv, xn, d, Lg.wk, d, d, ns);
@@ -981,7 +987,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
         x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
         if (q_folded) {   // both partial rows already hold the replicas' fan-in sum: nothing left to walk here
-          x.res.extra = ws + w.dln1; x.res.extra2 = ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
+          x.res.extra = ws + w.dln1; x.res.extra2 = w1 ? nullptr : ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
         }
         else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
       }
