@@ -416,23 +416,37 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
     float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
     float th = 0.f;
     const uint32_t drow = (uint32_t)(b * HF + h);
-    for (int k0 = 0; k0 < Sv; k0 += KPS) {
-      const int k = k0 + sub;
-      const bool on = k < Sv;
-      const int p = on ? sp[wv][k] : 0;
-      const size_t row = (size_t)b * S + p;
-      const float4 v4 = on ? f4_ld(a.vp + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float P = on ? a.attn[((size_t)b * HF + h) * S + p] : 0.f;
-      const float m = !on ? 0.f : (a.drop.thr ? drop_mult(a.drop, drow, (uint32_t)p) : 1.f);
-      float dot = f4_dot(dc4, v4);
-      for (int o = 1; o < lph; o <<= 1) dot += __shfl_xor(dot, o, 64);
-      const float dP = m * dot;
-      th = fmaf(P, dP, th);
-      if (on) {
-        const float4 dv4 = f4_scale(P * m, dc4);
-        f4_st(a.dkv + row * a.lddkv + D + c, dv4);
-        sv4.x += dv4.x; sv4.y += dv4.y; sv4.z += dv4.z; sv4.w += dv4.w;
-        if ((cl & (lph - 1)) == 0) { pl[wv][k][h] = P; dpl[wv][k][h] = dP; }
+    DropSpec drop = a.drop;                                  // the step word is read once, not per key
+    drop.step = drop_step(a.drop); drop.step_ptr = nullptr;
+    // (an idle lane group repeats key 0 — always a real row: the query position is valid — so every load is
+    // unconditional; W1_U steps of loads are in flight together)
+    constexpr int W1_U = 2;
+    for (int k0 = 0; k0 < Sv; k0 += KPS * W1_U) {
+      int kk[W1_U], pp[W1_U]; bool on[W1_U]; float4 v4[W1_U]; float Pv[W1_U];
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) {
+        kk[u] = k0 + u * KPS + sub;
+        on[u] = kk[u] < Sv;
+        pp[u] = sp[wv][on[u] ? kk[u] : 0];
+        const size_t row = (size_t)b * S + pp[u];
+        v4[u] = f4_ld(a.vp + row * D + c);
+        Pv[u] = a.attn[((size_t)b * HF + h) * S + pp[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) {
+        const size_t row = (size_t)b * S + pp[u];
+        const float P = on[u] ? Pv[u] : 0.f;
+        const float m = !on[u] ? 0.f : (drop.thr ? drop_mult(drop, drow, (uint32_t)pp[u]) : 1.f);
+        float dot = f4_dot(dc4, v4[u]);
+        for (int o = 1; o < lph; o <<= 1) dot += __shfl_xor(dot, o, 64);
+        const float dP = m * dot;
+        th = fmaf(P, dP, th);
+        if (on[u]) {
+          const float4 dv4 = f4_scale(P * m, dc4);
+          f4_st(a.dkv + row * a.lddkv + D + c, dv4);
+          sv4.x += dv4.x; sv4.y += dv4.y; sv4.z += dv4.z; sv4.w += dv4.w;
+          if ((cl & (lph - 1)) == 0) { pl[wv][kk[u]][h] = P; dpl[wv][kk[u]][h] = dP; }
+        }
       }
     }
 #pragma unroll
@@ -440,18 +454,24 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k0 = 0; k0 < Sv; k0 += KPS) {
-      const int k = k0 + sub;
-      const bool on = k < Sv;
-      const int p = on ? sp[wv][k] : 0;
-      const size_t row = (size_t)b * S + p;
-      const float4 k4 = on ? f4_ld(a.kp + row * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float g = on ? pl[wv][k][h] * (dpl[wv][k][h] - th) : 0.f;        // softmax backward
-      f4_fma(dq4, g, k4);
-      if (on) {
-        const float4 dk4 = f4_scale(g, q4);
-        f4_st(a.dkv + row * a.lddkv + c, dk4);
-        sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+    for (int k0 = 0; k0 < Sv; k0 += KPS * W1_U) {
+      int kk[W1_U], pp[W1_U]; bool on[W1_U]; float4 k4[W1_U];
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) {
+        kk[u] = k0 + u * KPS + sub;
+        on[u] = kk[u] < Sv;
+        pp[u] = sp[wv][on[u] ? kk[u] : 0];
+        k4[u] = f4_ld(a.kp + ((size_t)b * S + pp[u]) * D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) {
+        const float g = on[u] ? pl[wv][kk[u]][h] * (dpl[wv][kk[u]][h] - th) : 0.f;        // softmax backward
+        f4_fma(dq4, g, k4[u]);
+        if (on[u]) {
+          const float4 dk4 = f4_scale(g, q4);
+          f4_st(a.dkv + ((size_t)b * S + pp[u]) * a.lddkv + c, dk4);
+          sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+        }
       }
     }
 #pragma unroll
@@ -509,6 +529,94 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
     if (a.fanin_src) v += a.fanin_src[(size_t)bb * D + col];
     a.dxq_part[(size_t)bb * D + col] = v;
   }
+}
+
+// forward of the same form: pass 1 scores (K rows), pass 2 exp / dropout / context (V rows), then the softmax weights of
+// all S positions (0 at the masked ones) for the backward
+template <int LPR>
+__global__ __launch_bounds__(256) void attn_fwd_w1_kernel(const AttnArgs a) {
+  constexpr int D = 4 * LPR, KPS = 64 / LPR, W1_U = 2;
+  __shared__ int sp[4][64];
+  __shared__ float sc[4][64][W1_MAXH];
+  __shared__ float ls[4][W1_MAXH], mxl[4][W1_MAXH];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = (int)blockIdx.x * 4 + wv;
+  if (b >= a.n_in) return;
+  const int S = a.S, HF = a.H, lph = a.dh >> 2;
+  const int sub = lane / LPR, cl = lane % LPR, c = 4 * cl, h = cl / lph;
+  const unsigned long long vm = w1_valid(a, b, lane, sp[wv]);
+  const int Sv = __popcll(vm);
+  const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+  DropSpec drop = a.drop;
+  drop.step = drop_step(a.drop); drop.step_ptr = nullptr;
+  const uint32_t drow = (uint32_t)(b * HF + h);
+  float mx = -INFINITY;
+  for (int k0 = 0; k0 < Sv; k0 += KPS * W1_U) {
+    int kk[W1_U]; bool on[W1_U]; float4 k4[W1_U];
+#pragma unroll
+    for (int u = 0; u < W1_U; ++u) {
+      kk[u] = k0 + u * KPS + sub;
+      on[u] = kk[u] < Sv;
+      k4[u] = f4_ld(a.kp + ((size_t)b * S + sp[wv][on[u] ? kk[u] : 0]) * D + c);
+    }
+#pragma unroll
+    for (int u = 0; u < W1_U; ++u) {
+      float dot = f4_dot(q4, k4[u]);
+      for (int o = 1; o < lph; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      if (on[u]) {
+        mx = fmaxf(mx, dot);
+        if ((cl & (lph - 1)) == 0) sc[wv][kk[u]][h] = dot;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float lsum = 0.f;
+  float4 ctx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < Sv; k0 += KPS * W1_U) {
+    int kk[W1_U], pp[W1_U]; bool on[W1_U]; float4 v4[W1_U];
+#pragma unroll
+    for (int u = 0; u < W1_U; ++u) {
+      kk[u] = k0 + u * KPS + sub;
+      on[u] = kk[u] < Sv;
+      pp[u] = sp[wv][on[u] ? kk[u] : 0];
+      v4[u] = f4_ld(a.vp + ((size_t)b * S + pp[u]) * D + c);
+    }
+#pragma unroll
+    for (int u = 0; u < W1_U; ++u) {
+      if (!on[u]) continue;
+      const float e = expf(sc[wv][kk[u]][h] - mx);
+      lsum += e;
+      const float m = drop.thr ? drop_mult(drop, drow, (uint32_t)pp[u]) : 1.f;
+      f4_fma(ctx4, e * m, v4[u]);
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) { lsum += __shfl_xor(lsum, o, 64); ctx4 = f4_xor_add(ctx4, o); }
+  const float inv = 1.f / lsum;
+  if (sub == 0) {
+    f4_st(a.ctx + (size_t)b * D + c, f4_scale(inv, ctx4));
+    if ((cl & (lph - 1)) == 0) { ls[wv][h] = inv; mxl[wv][h] = mx; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < S) {                                            // lane = position: its softmax weights, 0 when masked
+    const bool v = (vm >> lane) & 1ull;
+    const int k = __popcll(vm & ((1ull << lane) - 1ull));
+    for (int hh = 0; hh < HF; ++hh)
+      a.attn[((size_t)b * HF + hh) * S + lane] = v ? expf(sc[wv][k][hh] - mxl[wv][hh]) * ls[wv][hh] : 0.f;
+  }
+}
+int launch_attn_fwd_w1(const AttnArgs& a, hipStream_t st) {
+  const dim3 grid(ps_cdiv(a.n_in, 4));
+  if (a.d == 128) hipLaunchKernelGGL(attn_fwd_w1_kernel<32>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(attn_fwd_w1_kernel<16>, grid, dim3(256), 0, st, a);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
 }
 
 bool attn_w1_fits(const AttnArgs& a) {

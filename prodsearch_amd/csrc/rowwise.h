@@ -156,6 +156,7 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
 bool attn_sq1_fits(const AttnArgs& a);
 bool attn_w1_fits(const AttnArgs& a);      // one wave per sequence (fan == 1, d 64 / 128)
 int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st);
+int launch_attn_fwd_w1(const AttnArgs& a, hipStream_t st);
 int attn_sq1_split(const AttnArgs& a);   // head groups (workgroups) per sequence the sq1 kernels will use
 
 struct EmbedBwdArgs {

@@ -57,7 +57,6 @@ struct RtmK {              // kernel-side view of one call
   // workspace
   float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *weight, *pv_scores, *pv_terms, *nvalid;
   int32_t *seqcnt, *vrows, *vcount;   // valid-row list of x (GemmProblem::ridx): per-sequence counts, rows, length
-  int count_words;                    // rtm_embed_bwd_kernel also counts the word occurrences (0: the forward did)
   int count_fwd;                      // rtm_embed4_kernel counts them (the counters were cleared by the query-encoder launch)
   float* loss3;
   // backward
@@ -71,6 +70,15 @@ struct RtmK {              // kernel-side view of one call
   int* wrank;                 // [B*R + B*K*R][WL] rank of a counted word among its word's occurrences, -1: not counted (count_fwd)
 };
 
+// waves of rtm_embed_bwd_kernel: EB_GROUPS four-review groups per wave on each side, EB_QSEQ query slots per wave
+#define EB_GROUPS 4
+#define EB_QSEQ 16
+static inline int rtm_eb_waves(int B, int K, int R, int* npos_w, int* nneg_w) {
+  const int np = ps_cdiv((int64_t)B * R, 4 * EB_GROUPS), nn = ps_cdiv((int64_t)B * K * R, 4 * EB_GROUPS);
+  if (npos_w) *npos_w = np;
+  if (nneg_w) *nneg_w = nn;
+  return np + nn + ps_cdiv((int64_t)B * (K + 1), EB_QSEQ);
+}
 static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
 
 static int rtm_check(const PsRtmDesc& D) {
@@ -134,7 +142,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
     const int64_t nr = (int64_t)r.Bseq * D.R * d;
     r.raw = rtake(cur, nr); r.yfs = rtake(cur, nr); r.dpre = rtake(cur, nr); r.dmean = rtake(cur, nr);
   }
-  r.segpart = eval ? 0 : rtake(cur, (int64_t)ps_cdiv((int64_t)r.Bseq * r.S, 4 * 16) * 3 * d);
+  r.segpart = eval ? 0 : rtake(cur, (int64_t)ps_cdiv(rtm_eb_waves(D.B, D.K, D.R, nullptr, nullptr), 4) * 3 * d);
   r.enc_base = cur;
   TRY(make_ws(E, w));
   r.total = cur + w.total;
@@ -776,140 +784,192 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
     }
 }
 
-// Backward of rtm_embed.  A wave owns EB_SPW consecutive (sequence, position) slots: lane i decodes slot i (one
-// coalesced read of the indices), a ballot keeps the real ones (27 % on a C4 batch) and the wave walks them two at a
-// time, so the dependent chain per wave is ~3 pairs instead of the 38 slots of the round-1 grid-stride loop (69 us,
-// latency-bound).  Lane l owns columns l, l + 64, ...  The segment-embedding gradient (3 rows fed by EVERY slot) is
-// summed in registers, combined over the workgroup's waves in LDS and PARKED as one [3][d] partial per workgroup
-// (`seg_part`, folded by the step's last launch, ColFoldList) instead of 3d same-address atomics per workgroup.
-#define EB_SPW 16
+// Backward of rtm_embed.  Like rtm_embed4_kernel it works on groups of the four review rows 4g .. 4g+3 of one side, which
+// share one Philox counter row: a lane evaluates the dropout words of its columns once for the four reviews, and the
+// (unconditional, all-real-address) loads of the four rows are in flight together — the wave's dependent chain is one round
+// trip per group, EB_GROUPS groups per wave.  (Round 1: one wave per slot in a 38-slot grid-stride walk, one Philox
+// evaluation per element: 69 us.)  Lane l owns columns l, l + 64, ...  The query slots (s = 0) ride as extra waves.
+// The segment-embedding gradient (3 rows fed by EVERY slot) is summed in registers, combined over the workgroup's waves
+// in LDS and PARKED as one [3][d] partial per workgroup (`seg_part`, folded by the step's last launch, ColFoldList)
+// instead of 3d same-address atomics per workgroup.
 template <int NK>      // columns per lane: d <= 64 * NK
-__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part) {
+__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part, int npos_w, int nneg_w, FDiv fR, FDiv fK, int dbg) {
   __shared__ float segs[4][3][64 * NK];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = (int)blockIdx.x * 4 + wv;
   const int d = a.d;
-  const int nslots = a.B * a.J * a.S;
   const int64_t rpad = a.RC - 1;
-  const int base = ((int)blockIdx.x * 4 + wv) * EB_SPW;
-  // ---- lane i < EB_SPW: where slot base + i sits
-  int my_n = 0, my_s = 0, my_b = 0, my_rev = 0, my_seg = 3, my_pos = 0;
-  int64_t my_ridx = rpad; size_t my_spos = 0;
-  bool okl = false;
-  if (lane < EB_SPW && base + lane < nslots) {
-    const int slot = base + lane;
-    my_n = fdiv(slot, a.fS); my_s = slot - my_n * a.S;
-    int j;
-    seq_decode(a, my_n, my_s, my_b, j, my_ridx, my_rev, my_seg, &my_spos);
-    my_pos = j == 0;
-    okl = my_s == 0 || my_ridx != rpad;
-  }
-  unsigned long long todo = __ballot(okl);
+  DropSpec dpos = a.d_pos, dneg = a.d_neg, dpv = a.d_pv;      // the step word is read once, not per element
+  dpos.step = drop_step(a.d_pos); dpos.step_ptr = nullptr;
+  dneg.step = drop_step(a.d_neg); dneg.step_ptr = nullptr;
+  dpv.step = drop_step(a.d_pv); dpv.step_ptr = nullptr;
+  if (dbg & 1) { dpos.thr = 0; dneg.thr = 0; }
   float sacc[3][NK];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
     for (int k = 0; k < NK; ++k) sacc[q][k] = 0.f;
-  while (todo) {
-    int li[2]; bool on[2];
-    li[0] = __ffsll((long long)todo) - 1; todo &= todo - 1; on[0] = true;
-    on[1] = todo != 0;
-    li[1] = on[1] ? __ffsll((long long)todo) - 1 : li[0];
-    if (on[1]) todo &= todo - 1;
-    int n[2], sx[2], bb[2], rev[2], seg[2]; bool pos[2];
-    float gk[2][NK], src[2][NK], dv[2][NK], cntv[2];
+  int colc[NK];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      n[u] = __shfl(my_n, li[u], 64); sx[u] = __shfl(my_s, li[u], 64); bb[u] = __shfl(my_b, li[u], 64);
-      rev[u] = __shfl(my_rev, li[u], 64); seg[u] = __shfl(my_seg, li[u], 64); pos[u] = __shfl(my_pos, li[u], 64) != 0;
-      const float* g = a.dx + ((size_t)n[u] * a.S + sx[u]) * d;
-      const bool rv = on[u] && sx[u] > 0;
-      const float* gm = a.dmean ? a.dmean + ((pos[u] ? (size_t)rev[u] : (size_t)a.B * a.R + rev[u])) * d : g;
-      const bool wantdv = rv && pos[u] && a.train_pv;
+  for (int k = 0; k < NK; ++k) colc[k] = lane + 64 * k < d ? lane + 64 * k : d - 1;
+  if (wave < npos_w + nneg_w) {
+    const bool pos = wave < npos_w;
+    const int w0 = pos ? wave : wave - npos_w;
+    const int nrev = pos ? a.B * a.R : a.B * a.K * a.R;
+    const DropSpec& ds = pos ? dpos : dneg;
+    const bool wantdv = pos && a.train_pv;
+    // lane i < 4 * EB_GROUPS decodes review row  4 * EB_GROUPS * w0 + i  (one coalesced read of the review ids / segment ids:
+    // group after group through scalar loads the decode alone took 20 us)
+    int my_n = 0, my_s = 1, my_seg = 3; int64_t my_rid = rpad; bool my_ok = false;
+    {
+      const int rr = w0 * 4 * EB_GROUPS + lane;
+      if (lane < 4 * EB_GROUPS && rr < nrev) {
+        const int base = fdiv(rr, fR), r = rr - base * a.R;
+        int b;
+        if (pos) { b = base; my_n = b * a.J; }
+        else { b = fdiv(base, fK); my_n = b * a.J + 1 + (base - b * a.K); }
+        my_s = r + 1;
+        my_rid = (pos ? a.pos_r : a.neg_r)[rr];
+        my_ok = my_rid != rpad;
+        my_seg = (int)(pos ? a.pos_seg : a.neg_seg)[(size_t)base * a.S + r + 1];
+      }
+    }
+    const unsigned long long okm = __ballot(my_ok);
+    for (int gi = 0; gi < EB_GROUPS; ++gi) {
+      const int gg = w0 * EB_GROUPS + gi;                   // review rows 4gg .. 4gg+3 of this side: one Philox counter row
+      if (!((okm >> (4 * gi)) & 0xfull) || (dbg & 4)) continue;
+      int nq[4], sq[4], segq[4], rrq[4]; bool okq[4]; int64_t ridq[4]; size_t sposq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src_lane = 4 * gi + q;
+        okq[q] = (okm >> src_lane) & 1ull;
+        const int sl = okq[q] ? src_lane : 4 * gi + (__ffsll((long long)((okm >> (4 * gi)) & 0xfull)) - 1);   // a dead row repeats a live one
+        rrq[q] = w0 * 4 * EB_GROUPS + sl;
+        nq[q] = __shfl(my_n, sl, 64); sq[q] = __shfl(my_s, sl, 64); segq[q] = __shfl(my_seg, sl, 64);
+        ridq[q] = __shfl((long long)my_rid, sl, 64);
+        const int base = pos ? fdiv(nq[q], a.fJ) : (fdiv(nq[q], a.fJ) * a.K + (nq[q] - fdiv(nq[q], a.fJ) * a.J - 1));
+        sposq[q] = (size_t)base * a.S + sq[q];
+      }
+      uint32_t dw[NK][4];
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
-        const int col = lane + 64 * k;
-        const bool in = on[u] && col < d;
-        gk[u][k] = in ? g[col] : 0.f;
-        // fs: the review vector reached x through tanh(f_W . raw + b); its input gradient d raw was left in a.dmean
-        src[u][k] = (in && rv && a.dmean) ? gm[col] : gk[u][k];
-        dv[u][k] = (wantdv && col < d) ? a.dvec[(size_t)rev[u] * d + col] : 0.f;
+        Philox4 t = {0u, 0u, 0u, 0u};
+        if (ds.thr) t = philox4x32_10((uint32_t)(lane + 64 * k), (uint32_t)gg, ds.site, ds.step, ds.k0, ds.k1);
+        dw[k][0] = t.x; dw[k][1] = t.y; dw[k][2] = t.z; dw[k][3] = t.w;
       }
-      cntv[u] = (rv && a.pvc) ? a.cnt[(size_t)n[u] * a.R + sx[u] - 1] : 1.f;
-    }
+      // every address is a real one (a dead row repeats the group's first, columns past d clamp), so the loads of the four
+      // rows are unconditional and in flight together
+      float gk[4][NK], src[4][NK], dvv[4][NK], cntv[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (!on[u]) continue;                            // wave-uniform
-      if (a.g_user_emb || a.g_item_emb) {              // user / item embedding rows of this position
-        const size_t spos = __shfl((unsigned long long)my_spos, li[u], 64);
-        const int64_t uid = a.g_user_emb ? (pos[u] ? a.pos_u : a.neg_u)[spos] : -1;
-        const int64_t iid = a.g_item_emb ? (pos[u] ? a.pos_i : a.neg_i)[spos] : -1;
+      for (int q = 0; q < 4; ++q) {
+        const float* g = a.dx + ((size_t)nq[q] * a.S + sq[q]) * d;
+        // fs: the review vector reached x through tanh(f_W . raw + b); its input gradient d raw was left in a.dmean
+        const float* gm = a.dmean ? a.dmean + ((pos ? (size_t)0 : (size_t)a.B * a.R) + rrq[q]) * d : g;
+        const float* dvp = wantdv ? a.dvec + (size_t)rrq[q] * d : g;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const int col = lane + 64 * k;
-          if (col < d) {
-            if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + col], gk[u][k]);
-            if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + col], gk[u][k]);
+        for (int k = 0; k < NK; ++k) { gk[q][k] = g[colc[k]]; src[q][k] = gm[colc[k]]; dvv[q][k] = dvp[colc[k]]; }
+        cntv[q] = a.pvc ? a.cnt[(size_t)nq[q] * a.R + sq[q] - 1] : 1.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!okq[q]) continue;                             // wave-uniform
+        if (a.g_user_emb || a.g_item_emb) {                // user / item embedding rows of this position
+          const int64_t uid = a.g_user_emb ? (pos ? a.pos_u : a.neg_u)[sposq[q]] : -1;
+          const int64_t iid = a.g_item_emb ? (pos ? a.pos_i : a.neg_i)[sposq[q]] : -1;
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const int col = lane + 64 * k;
+            if (col < d) {
+              if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + col], gk[q][k]);
+              if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + col], gk[q][k]);
+            }
           }
         }
-      }
-      if (a.use_seg && seg[u] < 3) {                   // row 3 is the padding_idx of seg_embeddings: no gradient
+        if (a.use_seg && segq[q] < 3) {                    // row 3 is the padding_idx of seg_embeddings: no gradient
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const float v = lane + 64 * k < d ? gk[q][k] : 0.f;
+            if (segq[q] == 0) sacc[0][k] += v;
+            else if (segq[q] == 1) sacc[1][k] += v;
+            else sacc[2][k] += v;
+          }
+        }
+        // through dropout_layer (and, pv positive with train_pv, the PV drop_layer + the PV-loss gradient)
+        float t[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-          if (seg[u] == 0) sacc[0][k] += gk[u][k];
-          else if (seg[u] == 1) sacc[1][k] += gk[u][k];
-          else sacc[2][k] += gk[u][k];
-        }
-      }
-      if (sx[u] == 0) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-          if (lane + 64 * k < d) atomicAdd(&a.dqe[(size_t)bb[u] * d + lane + 64 * k], gk[u][k]);
-        continue;
-      }
-      // through dropout_layer (and, pv positive with train_pv, the PV drop_layer + the PV-loss gradient)
-      float t[NK];
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const uint32_t col = (uint32_t)(lane + 64 * k);
-        t[k] = 0.f;
-        if ((int)col < d) {
-          float v = src[u][k] * drop_mult(pos[u] ? a.d_pos : a.d_neg, (uint32_t)rev[u], col);
-          if (pos[u] && a.train_pv) {
-            v += dv[u][k];
-            if (!a.pvc) v *= drop_mult(a.d_pv, (uint32_t)rev[u], col);
+          float v = src[q][k] * (ds.thr ? drop_word(ds, dw[k][q]) : 1.f);
+          if (wantdv) {
+            v += dvv[q][k];
+            if (!a.pvc) v *= drop_mult(dpv, (uint32_t)rrq[q], (uint32_t)(lane + 64 * k));
           }
           t[k] = v;
         }
+        if (!a.pvc) {
+          float* grow = a.g_table + (size_t)rclamp(ridq[q], rpad) * d;
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], t[k]);
+        } else {
+          // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
+          // 1.2 M word occurrences x 512 B of fp32 atomics per step ran at 0.7 TB/s; instead the row is rewritten in
+          // place as the per-word gradient (rtm_wreduce_kernel sums the rows of a word's occurrences through the index)
+          const float inv = 1.f / cntv[q];
+          float* gw = a.gs + ((size_t)nq[q] * a.S + sq[q]) * d;
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < d && !(dbg & 2)) gw[lane + 64 * k] = t[k] * inv;
+        }
       }
-      if (!a.pvc) {
-        const int64_t ridx = __shfl((long long)my_ridx, li[u], 64);
-        float* grow = a.g_table + (size_t)rclamp(ridx, rpad) * d;
+    }
+  } else {
+    // ---- query positions (s = 0) of EB_QSEQ sequences: segment / user / item rows and d query_emb
+    const int n0 = (wave - npos_w - nneg_w) * EB_QSEQ, nseq = a.B * a.J;
+    for (int i0 = 0; i0 < EB_QSEQ && n0 + i0 < nseq && !(dbg & 8); i0 += 4) {
+      float gk[4][NK]; int bq[4], segq[4]; bool on[4], posq[4]; size_t sposq[4];
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
-          if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], t[k]);
-      } else {
-        // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
-        // 1.2 M word occurrences x 512 B of fp32 atomics per step ran at 0.7 TB/s; instead the row is rewritten in
-        // place as the per-word gradient (rtm_wreduce_kernel sums the rows of a word's occurrences through the index)
-        const float inv = 1.f / cntv[u];
-        float* gw = a.gs + ((size_t)n[u] * a.S + sx[u]) * d;
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + i0 + q;
+        on[q] = n < nseq;
+        const int nc = on[q] ? n : n0;
+        const int b = fdiv(nc, a.fJ), j = nc - b * a.J;
+        bq[q] = b; posq[q] = j == 0;
+        sposq[q] = (posq[q] ? (size_t)b : (size_t)b * a.K + (j - 1)) * a.S;
+        segq[q] = (int)(posq[q] ? a.pos_seg : a.neg_seg)[sposq[q]];
+        const float* g = a.dx + (size_t)nc * a.S * d;
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
-          if (lane + 64 * k < d) gw[lane + 64 * k] = t[k] * inv;
-        if (a.count_words) {                           // the index is built behind this kernel (no side stream)
-          const int64_t* words;
-          if (pos[u]) words = (a.train_pv ? a.pos_pvc : a.pos_words) + ((size_t)bb[u] * a.R + sx[u] - 1) * a.WL;
-          else words = (a.train_pv ? a.neg_pvc : a.neg_words_rev) + (size_t)rev[u] * a.WL;
-          const uint8_t* wm = pos[u] ? a.wmask_pos : a.wmask_neg;
-          for (int w = lane; w < a.WL; w += 64) {
-            const int64_t wi = words[w];
-            if (word_ok(a, wm, (size_t)rev[u] * a.WL + w, wi)) atomicAdd(&a.wcnt[wi], 1);
+        for (int k = 0; k < NK; ++k) gk[q][k] = g[colc[k]];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!on[q]) continue;
+        if (a.g_user_emb || a.g_item_emb) {
+          const int64_t uid = a.g_user_emb ? (posq[q] ? a.pos_u : a.neg_u)[sposq[q]] : -1;
+          const int64_t iid = a.g_item_emb ? (posq[q] ? a.pos_i : a.neg_i)[sposq[q]] : -1;
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const int col = lane + 64 * k;
+            if (col < d) {
+              if (uid >= 0 && uid < a.U) atomicAdd(&a.g_user_emb[(size_t)uid * d + col], gk[q][k]);
+              if (iid >= 0 && iid < a.PI) atomicAdd(&a.g_item_emb[(size_t)iid * d + col], gk[q][k]);
+            }
           }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int col = lane + 64 * k;
+          if (col >= d) continue;
+          if (a.use_seg && segq[q] < 3) {
+            if (segq[q] == 0) sacc[0][k] += gk[q][k];
+            else if (segq[q] == 1) sacc[1][k] += gk[q][k];
+            else sacc[2][k] += gk[q][k];
+          }
+          atomicAdd(&a.dqe[(size_t)bq[q] * d + col], gk[q][k]);
         }
       }
     }
   }
-  if (!a.use_seg) return;
+  if (!a.use_seg || (dbg & 16)) return;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -1431,7 +1491,6 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   }
   const int eb = rtm_slot_blocks(r);
   if (k.pvc) k.gs = ws + r.enc_base + w.dx;
-  k.count_words = fwd_index ? 0 : 1;
   TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   if (D.review_encoder == PS_RENC_FS) {
     // through the review projection: d pre = dx * tanh', bias gradient, weight gradient, d raw = d pre . f_W
@@ -1447,11 +1506,15 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     k.dmean = ws + r.dmean;
   }
   {
-    const int nwg = ps_cdiv(r.Bseq * r.S, 4 * EB_SPW);
-    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
-    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
-    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
-    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, ws + r.segpart);
+    int npw, nnw;
+    const int nwg = ps_cdiv(rtm_eb_waves(B, D.K, D.R, &npw, &nnw), 4);
+    const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
+    float* sp = ws + r.segpart;
+    static const int ebdbg = getenv("PS_RTM_EB_DBG") ? atoi(getenv("PS_RTM_EB_DBG")) : 0;
+    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
+    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
+    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
+    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
     PS_LAUNCH_CHECK();
     if (D.use_seg_emb) {
       PS_REQUIRE(fold.n < PS_MAX_COLFOLD, "rtm backward: too many parked column sums");
@@ -1463,7 +1526,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   if (k.pvc) {
     if (!fwd_index) {
       const int V = (int)D.vocab_size;
-      TRY(rtm_build_index(k, r, V, false, st));
+      TRY(rtm_build_index(k, r, V, true, st));
     } else {
       TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
     }

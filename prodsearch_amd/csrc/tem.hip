@@ -487,7 +487,8 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
     attn_finish(a);
-    TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
+    if (attn_sq1_fits(a) && attn_w1_fits(a)) TRY(launch_attn_fwd_w1(a, st));
+    else TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
                       P.final_ln_g && P.final_ln_b;
     PS_REQUIRE(!fold_sc || fuse, "forward: folded scoring without the fused last layer");
@@ -852,9 +853,19 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         SideCtx* sc = side_ctx();
         TRY(launch_score_bwd(t, sc ? sc->stream : st));
       }
-      TRY(side_run(wg, 1, st));   // (a second side stream for W1 / Wo beside W2 measured 0.389 vs 0.368 ms: slower)
-      TRY(side_run(wg1, 1, st));
-      TRY(side_run(wgo, 1, st));
+      // (a second side stream for W1 / Wo beside W2 measured 0.389 vs 0.368 ms: slower)
+      // one launch for the three when the reduction is short (review transformer, 1.5k rows: three latency-bound launches of
+      // ~50 workgroups, 0.595 -> 0.570 ms/step); at C2 (8k rows) the grouped launch's 500 workgroups crowd the attention
+      // backward and the dX product on the main stream instead (0.318 -> 0.349 ms/step)
+      static const int wg_group_rows = getenv("PS_WGRAD_GROUP_ROWS") ? atoi(getenv("PS_WGRAD_GROUP_ROWS")) : 4096;
+      if (M2 <= wg_group_rows) {
+        GemmProblem all3[3] = {wg[0], wg1[0], wgo[0]};
+        TRY(side_run(all3, 3, st));
+      } else {
+        TRY(side_run(wg, 1, st));
+        TRY(side_run(wg1, 1, st));
+        TRY(side_run(wgo, 1, st));
+      }
     } else {
     // FFN backward
       GemmProblem p = gp(do2, d, 0, Lp.w2, F, 1, ws + w.da1, F, M2, F, d);      // d h1 = do2 . W2
