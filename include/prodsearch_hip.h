@@ -187,6 +187,7 @@ typedef struct PsAdamHyper {
   int32_t noam;        /* --decay_method noam                          */
   int32_t warmup_steps;/* --warmup_steps                               */
   float grad_scale;    /* multiplies every grad first (1/world for DP) */
+  int32_t zero_grads;  /* dense step: leave every gradient it consumed at 0 (the next zero_grad() is then free) */
 } PsAdamHyper;
 
 int64_t ps_adam_plan_bytes(int32_t n_tensors, const int64_t* numel_host);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const char* plan, cons
     if (chunk == 0 && gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
   }
   __syncthreads();
-  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay};
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads};
   adam_update_chunk(plan, chunk, a);
 }
 

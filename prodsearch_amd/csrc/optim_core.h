@@ -67,7 +67,7 @@ __device__ inline void adam_scalars(const PsAdamHyper& hp, float total_sumsq, in
   *norm_out = norm;
 }
 
-struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; };
+struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; int zero_g; };
 
 __device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& mm, float& vv) {
   gg *= a.gmul;
@@ -84,7 +84,7 @@ __device__ inline void adam_update_chunk(const char* plan, int chunk, const Adam
   const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
   const int t = find_tensor(plan, h, chunk);
   float* p = ((float* const*)(plan + h->off_p))[t];
-  const float* g = ((float* const*)(plan + h->off_g))[t];
+  float* g = ((float* const*)(plan + h->off_g))[t];
   float* m = ((float* const*)(plan + h->off_m))[t];
   float* v = ((float* const*)(plan + h->off_v))[t];
   const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
@@ -93,7 +93,7 @@ __device__ inline void adam_update_chunk(const char* plan, int chunk, const Adam
   const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 &&
                    end - beg == ADAM_CHUNK;
   if (vec) {
-    float4* p4 = (float4*)(p + beg); const float4* g4 = (const float4*)(g + beg);
+    float4* p4 = (float4*)(p + beg); float4* g4 = (float4*)(g + beg);
     float4* m4 = (float4*)(m + beg); float4* v4 = (float4*)(v + beg);
 #pragma unroll 2
     for (int i = 0; i < ADAM_CHUNK / 4 / 256; ++i) {
@@ -102,12 +102,14 @@ __device__ inline void adam_update_chunk(const char* plan, int chunk, const Adam
       adam_elem(a, pp.x, gg.x, mm.x, vv.x); adam_elem(a, pp.y, gg.y, mm.y, vv.y);
       adam_elem(a, pp.z, gg.z, mm.z, vv.z); adam_elem(a, pp.w, gg.w, mm.w, vv.w);
       p4[k] = pp; m4[k] = mm; v4[k] = vv;
+      if (a.zero_g) g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // PsAdamHyper::zero_grads: the step's memset rides here
     }
   } else {
     for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
       float pp = p[i], mm = m[i], vv = v[i];
       adam_elem(a, pp, g[i], mm, vv);
       p[i] = pp; m[i] = mm; v[i] = vv;
+      if (a.zero_g) g[i] = 0.f;
     }
   }
 }

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void rs_finalize_kernel(const PsAdamHyper hp,
 
 __global__ __launch_bounds__(256) void rs_update_kernel(const char* plan, int n_chunks, RowTables T,
                                                         const PsAdamHyper hp, const float* scal) {
-  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay};
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0};
   const int blk = blockIdx.x;
   if (blk < n_chunks) { adam_update_chunk(plan, blk, a); return; }
   const int k = rs_find(T, blk - n_chunks);

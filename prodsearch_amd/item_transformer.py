@@ -631,7 +631,8 @@ class ItemTransformerRanker(nn.Module):
         ps, gs = self._structs()
         st = self._stream()
         if grad_out is None and getattr(plan, 'staged', False) and self._use_step_api():
-            fresh = self._assign_grads()                   # zero_grad() folded into the replayed backward
+            fresh = self._assign_grads() and not self.__dict__.get('_grad_clean', False)   # zero_grad() folded into the replay
+            self.__dict__['_grad_clean'] = False
             _lib.check(lib.ps_tem_backward_step(plan.desc, ps, plan.ws.data_ptr(), gs, 1.0,
                                                 self._grad_flat.data_ptr() if fresh else None,
                                                 self._grad_flat.numel() if fresh else 0, st), 'ps_tem_backward_step')
@@ -641,7 +642,8 @@ class ItemTransformerRanker(nn.Module):
             batch_struct = _lib.PsTemBatch()
             _lib.check(lib.ps_tem_staged_batch(plan.desc, plan.ws.data_ptr(), batch_struct), 'ps_tem_staged_batch')
         if self._assign_grads():
-            self._zero_for_backward()
+            if not self.__dict__.get('_grad_clean', False):     # (clean: the last optimizer step left the buffer at 0)
+                self._zero_for_backward()
         elif self._row_sparse() and any(getattr(p, '_ps_rows', {}).get('dirty') for _, p, _ in self._sparse_tabs):
             raise NotImplementedError("row_sparse_adam: gradient accumulation over several backwards is not "
                                       "supported; call model.zero_grad() (trainer.py:76) or optim.step() first")
@@ -654,6 +656,7 @@ class ItemTransformerRanker(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._coalesce_touched(plan)
+        self.__dict__['_grad_clean'] = False
         go = None if grad_out is None else grad_out.contiguous().float()      # None: d loss / d loss = 1
         _lib.check(lib.ps_tem_backward(plan.desc, ps, batch_struct, plan.ws.data_ptr(), gs, 1.0,
                                        _lib.ptr(go), st), 'ps_tem_backward')

@@ -9,6 +9,9 @@ method the hot path uses (``main.py:62``).  ``step()`` is two kernel launches
 ``ps_clip_adam_dense``; dense semantics identical to ``torch.optim.Adam(eps=1e-9)``
 after ``clip_grad_norm_`` — parameters without a gradient are skipped, as there.
 """
+import os
+import weakref
+
 import torch
 
 from . import _lib
@@ -37,6 +40,7 @@ class Optimizer(object):
         self.weight_decay = weight_decay
         self.eps = 1e-9                      # optimizers.py:186-187
         self.grad_scale = 1.0                # 1/world_size under data parallelism
+        self.zero_grads_owner = None         # weakref to the model whose flat gradient buffer the dense step zeroes (build_optim)
         self.row_sparse = bool(row_sparse)   # extension: tables updated by touched rows only
         self.params = []
         self._plan = None
@@ -142,8 +146,14 @@ class Optimizer(object):
         st = torch.cuda.current_stream(dev).cuda_stream
         if plan['rows']:
             return self._step_rows(lib, plan, hp, dev, st)
+        owner = self.zero_grads_owner() if self.zero_grads_owner is not None else None
+        # only when the plan covers the model's whole flat gradient buffer (every view is the attached .grad)
+        zero = owner is not None and all(p.grad is v for p, v in owner._grad_views)
+        hp.zero_grads = int(zero)
         _lib.check(lib.ps_clip_adam_dense(plan['dev'].data_ptr(), plan['n_chunks'], hp, plan['state'].data_ptr(),
                                           plan['gnorm'].data_ptr(), st), 'ps_clip_adam_dense')
+        if zero:
+            owner.__dict__['_grad_clean'] = True
 
     def _step_rows(self, lib, plan, hp, dev, st):
         """Row-sparse step: dense plan for the small tensors + touched rows of every table, one global
@@ -207,6 +217,13 @@ def build_optim(args, model, checkpoint):
                       weight_decay=args.l2_lambda,
                       row_sparse=getattr(args, 'row_sparse_adam', False))
     optim.set_parameters(list(model.named_parameters()))
+    # The dense step leaves every gradient it consumed at zero (PsAdamHyper.zero_grads), so the memset of the next
+    # zero_grad() / backward (trainer.py:76-77) costs nothing.  Visible difference: ``p.grad`` reads 0 after ``optim.step()``
+    # where the reference still holds the step's gradient (nothing in it reads that).  ``args.keep_grads_after_step`` /
+    # ``PS_KEEP_GRADS=1`` restore the memset.
+    if hasattr(model, '_grad_flat') and not getattr(args, 'keep_grads_after_step', False) \
+            and os.environ.get('PS_KEEP_GRADS', '0') in ('', '0'):
+        optim.zero_grads_owner = weakref.ref(model)
     if getattr(args, 'train_from', '') != '' and checkpoint is not None:
         optim.load_state_dict(checkpoint['optim'])
     return optim

@@ -441,8 +441,9 @@ class ProductRanker(nn.Module):
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 raise RuntimeError("a foreign .grad tensor is attached; call model.zero_grad() before backward")
-        if fresh:
+        if fresh and not self.__dict__.get('_grad_clean', False):     # (clean: the last optimizer step left the buffer at 0)
             _lib.check(lib.ps_zero_floats(self._grad_flat.data_ptr(), self._grad_flat.numel(), st), 'ps_zero_floats')
+        self.__dict__['_grad_clean'] = False
         go = None if grad_out is None else grad_out.contiguous().float()          # None: d loss / d loss = 1
         _lib.check(lib.ps_rtm_backward(plan['desc'], ps, plan['batch'], plan['ws'].data_ptr(), gs, 1.0,
                                        None if go is None else go.data_ptr(), st), 'ps_rtm_backward')

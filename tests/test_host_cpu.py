@@ -37,7 +37,7 @@ def test_struct_layout_matches_header_sizes(lib):
     assert C.sizeof(_lib.PsLayerTensors) == 16 * 8
     assert C.sizeof(_lib.PsTemTensors) == 10 * 8 + _lib.PS_MAX_LAYERS * 16 * 8
     assert C.sizeof(_lib.PsTemBatch) == 7 * 8
-    assert C.sizeof(_lib.PsAdamHyper) == 36
+    assert C.sizeof(_lib.PsAdamHyper) == 40
 
 
 @pytest.mark.parametrize('over', [dict(), dict(inter_layers=2, sep_prod_emb=True),
