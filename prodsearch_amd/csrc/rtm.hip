@@ -25,6 +25,7 @@
 struct RtmWs {
   int Bseq, S, J;
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
+  int64_t loss_blk;         // [ceil(Bseq/4)] loss partials of rtm_score_kernel + its arrival ticket (must start at 0)
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
   int64_t wrank;
   int64_t wcnt, woff, wcur, wl;   // pvc backward: inverted index word -> review slots (int32 arrays; wl: int2 {slot, word})
@@ -125,6 +126,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.pv_terms = rtake(cur, npv);
   r.nvalid = rtake(cur, 4);
   r.seqcnt = rtake(cur, (int64_t)r.Bseq + 4);
+  r.loss_blk = rtake(cur, (int64_t)ps_cdiv(r.Bseq, 4) + 4);
   r.dvec = rtake(cur, (int64_t)D.B * D.R * d);
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
@@ -615,24 +617,53 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
 // ------------------------------------------------------------------ scores
 // also writes the loss weight of the sequence (ps_model.py:344-345): pos_weight for the positive, and for a
 // negative 1 iff it has at least one real review
-__global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out) {
-  const int lane = threadIdx.x & 63;
+// `fold_loss` (training without the PV loss): the workgroup's four loss terms are parked in loss_blk[blockIdx.x] and the
+// LAST workgroup to arrive (ticket) adds the partials up in block order — rtm_loss_kernel's result without its launch
+__global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out, int fold_loss, float* loss_blk, uint32_t* ticket) {
+  __shared__ float wterm[4];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (n >= a.B * a.J) return;
-  float s = 0.f;
-  for (int e = lane; e < a.d; e += 64) s += a.enc[(size_t)n * a.d + e] * a.wo_w[e];
-  s = wave_sum(s);
-  if (lane == 0) out[n] = s + a.wo_b[0];
-  if (!a.eval) {
-    const int b = fdiv(n, a.fJ), j = n - b * a.J;
-    float wgt;
-    if (j == 0) wgt = a.pos_weight ? (float)a.K : 1.f;
-    else {
-      bool any = false;
-      for (int r = lane; r < a.R; r += 64) any = any || (a.neg_r[((size_t)b * a.K + j - 1) * a.R + r] != a.RC - 1);
-      wgt = __ballot(any) != 0ull ? 1.f : 0.f;
+  float term = 0.f;
+  if (n < a.B * a.J) {
+    float s = 0.f;
+    for (int e = lane; e < a.d; e += 64) s += a.enc[(size_t)n * a.d + e] * a.wo_w[e];
+    s = wave_sum(s) + a.wo_b[0];
+    if (lane == 0) out[n] = s;
+    if (!a.eval) {
+      const int b = fdiv(n, a.fJ), j = n - b * a.J;
+      float wgt;
+      if (j == 0) wgt = a.pos_weight ? (float)a.K : 1.f;
+      else {
+        bool any = false;
+        for (int r = lane; r < a.R; r += 64) any = any || (a.neg_r[((size_t)b * a.K + j - 1) * a.R + r] != a.RC - 1);
+        wgt = __ballot(any) != 0ull ? 1.f : 0.f;
+      }
+      if (lane == 0) a.weight[n] = wgt;
+      term = wgt * softplus_f(j == 0 ? -s : s);
     }
-    if (lane == 0) a.weight[n] = wgt;
+  }
+  if (!fold_loss) return;
+  if (lane == 0) wterm[wv] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss_blk[blockIdx.x] = (wterm[0] + wterm[1]) + (wterm[2] + wterm[3]);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float ps = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) ps += __builtin_nontemporal_load(loss_blk + i);
+  ps = wave_sum(ps);
+  __syncthreads();
+  if (lane == 0) wterm[wv] = ps;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float psl = ((wterm[0] + wterm[1]) + (wterm[2] + wterm[3])) / (float)a.B;
+    a.loss3[0] = psl; a.loss3[1] = psl; a.loss3[2] = 0.f;
+    a.nvalid[0] = 0.f;
   }
 }
 
@@ -723,9 +754,11 @@ __global__ __launch_bounds__(256) void rtm_loss_kernel(const RtmK a) {
 }
 
 // ------------------------------------------------------------------ backward kernels
-__global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a) {
+__global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a, int zero_dqe) {
   extern __shared__ float acc[];                  // [d] partial of d wo_w, + 1 for d wo_b
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, K1 = a.K + 1;
+  if (zero_dqe)                                   // d query_emb collects atomics much later (rtm_embed_bwd_kernel): no memset launch
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < a.B * a.d; e += gridDim.x * 256) a.dqe[e] = 0.f;
   for (int e = threadIdx.x; e <= a.d; e += 256) acc[e] = 0.f;
   __syncthreads();
   const float sc = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
@@ -1344,6 +1377,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   const bool use_e4 = rtm_embed4_taken(D, k, r);
   k.count_fwd = rtm_counts_in_forward(D, k, r);
   if (k.count_fwd) { e.zero_i32 = k.wcnt; e.zero_n = (int)D.vocab_size + 1; }
+  if (!eval) e.clear_word = reinterpret_cast<uint32_t*>(ws + r.loss_blk + ps_cdiv(r.Bseq, 4));   // rtm_score_kernel's ticket
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {
     GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);
@@ -1393,8 +1427,11 @@ extern "C" int ps_rtm_forward(const PsRtmDesc* desc, const PsRtmTensors* params,
   hipStream_t st = (hipStream_t)stream;
   TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, false, k, st));
   k.loss3 = loss3;
-  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, k.scores);
+  const bool fold_loss = !k.train_pv;               // (the PV loss needs rtm_pv_fwd_kernel's terms: rtm_loss_kernel then)
+  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, k.scores, fold_loss ? 1 : 0,
+                     ws + r.loss_blk, reinterpret_cast<uint32_t*>(ws + r.loss_blk + ps_cdiv(r.Bseq, 4)));
   PS_LAUNCH_CHECK();
+  if (fold_loss) return PS_OK;
   if (k.train_pv) {
     const int ntask = k.B * k.R * k.W * (k.K + 1);
     int lpr = 1; while (lpr < k.d / 4 && lpr < 64) lpr <<= 1;
@@ -1415,7 +1452,7 @@ extern "C" int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, c
   TRY(rtm_make_ws(*desc, true, r, w, E));
   hipStream_t st = (hipStream_t)stream;
   TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, true, k, st));
-  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, scores);
+  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, scores, 0, nullptr, nullptr);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -1473,7 +1510,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));
   }
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k);
+  hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k, fwd_index || !k.pvc ? 1 : 0);
   PS_LAUNCH_CHECK();
   if (k.train_pv) {
     hipLaunchKernelGGL(rtm_pv_bwd_kernel, dim3(ps_cdiv(B * k.R, 4)), dim3(256), 0, st, k);
@@ -1485,8 +1522,8 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
   ColFoldList fold;
   fold.n = 0;
   // d query_emb (+, when the index is built here, the per-word counters right behind it, rtm_make_ws): one memset
-  {
-    const int64_t zend = k.pvc && !fwd_index ? r.wcnt + (((int64_t)D.vocab_size + 1 + 3) & ~(int64_t)3) : r.dqe + (((int64_t)B * d + 3) & ~(int64_t)3);
+  if (k.pvc && !fwd_index) {
+    const int64_t zend = r.wcnt + (((int64_t)D.vocab_size + 1 + 3) & ~(int64_t)3);
     PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)(zend - r.dqe), st));
   }
   const int eb = rtm_slot_blocks(r);
