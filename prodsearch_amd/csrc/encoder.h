@@ -39,6 +39,7 @@ WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const W
 // `fold_sc` (optional, TEM with replicas): item scoring + loss run in the epilogue of the last layer's fused kernel.
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
                        const Ws& w, hipStream_t st, bool rows_listed = false, const ScoreArgs* fold_sc = nullptr);
+bool enc_rowlist_taken(const PsTemDesc& D, const Ws& w, bool rows_listed);   // the encoder reads x through the valid-row list only
 // Backward of the above: reads w.denc (grad wrt w.enc), accumulates parameter grads into G, writes w.dx.
 // `fold` (optional): the LayerNorm backwards park their column sums in w.lnpart and append to this list; the caller
 // must hand it to a later launch_embed_scatter (EmbedBwdArgs::fold).  nullptr: plain atomics.

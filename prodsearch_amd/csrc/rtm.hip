@@ -408,7 +408,7 @@ struct E4Lds {
   uint32_t dw[4][256][4];          // [wave][column][review]: dropout words of the output row
 };
 template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
-__global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK) {
+__global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread) {
   __shared__ E4Lds L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * 4 + wv;
@@ -527,10 +527,11 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
   const int* wl = L.wid[wv][q];
   const float* tl = L.tm[wv][q];
-  for (int i0 = 0; i0 < maxn; i0 += 4) {
-    float4 rowv[4][NCHL]; float mt[4];
+  constexpr int E4_U = NCHL <= 2 ? 8 : 4;          // word rows in flight per 16-lane group
+  for (int i0 = 0; i0 < maxn; i0 += E4_U) {
+    float4 rowv[E4_U][NCHL]; float mt[E4_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < E4_U; ++u) {
       const bool on = i0 + u < myn;
       const int wi = on ? wl[i0 + u] : 0;
       mt[u] = on ? tl[i0 + u] : 0.f;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
         rowv[u][k] = on ? *reinterpret_cast<const float4*>(row + 64 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < E4_U; ++u)
 #pragma unroll
       for (int k = 0; k < NCHL; ++k) {
         v[k].x += rowv[u][k].x; v[k].y += rowv[u][k].y; v[k].z += rowv[u][k].z; v[k].w += rowv[u][k].w;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
   // occurrences of that word (a returning atomic on the word's counter, in flight under the rest of the kernel); the fill
   // then places the occurrence at  segment start + rank  without another atomic
-  int rka[4], rkb[4];
+  int rka[4] = {-1, -1, -1, -1}, rkb[4] = {-1, -1, -1, -1};
   if (a.count_fwd && any_ok) {
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
@@ -573,8 +574,10 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   const int rr = 4 * gg + q;
   const float cntf = (float)(nw > 0 ? nw : 1), inv = 1.f / cntf;
   if (c == 0) { a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f; a.cnt[(size_t)n * a.R + s - 1] = cntf; }
+  const bool skip_row = !ok && pads_unread && !need_unc;
 #pragma unroll
   for (int k = 0; k < NCHL; ++k) {
+    if (skip_row) break;
     const int col0 = 4 * c + 64 * k;
     const float unc[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
     const float cor[4] = {vc[k].x * inv, vc[k].y * inv, vc[k].z * inv, vc[k].w * inv};
@@ -1391,10 +1394,14 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
     if (use_e4) {
       const int npos = ps_cdiv((int64_t)B * D.R, 4), nneg = ps_cdiv((int64_t)B * D.K * D.R, 4);
       const dim3 grid(ps_cdiv(npos + nneg + r.Bseq, 4));
+      // x rows of padded positions: with the valid-row list nothing downstream reads them (the projections, the attention and
+      // the backward all walk the list), so they are not written either (18 us of the launch at C4, 73 % padding)
+      static const bool keep_pads = getenv("PS_RTM_WRITE_PADS") && atoi(getenv("PS_RTM_WRITE_PADS")) != 0;
+      const int pads_unread = enc_rowlist_taken(E, w, rtm_rows_listed(r, w)) && !k.raw && !keep_pads ? 1 : 0;
       const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
-      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
-      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
-      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK);
+      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
+      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
+      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
     } else {
       hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
     }

@@ -437,6 +437,19 @@ int side_join(hipStream_t main_st) {
   return PS_OK;
 }
 
+// does the (one-layer) encoder walk the valid-row list?  Then the rows of x at padded positions are never read, forward
+// or backward (K / V products, attention and their gradients all go through the list), and need not be written.
+bool enc_rowlist_taken(const PsTemDesc& D, const Ws& w, bool rows_listed) {
+  static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+  if (!(rows_on && rows_listed && D.n_layers == 1 && w.qpos == 0 && w.vrows != 0 && w.S <= 64)) return false;
+  const LayerWs& l = w.layer[0];
+  if (l.Sq != 1 || l.n_in != D.B) return false;
+  AttnArgs probe;
+  memset(&probe, 0, sizeof(probe));
+  probe.Sq = 1; probe.S = w.S; probe.d = D.d; probe.H = D.H;
+  return attn_sq1_fits(probe);
+}
+
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
                        const Ws& w, hipStream_t st, bool rows_listed, const ScoreArgs* fold_sc) {
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
@@ -465,18 +478,11 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       else g.p[2] = gp(xn + (size_t)w.qpos * d, S * d, 0, Lp.wq, d, 0, ws + l.qp, d, l.n_in, d, d);
       g.p[2].bias = Lp.bq; g.p[2].alpha = qscale;
       // valid rows only (EmbedArgs::vrows): the K / V rows of padded positions are never read (sq1_load zero-fills them)
-      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
-      if (rows_on && rows_listed && i == 0 && NL == 1 && l.Sq == 1 && w.qpos == 0 && w.vrows != 0 && l.n_in == B &&
-          S <= 64) {
-        AttnArgs probe;
-        memset(&probe, 0, sizeof(probe));
-        probe.Sq = 1; probe.S = S; probe.d = d; probe.H = D.H;
-        if (attn_sq1_fits(probe)) {
-          const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
-          const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
-          g.p[0].ridx = vr; g.p[0].rcount = vc;
-          g.p[1].ridx = vr; g.p[1].rcount = vc;
-        }
+      if (i == 0 && enc_rowlist_taken(D, w, rows_listed)) {
+        const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
+        const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
+        g.p[0].ridx = vr; g.p[0].rcount = vc;
+        g.p[1].ridx = vr; g.p[1].rcount = vc;
       }
       TRY(ps_launch_gemm(g, st));
     }

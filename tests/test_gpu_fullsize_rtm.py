@@ -55,7 +55,8 @@ def _check_forward(a, sd, m, batch, loss, keep, oloss):
     assert torch.equal(st['valid'].ne(0), mask)                                   # index work: bit-exact
     seq = torch.cat([keep['pos_seq'].unsqueeze(1), keep['neg_seq']], dim=1) * mask.unsqueeze(-1).float()
     seq = seq + ortm.positional_encoding(5000, D)[:R + 1]
-    assert rel_err(st['x'], seq) < 1e-4
+    # (rows of x at padded positions are never read — every consumer walks the valid-row list — and not written either)
+    assert rel_err(torch.nan_to_num(st["x"]) * mask.unsqueeze(-1), seq * mask.unsqueeze(-1)) < 1e-4
     assert rel_err(st['query_emb'], keep['query_emb']) < 1e-4
     enc = torch.cat([keep['enc_pos'].unsqueeze(1), keep['enc_neg']], dim=1)
     assert rel_err(st['enc'], enc) < 2e-4
@@ -131,7 +132,9 @@ def test_rtm_full_size_token_corruption_follows_the_philox_stream():
         loss_again = m2(batch2.to('cuda'), train_pv=False)
         st2 = _stages(m2)
     assert float(loss_again) == float(loss)             # same seed and step: identical bits
-    assert torch.equal(st1['x'], st2['x']) and torch.equal(st1['scores'], st2['scores'])
+    vm = st1['valid'].ne(0).unsqueeze(-1)
+    assert torch.equal(st1['valid'], st2['valid'])
+    assert torch.equal(torch.nan_to_num(st1['x']) * vm, torch.nan_to_num(st2['x']) * vm) and torch.equal(st1['scores'], st2['scores'])
 
 
 def test_rtm_full_size_training_step_with_reference_defaults_is_finite_and_learns():

@@ -73,7 +73,9 @@ def test_rtm_forward_matches_reference(case):
     seq = torch.cat([keep['pos_seq'].unsqueeze(1), keep['neg_seq']], dim=1) * mask.unsqueeze(-1).float()
     if g.args.use_pos_emb:
         seq = seq + ortm.positional_encoding(5000, d)[:S]
-    assert rel_err(m.workspace_view(plan, 'x', (B, J, S, d)).cpu(), seq) < 2e-4
+    # (rows of x at padded positions are never read — every consumer walks the valid-row list — and not written either)
+    mk = mask.unsqueeze(-1).float()
+    assert rel_err(torch.nan_to_num(m.workspace_view(plan, 'x', (B, J, S, d)).cpu()) * mk, seq * mk) < 2e-4
     enc = torch.cat([keep['enc_pos'].unsqueeze(1), keep['enc_neg']], dim=1)
     assert rel_err(m.workspace_view(plan, 'enc', (B, J, d)).cpu(), enc) < 2e-4
     assert torch.equal(m.workspace_view(plan, 'weight', (B, J)).cpu(), keep['weight'])
