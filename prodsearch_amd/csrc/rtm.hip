@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
 // in LDS and PARKED as one [3][d] partial per workgroup (`seg_part`, folded by the step's last launch, ColFoldList)
 // instead of 3d same-address atomics per workgroup.
 template <int NK>      // columns per lane: d <= 64 * NK
-__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part, int npos_w, int nneg_w, FDiv fR, FDiv fK, int dbg) {
+__global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part, int npos_w, int nneg_w, FDiv fR, FDiv fK) {
   __shared__ float segs[4][3][64 * NK];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = (int)blockIdx.x * 4 + wv;
@@ -839,7 +839,6 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
   dpos.step = drop_step(a.d_pos); dpos.step_ptr = nullptr;
   dneg.step = drop_step(a.d_neg); dneg.step_ptr = nullptr;
   dpv.step = drop_step(a.d_pv); dpv.step_ptr = nullptr;
-  if (dbg & 1) { dpos.thr = 0; dneg.thr = 0; }
   float sacc[3][NK];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
@@ -873,7 +872,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
     const unsigned long long okm = __ballot(my_ok);
     for (int gi = 0; gi < EB_GROUPS; ++gi) {
       const int gg = w0 * EB_GROUPS + gi;                   // review rows 4gg .. 4gg+3 of this side: one Philox counter row
-      if (!((okm >> (4 * gi)) & 0xfull) || (dbg & 4)) continue;
+      if (!((okm >> (4 * gi)) & 0xfull)) continue;
       int nq[4], sq[4], segq[4], rrq[4]; bool okq[4]; int64_t ridq[4]; size_t sposq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -954,14 +953,14 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
           float* gw = a.gs + ((size_t)nq[q] * a.S + sq[q]) * d;
 #pragma unroll
           for (int k = 0; k < NK; ++k)
-            if (lane + 64 * k < d && !(dbg & 2)) gw[lane + 64 * k] = t[k] * inv;
+            if (lane + 64 * k < d) gw[lane + 64 * k] = t[k] * inv;
         }
       }
     }
   } else {
     // ---- query positions (s = 0) of EB_QSEQ sequences: segment / user / item rows and d query_emb
     const int n0 = (wave - npos_w - nneg_w) * EB_QSEQ, nseq = a.B * a.J;
-    for (int i0 = 0; i0 < EB_QSEQ && n0 + i0 < nseq && !(dbg & 8); i0 += 4) {
+    for (int i0 = 0; i0 < EB_QSEQ && n0 + i0 < nseq; i0 += 4) {
       float gk[4][NK]; int bq[4], segq[4]; bool on[4], posq[4]; size_t sposq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1005,7 +1004,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
       }
     }
   }
-  if (!a.use_seg || (dbg & 16)) return;
+  if (!a.use_seg) return;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -1118,11 +1117,12 @@ __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk
 // run of equal words in registers and issues ONE atomic row per run (runs spanning waves meet in the atomics)
 __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
   const int T = a.wcnt[a.V];                         // the allocator's total (rtm_walloc_kernel)
-  const int base = wave * 64;
-  if (base >= T) return;
   const int d = a.d;                                 // lane l owns columns l, l+64, ... (< d <= 512)
+  // (the list length is only known on the device: a capped grid strides over it instead of one workgroup per 256 POSSIBLE
+  // occurrences, 30,000 launches of which 25,000 found nothing to do)
+  for (int base = wave0 * 64; base < T; base += nwave * 64) {
   const int e = base + lane;
   const int2 mine = e < T ? a.wl[e] : make_int2(-1, -1);
   const int my_slot = mine.x, my_word = mine.y;
@@ -1134,18 +1134,20 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
   if (d <= 128) {
     // d <= 128 (two columns per lane): 8 slot rows are requested before the first is added — one by one the loop is a
     // chain of 64 dependent L2 round trips per wave (149 us for the 594 MB of a C4 step)
-    for (int i0 = 0; i0 < n; i0 += 8) {
-      float r0[8], r1[8];
+    const int c0 = lane < d ? lane : d - 1, c1 = lane + 64 < d ? lane + 64 : d - 1;
+    constexpr int WR_U = 16;                         // rows in flight (unconditional loads: a dead entry repeats row 0)
+    for (int i0 = 0; i0 < n; i0 += WR_U) {
+      float r0[WR_U], r1[WR_U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < WR_U; ++u) {
         const int sl = __shfl(my_slot, (i0 + u) & 63, 64);
         const bool live = i0 + u < n;
         const float* row = a.gs + (size_t)(live ? sl : 0) * d;
-        r0[u] = live && lane < d ? row[lane] : 0.f;
-        r1[u] = live && lane + 64 < d ? row[lane + 64] : 0.f;
+        r0[u] = row[c0];
+        r1[u] = row[c1];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < WR_U; ++u) {
         if (i0 + u < n) {                            // wave-uniform
           const int w = __shfl(my_word, (i0 + u) & 63, 64);
           if (w != cur) {
@@ -1177,6 +1179,7 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], acc[k]);
+  }
 }
 
 // uncorrupted pvc review table for eval: out[i] = mean of the review's word rows, last row 0 (ps_model.py:186-203)
@@ -1554,11 +1557,10 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     const int nwg = ps_cdiv(rtm_eb_waves(B, D.K, D.R, &npw, &nnw), 4);
     const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
     float* sp = ws + r.segpart;
-    static const int ebdbg = getenv("PS_RTM_EB_DBG") ? atoi(getenv("PS_RTM_EB_DBG")) : 0;
-    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
-    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
-    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
-    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK, ebdbg);
+    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
+    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
+    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
+    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
     PS_LAUNCH_CHECK();
     if (D.use_seg_emb) {
       PS_REQUIRE(fold.n < PS_MAX_COLFOLD, "rtm backward: too many parked column sums");
@@ -1575,7 +1577,13 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
       TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
     }
     const int64_t max_occ = (int64_t)r.Bseq * D.R * D.WL;
-    hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)((max_occ + 255) / 256)), dim3(256), 0, st, k);
+    static const int wr_cap = getenv("PS_RTM_WR_WGS") ? atoi(getenv("PS_RTM_WR_WGS")) : 4096;
+    int64_t wr = (max_occ + 255) / 256;
+    if (wr > wr_cap) wr = wr_cap;
+    // (measured and dropped: the columns split over the XCDs — workgroup i takes d/8 columns of every entry, so that an XCD's
+    // L2 holds 1/8 of each gathered row and serves the 56 re-reads itself: 206 us against 66, each 4-lane entry stream keeps
+    // too few bytes in flight; this form reads 594 MB from the Infinity Cache at 8.9 TB/s)
+    hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, st, k);
     PS_LAUNCH_CHECK();
   }
   // query encoder backward (shared kernels) + scatter to the query word rows
