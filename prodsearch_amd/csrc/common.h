@@ -268,6 +268,10 @@ struct GemmProblem {
 struct GemmGroup {
   GemmProblem p[3];
   int n;
+  // flat form (weight gradients of different shapes in one launch): grid.x walks  sum_i tiles_i * ksplit_i  workgroups,
+  // problem i owns [flat0[i], flat0[i+1]): split-major, then row tile, then column tile; each problem keeps its own ksplit
+  int flat;
+  int flat0[4], flat_tm[3], flat_tiles[3];
 };
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream);

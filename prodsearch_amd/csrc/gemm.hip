@@ -111,8 +111,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   __shared__ float Bs[2][BK][LDT];
   __shared__ int kidx[IDX && TA == 1 ? KIDX_MAX : 1];
 
-  const int prob = blockIdx.z / g.p[0].ksplit;
-  const int split = blockIdx.z - prob * g.p[0].ksplit;
+  int prob, split, ftile = 0;
+  if (g.flat) {
+    const int L = blockIdx.x;
+    prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
+    const int t = L - g.flat0[prob];
+    split = t / g.flat_tiles[prob];
+    ftile = t - split * g.flat_tiles[prob];
+  } else {
+    prob = blockIdx.z / g.p[0].ksplit;
+    split = blockIdx.z - prob * g.p[0].ksplit;
+  }
   const GemmProblem& P = g.p[prob];
   const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
   const int nlist = listed ? *P.rcount : 0;
@@ -120,7 +129,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
   // so give every XCD whole ROW tiles: all column tiles that re-read one A row-tile share an L2.
   int tm = blockIdx.y, tn = blockIdx.x;
-  {
+  if (g.flat) {
+    tm = ftile % g.flat_tm[prob];
+    tn = ftile / g.flat_tm[prob];
+  } else {
     const int nx = gridDim.x, ny = gridDim.y;
     const int L = blockIdx.y * nx + blockIdx.x;       // dispatch order (x fastest)
     const int grp = L / (8 * nx), r = L - grp * 8 * nx;
@@ -347,6 +359,26 @@ static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGrou
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
   PS_REQUIRE(g.n >= 1 && g.n <= 3, "gemm: group size %d", g.n);
+  if (g.flat) {
+    GemmGroup f = g;
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+      f.flat0[i] = total;
+      if (i >= g.n) { f.flat_tm[i] = 1; f.flat_tiles[i] = 1; continue; }
+      int rc = validate(g.p[i]);
+      if (rc) return rc;
+      PS_REQUIRE(g.p[i].ta == 1 && g.p[i].tb == 1 && !needs_full(g.p[i]) && !g.p[i].ridx && g.p[i].accumulate == 2 && g.p[i].ksplit >= 1,
+                 "gemm: the flat group form takes plain weight-gradient problems");
+      f.flat_tm[i] = ps_cdiv(g.p[i].M, BM);
+      f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, BN);
+      total += f.flat_tiles[i] * g.p[i].ksplit;
+    }
+    f.flat0[3] = total;
+    for (int i = g.n; i < 3; ++i) f.flat0[i] = total + 1;      // never selected
+    launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   int maxM = 0, maxN = 0;
   bool full = false;
   for (int i = 0; i < g.n; ++i) {

@@ -269,6 +269,21 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.n = n;
+  bool same = true, plain = true;
+  for (int i = 0; i < n; ++i) {
+    same = same && ps[i].M == ps[0].M && ps[i].N == ps[0].N && ps[i].K == ps[0].K;
+    plain = plain && !ps[i].ridx;
+  }
+  if (n > 1 && !same && plain) {
+    // different shapes in one launch: the flat form (GemmGroup::flat) — every problem keeps the split count it would
+    // take alone, no idle workgroups for the tiles the smaller members do not have
+    for (int i = 0; i < n; ++i) {
+      g.p[i] = ps[i];
+      g.p[i].ksplit = pick_ksplit(ps_cdiv(ps[i].M, 64) * ps_cdiv(ps[i].N, 64), ps[i].K);
+    }
+    g.flat = 1;
+    return ps_launch_gemm(g, st);
+  }
   int tiles = 0, rows = 0;
   for (int i = 0; i < n; ++i) {
     tiles += ps_cdiv(ps[i].M, 64) * ps_cdiv(ps[i].N, 64);
@@ -860,10 +875,10 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         TRY(launch_score_bwd(t, sc ? sc->stream : st));
       }
       // (a second side stream for W1 / Wo beside W2 measured 0.389 vs 0.368 ms: slower)
-      // one launch for the three when the reduction is short (review transformer, 1.5k rows: three latency-bound launches of
-      // ~50 workgroups, 0.595 -> 0.570 ms/step); at C2 (8k rows) the grouped launch's 500 workgroups crowd the attention
-      // backward and the dX product on the main stream instead (0.318 -> 0.349 ms/step)
-      static const int wg_group_rows = getenv("PS_WGRAD_GROUP_ROWS") ? atoi(getenv("PS_WGRAD_GROUP_ROWS")) : 4096;
+      // one launch for the three (the flat group form: every member keeps its own split count; three launches of ~250
+      // latency-bound workgroups one after the other took 86 us at C2; review transformer 0.563 -> 0.543 ms/step, C2 0.3156 ->
+      // 0.3144).  PS_WGRAD_GROUP_ROWS=0 restores the separate launches.
+      static const int wg_group_rows = getenv("PS_WGRAD_GROUP_ROWS") ? atoi(getenv("PS_WGRAD_GROUP_ROWS")) : (1 << 30);
       if (M2 <= wg_group_rows) {
         GemmProblem all3[3] = {wg[0], wg1[0], wgo[0]};
         TRY(side_run(all3, 3, st));
@@ -979,7 +994,9 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // fork 2: they need the attention backward's dK / dV / dQ.  With the fused backward the side stream already
       // holds W2 / W1 / Wo (~90 us, the step's tail): the K/V/Q weight gradients then follow the dX GEMM on the MAIN
       // stream instead — one event less, and the side stream ends before the scatter does.
-      static const bool wg3_main_on = !(getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) != 0);
+      // (round 2: W2 / W1 / Wo are ONE launch of ~45 us now, the side stream is free again when the attention backward
+      // ends: the K / V / Q weight gradients go back to it, 0.3151 -> 0.3124 ms/step; PS_WG3_SIDE=0: main stream)
+      static const bool wg3_main_on = getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) == 0;
       const bool wg3_main = fused && wg3_main_on && ns <= 2 * M2;   // (review transformer: 78k K/V rows vs 1.5k replica rows -> side)
       // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the K/V
       // weight gradients (and the dX product below) run over the batch's row list instead of all n_in*S rows

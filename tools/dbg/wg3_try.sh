@@ -1,0 +1,3 @@
+for e in "X=1" "PS_WG3_SIDE=1" "PS_SCORE_BWD_MAIN=1" "PS_WG3_SIDE=1 PS_SIDE_LIGHT=0"; do
+env $e python bench.py --steps 300 --warmup 30 --cpu-steps 0 --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2 $e', d['ms_per_step'])"
+done
