@@ -619,6 +619,434 @@ int launch_attn_fwd_w1(const AttnArgs& a, hipStream_t st) {
   return PS_OK;
 }
 
+// ================================================================== one wave per (sequence, four heads), replicas inside
+// The dropout replicas of a sequence (fan = K + 1 at C2) share its K / V rows and softmax weights; only the dropout mask
+// of the weights and the context / d context rows differ.  A wave owns four heads (one Philox counter row: the group's
+// keep bits of a replica are FOUR ballots, lane = key) and keeps its keys' V rows, weights and d V / d P sums in
+// registers across the replica loop — no LDS staging, no barriers (the workgroup form: 14.5 / 29.6 us at C2 for ~0.1
+// GFLOP).  The forward leaves the keep bits in `amask` ([n_in*fan][H] words, bit = key rank) for the backward.
+// Lanes: LPR = dh lanes cover the group's 4*dh columns of a row (float4 each), 64/LPR keys per step, up to MAXK steps.
+template <int DH, int MAXK>
+__global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint32_t* amask, int nchunk) {
+  constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4;
+  __shared__ int sp[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int NHG = a.H >> 2, D = a.d, S = a.S, HF = a.H;
+  // wave -> (sequence, head group, replica chunk): the replicas are independent in the forward, so `nchunk` waves share a
+  // (sequence, head group) — each repeats the short softmax, each takes fan / nchunk replicas (768 waves of 21 serial
+  // replicas left the chip idle: 15 us)
+  const int gw = (int)blockIdx.x * 4 + wv, ch = gw % nchunk, gq = gw / nchunk, b = gq / NHG, hg = gq - b * NHG;
+  if (b >= a.n_in) return;
+  const int jper = (a.fan + nchunk - 1) / nchunk, jbeg = ch * jper, jend = min(a.fan, jbeg + jper);
+  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
+  const unsigned long long vm = w1_valid(a, b, lane, sp[wv]);
+  const int Sv = __popcll(vm);
+  const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+  // scores of my keys, softmax over all keys of the head
+  float4 v4[MAXK]; float P[MAXK]; int pk[MAXK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int k = i * KPS + sub;
+    pk[i] = sp[wv][k < Sv ? k : 0];
+    const size_t row = (size_t)b * S + pk[i];
+    const float4 k4 = f4_ld(a.kp + row * D + c);
+    v4[i] = f4_ld(a.vp + row * D + c);
+    float dot = f4_dot(q4, k4);
+#pragma unroll
+    for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+    P[i] = k < Sv ? dot : -INFINITY;
+    mx = fmaxf(mx, P[i]);
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float lsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) { P[i] = i * KPS + sub < Sv ? expf(P[i] - mx) : 0.f; lsum += P[i]; }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
+  const float inv = 1.f / lsum;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    P[i] *= inv;
+    if (ch == 0 && i * KPS + sub < Sv && (cl & (LPH - 1)) == 0) a.attn[((size_t)b * HF + h) * S + pk[i]] = P[i];
+  }
+  if (ch == 0 && lane < S && !((vm >> lane) & 1ull))         // masked positions: weight 0 (lane = position)
+    for (int hh = 0; hh < 4; ++hh) a.attn[((size_t)b * HF + 4 * hg + hh) * S + lane] = 0.f;
+  // replicas
+  DropSpec drop = a.drop;
+  drop.step = drop_step(a.drop); drop.step_ptr = nullptr;
+  const int mykey = sp[wv][lane < Sv ? lane : 0];
+  for (int j = jbeg; j < jend; ++j) {
+    const size_t rrow = (size_t)b * a.fan + j;
+    uint32_t keep[4] = {~0u, ~0u, ~0u, ~0u};
+    if (drop.thr) {
+      const Philox4 r = philox4x32_10((uint32_t)mykey, (uint32_t)(rrow * HF + 4 * hg) >> 2, drop.site, drop.step, drop.k0, drop.k1);
+      const bool live = lane < Sv;
+      keep[0] = (uint32_t)__ballot(live && r.x >= drop.thr); keep[1] = (uint32_t)__ballot(live && r.y >= drop.thr);
+      keep[2] = (uint32_t)__ballot(live && r.z >= drop.thr); keep[3] = (uint32_t)__ballot(live && r.w >= drop.thr);
+    }
+    if (amask && lane < 4) amask[rrow * HF + 4 * hg + lane] = lane == 0 ? keep[0] : (lane == 1 ? keep[1] : (lane == 2 ? keep[2] : keep[3]));
+    const uint32_t kh = hl == 0 ? keep[0] : (hl == 1 ? keep[1] : (hl == 2 ? keep[2] : keep[3]));
+    float4 ctx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = i * KPS + sub;
+      const float m = (k < Sv && ((kh >> k) & 1u)) ? drop.scale : 0.f;
+      f4_fma(ctx4, P[i] * (drop.thr ? m : (k < Sv ? 1.f : 0.f)), v4[i]);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) ctx4 = f4_xor_add(ctx4, o);
+    if (sub == 0) f4_st(a.ctx + rrow * D + c, ctx4);
+  }
+}
+
+template <int DH, int MAXK>
+__global__ __launch_bounds__(256) void attn_bwd_wf_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
+  constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, MAXD = 256;
+  __shared__ int sp[4][64];
+  __shared__ float dqs[4][HC];                                // [wave]: the wave's dq columns
+  __shared__ float part[4][MAXD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NHG = a.H >> 2, D = a.d, S = a.S, HF = a.H;
+  const int gw = (int)blockIdx.x * 4 + wv, b = gw / NHG, hg = gw - b * NHG;
+  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
+  if (b < a.n_in) {
+    const unsigned long long vm = w1_valid(a, b, lane, sp[wv]);
+    const int Sv = __popcll(vm);
+    const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+    float4 v4[MAXK], dv4[MAXK]; float P[MAXK], dP[MAXK]; int pk[MAXK];
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = i * KPS + sub;
+      pk[i] = sp[wv][k < Sv ? k : 0];
+      v4[i] = f4_ld(a.vp + ((size_t)b * S + pk[i]) * D + c);
+      P[i] = a.attn[((size_t)b * HF + h) * S + pk[i]];
+      if (k >= Sv) P[i] = 0.f;
+      dv4[i] = make_float4(0.f, 0.f, 0.f, 0.f); dP[i] = 0.f;
+    }
+    // keep bits of all replicas: lane l holds word l (and l + 64) of the sequence's [fan][4] words of this head group
+    const bool masked = a.drop.thr != 0u;
+    uint32_t mw0 = ~0u, mw1 = ~0u;
+    if (masked) {
+      const int nwords = a.fan * 4;
+      if (lane < nwords) mw0 = amask[((size_t)b * a.fan + (lane >> 2)) * HF + 4 * hg + (lane & 3)];
+      if (lane + 64 < nwords) mw1 = amask[((size_t)b * a.fan + ((lane + 64) >> 2)) * HF + 4 * hg + (lane & 3)];
+    }
+    const float scale = masked ? a.drop.scale : 1.f;
+    // d context rows four replicas at a time, the next four requested before the current four are used (one row per
+    // iteration behind a one-deep prefetch left the wave waiting ~2 us per replica: 53 us)
+    constexpr int WF_B = 4;
+    float4 nx4[WF_B];
+#pragma unroll
+    for (int u = 0; u < WF_B; ++u) nx4[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (u < a.fan ? u : 0)) * D + c);
+    for (int j0 = 0; j0 < a.fan; j0 += WF_B) {
+      float4 cu4[WF_B];
+#pragma unroll
+      for (int u = 0; u < WF_B; ++u) cu4[u] = nx4[u];
+#pragma unroll
+      for (int u = 0; u < WF_B; ++u) {
+        const int jn = j0 + WF_B + u;
+        nx4[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (jn < a.fan ? jn : 0)) * D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < WF_B; ++u) {
+        const int j = j0 + u;
+        if (j >= a.fan) break;
+        const int wi = j * 4 + hl;
+        const uint32_t kh = wi < 64 ? __shfl(mw0, wi, 64) : __shfl(mw1, wi - 64, 64);
+#pragma unroll
+        for (int i = 0; i < MAXK; ++i) {
+          const int k = i * KPS + sub;
+          const float m = ((kh >> k) & 1u) ? scale : 0.f;
+          float dot = f4_dot(cu4[u], v4[i]);
+#pragma unroll
+          for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+          dP[i] = fmaf(m, dot, dP[i]);
+          f4_fma(dv4[i], P[i] * m, cu4[u]);
+        }
+      }
+    }
+    float th = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) th = fmaf(P[i], dP[i], th);
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) th += __shfl_xor(th, o, 64);
+    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = i * KPS + sub;
+      const size_t row = (size_t)b * S + pk[i];
+      const float4 k4 = f4_ld(a.kp + row * D + c);
+      const float g = P[i] * (dP[i] - th);                     // softmax backward (0 for a dead key: P = 0)
+      f4_fma(dq4, g, k4);
+      if (k < Sv) {
+        const float4 dk4 = f4_scale(g, q4);
+        f4_st(a.dkv + row * a.lddkv + c, dk4);
+        f4_st(a.dkv + row * a.lddkv + D + c, dv4[i]);
+        sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+        sv4.x += dv4[i].x; sv4.y += dv4[i].y; sv4.z += dv4[i].z; sv4.w += dv4[i].w;
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { dq4 = f4_xor_add(dq4, o); sk4 = f4_xor_add(sk4, o); sv4 = f4_xor_add(sv4, o); }
+    if (!pads_unread) {                                      // masked positions: exact zeros (dense consumers read them)
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = 0; s0 < S; s0 += KPS) {
+        const int s = s0 + sub;
+        if (s < S && !((vm >> s) & 1ull)) {
+          float* o = a.dkv + ((size_t)b * S + s) * a.lddkv;
+          f4_st(o + c, z); f4_st(o + D + c, z);
+        }
+      }
+    }
+    dq4 = f4_scale(a.qscale, dq4);
+    if (sub == 0) {
+      f4_st(a.dq + (size_t)b * a.lddq + c, dq4);
+      f4_st(&dqs[wv][4 * cl], dq4);
+      if (a.bias_part) {                                     // parked: folded by the step's last launch
+        float* bp = a.bias_part + (size_t)b * 3 * D + c;
+        f4_st(bp, dq4); f4_st(bp + D, sk4); f4_st(bp + 2 * D, sv4);
+      } else {
+        const float dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w}, skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w}, svv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&a.dbq[c + e], dqv[e]); atomicAdd(&a.dbk[c + e], skv[e]); atomicAdd(&a.dbv[c + e], svv[e]);
+        }
+      }
+    }
+  } else if (sub == 0) {
+    f4_st(&dqs[wv][4 * cl], make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  if (!a.wq) return;
+  // d x[query row] = dq . Wq + the fan-in residual rows: the workgroup's 4 / NHG sequences together; thread (pt, i) owns
+  // output column i and 1/NP of the D query features (and of the replicas of the fan-in sum)
+  __syncthreads();
+  const int NP = 256 / D, nseq = 4 / NHG;                    // D = 128: two parts; D = 256: one
+  const int i = tid % D, pt = tid / D, KP = D / NP;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pt < NP) {
+    const float* wcol = a.wq + (size_t)(pt * KP) * D + i;
+#pragma unroll 8
+    for (int k = 0; k < KP; ++k) {
+      const float w2 = wcol[(size_t)k * D];
+      const int kk = pt * KP + k, hw = kk / HC, off = kk - hw * HC;     // feature kk sits in head-group wave hw of each sequence
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq)
+        if (sq < nseq) acc[sq] = fmaf(dqs[sq * NHG + hw][off], w2, acc[sq]);
+    }
+    if (a.fanin_src)
+      for (int sq = 0; sq < nseq; ++sq) {
+        const int bb = (int)blockIdx.x * nseq + sq;
+        if (bb >= a.n_in) break;
+        for (int j = pt; j < a.fan; j += NP) acc[sq] += a.fanin_src[((size_t)bb * a.fan + j) * D + i];
+      }
+  }
+  for (int sq = 0; sq < nseq; ++sq) {
+    const int bb = (int)blockIdx.x * nseq + sq;
+    __syncthreads();
+    if (pt < NP) part[pt][i] = acc[sq];
+    __syncthreads();
+    if (tid < D && bb < a.n_in) {
+      float v = 0.f;
+      for (int q = 0; q < NP; ++q) v += part[q][tid];
+      a.dxq_part[(size_t)bb * D + tid] = v;
+    }
+  }
+}
+
+// Backward with the replicas of a (sequence, head group) split over the FOUR waves of a workgroup (d = 128, H = 8: two
+// workgroups per sequence).  Each wave repeats the short set-up and sums d V / d P over its 5-6 replicas (their d context
+// rows all requested up front); the partial sums meet in LDS, wave 0 finishes (softmax backward, d K / d V rows, dq) and the
+// workgroup multiplies its 64 dq values into Wq — 32 weights per thread, requested before the barriers — into one of the
+// sequence's two partial rows (AttnArgs::dxq_part, like the LDS form).  Registers <= 170 keep three workgroups on a CU: all
+// 768 resident at once.  (One wave per (sequence, head group): 37 us, a serial chain of 21 replicas on a mostly idle chip;
+// eight waves per sequence in one workgroup: 18 us alone but two rounds of 256-register workgroups, 40 us in the step; the
+// LDS workgroup form: 29 us.)
+template <int MAXK>
+__global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
+  constexpr int DH = 16, LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 128, NV = 5 * MAXK, JB = 6;
+  __shared__ int sp[4][64];
+  __shared__ float red[4][NV][64];                            // [wave][value][lane]
+  __shared__ float dqs[HC];
+  __shared__ float part[D];
+  const int tid = threadIdx.x, lane = tid & 63, ch = tid >> 6;
+  const int S = a.S, HF = a.H;
+  const int b = (int)blockIdx.x >> 1, hg = (int)blockIdx.x & 1;
+  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
+  const bool fold_q = a.wq != nullptr;
+  const unsigned long long vm = w1_valid(a, b, lane, sp[ch]);
+  const int Sv = __popcll(vm);
+  float4 v4[MAXK], dv4[MAXK]; float P[MAXK], dP[MAXK];
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int k = i * KPS + sub;
+    const int p = sp[ch][k < Sv ? k : 0];
+    v4[i] = f4_ld(a.vp + ((size_t)b * S + p) * D + c);
+    P[i] = a.attn[((size_t)b * HF + h) * S + p];
+    if (k >= Sv) P[i] = 0.f;
+    dv4[i] = make_float4(0.f, 0.f, 0.f, 0.f); dP[i] = 0.f;
+  }
+  const int jper = (a.fan + 3) >> 2, jbeg = ch * jper, jend = min(a.fan, jbeg + jper), nj = max(0, jend - jbeg);   // nj <= JB (fits)
+  const bool masked = a.drop.thr != 0u;
+  uint32_t mw = ~0u;                                          // lane l: keep word of (replica jbeg + l/4, head l&3)
+  if (masked && lane < nj * 4) mw = amask[((size_t)b * a.fan + jbeg + (lane >> 2)) * HF + 4 * hg + (lane & 3)];
+  const float scale = masked ? a.drop.scale : 1.f;
+  {
+    float4 dc[JB];
+#pragma unroll
+    for (int u = 0; u < JB; ++u) dc[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (u < nj ? jbeg + u : 0)) * D + c);
+#pragma unroll
+    for (int u = 0; u < JB; ++u) {
+      if (u >= nj) break;
+      const uint32_t kh = __shfl(mw, u * 4 + hl, 64);
+#pragma unroll
+      for (int i = 0; i < MAXK; ++i) {
+        const int k = i * KPS + sub;
+        const float m = ((kh >> k) & 1u) ? scale : 0.f;
+        float dot = f4_dot(dc[u], v4[i]);
+#pragma unroll
+        for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+        dP[i] = fmaf(m, dot, dP[i]);
+        f4_fma(dv4[i], P[i] * m, dc[u]);
+      }
+    }
+  }
+  // the tail's weights: thread (half, i) owns output column i and 32 of this group's 64 query features; requested now
+  // (the d context rows are consumed), used after the two barriers below
+  float wq[32];
+  if (fold_q) {
+    const int i = tid & 127, half = tid >> 7;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
+  }
+  if (ch != 0) {
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      red[ch][5 * i + 0][lane] = dv4[i].x; red[ch][5 * i + 1][lane] = dv4[i].y; red[ch][5 * i + 2][lane] = dv4[i].z;
+      red[ch][5 * i + 3][lane] = dv4[i].w; red[ch][5 * i + 4][lane] = dP[i];
+    }
+  }
+  __syncthreads();
+  if (ch == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i)
+#pragma unroll
+      for (int o = 1; o < 4; ++o) {
+        dv4[i].x += red[o][5 * i + 0][lane]; dv4[i].y += red[o][5 * i + 1][lane]; dv4[i].z += red[o][5 * i + 2][lane];
+        dv4[i].w += red[o][5 * i + 3][lane]; dP[i] += red[o][5 * i + 4][lane];
+      }
+    const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+    float th = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) th = fmaf(P[i], dP[i], th);
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) th += __shfl_xor(th, o, 64);
+    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = i * KPS + sub;
+      const size_t row = (size_t)b * S + sp[0][k < Sv ? k : 0];
+      const float4 k4 = f4_ld(a.kp + row * D + c);
+      const float g = P[i] * (dP[i] - th);                     // softmax backward (0 for a dead key: P = 0)
+      f4_fma(dq4, g, k4);
+      if (k < Sv) {
+        const float4 dk4 = f4_scale(g, q4);
+        f4_st(a.dkv + row * a.lddkv + c, dk4);
+        f4_st(a.dkv + row * a.lddkv + D + c, dv4[i]);
+        sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+        sv4.x += dv4[i].x; sv4.y += dv4[i].y; sv4.z += dv4[i].z; sv4.w += dv4[i].w;
+      }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { dq4 = f4_xor_add(dq4, o); sk4 = f4_xor_add(sk4, o); sv4 = f4_xor_add(sv4, o); }
+    dq4 = f4_scale(a.qscale, dq4);
+    if (sub == 0) {
+      f4_st(a.dq + (size_t)b * a.lddq + c, dq4);
+      f4_st(&dqs[4 * cl], dq4);
+      if (a.bias_part) {                                     // parked: folded by the step's last launch
+        float* bp = a.bias_part + (size_t)b * 3 * D + c;
+        f4_st(bp, dq4); f4_st(bp + D, sk4); f4_st(bp + 2 * D, sv4);
+      } else {
+        const float dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w}, skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w}, svv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(&a.dbq[c + e], dqv[e]); atomicAdd(&a.dbk[c + e], skv[e]); atomicAdd(&a.dbv[c + e], svv[e]);
+        }
+      }
+    }
+  } else if (ch == 1 && !pads_unread) {                      // masked positions: exact zeros (dense consumers read them)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < S; s0 += KPS) {
+      const int s = s0 + sub;
+      if (s < S && !((vm >> s) & 1ull)) {
+        float* o = a.dkv + ((size_t)b * S + s) * a.lddkv;
+        f4_st(o + c, z); f4_st(o + D + c, z);
+      }
+    }
+  }
+  if (!fold_q) return;
+  __syncthreads();
+  {
+    const int i = tid & 127, half = tid >> 7;
+    float acc = 0.f;
+    if (a.fanin_src && (i >> 6) == hg)                       // this group's 64 columns of the replicas' fan-in sum
+      for (int j = half; j < a.fan; j += 2) acc += a.fanin_src[((size_t)b * a.fan + j) * D + i];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf(dqs[half * 32 + k], wq[k], acc);
+    if (half == 1) part[i] = acc;
+    __syncthreads();
+    if (half == 0) a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
+  }
+}
+static bool attn_wf4_fits(const AttnArgs& a) {
+  static const bool on = !(getenv("PS_ATTN_WF4") && atoi(getenv("PS_ATTN_WF4")) == 0);
+  return on && a.d == 128 && a.H == 8 && a.dh == 16 && a.S <= 32 && a.fan >= 4 && a.fan <= 24;
+}
+
+// shapes the replica form takes: 4*dh columns per wave (dh 16 or 32), H/4 waves per sequence dividing the workgroup,
+// keys within its register budget, keep bits within one word
+static inline int wf_maxk(const AttnArgs& a) { return a.dh == 16 ? 8 : 16; }
+static inline bool wf_short(const AttnArgs& a) { return a.dh == 16 && a.S <= 24; }     // 6 key steps instead of 8
+// the replica form's backward writes TWO partial dQ.Wq rows per sequence (one per head group), like the LDS form
+bool attn_bwd_wf_two_partials(const AttnArgs& a) { return attn_wf_fits(a) && attn_wf4_fits(a); }
+bool attn_wf_fits(const AttnArgs& a) {
+  static const bool on = !(getenv("PS_ATTN_WF") && atoi(getenv("PS_ATTN_WF")) == 0);
+  if (!(on && a.Sq == 1 && a.fan >= 1 && (a.dh == 16 || a.dh == 32) && a.H % 4 == 0 && a.dh * a.H == a.d && a.d <= 256)) return false;
+  const int nhg = a.H / 4;
+  if (nhg != 1 && nhg != 2 && nhg != 4) return false;
+  const int kps = 64 / a.dh;
+  return a.S <= 32 && a.S <= kps * wf_maxk(a) && a.fan * 4 <= 128;
+}
+int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
+  PS_REQUIRE(attn_wf_fits(a) && amask, "attention(wf): unsupported shape");
+  static const int env_ch = getenv("PS_ATTN_WF_CHUNKS") ? atoi(getenv("PS_ATTN_WF_CHUNKS")) : 0;
+  int nch = env_ch > 0 ? env_ch : (a.fan >= 12 ? 4 : (a.fan >= 4 ? 2 : 1));
+  if (nch > a.fan) nch = a.fan;
+  const dim3 grid(ps_cdiv(a.n_in * (a.H / 4) * nch, 4));
+  if (wf_short(a)) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, nch);
+  else if (a.dh == 16) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, nch);
+  else hipLaunchKernelGGL((attn_fwd_wf_kernel<32, 16>), grid, dim3(256), 0, st, a, amask, nch);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st) {
+  PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
+  PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(wf): folded dQ.Wq needs its output row buffer");
+  if (attn_wf4_fits(a)) {   // replicas over four waves: two partial dQ.Wq rows per sequence (attn_bwd_wf_two_partials)
+    if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<6>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+    else hipLaunchKernelGGL((attn_bwd_wf4_kernel<8>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
+  const dim3 grid(ps_cdiv(a.n_in * (a.H / 4), 4));
+  if (wf_short(a)) hipLaunchKernelGGL((attn_bwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  else if (a.dh == 16) hipLaunchKernelGGL((attn_bwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL((attn_bwd_wf_kernel<32, 16>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 bool attn_w1_fits(const AttnArgs& a) {
   static const bool on = !(getenv("PS_ATTN_W1") && atoi(getenv("PS_ATTN_W1")) == 0);
   const int lph = a.dh / 4;

@@ -7,6 +7,7 @@
 struct LayerWs {
   int n_in, fan, n_out, Sq, M2;
   int64_t xn, pre_stats, kp, vp, qp, attn, ctx, y1, ff_stats, ln1, a1, h1, y2;
+  int64_t amask;            // uint32 [n_in*fan][H]: keep bits of the attention dropout (attn_fwd_wf_kernel -> its backward)
 };
 struct Ws {
   int R, S, Mf, qpos;

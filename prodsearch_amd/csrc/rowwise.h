@@ -158,6 +158,10 @@ bool attn_sq1_fits(const AttnArgs& a);
 bool attn_w1_fits(const AttnArgs& a);      // one wave per sequence (fan == 1, d 64 / 128)
 int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st);
 int launch_attn_fwd_w1(const AttnArgs& a, hipStream_t st);
+bool attn_wf_fits(const AttnArgs& a);      // one wave per (sequence, four heads), dropout replicas inside (S <= 32)
+int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st);
+int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st);
+bool attn_bwd_wf_two_partials(const AttnArgs& a);   // ... and its backward leaves two partial dQ.Wq rows per sequence
 int attn_sq1_split(const AttnArgs& a);   // head groups (workgroups) per sequence the sq1 kernels will use
 
 struct EmbedBwdArgs {

@@ -135,6 +135,7 @@ int make_ws(const PsTemDesc& D, Ws& w) {
     l.vp = take(cur, ns * d);
     l.qp = take(cur, (int64_t)l.n_in * l.Sq * d);
     l.attn = take(cur, (int64_t)l.n_in * D.H * l.Sq * S);
+    l.amask = take(cur, (int64_t)l.n_in * l.fan * D.H);
     l.ctx = take(cur, (int64_t)l.M2 * d);
     l.y1 = take(cur, (int64_t)l.M2 * d);
     l.ff_stats = take(cur, (int64_t)l.M2 * 2);
@@ -356,7 +357,14 @@ static SideCtx* side_ctx() {
   if (state == 0) {
     state = -1;
     if (!env_on("PS_NO_SIDE")) {
-      bool ok = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking) == hipSuccess;
+      // the side stream carries filler (weight gradients, table scatters): LOWEST priority, so that when both streams have
+      // workgroups ready the dependent chain of the main stream is dispatched first (PS_SIDE_PRIO=0: default priority)
+      static const bool low_prio = !(getenv("PS_SIDE_PRIO") && atoi(getenv("PS_SIDE_PRIO")) == 0);
+      int prio_lo = 0, prio_hi = 0;
+      bool ok = false;
+      if (low_prio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi)
+        ok = hipStreamCreateWithPriority(&ctx.stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); ok = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking) == hipSuccess; }
       for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&ctx.ev[i], hipEventDisableTiming) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&ctx.join, hipEventDisableTiming) == hipSuccess;
       ctx.next = 0; ctx.used = false;
@@ -508,7 +516,8 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
     a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
     a.drop = make_drop(D, PS_SITE_ATTN(i));
     attn_finish(a);
-    if (attn_sq1_fits(a) && attn_w1_fits(a)) TRY(launch_attn_fwd_w1(a, st));
+    if (attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a)) TRY(launch_attn_fwd_wf(a, reinterpret_cast<uint32_t*>(ws + l.amask), st));
+    else if (attn_sq1_fits(a) && attn_w1_fits(a)) TRY(launch_attn_fwd_w1(a, st));
     else TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
                       P.final_ln_g && P.final_ln_b;
@@ -965,15 +974,17 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       }
       // first layer, one query row per sequence, d == 128: dQ.Wq rides in the attention backward's tail (two partial
       // rows per sequence in the free d ln1 buffer) instead of a [n_in,128]x[128,128] GEMM launch of its own
-      const bool w1 = sq1 && attn_w1_fits(a);           // one wave per sequence (no replicas)
+      const bool wf = sq1 && a.fan > 1 && attn_wf_fits(a);   // one wave per (sequence, four heads), replicas inside
+      const bool w1 = wf || (sq1 && attn_w1_fits(a));       // one wave per sequence (no replicas)
       const bool q_folded = sq1 && !qall && i == 0 && ps_fusion_enabled() &&
-                            (w1 ? (size_t)l.n_in <= (size_t)M2
+                            (w1 ? (size_t)(wf ? 2 : 1) * l.n_in <= (size_t)M2
                                 : d == 128 && attn_sq1_split(a) == 2 && (size_t)2 * l.n_in <= (size_t)M2);
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
       // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
       static const bool rows_on0 = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
       const bool listed0 = rows_on0 && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
-      if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1), st));
+      if (wf) TRY(launch_attn_bwd_wf(a, reinterpret_cast<const uint32_t*>(ws + l.amask), listed0 && (q_folded || l.fan == 1), st));
+      else if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1), st));
       else TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
@@ -1021,7 +1032,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         x.res.mode = RES_FANIN; x.res.ptr = ws + w.dy1; x.res.ld = d; x.res.Sq = l.Sq; x.res.fan = l.fan;
         x.res.S = S; x.res.qpos = w.qpos; res_finish(x.res);
         if (q_folded) {   // both partial rows already hold the replicas' fan-in sum: nothing left to walk here
-          x.res.extra = ws + w.dln1; x.res.extra2 = w1 ? nullptr : ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
+          x.res.extra = ws + w.dln1; x.res.extra2 = (w1 && !(wf && attn_bwd_wf_two_partials(a))) ? nullptr : ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
         }
         else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
       }
