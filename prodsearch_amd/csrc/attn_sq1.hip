@@ -701,160 +701,6 @@ __global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint
   }
 }
 
-template <int DH, int MAXK>
-__global__ __launch_bounds__(256) void attn_bwd_wf_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
-  constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, MAXD = 256;
-  __shared__ int sp[4][64];
-  __shared__ float dqs[4][HC];                                // [wave]: the wave's dq columns
-  __shared__ float part[4][MAXD];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int NHG = a.H >> 2, D = a.d, S = a.S, HF = a.H;
-  const int gw = (int)blockIdx.x * 4 + wv, b = gw / NHG, hg = gw - b * NHG;
-  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
-  if (b < a.n_in) {
-    const unsigned long long vm = w1_valid(a, b, lane, sp[wv]);
-    const int Sv = __popcll(vm);
-    const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
-    float4 v4[MAXK], dv4[MAXK]; float P[MAXK], dP[MAXK]; int pk[MAXK];
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      const int k = i * KPS + sub;
-      pk[i] = sp[wv][k < Sv ? k : 0];
-      v4[i] = f4_ld(a.vp + ((size_t)b * S + pk[i]) * D + c);
-      P[i] = a.attn[((size_t)b * HF + h) * S + pk[i]];
-      if (k >= Sv) P[i] = 0.f;
-      dv4[i] = make_float4(0.f, 0.f, 0.f, 0.f); dP[i] = 0.f;
-    }
-    // keep bits of all replicas: lane l holds word l (and l + 64) of the sequence's [fan][4] words of this head group
-    const bool masked = a.drop.thr != 0u;
-    uint32_t mw0 = ~0u, mw1 = ~0u;
-    if (masked) {
-      const int nwords = a.fan * 4;
-      if (lane < nwords) mw0 = amask[((size_t)b * a.fan + (lane >> 2)) * HF + 4 * hg + (lane & 3)];
-      if (lane + 64 < nwords) mw1 = amask[((size_t)b * a.fan + ((lane + 64) >> 2)) * HF + 4 * hg + (lane & 3)];
-    }
-    const float scale = masked ? a.drop.scale : 1.f;
-    // d context rows four replicas at a time, the next four requested before the current four are used (one row per
-    // iteration behind a one-deep prefetch left the wave waiting ~2 us per replica: 53 us)
-    constexpr int WF_B = 4;
-    float4 nx4[WF_B];
-#pragma unroll
-    for (int u = 0; u < WF_B; ++u) nx4[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (u < a.fan ? u : 0)) * D + c);
-    for (int j0 = 0; j0 < a.fan; j0 += WF_B) {
-      float4 cu4[WF_B];
-#pragma unroll
-      for (int u = 0; u < WF_B; ++u) cu4[u] = nx4[u];
-#pragma unroll
-      for (int u = 0; u < WF_B; ++u) {
-        const int jn = j0 + WF_B + u;
-        nx4[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (jn < a.fan ? jn : 0)) * D + c);
-      }
-#pragma unroll
-      for (int u = 0; u < WF_B; ++u) {
-        const int j = j0 + u;
-        if (j >= a.fan) break;
-        const int wi = j * 4 + hl;
-        const uint32_t kh = wi < 64 ? __shfl(mw0, wi, 64) : __shfl(mw1, wi - 64, 64);
-#pragma unroll
-        for (int i = 0; i < MAXK; ++i) {
-          const int k = i * KPS + sub;
-          const float m = ((kh >> k) & 1u) ? scale : 0.f;
-          float dot = f4_dot(cu4[u], v4[i]);
-#pragma unroll
-          for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
-          dP[i] = fmaf(m, dot, dP[i]);
-          f4_fma(dv4[i], P[i] * m, cu4[u]);
-        }
-      }
-    }
-    float th = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) th = fmaf(P[i], dP[i], th);
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) th += __shfl_xor(th, o, 64);
-    float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      const int k = i * KPS + sub;
-      const size_t row = (size_t)b * S + pk[i];
-      const float4 k4 = f4_ld(a.kp + row * D + c);
-      const float g = P[i] * (dP[i] - th);                     // softmax backward (0 for a dead key: P = 0)
-      f4_fma(dq4, g, k4);
-      if (k < Sv) {
-        const float4 dk4 = f4_scale(g, q4);
-        f4_st(a.dkv + row * a.lddkv + c, dk4);
-        f4_st(a.dkv + row * a.lddkv + D + c, dv4[i]);
-        sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
-        sv4.x += dv4[i].x; sv4.y += dv4[i].y; sv4.z += dv4[i].z; sv4.w += dv4[i].w;
-      }
-    }
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) { dq4 = f4_xor_add(dq4, o); sk4 = f4_xor_add(sk4, o); sv4 = f4_xor_add(sv4, o); }
-    if (!pads_unread) {                                      // masked positions: exact zeros (dense consumers read them)
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = 0; s0 < S; s0 += KPS) {
-        const int s = s0 + sub;
-        if (s < S && !((vm >> s) & 1ull)) {
-          float* o = a.dkv + ((size_t)b * S + s) * a.lddkv;
-          f4_st(o + c, z); f4_st(o + D + c, z);
-        }
-      }
-    }
-    dq4 = f4_scale(a.qscale, dq4);
-    if (sub == 0) {
-      f4_st(a.dq + (size_t)b * a.lddq + c, dq4);
-      f4_st(&dqs[wv][4 * cl], dq4);
-      if (a.bias_part) {                                     // parked: folded by the step's last launch
-        float* bp = a.bias_part + (size_t)b * 3 * D + c;
-        f4_st(bp, dq4); f4_st(bp + D, sk4); f4_st(bp + 2 * D, sv4);
-      } else {
-        const float dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w}, skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w}, svv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          atomicAdd(&a.dbq[c + e], dqv[e]); atomicAdd(&a.dbk[c + e], skv[e]); atomicAdd(&a.dbv[c + e], svv[e]);
-        }
-      }
-    }
-  } else if (sub == 0) {
-    f4_st(&dqs[wv][4 * cl], make_float4(0.f, 0.f, 0.f, 0.f));
-  }
-  if (!a.wq) return;
-  // d x[query row] = dq . Wq + the fan-in residual rows: the workgroup's 4 / NHG sequences together; thread (pt, i) owns
-  // output column i and 1/NP of the D query features (and of the replicas of the fan-in sum)
-  __syncthreads();
-  const int NP = 256 / D, nseq = 4 / NHG;                    // D = 128: two parts; D = 256: one
-  const int i = tid % D, pt = tid / D, KP = D / NP;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (pt < NP) {
-    const float* wcol = a.wq + (size_t)(pt * KP) * D + i;
-#pragma unroll 8
-    for (int k = 0; k < KP; ++k) {
-      const float w2 = wcol[(size_t)k * D];
-      const int kk = pt * KP + k, hw = kk / HC, off = kk - hw * HC;     // feature kk sits in head-group wave hw of each sequence
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq)
-        if (sq < nseq) acc[sq] = fmaf(dqs[sq * NHG + hw][off], w2, acc[sq]);
-    }
-    if (a.fanin_src)
-      for (int sq = 0; sq < nseq; ++sq) {
-        const int bb = (int)blockIdx.x * nseq + sq;
-        if (bb >= a.n_in) break;
-        for (int j = pt; j < a.fan; j += NP) acc[sq] += a.fanin_src[((size_t)bb * a.fan + j) * D + i];
-      }
-  }
-  for (int sq = 0; sq < nseq; ++sq) {
-    const int bb = (int)blockIdx.x * nseq + sq;
-    __syncthreads();
-    if (pt < NP) part[pt][i] = acc[sq];
-    __syncthreads();
-    if (tid < D && bb < a.n_in) {
-      float v = 0.f;
-      for (int q = 0; q < NP; ++q) v += part[q][tid];
-      a.dxq_part[(size_t)bb * D + tid] = v;
-    }
-  }
-}
-
 // Backward with the replicas of a (sequence, head group) split over the FOUR waves of a workgroup (d = 128, H = 8: two
 // workgroups per sequence).  Each wave repeats the short set-up and sums d V / d P over its 5-6 replicas (their d context
 // rows all requested up front); the partial sums meet in LDS, wave 0 finishes (softmax backward, d K / d V rows, dq) and the
@@ -999,50 +845,31 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
     if (half == 0) a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
   }
 }
+// shape the replica form is built for (both directions): d = 128, 8 heads — two four-head groups per sequence — keys
+// within the register budget and their keep bits within one word, the replicas of a chunk within the backward's row batch
 static bool attn_wf4_fits(const AttnArgs& a) {
-  static const bool on = !(getenv("PS_ATTN_WF4") && atoi(getenv("PS_ATTN_WF4")) == 0);
-  return on && a.d == 128 && a.H == 8 && a.dh == 16 && a.S <= 32 && a.fan >= 4 && a.fan <= 24;
-}
-
-// shapes the replica form takes: 4*dh columns per wave (dh 16 or 32), H/4 waves per sequence dividing the workgroup,
-// keys within its register budget, keep bits within one word
-static inline int wf_maxk(const AttnArgs& a) { return a.dh == 16 ? 8 : 16; }
-static inline bool wf_short(const AttnArgs& a) { return a.dh == 16 && a.S <= 24; }     // 6 key steps instead of 8
-// the replica form's backward writes TWO partial dQ.Wq rows per sequence (one per head group), like the LDS form
-bool attn_bwd_wf_two_partials(const AttnArgs& a) { return attn_wf_fits(a) && attn_wf4_fits(a); }
-bool attn_wf_fits(const AttnArgs& a) {
   static const bool on = !(getenv("PS_ATTN_WF") && atoi(getenv("PS_ATTN_WF")) == 0);
-  if (!(on && a.Sq == 1 && a.fan >= 1 && (a.dh == 16 || a.dh == 32) && a.H % 4 == 0 && a.dh * a.H == a.d && a.d <= 256)) return false;
-  const int nhg = a.H / 4;
-  if (nhg != 1 && nhg != 2 && nhg != 4) return false;
-  const int kps = 64 / a.dh;
-  return a.S <= 32 && a.S <= kps * wf_maxk(a) && a.fan * 4 <= 128;
+  return on && a.Sq == 1 && a.d == 128 && a.H == 8 && a.dh == 16 && a.S <= 32 && a.fan >= 4 && a.fan <= 24;
 }
+bool attn_wf_fits(const AttnArgs& a) { return attn_wf4_fits(a); }
+// its backward writes TWO partial dQ.Wq rows per sequence (one per head group), like the LDS form
+bool attn_bwd_wf_two_partials(const AttnArgs& a) { return attn_wf4_fits(a); }
 int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention(wf): unsupported shape");
   static const int env_ch = getenv("PS_ATTN_WF_CHUNKS") ? atoi(getenv("PS_ATTN_WF_CHUNKS")) : 0;
-  int nch = env_ch > 0 ? env_ch : (a.fan >= 12 ? 4 : (a.fan >= 4 ? 2 : 1));
+  int nch = env_ch > 0 ? env_ch : (a.fan >= 12 ? 4 : 2);
   if (nch > a.fan) nch = a.fan;
   const dim3 grid(ps_cdiv(a.n_in * (a.H / 4) * nch, 4));
-  if (wf_short(a)) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, nch);
-  else if (a.dh == 16) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, nch);
-  else hipLaunchKernelGGL((attn_fwd_wf_kernel<32, 16>), grid, dim3(256), 0, st, a, amask, nch);
+  if (a.S <= 24) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, nch);
+  else hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, nch);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
   PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(wf): folded dQ.Wq needs its output row buffer");
-  if (attn_wf4_fits(a)) {   // replicas over four waves: two partial dQ.Wq rows per sequence (attn_bwd_wf_two_partials)
-    if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<6>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-    else hipLaunchKernelGGL((attn_bwd_wf4_kernel<8>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-    PS_LAUNCH_CHECK();
-    return PS_OK;
-  }
-  const dim3 grid(ps_cdiv(a.n_in * (a.H / 4), 4));
-  if (wf_short(a)) hipLaunchKernelGGL((attn_bwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-  else if (a.dh == 16) hipLaunchKernelGGL((attn_bwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-  else hipLaunchKernelGGL((attn_bwd_wf_kernel<32, 16>), grid, dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<6>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<8>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
