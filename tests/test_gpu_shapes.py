@@ -55,6 +55,13 @@ def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
     (130, 3, 12, 5, 1, 96, 8, 0.1, 0.1),     # ragged batch (not a multiple of any tile), d not a power of two, dropout
     (2, 5, 20, 8, 3, 128, 8, 0.0, 0.1),
     (50, 20, 9, 4, 1, 128, 8, 0.2, 0.1),     # 1,050 replica rows: the fused per-replica kernels with a partial last tile
+    # the attention forms (attn_sq1.hip): replicas inside a wave (d = 128, 8 heads, 4..24 replicas, <= 32 positions) ...
+    (6, 23, 29, 4, 1, 128, 8, 0.2, 0.1),     # 30 positions (8 key steps), 24 replicas (chunks of 6)
+    (9, 3, 31, 4, 1, 128, 8, 0.1, 0.1),      # 32 positions, 4 replicas (one per wave)
+    (7, 2, 12, 4, 1, 128, 8, 0.1, 0.1),      # ... 3 replicas: the LDS workgroup form
+    (6, 4, 40, 4, 1, 128, 8, 0.1, 0.1),      # ... 41 positions with dropout: the LDS workgroup form
+    (6, 4, 40, 4, 1, 128, 8, 0.1, 0.0),      # ... no replicas: one wave per sequence, 32 lanes per row
+    (6, 4, 40, 4, 1, 64, 4, 0.1, 0.0),       # ... and 16 lanes per row (d = 64)
 ])
 def test_edge_shapes_match_oracle(B, K, L, Q, W, d, H, zero_hist, dropout):
     """Edge cases of the batch layout: tiny and ragged batches, zero-history users,
