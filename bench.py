@@ -160,26 +160,27 @@ class RtmWorkload(object):
         return "train (u,q,i,neg) tuples/sec at bs=%d, %d neg, d=128 (review_transformer)" % (C4['B'], C4['K'])
 
     def roofline_spec(self):
-        """rtm_embed_kernel (review vectors, PVC.py:46-61): per valid review slot its WL int64 word ids, per word that is
+        """rtm_embed4_kernel (review vectors, PVC.py:46-61): per valid review slot its WL int64 word ids, per word that is
         neither padding nor dropped by the token corruption one 4d-byte row (expected count: the Philox masks are drawn
-        on the device), and the [Bseq, S, d] encoder input it writes."""
+        on the device), the rows of the encoder input it writes and the per-word ranks it leaves for the backward."""
         c, d = C4, 128
         b0 = self.cpu_batches[0]
         pad_r = c['RC'] - 1
         slots = int((b0.pos_prod_ridxs != pad_r).sum() + (b0.neg_prod_ridxs != pad_r).sum())
-        S = c['U'] + c['I'] + 1
-        out_bytes = c['B'] * (c['K'] + 1) * S * d * 4
-        if self.a.encoder == 'pvc':
+        nseq = c['B'] * (c['K'] + 1)
+        out_bytes = (slots + nseq) * d * 4              # x: the real positions + one query row per sequence (padded
+        if self.a.encoder == 'pvc':                     # positions are neither read nor written: DESIGN.md 7c)
             words = int((b0.pos_prod_rword_idxs != V_WORDS - 1).sum() + (b0.neg_prod_rword_idxs != V_WORDS - 1).sum())
             rows = words * (1.0 - 0.9)
-            nbytes = slots * c['WL'] * 8 + rows * 4 * d + out_bytes
-            note = "%d review slots x %d ids + %.0f surviving word rows (%.0f non-pad words x 0.1) + %d B of x" % (
-                slots, c['WL'], rows, words, out_bytes)
+            rank_bytes = slots * c['WL'] * 4            # first pass of the backward's inverted index rides in this kernel
+            nbytes = slots * c['WL'] * 8 + rows * 4 * d + out_bytes + rank_bytes
+            note = "%d review slots x %d ids + %.0f surviving word rows (%.0f non-pad words x 0.1) + %d B of x + %d B of word ranks" % (
+                slots, c['WL'], rows, words, out_bytes, rank_bytes)
         else:
             nbytes = slots * (8 + 4 * d) + out_bytes
             note = "%d review rows + %d B of x" % (slots, out_bytes)
         return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
-                    kernel="rtm_embed_kernel (review-vector gather + mean-pool; %s)" % note, traffic_key=None, extra={})
+                    kernel="rtm_embed4_kernel (review-vector gather + mean-pool + word ranks; %s)" % note, traffic_key=None, extra={})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_rtm(self, n_steps)

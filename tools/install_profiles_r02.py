@@ -9,7 +9,7 @@ for a, b in (('bench.json', '_bench.json'), ('rtm_bench.json', '_rtm_bench.json'
     if os.path.exists(os.path.join(src, a)):
         open(os.path.join(dst, rnd + b), 'w').write(last(a))
 for a, b in (('bench_kernel_stats.csv', '_bench_kernel_stats.csv'), ('rtm_kernel_stats.csv', '_rtm_kernel_stats.csv'),
-             ('step_timeline.txt', '_step_timeline.txt'), ('mfma_utilisation.md', '_mfma_utilisation.md'),
+             ('step_timeline.txt', '_step_timeline.txt'), ('rtm_step_timeline.txt', '_rtm_step_timeline.txt'), ('mfma_utilisation.md', '_mfma_utilisation.md'),
              ('sq_counters.txt', '_sq_counters.txt'), ('inst_counters.txt', '_inst_counters.txt'),
              ('rtm_embed_pmc.txt', '_rtm_embed_pmc.txt'), ('gather_score_c5_pmc.txt', '_gather_score_c5_pmc.txt'),
              ('gather_c5.log', '_gather_c5_shape.jsonl')):

@@ -19,6 +19,7 @@ echo "mfma / sq counters done"
 python bench.py --workload c4 --steps 200 --warmup 20 > $O/rtm_bench.json 2> $O/rtm_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rtm_prof -- python3 bench.py --workload c4 --steps 60 --warmup 10 --cpu-steps 0 --no-extras > $O/rtm_prof.json 2> $O/rtm_prof.err
 cp $(ls -t $(find $O/rtm_prof -name '*kernel_stats.csv') | head -1) $O/rtm_kernel_stats.csv
+python tools/trace_step.py $O/rtm_prof > $O/rtm_step_timeline.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rf -- python3 tools/rtm_embed_only.py > $O/pmc_rf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_rw -- python3 tools/rtm_embed_only.py > $O/pmc_rw.log 2>&1
 ( echo "rocprofv3 --pmc FETCH_SIZE -- python3 tools/rtm_embed_only.py   (per-launch average, KB; gfx950: x2 for 16-B/lane streaming reads)"; python tools/pmc_summary.py $O/pmc_rf | grep -E "kernel|rtm_embed"; echo; echo "rocprofv3 --pmc WRITE_SIZE -- python3 tools/rtm_embed_only.py"; python tools/pmc_summary.py $O/pmc_rw | grep -E "kernel|rtm_embed"; tail -1 $O/pmc_rf.log ) > $O/rtm_embed_pmc.txt
