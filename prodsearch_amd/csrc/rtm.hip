@@ -1323,6 +1323,9 @@ static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hip
     hipLaunchKernelGGL(rtm_windex_kernel<0>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
     PS_LAUNCH_CHECK();
   }
+  // the allocator's running total starts at 0 on EVERY build: a second backward over the same forward (retain_graph) must
+  // lay the list out from the start again, not behind the first one (the counts themselves are the forward's and stay)
+  if (!count) PS_CHECK_HIP(hipMemsetAsync(k.wcnt + V, 0, sizeof(int), st));
   hipLaunchKernelGGL(rtm_walloc_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.wcnt, k.woff, k.wcur, k.wcnt + V, V);
   PS_LAUNCH_CHECK();
   if (k.count_fwd) hipLaunchKernelGGL(rtm_windex_kernel<2>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);

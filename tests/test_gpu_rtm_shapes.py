@@ -57,3 +57,32 @@ def test_rtm_wide_and_ragged_shapes_match_the_oracle(d, heads, B, K, u_lim, i_li
         checked += 1
     assert checked >= 16
     m.check_index_errors() if hasattr(m, 'check_index_errors') else None
+
+
+def test_second_backward_over_the_same_forward_accumulates_the_same_gradient():
+    """``loss.backward(retain_graph=True); loss.backward()``: the second backward rebuilds the inverted index of the word
+    gradient from the forward's counts (its allocator must start from 0 again) and adds the same gradient once more."""
+    from prodsearch_amd import ProductRanker, default_args, synth, rtm_data
+    V, RC, B, K, WL = 1500, 900, 6, 2, 40
+    a = default_args(model_name='review_transformer', review_encoder_name='pvc', embedding_size=128, heads=8, ff_size=256,
+                     inter_layers=1, neg_per_pos=K, dropout=0.0, corrupt_rate=0.0, lr=0.0005, review_word_limit=WL,
+                     uprev_review_limit=5, iprev_review_limit=6)
+    wd = synth.make_word_dists(V)
+    rng = synth.rng_for(5)
+    rw = torch.from_numpy(rng.integers(0, V - 1, size=(RC, WL)))
+    rw[-1] = V - 1
+    torch.manual_seed(0)
+    m = ProductRanker(a, 'cuda', V, RC, 50, 60, rw, None, word_dists=wd)
+    batch = rtm_data.make_rtm_batch(22, B, K, RC, V, rw, Q=5, u_lim=5, i_lim=6, W=1, train_pv=False, encoder='pvc',
+                                    word_dists=wd)
+    m.train()
+    loss = m(batch.to('cuda'), train_pv=False)
+    m.zero_grad()
+    loss.backward(retain_graph=True)
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    loss.backward()
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        if p.grad is None or float(g1[n].abs().max()) == 0.0:
+            continue
+        assert rel_err(p.grad.cpu(), (2 * g1[n]).cpu()) < 1e-5, n
