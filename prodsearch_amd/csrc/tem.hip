@@ -389,7 +389,7 @@ static SideCtx* side_ctx() {
   return state == 1 ? &ctx : nullptr;
 }
 static int& side_mode_slot() {
-  static int v = getenv("PS_SIDE_MODE") ? atoi(getenv("PS_SIDE_MODE")) : 2;
+  static int v = getenv("PS_SIDE_MODE") ? atoi(getenv("PS_SIDE_MODE")) : 3;
   return v;
 }
 extern "C" int ps_set_side_mode(int mode) {
@@ -408,7 +408,8 @@ int side_fork(hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c) return PS_OK;
   // measured (ms/step, back-to-back launch cost on the main stream afterwards): events only 0.3527 / 4.19 us; forks as value
-  // ops 0.3525 / 4.23; joins 0.3444 / 4.22; both 0.3435 / 9.5 (!) -> only the JOIN uses them
+  // ops 0.3525 / 4.23; joins 0.3444 / 4.22; both 0.3435 / 9.5 (!) -> round 1: only the JOIN used them.  Round 2 (two forks per
+  // backward, shorter kernels between them): events 0.3065, forks 0.3023, joins 0.3033, both 0.2980 -> both
   const int side_mode = side_mode_slot();   // bit 0: forks, bit 1: joins as value ops
   if (c->flag && c->light && (side_mode & 1) && !stream_capturing(main_st)) {
     ++c->fork_seq;
