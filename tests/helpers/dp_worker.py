@@ -75,9 +75,53 @@ def run(mode, Bg, steps, rank, world, exchange_factory):
     return out
 
 
+def run_rtm(Bg, steps, rank, world, exchange_factory):
+    """The same for the review transformer (pvc encoder, no PV loss: the product-score loss is a batch mean,
+    ps_model.py:344-358; dropout and token corruption 0)."""
+    import copy
+    import numpy as np
+    import torch
+    from prodsearch_amd import ProductRanker, build_optim, default_args, synth, rtm_data
+    V, RC, K, WL, U, I = 3000, 2500, 3, 40, 6, 8
+    a = default_args(model_name='review_transformer', review_encoder_name='pvc', embedding_size=128, heads=8, ff_size=512,
+                     inter_layers=1, neg_per_pos=K, dropout=0.0, corrupt_rate=0.0, lr=0.002, review_word_limit=WL,
+                     uprev_review_limit=U, iprev_review_limit=I)
+    wd = synth.make_word_dists(V)
+    rng = synth.rng_for(17)
+    rw = torch.from_numpy(rng.integers(0, V - 1, size=(RC, WL)))
+    lens = torch.from_numpy(rng.integers(1, WL + 1, size=RC))
+    rw[torch.arange(WL)[None, :] >= lens[:, None]] = V - 1
+    rw[-1] = V - 1
+    torch.manual_seed(4321)
+    m = ProductRanker(a, 'cuda', V, RC, 50, 60, rw, None, word_dists=wd)
+    optim = build_optim(a, m, None)
+    exchange = exchange_factory(m, optim)
+    batch = rtm_data.make_rtm_batch(91, Bg, K, RC, V, rw, Q=6, u_lim=U, i_lim=I, W=1, train_pv=False, encoder='pvc',
+                                    word_dists=wd)
+    per = Bg // world
+    b = copy.copy(batch)
+    for k, v in vars(batch).items():
+        if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == Bg:
+            setattr(b, k, v[rank * per:(rank + 1) * per].contiguous())
+    b = b.to('cuda')
+    m.train()
+    for s in range(steps):
+        loss = m(b, train_pv=False)
+        m.zero_grad()
+        loss.backward()
+        exchange()
+        optim.step()
+    torch.cuda.synchronize()
+    out = {'__loss': np.float32(float(loss.detach())), '__ms': np.float64(0.0)}
+    for n, p in m.named_parameters():
+        out[n] = p.detach().cpu().numpy()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', default='dense')
+    ap.add_argument('--model', default='tem')
     ap.add_argument('--global-batch', type=int, default=384)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--out', required=True)
@@ -86,7 +130,10 @@ def main():
     import torch
     from prodsearch_amd import dist as pdist
     rank, local, world = pdist.init_from_env(backend='gloo')
-    out = run(a.mode, a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o))
+    if a.model == 'rtm':
+        out = run_rtm(a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o))
+    else:
+        out = run(a.mode, a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o))
     np.savez(a.out + '.rank%d.npz' % rank, **out)
     if world > 1:
         torch.distributed.barrier()

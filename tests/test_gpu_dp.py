@@ -30,13 +30,13 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, out, world=2, steps=2):
+def _run_ranks(mode, out, world=2, steps=2, extra=()):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, WORKER, '--mode', mode, '--steps', str(steps), '--out', out],
+        procs.append(subprocess.Popen([sys.executable, WORKER, '--mode', mode, '--steps', str(steps), '--out', out] + list(extra),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -96,3 +96,31 @@ def test_sparse_exchange_is_not_slower_than_twice_the_dense_one(tmp_path):
     t_d, t_s = float(dense[0]['__ms']), float(sparse[0]['__ms'])
     print("2-rank gloo dry run, ms/step: dense %.3f, sparse %.3f" % (t_d, t_s))
     assert t_s < 2.0 * t_d + 0.5
+
+
+def test_review_transformer_two_ranks_of_32_equal_one_rank_of_64(tmp_path):
+    """The same for the review transformer (dense exchange): its step carries state across kernels that the TEM step does
+    not have — the word counts / ranks of the inverted index, the loss ticket, the parked segment-embedding partials."""
+    sys.path.insert(0, os.path.join(HERE, 'helpers'))
+    import dp_worker
+
+    class _NoExchange(object):
+        def __call__(self):
+            return None
+
+    lr, steps = 0.002, 2
+    single = dp_worker.run_rtm(64, steps, 0, 1, lambda m, o: _NoExchange())
+    r0, r1 = _run_ranks('dense', str(tmp_path / 'dp_rtm'), 2, steps, extra=('--model', 'rtm', '--global-batch', '64'))
+    for k in r0:
+        if not k.startswith('__'):
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k       # bitwise lock step
+    checked = 0
+    for k, ref in single.items():
+        if k.startswith('__') or k.endswith('linear_keys.bias') or float(np.abs(ref).max()) == 0.0:
+            continue
+        got = r0[k]
+        tol = 2e-3 * float(np.abs(ref).max()) + 0.02 * lr * steps
+        assert float(np.abs(got - ref).max()) < tol, (k, float(np.abs(got - ref).max()), tol)
+        checked += 1
+    assert checked >= 18
+    assert abs(0.5 * (r0['__loss'] + r1['__loss']) - single['__loss']) < 2e-3 * abs(single['__loss'])
