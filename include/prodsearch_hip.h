@@ -123,11 +123,12 @@ const char* ps_last_error(void);
  * this many replica rows upwards (default 1024, env PS_FUSE_BWD_MIN; below it five short launches are as fast).  The
  * parity tests set it to 1 to drive the fused kernel through the small golden cases.  Returns the previous value. */
 int ps_set_fuse_bwd_min(int rows);
-/* Tuning knob: how the backward's side stream rejoins the main stream on short steps.  Bit 1 (default, env PS_SIDE_MODE=2):
- * the join is a stream write-value / wait-value pair instead of an event pair (-9 us per step at C2); bit 0: the forks
- * too (no gain, and back-to-back launches on the stream get slower).  0 = event pairs only.  The wait is a spinning
- * one-thread kernel: tools that let only one kernel run at a time (counter-collecting profilers) are recognised from
- * their environment and always get events (PS_SIDE_EVENTS=1 forces that).  Returns the previous value. */
+/* Tuning knob: how the backward's side stream crosses the main stream on short steps.  Bit 1: the join is a stream
+ * write-value / wait-value pair instead of an event pair (-9 us per step at C2 in round 1); bit 0: the forks too (no gain
+ * with round 1's one fork; with round 2's two forks per backward both together are worth 5-8 us).  Default 3 (env
+ * PS_SIDE_MODE), 0 = event pairs only.  The wait is a spinning one-thread kernel: tools that let only one kernel run at a
+ * time (counter-collecting profilers) are recognised from their environment and always get events (PS_SIDE_EVENTS=1
+ * forces that).  Returns the previous value. */
 int ps_set_side_mode(int mode);
 
 /* Workspace the caller allocates once per shape (bytes) and its layout. */
