@@ -1303,6 +1303,7 @@ struct MlpBwdWsLds {
   float Ws[2][MBK * WLB];       // weight slab ring
   float Cs[2][MBM * YLD];       // accumulator tiles handed to the epilogues (row-major); [1] doubles as the LayerNorm
                                 // stages' column-sum scratch [3][8 waves][128]
+  float b1red[2][4][MD];        // b1 column sums of the four helper waves, chunk parity: summed before they are parked
 };
 static_assert(sizeof(MlpBwdWsLds) <= 160 * 1024, "wave-specialised MLP backward: LDS budget");
 static_assert(3 * 8 * MD <= MBM * YLD, "column-sum scratch must fit an accumulator tile");
@@ -1552,15 +1553,21 @@ __global__ __launch_bounds__(WS_THREADS, 2) void mlp_bwd_ws_kernel(const MlpBwdA
         if (m < M) *reinterpret_cast<float2*>(a.da1 + (size_t)m * a.F + f0) = make_float2(v0, v1);
         csb[0] += v0; csb[1] += v1;
       }
-      // one parked row per (workgroup, helper wave): part_b1[(4*wg + hw)][slot 0][F]
-      if (r == SPP - 1)
-        *reinterpret_cast<float2*>(a.part_b1 + ((size_t)(blockIdx.x * 4 + hw) * 3) * a.F + f0) = make_float2(csb[0], csb[1]);
+      // the four helper waves' sums meet in LDS (chunk parity) and are parked as ONE row per workgroup behind this step's
+      // barrier: part_b1[wg][slot 0][F] (a row per helper wave made the fold of the step's last launch walk 1,008 rows)
+      if (r == SPP - 1) { L.b1red[pc & 1][hw][2 * lane] = csb[0]; L.b1red[pc & 1][hw][2 * lane + 1] = csb[1]; }
     }
     if (r == SPP - 1 && kind == 1 && c == nchunk - 1) {
       __syncthreads();
       ff_ln_stage();
     }
     __syncthreads();
+    if (epi && r == SPP - 1 && hw == 0) {
+      const float* q = &L.b1red[pc & 1][0][0];
+      const float s0 = (q[2 * lane] + q[MD + 2 * lane]) + (q[2 * MD + 2 * lane] + q[3 * MD + 2 * lane]);
+      const float s1 = (q[2 * lane + 1] + q[MD + 2 * lane + 1]) + (q[2 * MD + 2 * lane + 1] + q[3 * MD + 2 * lane + 1]);
+      *reinterpret_cast<float2*>(a.part_b1 + ((size_t)blockIdx.x * 3) * a.F + f0) = make_float2(s0, s1);
+    }
   };
   for (int s = 0; s < NS; s += 2) {
     helper_step(s, wr1);
@@ -1573,8 +1580,8 @@ bool mlp_bwd_ws_enabled() {
   return on;
 }
 int mlp_bwd_fused_blocks(int M) { return ps_cdiv(M, MBM); }
-// parked rows of the b1 column sums: one per workgroup, or one per (workgroup, helper wave) in the wave-specialised form
-int mlp_bwd_b1_rows(int M, int F) { return (mlp_bwd_ws_enabled() && F >= 256 ? 4 : 1) * ps_cdiv(M, MBM); }
+// parked rows of the b1 column sums: one per workgroup
+int mlp_bwd_b1_rows(int M, int F) { (void)F; return ps_cdiv(M, MBM); }
 
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.F % 128 == 0 && a.M > 0, "fused mlp backward: F=%d M=%d", a.F, a.M);
