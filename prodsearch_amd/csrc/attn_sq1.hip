@@ -709,53 +709,62 @@ __global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint
 // 768 resident at once.  (One wave per (sequence, head group): 37 us, a serial chain of 21 replicas on a mostly idle chip;
 // eight waves per sequence in one workgroup: 18 us alone but two rounds of 256-register workgroups, 40 us in the step; the
 // LDS workgroup form: 29 us.)
-template <int MAXK>
+template <int DH, int MAXK, int NH>   // DH = 16: d = 128 (C2); DH = 32: d = 256 (C5 shard; its dQ.Wq is a GEMM of its own: no tail)
 __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
-  constexpr int DH = 16, LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 128, NV = 5 * MAXK, JB = 6;
+  // keys of a lane group: i = hf * MAXK + ii, hf < NH (the key range is walked in NH parts so that only MAXK V rows and
+  // d V sums are in registers at a time: d = 256 needs 11 keys per group for 21 positions)
+  constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 8 * DH, NK = NH * MAXK, NV = 5 * NK, JB = 6;
   __shared__ int sp[4][64];
   __shared__ float red[4][NV][64];                            // [wave][value][lane]
   __shared__ float dqs[HC];
-  __shared__ float part[D];
+  __shared__ float part[128];
   const int tid = threadIdx.x, lane = tid & 63, ch = tid >> 6;
   const int S = a.S, HF = a.H;
   const int b = (int)blockIdx.x >> 1, hg = (int)blockIdx.x & 1;
   const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
-  const bool fold_q = a.wq != nullptr;
+  const bool fold_q = a.wq != nullptr && DH == 16;
   const unsigned long long vm = w1_valid(a, b, lane, sp[ch]);
   const int Sv = __popcll(vm);
-  float4 v4[MAXK], dv4[MAXK]; float P[MAXK], dP[MAXK];
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    const int k = i * KPS + sub;
-    const int p = sp[ch][k < Sv ? k : 0];
-    v4[i] = f4_ld(a.vp + ((size_t)b * S + p) * D + c);
-    P[i] = a.attn[((size_t)b * HF + h) * S + p];
-    if (k >= Sv) P[i] = 0.f;
-    dv4[i] = make_float4(0.f, 0.f, 0.f, 0.f); dP[i] = 0.f;
-  }
   const int jper = (a.fan + 3) >> 2, jbeg = ch * jper, jend = min(a.fan, jbeg + jper), nj = max(0, jend - jbeg);   // nj <= JB (fits)
   const bool masked = a.drop.thr != 0u;
   uint32_t mw = ~0u;                                          // lane l: keep word of (replica jbeg + l/4, head l&3)
   if (masked && lane < nj * 4) mw = amask[((size_t)b * a.fan + jbeg + (lane >> 2)) * HF + 4 * hg + (lane & 3)];
   const float scale = masked ? a.drop.scale : 1.f;
-  {
-    float4 dc[JB];
+  float4 dc[JB];                                              // this wave's d context rows, all requested up front
 #pragma unroll
-    for (int u = 0; u < JB; ++u) dc[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (u < nj ? jbeg + u : 0)) * D + c);
+  for (int u = 0; u < JB; ++u) dc[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (u < nj ? jbeg + u : 0)) * D + c);
+  float P[NK];
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) {
+    float4 v4[MAXK], dv4[MAXK]; float dP[MAXK];
+#pragma unroll
+    for (int ii = 0; ii < MAXK; ++ii) {
+      const int k = (hf * MAXK + ii) * KPS + sub;
+      const int p = sp[ch][k < Sv ? k : 0];
+      v4[ii] = f4_ld(a.vp + ((size_t)b * S + p) * D + c);
+      P[hf * MAXK + ii] = k < Sv ? a.attn[((size_t)b * HF + h) * S + p] : 0.f;
+      dv4[ii] = make_float4(0.f, 0.f, 0.f, 0.f); dP[ii] = 0.f;
+    }
 #pragma unroll
     for (int u = 0; u < JB; ++u) {
       if (u >= nj) break;
       const uint32_t kh = __shfl(mw, u * 4 + hl, 64);
 #pragma unroll
-      for (int i = 0; i < MAXK; ++i) {
-        const int k = i * KPS + sub;
+      for (int ii = 0; ii < MAXK; ++ii) {
+        const int k = (hf * MAXK + ii) * KPS + sub;
         const float m = ((kh >> k) & 1u) ? scale : 0.f;
-        float dot = f4_dot(dc[u], v4[i]);
+        float dot = f4_dot(dc[u], v4[ii]);
 #pragma unroll
         for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
-        dP[i] = fmaf(m, dot, dP[i]);
-        f4_fma(dv4[i], P[i] * m, dc[u]);
+        dP[ii] = fmaf(m, dot, dP[ii]);
+        f4_fma(dv4[ii], P[hf * MAXK + ii] * m, dc[u]);
       }
+    }
+#pragma unroll
+    for (int ii = 0; ii < MAXK; ++ii) {
+      const int i = hf * MAXK + ii;
+      red[ch][5 * i + 0][lane] = dv4[ii].x; red[ch][5 * i + 1][lane] = dv4[ii].y; red[ch][5 * i + 2][lane] = dv4[ii].z;
+      red[ch][5 * i + 3][lane] = dv4[ii].w; red[ch][5 * i + 4][lane] = dP[ii];
     }
   }
   // the tail's weights: thread (half, i) owns output column i and 32 of this group's 64 query features; requested now
@@ -766,42 +775,37 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
 #pragma unroll
     for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
   }
-  if (ch != 0) {
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      red[ch][5 * i + 0][lane] = dv4[i].x; red[ch][5 * i + 1][lane] = dv4[i].y; red[ch][5 * i + 2][lane] = dv4[i].z;
-      red[ch][5 * i + 3][lane] = dv4[i].w; red[ch][5 * i + 4][lane] = dP[i];
-    }
-  }
   __syncthreads();
   if (ch == 0) {
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i)
-#pragma unroll
-      for (int o = 1; o < 4; ++o) {
-        dv4[i].x += red[o][5 * i + 0][lane]; dv4[i].y += red[o][5 * i + 1][lane]; dv4[i].z += red[o][5 * i + 2][lane];
-        dv4[i].w += red[o][5 * i + 3][lane]; dP[i] += red[o][5 * i + 4][lane];
-      }
     const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+    float dPs[NK];
     float th = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXK; ++i) th = fmaf(P[i], dP[i], th);
+    for (int i = 0; i < NK; ++i) {
+      dPs[i] = (red[0][5 * i + 4][lane] + red[1][5 * i + 4][lane]) + (red[2][5 * i + 4][lane] + red[3][5 * i + 4][lane]);
+      th = fmaf(P[i], dPs[i], th);
+    }
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) th += __shfl_xor(th, o, 64);
     float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
 #pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
+    for (int i = 0; i < NK; ++i) {
       const int k = i * KPS + sub;
       const size_t row = (size_t)b * S + sp[0][k < Sv ? k : 0];
       const float4 k4 = f4_ld(a.kp + row * D + c);
-      const float g = P[i] * (dP[i] - th);                     // softmax backward (0 for a dead key: P = 0)
+      const float g = P[i] * (dPs[i] - th);                    // softmax backward (0 for a dead key: P = 0)
       f4_fma(dq4, g, k4);
       if (k < Sv) {
+        float4 dvs;
+        dvs.x = (red[0][5 * i + 0][lane] + red[1][5 * i + 0][lane]) + (red[2][5 * i + 0][lane] + red[3][5 * i + 0][lane]);
+        dvs.y = (red[0][5 * i + 1][lane] + red[1][5 * i + 1][lane]) + (red[2][5 * i + 1][lane] + red[3][5 * i + 1][lane]);
+        dvs.z = (red[0][5 * i + 2][lane] + red[1][5 * i + 2][lane]) + (red[2][5 * i + 2][lane] + red[3][5 * i + 2][lane]);
+        dvs.w = (red[0][5 * i + 3][lane] + red[1][5 * i + 3][lane]) + (red[2][5 * i + 3][lane] + red[3][5 * i + 3][lane]);
         const float4 dk4 = f4_scale(g, q4);
         f4_st(a.dkv + row * a.lddkv + c, dk4);
-        f4_st(a.dkv + row * a.lddkv + D + c, dv4[i]);
+        f4_st(a.dkv + row * a.lddkv + D + c, dvs);
         sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
-        sv4.x += dv4[i].x; sv4.y += dv4[i].y; sv4.z += dv4[i].z; sv4.w += dv4[i].w;
+        sv4.x += dvs.x; sv4.y += dvs.y; sv4.z += dvs.z; sv4.w += dvs.w;
       }
     }
 #pragma unroll
@@ -845,11 +849,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
     if (half == 0) a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
   }
 }
-// shape the replica form is built for (both directions): d = 128, 8 heads — two four-head groups per sequence — keys
+// shapes the replica form is built for (both directions): 8 heads — two four-head groups per sequence — of 16 (d = 128)
+// or 32 (d = 256, <= 24 positions) columns, keys
 // within the register budget and their keep bits within one word, the replicas of a chunk within the backward's row batch
 static bool attn_wf4_fits(const AttnArgs& a) {
   static const bool on = !(getenv("PS_ATTN_WF") && atoi(getenv("PS_ATTN_WF")) == 0);
-  return on && a.Sq == 1 && a.d == 128 && a.H == 8 && a.dh == 16 && a.S <= 32 && a.fan >= 4 && a.fan <= 24;
+  return on && a.Sq == 1 && a.H == 8 && ((a.d == 128 && a.dh == 16 && a.S <= 32) || (a.d == 256 && a.dh == 32 && a.S <= 24)) &&
+         a.fan >= 4 && a.fan <= 24;
 }
 bool attn_wf_fits(const AttnArgs& a) { return attn_wf4_fits(a); }
 // its backward writes TWO partial dQ.Wq rows per sequence (one per head group), like the LDS form
@@ -860,16 +866,18 @@ int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
   int nch = env_ch > 0 ? env_ch : (a.fan >= 12 ? 4 : 2);
   if (nch > a.fan) nch = a.fan;
   const dim3 grid(ps_cdiv(a.n_in * (a.H / 4) * nch, 4));
-  if (a.S <= 24) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, nch);
+  if (a.dh == 32) hipLaunchKernelGGL((attn_fwd_wf_kernel<32, 12>), grid, dim3(256), 0, st, a, amask, nch);
+  else if (a.S <= 24) hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 6>), grid, dim3(256), 0, st, a, amask, nch);
   else hipLaunchKernelGGL((attn_fwd_wf_kernel<16, 8>), grid, dim3(256), 0, st, a, amask, nch);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
-  PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(wf): folded dQ.Wq needs its output row buffer");
-  if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<6>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<8>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128), "attention bwd(wf): folded dQ.Wq needs d == 128 and its output row buffer");
+  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -978,7 +978,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       const bool wf = sq1 && a.fan > 1 && attn_wf_fits(a);   // one wave per (sequence, four heads), replicas inside
       const bool w1 = wf || (sq1 && attn_w1_fits(a));       // one wave per sequence (no replicas)
       const bool q_folded = sq1 && !qall && i == 0 && ps_fusion_enabled() &&
-                            (w1 ? (size_t)(wf ? 2 : 1) * l.n_in <= (size_t)M2
+                            (w1 ? (!wf || d == 128) && (size_t)(wf ? 2 : 1) * l.n_in <= (size_t)M2
                                 : d == 128 && attn_sq1_split(a) == 2 && (size_t)2 * l.n_in <= (size_t)M2);
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
       // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
