@@ -25,7 +25,7 @@
 struct RtmWs {
   int Bseq, S, J;
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
-  int64_t loss_blk;         // [ceil(Bseq/4)] loss partials of rtm_score_kernel + its arrival ticket (must start at 0)
+  int64_t loss_blk;         // the 64-bit loss / arrival word of rtm_score_kernel (cleared by the query-encoder launch)
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
   int64_t wrank;
   int64_t wcnt, woff, wcur, wl;   // pvc backward: inverted index word -> review slots (int32 arrays; wl: int2 {slot, word})
@@ -126,7 +126,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.pv_terms = rtake(cur, npv);
   r.nvalid = rtake(cur, 4);
   r.seqcnt = rtake(cur, (int64_t)r.Bseq + 4);
-  r.loss_blk = rtake(cur, (int64_t)ps_cdiv(r.Bseq, 4) + 4);
+  r.loss_blk = rtake(cur, 4);
   r.dvec = rtake(cur, (int64_t)D.B * D.R * d);
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
@@ -620,11 +620,13 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
 // ------------------------------------------------------------------ scores
 // also writes the loss weight of the sequence (ps_model.py:344-345): pos_weight for the positive, and for a
 // negative 1 iff it has at least one real review
-// `fold_loss` (training without the PV loss): the workgroup's four loss terms are parked in loss_blk[blockIdx.x] and the
-// LAST workgroup to arrive (ticket) adds the partials up in block order — rtm_loss_kernel's result without its launch
-__global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out, int fold_loss, float* loss_blk, uint32_t* ticket) {
+// `fold_loss` (training without the PV loss): the workgroup adds its four loss terms to ONE 64-bit word with a returning
+// agent-scope atomic — fixed point (2^-20 units: integer adds, so the total does not depend on the arrival order) in the
+// low 48 bits, the arrival count above them — and the workgroup that sees the count complete holds the total in the
+// value it got back: rtm_loss_kernel's result without its launch and without a device-scope fence (which on this part
+// writes back the XCD's L2: the first form, partials + __threadfence + ticket, doubled this kernel's 6 us).
+__global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out, int fold_loss, unsigned long long* ticket) {
   __shared__ float wterm[4];
-  __shared__ int last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   float term = 0.f;
@@ -650,23 +652,15 @@ __global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out
   if (lane == 0) wterm[wv] = term;
   __syncthreads();
   if (threadIdx.x == 0) {
-    loss_blk[blockIdx.x] = (wterm[0] + wterm[1]) + (wterm[2] + wterm[3]);
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  float ps = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) ps += __builtin_nontemporal_load(loss_blk + i);
-  ps = wave_sum(ps);
-  __syncthreads();
-  if (lane == 0) wterm[wv] = ps;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float psl = ((wterm[0] + wterm[1]) + (wterm[2] + wterm[3])) / (float)a.B;
-    a.loss3[0] = psl; a.loss3[1] = psl; a.loss3[2] = 0.f;
-    a.nvalid[0] = 0.f;
+    const float mine_f = (wterm[0] + wterm[1]) + (wterm[2] + wterm[3]);           // >= 0: weights and softplus are
+    const unsigned long long mine = (unsigned long long)llrintf(mine_f * 1048576.f) + (1ull << 48);
+    const unsigned long long old = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 48) == (unsigned long long)gridDim.x - 1ull) {
+      const unsigned long long tot = (old + mine) & ((1ull << 48) - 1ull);
+      const float psl = (float)((double)tot * (1.0 / 1048576.0)) / (float)a.B;
+      a.loss3[0] = psl; a.loss3[1] = psl; a.loss3[2] = 0.f;
+      a.nvalid[0] = 0.f;
+    }
   }
 }
 
@@ -1386,7 +1380,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   const bool use_e4 = rtm_embed4_taken(D, k, r);
   k.count_fwd = rtm_counts_in_forward(D, k, r);
   if (k.count_fwd) { e.zero_i32 = k.wcnt; e.zero_n = (int)D.vocab_size + 1; }
-  if (!eval) e.clear_word = reinterpret_cast<uint32_t*>(ws + r.loss_blk + ps_cdiv(r.Bseq, 4));   // rtm_score_kernel's ticket
+  if (!eval) e.clear_word = reinterpret_cast<uint32_t*>(ws + r.loss_blk);   // rtm_score_kernel's 64-bit loss word
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {
     GemmProblem p = gp(ws + r.qmean, d, 0, P.fs_w, d, 0, ws + r.query_emb, d, B, d, d);
@@ -1441,8 +1435,9 @@ extern "C" int ps_rtm_forward(const PsRtmDesc* desc, const PsRtmTensors* params,
   TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, false, k, st));
   k.loss3 = loss3;
   const bool fold_loss = !k.train_pv;               // (the PV loss needs rtm_pv_fwd_kernel's terms: rtm_loss_kernel then)
+  PS_REQUIRE(!fold_loss || ps_cdiv(r.Bseq, 4) < 65536, "rtm forward: too many sequences for the folded loss");
   hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, k.scores, fold_loss ? 1 : 0,
-                     ws + r.loss_blk, reinterpret_cast<uint32_t*>(ws + r.loss_blk + ps_cdiv(r.Bseq, 4)));
+                     reinterpret_cast<unsigned long long*>(ws + r.loss_blk));
   PS_LAUNCH_CHECK();
   if (fold_loss) return PS_OK;
   if (k.train_pv) {
@@ -1465,7 +1460,7 @@ extern "C" int ps_rtm_score(const PsRtmDesc* desc, const PsRtmTensors* params, c
   TRY(rtm_make_ws(*desc, true, r, w, E));
   hipStream_t st = (hipStream_t)stream;
   TRY(rtm_encode(*desc, *params, *batch, ws, r, w, E, true, k, st));
-  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, scores, 0, nullptr, nullptr);
+  hipLaunchKernelGGL(rtm_score_kernel, dim3(ps_cdiv(r.Bseq, 4)), dim3(256), 0, st, k, scores, 0, nullptr);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
