@@ -16,8 +16,8 @@ static inline int64_t align16(int64_t x) { return (x + 15) & ~(int64_t)15; }
 extern "C" int64_t ps_adam_plan_bytes(int32_t n, const int64_t* numel) {
   int64_t chunks = 0;
   for (int i = 0; i < n; ++i) chunks += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
-  return align16(sizeof(AdamPlanHeader)) + 4 * align16(8 * (int64_t)n) + align16(8 * (int64_t)n) +
-         align16(4 * (int64_t)(n + 1)) + align16(4 * chunks);
+  return align16(sizeof(AdamPlanHeader)) + align16((int64_t)sizeof(AdamChunkRec) * chunks) + 4 * align16(8 * (int64_t)n) +
+         align16(8 * (int64_t)n) + align16(4 * (int64_t)(n + 1)) + align16(4 * chunks);
 }
 
 extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const* g, float* const* m,
@@ -25,7 +25,10 @@ extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const*
   PS_REQUIRE(n > 0, "adam plan: no tensors");
   char* base = (char*)plan_host;
   AdamPlanHeader h;
-  int64_t off = align16(sizeof(AdamPlanHeader));
+  int64_t total_chunks = 0;
+  for (int i = 0; i < n; ++i) total_chunks += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  int64_t off = ADAM_REC_OFF + align16((int64_t)sizeof(AdamChunkRec) * total_chunks);
+  AdamChunkRec* recs = (AdamChunkRec*)(base + ADAM_REC_OFF);
   h.off_p = off; off += align16(8 * (int64_t)n);
   h.off_g = off; off += align16(8 * (int64_t)n);
   h.off_m = off; off += align16(8 * (int64_t)n);
@@ -46,7 +49,13 @@ extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const*
     chunk0[i] = (int32_t)chunks;
     const int64_t nc = (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
     PS_REQUIRE(chunks + nc < (1 << 30), "adam plan: too many chunks");
-    for (int64_t c = 0; c < nc; ++c) chunk_tensor[chunks + c] = i;
+    for (int64_t c = 0; c < nc; ++c) {
+      chunk_tensor[chunks + c] = i;
+      const int64_t beg = c * ADAM_CHUNK, left = numel[i] - beg;
+      AdamChunkRec& r = recs[chunks + c];
+      r.p = p[i] + beg; r.g = g[i] + beg; r.m = m[i] + beg; r.v = v[i] + beg;
+      r.n = (int32_t)(left < ADAM_CHUNK ? left : ADAM_CHUNK); r.pad_ = 0;
+    }
     chunks += nc;
   }
   chunk0[n] = (int32_t)chunks;

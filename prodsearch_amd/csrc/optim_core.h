@@ -9,8 +9,16 @@ struct AdamPlanHeader {
   int32_t n_tensors;
   int32_t n_chunks;
   int64_t off_p, off_g, off_m, off_v, off_numel, off_chunk0;   // byte offsets inside the plan
-  int64_t off_chunk_tensor;           // int32[n_chunks]: the tensor each chunk belongs to (one load instead of a
-};                                    // binary search = log2(n_tensors) dependent loads at the head of every block)
+  int64_t off_chunk_tensor;           // int32[n_chunks]: the tensor each chunk belongs to
+};
+// One record per chunk, at a FIXED offset behind the header: a block reads its four pointers (already advanced to the chunk)
+// and its element count with ONE dependent load — header -> tensor index -> pointer / numel / first chunk -> data was a
+// chain of four, and with every block of the launch resident at once that chain is most of the sum-of-squares kernel.
+struct AdamChunkRec { float* p; float* g; float* m; float* v; int32_t n; int32_t pad_; };
+#define ADAM_REC_OFF ((int64_t)((sizeof(AdamPlanHeader) + 15) & ~(size_t)15))
+__host__ __device__ inline const AdamChunkRec* adam_chunk_recs(const char* plan) {
+  return reinterpret_cast<const AdamChunkRec*>(plan + ADAM_REC_OFF);
+}
 
 __device__ inline int find_tensor(const char* plan, const AdamPlanHeader* h, int chunk) {
   return ((const int32_t*)(plan + h->off_chunk_tensor))[chunk];
@@ -28,13 +36,9 @@ __device__ inline float block_sum_256(float v, float* sh) {
 
 // Sum of (g*grad_scale)^2 over one ADAM_CHUNK of the plan (block-wide result).
 __device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad_scale, float* sh) {
-  const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
-  const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
-  const int t = find_tensor(plan, h, chunk);
-  const float* g = ((float* const*)(plan + h->off_g))[t];
-  const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
-  const int64_t beg = (int64_t)(chunk - chunk0[t]) * ADAM_CHUNK;
-  const int64_t end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+  const AdamChunkRec rec = adam_chunk_recs(plan)[chunk];
+  const float* g = rec.g;                              // (advanced to the chunk)
+  const int64_t beg = 0, end = rec.n;
   float s = 0.f;
   if ((((uintptr_t)g) & 15) == 0 && end - beg == ADAM_CHUNK) {
     const float4* g4 = (const float4*)(g + beg);
@@ -80,16 +84,9 @@ __device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& 
 
 // clip + Adam over one ADAM_CHUNK of the plan.
 __device__ inline void adam_update_chunk(const char* plan, int chunk, const AdamScal& a) {
-  const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
-  const int32_t* chunk0 = (const int32_t*)(plan + h->off_chunk0);
-  const int t = find_tensor(plan, h, chunk);
-  float* p = ((float* const*)(plan + h->off_p))[t];
-  float* g = ((float* const*)(plan + h->off_g))[t];
-  float* m = ((float* const*)(plan + h->off_m))[t];
-  float* v = ((float* const*)(plan + h->off_v))[t];
-  const int64_t n = ((const int64_t*)(plan + h->off_numel))[t];
-  const int64_t beg = (int64_t)(chunk - chunk0[t]) * ADAM_CHUNK;
-  const int64_t end = beg + ADAM_CHUNK < n ? beg + ADAM_CHUNK : n;
+  const AdamChunkRec rec = adam_chunk_recs(plan)[chunk];
+  float* p = rec.p; float* g = rec.g; float* m = rec.m; float* v = rec.v;    // (advanced to the chunk)
+  const int64_t beg = 0, end = rec.n;
   const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 &&
                    end - beg == ADAM_CHUNK;
   if (vec) {
