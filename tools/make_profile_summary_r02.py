@@ -59,7 +59,10 @@ one grouped weight-gradient launch on a max-shape grid (81 %% idle workgroups: 0
 (every kernel ~2x slower); lowest stream priority for the side stream (no effect, kept); LDS hash aggregation of the word counts
 (slower: a chunk's words are mostly distinct); the inverted index built under the forward gather (slows it 87 -> 144 µs) or with the old
 per-occurrence atomics; XCD column split of the word-gradient reduce (206 vs 66 µs); one wave per (sequence, head group) with 21 serial
-replicas (37 µs) and eight waves per sequence (two rounds of 256-register workgroups, 40 µs in the step) before the four-wave form (16-19 µs).
+replicas (37 µs) and eight waves per sequence (two rounds of 256-register workgroups, 40 µs in the step) before the four-wave form
+(12.5 µs alone); a ticketed two-pass split reduction of the weight gradients (partials stored, last arriver adds them in split order:
+deterministic, no fp32 atomics, but 122 vs 44 µs — the device-scope release before each workgroup's ticket writes back its XCD's L2; the
+same fence doubled the review transformer's score kernel until its loss went through one fixed-point atomic instead).
 ''' % (b['value'], b['ms_per_step'], b['median_ms_per_step'], b['p10_p90_ms_per_step'][0], b['p10_p90_ms_per_step'][1], launches.strip(),
        b['roofline']['achieved'], b['roofline']['frac'], b['roofline']['us_per_launch'], table('r02_bench_kernel_stats.csv', 17),
        r['value'], r['ms_per_step'], r['median_ms_per_step'], r['roofline']['achieved'], r['roofline']['frac'],
