@@ -261,6 +261,8 @@ struct GemmProblem {
   //   ta == 0:            logical row i of A / C / residual is physical row ridx[i]; M is the list length on the device
   //   ta == 1 && tb == 1: logical reduction row k of A and B is physical row ridx[k]; K is the list length
   const int32_t* ridx; const int32_t* rcount;
+  int64_t split_stride;                 // split s of a split reduction writes at C + s * split_stride (deterministic mode: every split
+                                        // stores its own partial matrix, a second launch adds them up in split order)
   int no_deep;                          // never pick the 128-deep-slab form (133 KB of LDS per workgroup): for small products that
                                         // run BESIDE other launches, where that footprint starves them of CUs
 };
@@ -275,3 +277,8 @@ struct GemmGroup {
 };
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream);
+// PS_DETERMINISTIC=1 / ps_set_deterministic(1): bitwise run-to-run reproducible TEM training steps — one stream,
+// weight gradients through per-split partials + an ordered sum, table scatters by sole-owner waves walking the tasks in order.
+bool ps_deterministic();
+// deterministic mode's library-owned scratch: per device and slot (0: split reductions, 1: score backward), grow-only
+float* ps_det_scratch(int slot, size_t floats, hipStream_t st);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const bool col_ok = col < N;
   const float bias = (P.bias && col_ok && split == 0) ? P.bias[col] : 0.f;
   const float alpha = P.alpha;
-  float* const C = P.C;
+  float* const C = P.C + (size_t)split * P.split_stride;
   const int ldc = P.ldc, accumulate = P.accumulate;
   if (!FULL) {
 #pragma unroll
@@ -330,7 +330,8 @@ static int validate(const GemmProblem& p) {
   for (int s = 0; s < nseg; ++s)
     PS_REQUIRE(p.Bseg[s] && ((uintptr_t)p.Bseg[s] & 15) == 0, "gemm: B segment %d null/unaligned", s);
   PS_REQUIRE(p.ksplit >= 1, "gemm: ksplit");
-  if (p.ksplit > 1) PS_REQUIRE(p.accumulate == 2 && !needs_full(p), "gemm: split reduction needs a plain atomic epilogue");
+  if (p.ksplit > 1) PS_REQUIRE((p.accumulate == 2 || (p.accumulate == 0 && p.split_stride > 0)) && !needs_full(p),
+                               "gemm: split reduction needs a plain atomic epilogue (or per-split outputs)");
   return PS_OK;
 }
 
@@ -367,7 +368,8 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
       if (i >= g.n) { f.flat_tm[i] = 1; f.flat_tiles[i] = 1; continue; }
       int rc = validate(g.p[i]);
       if (rc) return rc;
-      PS_REQUIRE(g.p[i].ta == 1 && g.p[i].tb == 1 && !needs_full(g.p[i]) && !g.p[i].ridx && g.p[i].accumulate == 2 && g.p[i].ksplit >= 1,
+      PS_REQUIRE(g.p[i].ta == 1 && g.p[i].tb == 1 && !needs_full(g.p[i]) && !g.p[i].ridx && g.p[i].ksplit >= 1 &&
+                 (g.p[i].accumulate == 2 || (g.p[i].accumulate == 0 && g.p[i].split_stride > 0)),
                  "gemm: the flat group form takes plain weight-gradient problems");
       f.flat_tm[i] = ps_cdiv(g.p[i].M, BM);
       f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, BN);

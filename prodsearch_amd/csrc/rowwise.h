@@ -182,6 +182,7 @@ struct EmbedBwdArgs {
   // g_fs_b.  Replaces a tanh-backward launch and a [B,d]x[d,d] GEMM launch on the tail of the backward.
   const float* fsb_dqe; int fsb_lddqe; const float* fsb_qe; const float* fsb_w; float* g_fs_b;
   ColFoldList fold;              // parked column sums to add up (n = 0: none)
+  float* det_dm;                 // deterministic mode + fused FS backward: [B,d] buffer for the rows' d mean (scattered by the sole-owner pass)
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 

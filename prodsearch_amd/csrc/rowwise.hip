@@ -1013,8 +1013,212 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
     }
 }
 
+// Deterministic form of the table scatter above (ps_deterministic): every gradient row has ONE owner — half-wave
+// o = row % owners — and an owner walks the task lists in task order, so the fp32 additions into a row happen in the same
+// order in every run (the atomics remain, but no two waves ever add into one row).  Lists: item tasks (b, j) -> item row,
+// the row's word-task term -> target item row, word tasks -> word row; biases ride with their tasks.
+// A popular row's tasks all fall to one owner (Zipf: ~100 history slots of a C2 batch hold the top item), so the walk
+// keeps that chain short: keys of 8 x 32 tasks per round trip, and an owner's matches are FETCHED four at a time (their
+// operand rows in flight together) before they are COMMITTED — the atomics — in task order.
+#define SBD_OWNERS_PER_WG 8
+template <int EPL> struct DetItemT { float v[EPL]; float bias; int64_t row; };     // EPL = 32-column groups per row (>= d/32)      // one task's finished contribution: row values (+ bias entry)
+// fetch(t, item) fills the contribution of task t; the walk adds it to table[row] (skipped for row == skip_row) and to
+// bias[row] (if given).  Consecutive matches of one row are summed in registers first (in task order) — a popular row's
+// chain is then one atomic per up to DW_B tasks.
+template <int EPL, class KeyF, class FetchF>
+__device__ inline void det_owner_walk(int ntask, int owner, int nown, int hl, int d, float* table, float* bias, int64_t skip_row,
+                                      KeyF key, FetchF fetch) {
+  // A round = DW_U chunks of 32 tasks: all their keys are requested together, lane u of the half-wave keeps the match
+  // mask of chunk u, and the round's matches are then taken DW_B at a time ACROSS the chunks (a popular row has a match
+  // every few chunks: batching inside one chunk left every fetch alone with its round trip).
+  constexpr int DW_U = 32, DW_B = 8;
+  const int epl = d >> 5, c = hl, base = (int)(threadIdx.x & 32);
+  for (int t0 = 0; t0 < ntask; t0 += 32 * DW_U) {
+    uint32_t mymask = 0u;
+    {
+      int64_t kk[DW_U];
+#pragma unroll
+      for (int u = 0; u < DW_U; ++u) {
+        const int t = t0 + 32 * u + hl;
+        kk[u] = t < ntask ? key(t) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < DW_U; ++u) {
+        const bool mine = kk[u] >= 0 && (int)((uint32_t)kk[u] & (uint32_t)(nown - 1)) == owner;   // nown: a power of two
+        const unsigned long long bm = __ballot(mine);
+        if (hl == u) mymask = (uint32_t)(bm >> base);
+      }
+    }
+    int u = 0;
+    uint32_t m = (uint32_t)__shfl((int)mymask, base, 64);
+    for (;;) {
+      int ids[DW_B], n = 0;
+#pragma unroll
+      for (int q = 0; q < DW_B; ++q) {
+        while (!m && u < DW_U - 1) { ++u; m = (uint32_t)__shfl((int)mymask, base + u, 64); }
+        if (m) { ids[q] = t0 + 32 * u + __ffs((int)m) - 1; m &= m - 1; n = q + 1; }
+      }
+      if (n == 0) break;
+      DetItemT<EPL> it[DW_B];
+#pragma unroll
+      for (int q = 0; q < DW_B; ++q)
+        if (q < n) fetch(ids[q], it[q]);
+      // commit, in task order; runs of one row first meet in registers
+      float acc[EPL]; float bacc = 0.f; int64_t cur = -1;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q <= DW_B; ++q) {
+        const bool have = q < n;
+        const int64_t row = have ? it[q < DW_B ? q : 0].row : -2;
+        if (cur >= 0 && row != cur) {                          // flush the finished run (half-wave uniform)
+          if (cur != skip_row) {
+            float* dst = table + (size_t)cur * d;
+#pragma unroll
+            for (int k = 0; k < EPL; ++k)
+              if (k < epl) atomicAdd(&dst[c + 32 * k], acc[k]);
+          }
+          if (bias && c == 0) atomicAdd(&bias[cur], bacc);
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) acc[k] = 0.f;
+          bacc = 0.f;
+        }
+        if (have) {
+          cur = row;
+#pragma unroll
+          for (int k = 0; k < EPL; ++k) acc[k] += it[q < DW_B ? q : 0].v[k];
+          bacc += it[q < DW_B ? q : 0].bias;
+        } else {
+          cur = -1;
+        }
+      }
+    }
+  }
+}
+// term of the target item's gradient that batch row b's word tasks contribute (fixed order): term[b][d], one half-wave per row
+__global__ __launch_bounds__(256) void score_bwd_det_terms_kernel(const ScoreArgs a, float* term) {
+  const int tid = threadIdx.x, hl = tid & 31, c = hl;
+  const int b = (int)blockIdx.x * 8 + (tid >> 5);
+  if (b >= a.B) return;
+  const int d = a.d, epl = d >> 5, K1 = a.K + 1, nt = a.W * K1;
+  const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+  int cnt = 0;
+  for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
+  const float cf = invB / (float)(cnt > 0 ? cnt : 1);
+  float v[BW_MAXE];
+#pragma unroll
+  for (int k = 0; k < BW_MAXE; ++k) v[k] = 0.f;
+  for (int u0 = 0; u0 < nt; u0 += 32) {                        // lane = word task: its coefficient and word id, once
+    const int u = u0 + hl;
+    float ds = 0.f; int64_t idx = 0;
+    if (u < nt) {
+      const int w = u / K1, j = u - w * K1;
+      const int64_t pw = a.pos_words[(size_t)b * a.W + w];
+      if (pw != a.V - 1) {
+        idx = clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+        const float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
+        ds = (j == 0 ? sigmoid_f(s) - 1.f : sigmoid_f(s)) * cf;
+      }
+    }
+    const int cntu = min(32, nt - u0), base = (threadIdx.x & 32);
+    for (int i = 0; i < cntu; ++i) {                           // in task order
+      const float dsi = __shfl(ds, base + i, 64);
+      const int64_t idi = __shfl((long long)idx, base + i, 64);
+      const float* wrow = a.word_emb + (size_t)idi * d;
+#pragma unroll
+      for (int k = 0; k < BW_MAXE; ++k)
+        if (k < epl) v[k] = fmaf(dsi, wrow[c + 32 * k], v[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BW_MAXE; ++k)
+    if (k < epl) term[(size_t)b * d + c + 32 * k] = v[k];
+}
+template <int EPL>
+__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void score_bwd_det_kernel(const ScoreArgs a, const float* term) {
+  typedef DetItemT<EPL> DetItem;
+  const int tid = threadIdx.x, hl = tid & 31, c = hl;
+  const int owner = (int)blockIdx.x * SBD_OWNERS_PER_WG + (tid >> 5), nown = (int)gridDim.x * SBD_OWNERS_PER_WG;
+  const int d = a.d, epl = d >> 5, K1 = a.K + 1;
+  const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+  const float wpos = a.pos_weight ? (float)a.K : 1.f;
+  auto item_idx = [&](int t) -> int64_t {
+    const int b = fdiv(t, a.fK1), j = t - b * K1;
+    return clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+  };
+  auto word_idx = [&](int u) -> int64_t {                      // -1: masked window slot (get_vector_mean)
+    const int b = fdiv(u, a.fWK1), r = u - b * a.W * K1, w = r / K1, j = r - w * K1;
+    const int64_t pw = a.pos_words[(size_t)b * a.W + w];
+    if (pw == a.V - 1) return -1;
+    return clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+  };
+  // ---- item tasks (the pad row P: only its bias entry is touched)
+  det_owner_walk<EPL>(a.B * K1, owner, nown, hl, d, a.g_product_emb, a.bias_product ? a.g_product_bias : nullptr, a.P, item_idx,
+    [&](int t, DetItem& it) {
+      const int b = fdiv(t, a.fK1), j = t - b * K1;
+      it.row = item_idx(t);
+      const float s = a.item_scores[(size_t)b * K1 + j];
+      const float* encr = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * d;
+      float ev[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) ev[k] = k < epl ? encr[c + 32 * k] : 0.f;
+      const float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) it.v[k] = ds * ev[k];
+      it.bias = ds;
+    });
+  // ---- the rows' word tasks: their term of the target item's gradient (computed by score_bwd_det_terms_kernel) ...
+  det_owner_walk<EPL>(a.B, owner, nown, hl, d, a.g_product_emb, nullptr, a.P,
+    [&](int b) -> int64_t { const int64_t tb = clamp_idx(a.target[b], a.P); return tb == a.P ? -1 : tb; },
+    [&](int b, DetItem& it) {
+      it.row = clamp_idx(a.target[b], a.P);
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? term[(size_t)b * d + c + 32 * k] : 0.f;
+      it.bias = 0.f;
+    });
+  // ---- ... and the word rows
+  det_owner_walk<EPL>(a.B * a.W * K1, owner, nown, hl, d, a.g_word_emb, a.g_word_bias, a.V - 1, word_idx,
+    [&](int u, DetItem& it) {
+      const int b = fdiv(u, a.fWK1), r = u - b * a.W * K1, w = r / K1, j = r - w * K1;
+      it.row = word_idx(u);
+      const float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
+      const float* prow = a.product_emb + (size_t)clamp_idx(a.target[b], a.P) * d;
+      float pv[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) pv[k] = k < epl ? prow[c + 32 * k] : 0.f;
+      int cnt = 0;
+      for (int w2 = 0; w2 < a.W; ++w2) cnt += (a.pos_words[(size_t)b * a.W + w2] != a.V - 1);
+      const float ds = (j == 0 ? sigmoid_f(s) - 1.f : sigmoid_f(s)) * (invB / (float)(cnt > 0 ? cnt : 1));
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) it.v[k] = ds * pv[k];
+      it.bias = ds;
+    });
+}
+
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0 && a.d <= 32 * BW_MAXE, "score bwd: d=%d unsupported", a.d);
+  if (ps_deterministic()) {
+    // d enc (part 1: no table scatter) keeps its kernel — its sums are per row, in a fixed order; the table scatter
+    // (part 2) goes through the sole-owner form
+    if (a.denc && a.part != 2) {
+      ScoreArgs e = a;
+      e.part = 1;
+      const int iw = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
+      hipLaunchKernelGGL(score_bwd_kernel, dim3((a.R > 1 ? 2 : 1) * a.B + iw), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, e);
+      PS_LAUNCH_CHECK();
+    }
+    if (a.part != 1) {
+      float* term = ps_det_scratch(1, (size_t)a.B * a.d, st);
+      PS_REQUIRE(term, "score bwd: deterministic mode has no scratch (allocation failed or stream capture)");
+      hipLaunchKernelGGL(score_bwd_det_terms_kernel, dim3(ps_cdiv(a.B, 8)), dim3(256), 0, st, a, term);
+      PS_LAUNCH_CHECK();
+      if (a.d <= 128) hipLaunchKernelGGL(score_bwd_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
+      else if (a.d <= 256) hipLaunchKernelGGL(score_bwd_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
+      else hipLaunchKernelGGL(score_bwd_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
+      PS_LAUNCH_CHECK();
+    }
+    return PS_OK;
+  }
   const int item_wgs = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
   hipLaunchKernelGGL(score_bwd_kernel, dim3((a.R > 1 ? 2 : 1) * a.B + item_wgs), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
   PS_LAUNCH_CHECK();
@@ -1076,6 +1280,10 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
       dm_s[e] = s * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)e) * inv;
     }
     __syncthreads();
+    if (a.det_dm) {                                // deterministic mode: the sole-owner pass scatters these rows
+      for (int e = tid; e < d; e += 256) a.det_dm[(size_t)b * d + e] = dm_s[e];
+      return;
+    }
     for (int q = tid >> 5; q < a.Q; q += 8) {
       const int64_t idx = a.qw[(size_t)b * a.Q + q];
       if (idx == a.V - 1 || idx < 0 || idx >= a.V) continue;
@@ -1180,12 +1388,56 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
   }
 }
 
+// Deterministic form of the two scatters above (see score_bwd_det_kernel): history rows, then query-word rows.
+template <int EPL>
+__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void embed_scatter_det_kernel(const EmbedBwdArgs a) {
+  typedef DetItemT<EPL> DetItem;
+  const int tid = threadIdx.x, hl = tid & 31, c = hl;
+  const int owner = (int)blockIdx.x * SBD_OWNERS_PER_WG + (tid >> 5), nown = (int)gridDim.x * SBD_OWNERS_PER_WG;
+  const int d = a.d, epl = d >> 5;
+  if (a.tem)
+    det_owner_walk<EPL>(a.B * a.L, owner, nown, hl, d, a.g_hist_tab, nullptr, -1,
+      [&](int t) -> int64_t { const int64_t idx = a.ui[t]; return (idx == a.P || idx < 0 || idx > a.P) ? -1 : idx; },
+      [&](int t, DetItem& it) {
+        const int b = t / a.L, l = t - b * a.L;
+        it.row = a.ui[t];
+        const float* src = a.dx + ((size_t)b * a.S + 1 + l) * d;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? src[c + 32 * k] : 0.f;
+        it.bias = 0.f;
+      });
+  det_owner_walk<EPL>(a.B * a.Q, owner, nown, hl, d, a.g_word_emb, nullptr, -1,
+    [&](int u) -> int64_t { const int64_t idx = a.qw[u]; return (idx == a.V - 1 || idx < 0 || idx >= a.V) ? -1 : idx; },
+    [&](int u, DetItem& it) {
+      const int b = u / a.Q;
+      it.row = a.qw[u];
+      it.bias = 0.f;
+      if (a.det_dm) {
+        const float* src = a.det_dm + (size_t)b * d;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? src[c + 32 * k] : 0.f;
+      } else {
+        int cnt = 0;
+        for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+        const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+        const float* src = a.dqmean_d + (size_t)b * d;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+          it.v[k] = k < epl ? src[c + 32 * k] * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)(c + 32 * k)) * inv : 0.f;
+      }
+    });
+}
+
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 32 == 0, "embed scatter: d %% 32");
   const bool fsb = a.fsb_w != nullptr;
   PS_REQUIRE(!fsb || (a.fsb_dqe && a.fsb_qe && a.g_fs_b && a.g_fs_w && a.fw_x && a.d <= 1024),
              "embed scatter: fused FS backward operands missing");
+  const bool det = ps_deterministic();
+  PS_REQUIRE(!det || !fsb || a.det_dm, "embed scatter: deterministic mode needs the d-mean buffer");
+  PS_REQUIRE(!det || a.d <= 32 * BW_MAXE, "embed scatter: deterministic mode supports d <= %d", 32 * BW_MAXE);
   int ntask = (a.tem ? a.B * a.L : 0) + (fsb ? 0 : a.B * a.Q);   // fused: the query words are scattered by the row workgroups
+  if (det) ntask = 0;                                            // ... deterministic mode: by the sole-owner pass below
   const int nsb = ps_cdiv(ntask, 8);
   const int nq = fsb ? a.B : 0;
   const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
@@ -1193,8 +1445,18 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   int nfold = 0;
   for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 32);
   const size_t lds = fsb ? sizeof(float) * (size_t)(256 / (a.d / 4) + 2) * a.d : 0;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(nq + nsb + nfw + nfold), dim3(256), lds, st, a, ntask, nq, nfw, nfold);
-  PS_LAUNCH_CHECK();
+  EmbedBwdArgs a2 = a;
+  if (!det) a2.det_dm = nullptr;
+  if (nq + nsb + nfw + nfold > 0) {
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(nq + nsb + nfw + nfold), dim3(256), lds, st, a2, ntask, nq, nfw, nfold);
+    PS_LAUNCH_CHECK();
+  }
+  if (det) {
+    if (a.d <= 128) hipLaunchKernelGGL(embed_scatter_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
+    else if (a.d <= 256) hipLaunchKernelGGL(embed_scatter_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
+    else hipLaunchKernelGGL(embed_scatter_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
+    PS_LAUNCH_CHECK();
+  }
   return PS_OK;
 }
 

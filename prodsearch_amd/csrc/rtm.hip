@@ -1597,6 +1597,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     if (ps_fusion_enabled() && d <= 128) {   // whole FS backward inside the scatter launch (EmbedBwdArgs::fsb_*)
       e.fw_x = ws + r.qmean; e.g_fs_w = G.fs_w;
       e.fsb_dqe = ws + r.dqe; e.fsb_lddqe = d; e.fsb_qe = ws + r.query_emb; e.fsb_w = params->fs_w; e.g_fs_b = G.fs_b;
+      e.det_dm = ws + r.dqmean;                   // (deterministic mode only: launch_embed_scatter)
     } else {
       TRY(launch_tanh_bwd(ws + r.dqe, d, ws + r.query_emb, ws + r.dqpre, G.fs_b, B, d, st));
       GemmProblem p = gp(ws + r.dqpre, d, 0, params->fs_w, d, 1, ws + r.dqmean, d, B, d, d);

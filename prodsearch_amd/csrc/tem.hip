@@ -266,6 +266,64 @@ static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, but at 
   if (ks > want) ks = want;
   return ks < 1 ? 1 : ks;
 }
+// ---- deterministic mode (PS_DETERMINISTIC=1 or ps_set_deterministic): see common.h / DESIGN.md 5e
+static int& det_slot() {
+  static int v = getenv("PS_DETERMINISTIC") ? atoi(getenv("PS_DETERMINISTIC")) : 0;
+  return v;
+}
+bool ps_deterministic() { return det_slot() != 0; }
+extern "C" int ps_set_deterministic(int on) {
+  const int old = det_slot();
+  det_slot() = on ? 1 : 0;
+  return old;
+}
+// scratch of the ordered split reduction: per device, grow-only, allocated outside any stream capture
+static float* det_scratch(size_t floats, hipStream_t st) { return ps_det_scratch(0, floats, st); }
+// dW[i] += sum_s part[s][i], s ascending: the second pass of a deterministic split reduction
+__global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* part, int ks, int64_t n, float* dW) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < ks; s0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (size_t)(s0 + u < ks ? s0 + u : s0) * n + i);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < ks) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  float4 d = *reinterpret_cast<float4*>(dW + i);
+  d.x += acc.x; d.y += acc.y; d.z += acc.z; d.w += acc.w;
+  *reinterpret_cast<float4*>(dW + i) = d;
+}
+static int run_wgrads_det(GemmGroup& g, hipStream_t st) {
+  // every member writes ks partial matrices [M][N] (plain stores), then one ordered sum per member
+  size_t total = 0;
+  for (int i = 0; i < g.n; ++i) {
+    PS_REQUIRE(g.p[i].ldc == g.p[i].N && (g.p[i].M * (int64_t)g.p[i].N) % 4 == 0 && !g.p[i].bias,
+               "deterministic weight gradient: contiguous, bias-free output expected");
+    total += (size_t)g.p[i].ksplit * g.p[i].M * g.p[i].N;
+  }
+  float* sc = det_scratch(total, st);
+  PS_REQUIRE(sc, "deterministic mode: no scratch for the split reduction (allocation failed or stream capture)");
+  PS_CHECK_HIP(hipMemsetAsync(sc, 0, total * sizeof(float), st));     // splits without slabs (row lists) leave zeros
+  float* dW[3]; float* part[3];
+  size_t off = 0;
+  for (int i = 0; i < g.n; ++i) {
+    GemmProblem& p = g.p[i];
+    dW[i] = p.C; part[i] = sc + off;
+    p.C = part[i]; p.accumulate = 0; p.split_stride = (int64_t)p.M * p.N;
+    off += (size_t)p.ksplit * p.M * p.N;
+  }
+  TRY(ps_launch_gemm(g, st));
+  for (int i = 0; i < g.n; ++i) {
+    const int64_t n = (int64_t)g.p[i].M * g.p[i].N;
+    hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)ps_cdiv(n / 4, 256)), dim3(256), 0, st, part[i], g.p[i].ksplit, n, dW[i]);
+    PS_LAUNCH_CHECK();
+  }
+  return PS_OK;
+}
+
 // (measured and dropped, round 2: a two-pass split reduction — every split stores its partial tile in scratch, takes a ticket,
 // the last arriver of a tile adds the partials up in split order — deterministic and free of fp32 atomics, but 122 us against
 // 44 for the grouped launch at C2 and 0.395 against 0.292 ms per step: the device-scope release each of the 600 workgroups
@@ -287,6 +345,7 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
       g.p[i].ksplit = pick_ksplit(ps_cdiv(ps[i].M, 64) * ps_cdiv(ps[i].N, 64), ps[i].K);
     }
     g.flat = 1;
+    if (ps_deterministic()) return run_wgrads_det(g, st);
     return ps_launch_gemm(g, st);
   }
   int tiles = 0, rows = 0;
@@ -301,6 +360,7 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
       if (ks < need) ks = need;
     }
   for (int i = 0; i < n; ++i) { g.p[i] = ps[i]; g.p[i].ksplit = ks; }
+  if (ps_deterministic() && ks > 1) return run_wgrads_det(g, st);
   return ps_launch_gemm(g, st);
 }
 
@@ -350,6 +410,7 @@ static bool dispatch_may_be_serialised() {
   return !(getenv("ROCP_TOOL_LIBRARIES") && getenv("ROCPROF_KERNEL_TRACE"));
 }
 static SideCtx* side_ctx() {
+  if (ps_deterministic()) return nullptr;              // one stream: the order in which kernels add into a table is the launch order
   static SideCtx ctxs[PS_MAX_DEVICES];
   static int states[PS_MAX_DEVICES];           // 0 = uninitialised, 1 = ready, -1 = disabled
   static std::mutex mu;
@@ -405,6 +466,25 @@ static bool stream_capturing(hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
   return cs != hipStreamCaptureStatusNone;
+}
+float* ps_det_scratch(int slot, size_t floats, hipStream_t st) {
+  static float* buf[PS_MAX_DEVICES][2];
+  static size_t cap[PS_MAX_DEVICES][2];
+  static std::mutex mu;
+  int dev = 0;
+  if (slot < 0 || slot > 1) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PS_MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (cap[dev][slot] < floats) {
+    if (stream_capturing(st)) return nullptr;
+    (void)hipStreamSynchronize(st);                      // the old buffer may still be read by a queued launch
+    if (buf[dev][slot]) (void)hipFree(buf[dev][slot]);
+    buf[dev][slot] = nullptr; cap[dev][slot] = 0;
+    const size_t want = floats + floats / 4;
+    if (hipMalloc((void**)&buf[dev][slot], want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    cap[dev][slot] = want;
+  }
+  return buf[dev][slot];
 }
 // fork: everything enqueued on the main stream so far is visible to later side-stream work.  Each fork costs the
 // main stream one event packet (~6 us before its next kernel, measured), so callers batch their weight gradients.
@@ -1126,6 +1206,7 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     if (ps_fusion_enabled() && d <= 128) {
       // ... and so does the rest of the FS backward: tanh', d mean = dqpre . f_W (per-row mat-vec), bias gradient
       e.fsb_dqe = dqe; e.fsb_lddqe = lddqe; e.fsb_qe = ws + w.query_emb; e.fsb_w = P.fs_w; e.g_fs_b = G.fs_b;
+      e.det_dm = ws + w.dqmean;                   // (deterministic mode only: launch_embed_scatter)
     } else {
       TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
       GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W

@@ -155,6 +155,8 @@ class _Plan(object):
 class ItemTransformerRanker(nn.Module):
     def __init__(self, args, device, vocab_size, product_size, vocab_words, word_dists=None):
         super(ItemTransformerRanker, self).__init__()
+        if getattr(args, 'deterministic', False):      # bitwise reproducible steps (process-wide switch, ps_set_deterministic)
+            _lib.load().ps_set_deterministic(1)
         if args.model_name not in ('item_transformer', 'QEM'):
             raise NotImplementedError("model_name %r is outside the hot path (item_transformer/QEM only)"
                                       % args.model_name)
