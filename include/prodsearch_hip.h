@@ -133,7 +133,7 @@ int ps_set_side_mode(int mode);
 /* Deterministic mode (env PS_DETERMINISTIC=1, no reference counterpart: the reference's CUDA index_add_ / embedding backward are
  * not deterministic either): the item-transformer training step becomes bitwise reproducible run to run — everything on one
  * stream, weight gradients as per-split partial matrices added up in split order by a second launch, table scatters by
- * sole-owner half-waves that walk the task lists in order.  ~3.5x the default step time (1.03 ms at C2: a
+ * sole-owner half-waves that walk the task lists in order.  ~2.6x the default step time (0.78 ms at C2: a
  * popular row's additions are one chain); allocates scratch buffers on first use; process-wide.  The review transformer runs
  * in this mode too but keeps its own fp32-atomic reductions.  Returns the previous value. */
 int ps_set_deterministic(int on);

@@ -1025,9 +1025,9 @@ template <int EPL> struct DetItemT { float v[EPL]; float bias; int64_t row; };  
 // fetch(t, item) fills the contribution of task t; the walk adds it to table[row] (skipped for row == skip_row) and to
 // bias[row] (if given).  Consecutive matches of one row are summed in registers first (in task order) — a popular row's
 // chain is then one atomic per up to DW_B tasks.
-template <int EPL, class KeyF, class FetchF>
+template <int EPL, class FetchF>
 __device__ inline void det_owner_walk(int ntask, int owner, int nown, int hl, int d, float* table, float* bias, int64_t skip_row,
-                                      KeyF key, FetchF fetch) {
+                                      const int32_t* keys, FetchF fetch) {
   // A round = DW_U chunks of 32 tasks: all their keys are requested together, lane u of the half-wave keeps the match
   // mask of chunk u, and the round's matches are then taken DW_B at a time ACROSS the chunks (a popular row has a match
   // every few chunks: batching inside one chunk left every fetch alone with its round trip).
@@ -1036,11 +1036,12 @@ __device__ inline void det_owner_walk(int ntask, int owner, int nown, int hl, in
   for (int t0 = 0; t0 < ntask; t0 += 32 * DW_U) {
     uint32_t mymask = 0u;
     {
-      int64_t kk[DW_U];
+      int32_t kk[DW_U];                                      // (keys: row ids precomputed by a parallel pass, -1 = no task)
 #pragma unroll
       for (int u = 0; u < DW_U; ++u) {
         const int t = t0 + 32 * u + hl;
-        kk[u] = t < ntask ? key(t) : -1;
+        kk[u] = keys[t < ntask ? t : ntask - 1];
+        if (t >= ntask) kk[u] = -1;
       }
 #pragma unroll
       for (int u = 0; u < DW_U; ++u) {
@@ -1095,12 +1096,33 @@ __device__ inline void det_owner_walk(int ntask, int owner, int nown, int hl, in
     }
   }
 }
-// term of the target item's gradient that batch row b's word tasks contribute (fixed order): term[b][d], one half-wave per row
-__global__ __launch_bounds__(256) void score_bwd_det_terms_kernel(const ScoreArgs a, float* term) {
+// Parallel pre-pass of the deterministic score backward: (1) the keys (gradient-row ids, -1 = no task) of the three task
+// lists as int32 arrays — every owner reads them 2,048 times over, so they are computed once; (2) the term of the target
+// item's gradient that batch row b's word tasks contribute (fixed order): term[b][d], one half-wave per row.
+// keys layout: [B*K1] item tasks, [B] target rows, [B*W*K1] word tasks.
+__global__ __launch_bounds__(256) void score_bwd_det_pre_kernel(const ScoreArgs a, float* term, int32_t* keys) {
   const int tid = threadIdx.x, hl = tid & 31, c = hl;
+  const int d = a.d, epl = d >> 5, K1 = a.K + 1, nt = a.W * K1;
+  const int nitem = a.B * K1, nword = a.B * nt;
+  {
+    const int g = (int)blockIdx.x * 256 + tid, gn = (int)gridDim.x * 256;
+    for (int t = g; t < nitem; t += gn) {
+      const int b = fdiv(t, a.fK1), j = t - b * K1;
+      keys[t] = (int32_t)clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+    }
+    for (int b = g; b < a.B; b += gn) {
+      const int64_t tb = clamp_idx(a.target[b], a.P);
+      keys[nitem + b] = tb == a.P ? -1 : (int32_t)tb;
+    }
+    for (int u = g; u < nword; u += gn) {
+      const int b = fdiv(u, a.fWK1), r = u - b * nt, w = fdiv(r, a.fK1), j = r - w * K1;
+      const int64_t pw = a.pos_words[(size_t)b * a.W + w];
+      keys[nitem + a.B + u] = pw == a.V - 1 ? -1
+          : (int32_t)clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+    }
+  }
   const int b = (int)blockIdx.x * 8 + (tid >> 5);
   if (b >= a.B) return;
-  const int d = a.d, epl = d >> 5, K1 = a.K + 1, nt = a.W * K1;
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
   int cnt = 0;
   for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
@@ -1135,28 +1157,20 @@ __global__ __launch_bounds__(256) void score_bwd_det_terms_kernel(const ScoreArg
     if (k < epl) term[(size_t)b * d + c + 32 * k] = v[k];
 }
 template <int EPL>
-__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void score_bwd_det_kernel(const ScoreArgs a, const float* term) {
+__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void score_bwd_det_kernel(const ScoreArgs a, const float* term, const int32_t* keys) {
   typedef DetItemT<EPL> DetItem;
   const int tid = threadIdx.x, hl = tid & 31, c = hl;
   const int owner = (int)blockIdx.x * SBD_OWNERS_PER_WG + (tid >> 5), nown = (int)gridDim.x * SBD_OWNERS_PER_WG;
   const int d = a.d, epl = d >> 5, K1 = a.K + 1;
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
   const float wpos = a.pos_weight ? (float)a.K : 1.f;
-  auto item_idx = [&](int t) -> int64_t {
-    const int b = fdiv(t, a.fK1), j = t - b * K1;
-    return clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
-  };
-  auto word_idx = [&](int u) -> int64_t {                      // -1: masked window slot (get_vector_mean)
-    const int b = fdiv(u, a.fWK1), r = u - b * a.W * K1, w = r / K1, j = r - w * K1;
-    const int64_t pw = a.pos_words[(size_t)b * a.W + w];
-    if (pw == a.V - 1) return -1;
-    return clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
-  };
+  const int nitem = a.B * K1;
+  const int32_t* keys_item = keys; const int32_t* keys_tgt = keys + nitem; const int32_t* keys_word = keys + nitem + a.B;
   // ---- item tasks (the pad row P: only its bias entry is touched)
-  det_owner_walk<EPL>(a.B * K1, owner, nown, hl, d, a.g_product_emb, a.bias_product ? a.g_product_bias : nullptr, a.P, item_idx,
+  det_owner_walk<EPL>(a.B * K1, owner, nown, hl, d, a.g_product_emb, a.bias_product ? a.g_product_bias : nullptr, a.P, keys_item,
     [&](int t, DetItem& it) {
       const int b = fdiv(t, a.fK1), j = t - b * K1;
-      it.row = item_idx(t);
+      it.row = keys_item[t];
       const float s = a.item_scores[(size_t)b * K1 + j];
       const float* encr = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * d;
       float ev[EPL];
@@ -1168,19 +1182,18 @@ __global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void score_bwd_det_kernel(c
       it.bias = ds;
     });
   // ---- the rows' word tasks: their term of the target item's gradient (computed by score_bwd_det_terms_kernel) ...
-  det_owner_walk<EPL>(a.B, owner, nown, hl, d, a.g_product_emb, nullptr, a.P,
-    [&](int b) -> int64_t { const int64_t tb = clamp_idx(a.target[b], a.P); return tb == a.P ? -1 : tb; },
+  det_owner_walk<EPL>(a.B, owner, nown, hl, d, a.g_product_emb, nullptr, a.P, keys_tgt,
     [&](int b, DetItem& it) {
-      it.row = clamp_idx(a.target[b], a.P);
+      it.row = keys_tgt[b];
 #pragma unroll
       for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? term[(size_t)b * d + c + 32 * k] : 0.f;
       it.bias = 0.f;
     });
   // ---- ... and the word rows
-  det_owner_walk<EPL>(a.B * a.W * K1, owner, nown, hl, d, a.g_word_emb, a.g_word_bias, a.V - 1, word_idx,
+  det_owner_walk<EPL>(a.B * a.W * K1, owner, nown, hl, d, a.g_word_emb, a.g_word_bias, a.V - 1, keys_word,
     [&](int u, DetItem& it) {
       const int b = fdiv(u, a.fWK1), r = u - b * a.W * K1, w = r / K1, j = r - w * K1;
-      it.row = word_idx(u);
+      it.row = keys_word[u];
       const float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
       const float* prow = a.product_emb + (size_t)clamp_idx(a.target[b], a.P) * d;
       float pv[EPL];
@@ -1208,13 +1221,15 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
       PS_LAUNCH_CHECK();
     }
     if (a.part != 1) {
-      float* term = ps_det_scratch(1, (size_t)a.B * a.d, st);
+      const size_t nkeys = (size_t)a.B * (a.K + 1) * (1 + a.W) + a.B;
+      float* term = ps_det_scratch(1, (size_t)a.B * a.d + nkeys + 4, st);
       PS_REQUIRE(term, "score bwd: deterministic mode has no scratch (allocation failed or stream capture)");
-      hipLaunchKernelGGL(score_bwd_det_terms_kernel, dim3(ps_cdiv(a.B, 8)), dim3(256), 0, st, a, term);
+      int32_t* keys = reinterpret_cast<int32_t*>(term + (size_t)a.B * a.d);
+      hipLaunchKernelGGL(score_bwd_det_pre_kernel, dim3(ps_cdiv(a.B, 8)), dim3(256), 0, st, a, term, keys);
       PS_LAUNCH_CHECK();
-      if (a.d <= 128) hipLaunchKernelGGL(score_bwd_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
-      else if (a.d <= 256) hipLaunchKernelGGL(score_bwd_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
-      else hipLaunchKernelGGL(score_bwd_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term);
+      if (a.d <= 128) hipLaunchKernelGGL(score_bwd_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term, keys);
+      else if (a.d <= 256) hipLaunchKernelGGL(score_bwd_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term, keys);
+      else hipLaunchKernelGGL(score_bwd_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a, term, keys);
       PS_LAUNCH_CHECK();
     }
     return PS_OK;
@@ -1389,28 +1404,34 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
 }
 
 // Deterministic form of the two scatters above (see score_bwd_det_kernel): history rows, then query-word rows.
+// keys of the two task lists (history slots, query-word slots): int32 row ids, -1 = no task
+__global__ __launch_bounds__(256) void embed_scatter_det_keys_kernel(const EmbedBwdArgs a, int32_t* keys) {
+  const int g = (int)blockIdx.x * 256 + (int)threadIdx.x, gn = (int)gridDim.x * 256;
+  const int nh = a.tem ? a.B * a.L : 0;
+  for (int t = g; t < nh; t += gn) { const int64_t idx = a.ui[t]; keys[t] = (idx == a.P || idx < 0 || idx > a.P) ? -1 : (int32_t)idx; }
+  for (int u = g; u < a.B * a.Q; u += gn) { const int64_t idx = a.qw[u]; keys[nh + u] = (idx == a.V - 1 || idx < 0 || idx >= a.V) ? -1 : (int32_t)idx; }
+}
 template <int EPL>
-__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void embed_scatter_det_kernel(const EmbedBwdArgs a) {
+__global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void embed_scatter_det_kernel(const EmbedBwdArgs a, const int32_t* keys) {
   typedef DetItemT<EPL> DetItem;
+  const int nh = a.tem ? a.B * a.L : 0;
   const int tid = threadIdx.x, hl = tid & 31, c = hl;
   const int owner = (int)blockIdx.x * SBD_OWNERS_PER_WG + (tid >> 5), nown = (int)gridDim.x * SBD_OWNERS_PER_WG;
   const int d = a.d, epl = d >> 5;
   if (a.tem)
-    det_owner_walk<EPL>(a.B * a.L, owner, nown, hl, d, a.g_hist_tab, nullptr, -1,
-      [&](int t) -> int64_t { const int64_t idx = a.ui[t]; return (idx == a.P || idx < 0 || idx > a.P) ? -1 : idx; },
+    det_owner_walk<EPL>(a.B * a.L, owner, nown, hl, d, a.g_hist_tab, nullptr, -1, keys,
       [&](int t, DetItem& it) {
         const int b = t / a.L, l = t - b * a.L;
-        it.row = a.ui[t];
+        it.row = keys[t];
         const float* src = a.dx + ((size_t)b * a.S + 1 + l) * d;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? src[c + 32 * k] : 0.f;
         it.bias = 0.f;
       });
-  det_owner_walk<EPL>(a.B * a.Q, owner, nown, hl, d, a.g_word_emb, nullptr, -1,
-    [&](int u) -> int64_t { const int64_t idx = a.qw[u]; return (idx == a.V - 1 || idx < 0 || idx >= a.V) ? -1 : idx; },
+  det_owner_walk<EPL>(a.B * a.Q, owner, nown, hl, d, a.g_word_emb, nullptr, -1, keys + nh,
     [&](int u, DetItem& it) {
       const int b = u / a.Q;
-      it.row = a.qw[u];
+      it.row = keys[nh + u];
       it.bias = 0.f;
       if (a.det_dm) {
         const float* src = a.det_dm + (size_t)b * d;
@@ -1452,9 +1473,14 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
     PS_LAUNCH_CHECK();
   }
   if (det) {
-    if (a.d <= 128) hipLaunchKernelGGL(embed_scatter_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
-    else if (a.d <= 256) hipLaunchKernelGGL(embed_scatter_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
-    else hipLaunchKernelGGL(embed_scatter_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2);
+    const size_t nkeys = (size_t)a.B * ((a.tem ? a.L : 0) + a.Q);
+    int32_t* keys = reinterpret_cast<int32_t*>(ps_det_scratch(1, nkeys + 4, st));   // (the score backward's use of the slot is over)
+    PS_REQUIRE(keys, "embed scatter: deterministic mode has no scratch (allocation failed or stream capture)");
+    hipLaunchKernelGGL(embed_scatter_det_keys_kernel, dim3(ps_cdiv((int64_t)nkeys, 1024)), dim3(256), 0, st, a2, keys);
+    PS_LAUNCH_CHECK();
+    if (a.d <= 128) hipLaunchKernelGGL(embed_scatter_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2, keys);
+    else if (a.d <= 256) hipLaunchKernelGGL(embed_scatter_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2, keys);
+    else hipLaunchKernelGGL(embed_scatter_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, a2, keys);
     PS_LAUNCH_CHECK();
   }
   return PS_OK;
