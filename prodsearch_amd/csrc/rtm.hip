@@ -402,14 +402,15 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
 //   4. mean, dropout (the wave's 128 dropout evaluations shared through LDS), segment / user / item rows, key mask,
 //      positional row -> x.   Query positions (s = 0) and the per-sequence counts ride as extra waves of the launch.
 #define E4_LIST 128
+template <int NCHL>
 struct E4Lds {
   int wid[4][4][E4_LIST];          // [wave][review][entry]
   float tm[4][4][E4_LIST];
-  uint32_t dw[4][256][4];          // [wave][column][review]: dropout words of the output row
+  uint32_t dw[4][64 * NCHL][4];    // [wave][column][review]: dropout words of the output row (d = 64 * NCHL columns)
 };
 template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
 __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread) {
-  __shared__ E4Lds L;
+  __shared__ E4Lds<NCHL> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x * 4 + wv;
   const int d = a.d;
