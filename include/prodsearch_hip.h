@@ -137,6 +137,12 @@ int ps_set_side_mode(int mode);
  * popular row's additions are one chain); allocates scratch buffers on first use; process-wide.  The review transformer runs
  * in this mode too but keeps its own fp32-atomic reductions.  Returns the previous value. */
 int ps_set_deterministic(int on);
+/* Product form of the large linears (no reference counterpart).  mode 1: launches with enough tiles to fill the chip take
+ * the bf16x3 kernel — every fp32 operand split exactly into three bf16 values, six v_mfma_f32_32x32x16_bf16 per product step,
+ * fp32 accumulation: as accurate as the fp32 MFMA (1.1e-7 of sum|a b|) at a third of its cycles; mode 0: the fp32 MFMA
+ * everywhere.  force_shape -1: tile chosen by the launch's size; 0 / 1 / 2: 64x64 / 128x64 / 128x128 for every launch that
+ * has an instantiation (tests).  Env PS_GEMM_X3 / PS_GEMM_X3_SHAPE set the initial values.  Process-wide. */
+int ps_gemm_x3_config(int mode, int force_shape);
 
 /* Workspace the caller allocates once per shape (bytes) and its layout. */
 int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);

@@ -110,6 +110,7 @@ SYMBOLS = {
     'ps_set_fuse_bwd_min': (C.c_int, [C.c_int]),
     'ps_set_side_mode': (C.c_int, [C.c_int]),
     'ps_set_deterministic': (C.c_int, [C.c_int]),
+    'ps_gemm_x3_config': (C.c_int, [C.c_int, C.c_int]),
     'ps_tem_workspace_layout': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemWsLayout)]),
     'ps_tem_forward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -103,6 +103,103 @@ __device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16],
   }
 }
 
+// ---------------------------------------------------------------------- epilogues (shared by both product forms)
+// One 64x64 tile whose four 32x32 accumulators sit in the workgroup's four waves (wave (wm, wn), MFMA 32x32 C layout).
+template <int TA, int IDX>
+__device__ __forceinline__ void epi_plain(const GemmProblem& P, const f32x16& acc, int m0, int n0, int split, int M, int N,
+                                          bool listed, int wm, int wn, int l31, int h) {
+  const int col = n0 + wn * 32 + l31;
+  const bool col_ok = col < N;
+  const float bias = (P.bias && col_ok && split == 0) ? P.bias[col] : 0.f;
+  const float alpha = P.alpha;
+  float* const C = P.C + (size_t)split * P.split_stride;
+  const int ldc = P.ldc, accumulate = P.accumulate;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (col_ok && row < M) {
+      const float v = (acc[r] + bias) * alpha;
+      const size_t off = (size_t)((listed && TA == 0) ? P.ridx[row] : row) * ldc + col;
+      if (accumulate == 0) C[off] = v;
+      else if (accumulate == 1) C[off] += v;
+      else atomicAdd(&C[off], v);
+    }
+  }
+}
+
+__device__ __forceinline__ void epi_stage(float (*Ct)[LDT], const f32x16& acc, int wm, int wn, int l31, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ct[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h][wn * 32 + l31] = acc[r];
+}
+
+template <int TA, int IDX>
+__device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)[LDT], int m0, int n0, int tm, int split,
+                                         int M, int N, bool listed, int tid) {
+  float* const C = P.C + (size_t)split * P.split_stride;
+  const float alpha = P.alpha;
+  const int ldc = P.ldc, accumulate = P.accumulate;
+  const int ccol = tid & 63, gcol = n0 + ccol;
+  if (gcol >= N) return;
+  const float cbias = (P.bias && split == 0) ? P.bias[gcol] : 0.f;
+  const int act = P.act;
+  const DropSpec drop = P.drop;
+  const bool dropping = drop.thr != 0u, has_res = P.res.mode != RES_NONE;
+  const float add2 = (P.out2 && P.add2) ? P.add2[gcol] : 0.f;
+  float csum = 0.f;
+  // global operands of the epilogue (activation aux, residual) for row group i; fetched one group
+  // AHEAD of its use so the rolled loop does not serialise four global-latency round trips
+  const bool need_aux = act == ACT_GELU_BWD || act == ACT_TANH_BWD;
+  struct Pre { float aux[4], res[4]; int prow[4]; };
+  auto preload = [&](int i, Pre& pr) {
+    const int rbase = m0 + 4 * ((tid >> 6) + 4 * i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lrow = rbase + q;
+      const bool ok = i < 4 && lrow < M;
+      const int row = (listed && TA == 0 && ok) ? P.ridx[lrow] : lrow;      // physical row of the operands
+      pr.prow[q] = row;
+      pr.aux[q] = (need_aux && ok) ? P.act_aux[(size_t)row * ldc + gcol] : 0.f;
+      pr.res[q] = (has_res && ok) ? res_value(P.res, row, gcol) : 0.f;
+    }
+  };
+  Pre cur, nxt;
+  preload(0, cur);
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int lrow = 4 * ((tid >> 6) + 4 * i);
+    const int rbase = m0 + lrow;
+    if (rbase >= M) break;
+    preload(i + 1, nxt);
+    Philox4 rnd = {0u, 0u, 0u, 0u};
+    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + q;
+      if (row >= M) break;
+      float v = (Ct[lrow + q][ccol] + cbias) * alpha;
+      const size_t off = (size_t)((IDX && TA == 0) ? cur.prow[q] : row) * ldc + gcol;
+      if (P.aux_out) P.aux_out[off] = v;
+      if (act == ACT_GELU) v = gelu_tanh_f(v);
+      else if (act == ACT_TANH) v = tanh_fast(v);
+      else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(cur.aux[q]);
+      else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
+      if (dropping) {
+        const uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
+        v *= drop_word(drop, wv);
+      }
+      v += cur.res[q];
+      csum += v;
+      if (P.out2) P.out2[(size_t)((IDX && TA == 0) ? cur.prow[q] : row) * P.ld2 + gcol] = v + add2;
+      if (accumulate == 0) C[off] = v;
+      else if (accumulate == 1) C[off] += v;
+      else atomicAdd(&C[off], v);
+    }
+    cur = nxt;
+  }
+  if (P.colsum_part) P.colsum_part[((size_t)(4 * tm + (tid >> 6)) * 3) * N + gcol] = csum;   // one parked row per (tile, row group)
+  else if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
+}
+
 #define KIDX_MAX PS_GEMM_KIDX_MAX
 template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
@@ -223,93 +320,288 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   }
 
   // ------------------------------------------------------------------ epilogue
-  const int col = n0 + wn * 32 + l31;
-  const bool col_ok = col < N;
-  const float bias = (P.bias && col_ok && split == 0) ? P.bias[col] : 0.f;
-  const float alpha = P.alpha;
-  float* const C = P.C + (size_t)split * P.split_stride;
-  const int ldc = P.ldc, accumulate = P.accumulate;
   if (!FULL) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (col_ok && row < M) {
-        const float v = (acc[r] + bias) * alpha;
-        const size_t off = (size_t)((listed && TA == 0) ? P.ridx[row] : row) * ldc + col;
-        if (accumulate == 0) C[off] = v;
-        else if (accumulate == 1) C[off] += v;
-        else atomicAdd(&C[off], v);
-      }
-    }
+    epi_plain<TA, IDX>(P, acc, m0, n0, split, M, N, listed, wm, wn, l31, h);
     return;
   }
   // FULL: stage the 64x64 tile through LDS so that the (large) epilogue body exists ONCE in the
   // instruction stream: thread t owns column t&63 and rows 4*((t>>6)+4i)+q  (i,q < 4); the four q-rows
   // of one i share a Philox call (counter (col, row>>2), word row&3); stores are 256-B coalesced.
   float (*Ct)[LDT] = reinterpret_cast<float (*)[LDT]>(&As[0][0][0]);   // 64x65 floats fit As for BK >= 32
-#pragma unroll
-  for (int r = 0; r < 16; ++r) Ct[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h][wn * 32 + l31] = acc[r];
+  epi_stage(Ct, acc, wm, wn, l31, h);
   __syncthreads();
-  const int ccol = tid & 63, gcol = n0 + ccol;
-  if (gcol >= N) return;
-  const float cbias = (P.bias && split == 0) ? P.bias[gcol] : 0.f;
-  const int act = P.act;
-  const DropSpec drop = P.drop;
-  const bool dropping = drop.thr != 0u, has_res = P.res.mode != RES_NONE;
-  const float add2 = (P.out2 && P.add2) ? P.add2[gcol] : 0.f;
-  float csum = 0.f;
-  // global operands of the epilogue (activation aux, residual) for row group i; fetched one group
-  // AHEAD of its use so the rolled loop does not serialise four global-latency round trips
-  const bool need_aux = act == ACT_GELU_BWD || act == ACT_TANH_BWD;
-  struct Pre { float aux[4], res[4]; int prow[4]; };
-  auto preload = [&](int i, Pre& pr) {
-    const int rbase = m0 + 4 * ((tid >> 6) + 4 * i);
+  epi_full<TA, IDX>(P, Ct, m0, n0, tm, split, M, N, listed, tid);
+}
+
+// ====================================================================== bf16x3 product form
+// v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (4,445 cycles per 32x32x128 product); the same product as SIX
+// v_mfma_f32_32x32x16_bf16 over a three-way bf16 split of both operands (x = hi + mid + lo: 3 x 8 = 24 mantissa bits, an
+// exact decomposition;  hl + lh + mm + hm + mh + hh, fp32 accumulation) costs 1,457 and is as accurate (max error /
+// sum|a b| against fp64: 1.10e-7, the fp32 MFMA's own 1.13e-7 — tools/micro/bf16x3.hip, profiles/r02_mlp_notes.md).
+// This kernel is gemm_f32_kernel with that product for the large launches (the d = 256 step's linears over 21,504 rows,
+// the review transformer's over 78k): tile (64 MT) x (64 NT), each of the 4 waves owns the 32x32 accumulator (wm, wn) of
+// every 64x64 quadrant — so the epilogues above serve unchanged, quadrant by quadrant — 32-deep slabs; fp32 operands
+// are fetched one slab ahead into registers, split on their way into LDS (three planes per operand, [row][32 k] bf16,
+// 16-byte chunks XOR-swizzled by (row >> 2) & 3 so that ds_read_b128 by its lane groups and ds_write_b128 by 8-lane
+// groups are conflict-free), and read back as whole MFMA operands (one ds_read_b128 per plane and 32 rows x 16 k).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define X3K 32
+
+__device__ __forceinline__ int x3g_off(int row, int chunk) { return row * X3K + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+// two adjacent reduction elements -> one packed pair per plane
+__device__ __forceinline__ void x3g_split2(float x0, float x1, uint32_t& hi, uint32_t& mi, uint32_t& lo) {
+  f32x2 v = {x0, x1};
+  bf16x2 b = __builtin_convertvector(v, bf16x2);                         // v_cvt_pk_bf16_f32 (round to nearest even)
+  hi = __builtin_bit_cast(uint32_t, b);
+  v -= f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};   // v_pk_add_f32: exact
+  b = __builtin_convertvector(v, bf16x2);
+  mi = __builtin_bit_cast(uint32_t, b);
+  v -= f32x2{__uint_as_float(mi << 16), __uint_as_float(mi & 0xffff0000u)};
+  b = __builtin_convertvector(v, bf16x2);
+  lo = __builtin_bit_cast(uint32_t, b);
+}
+// eight consecutive reduction elements of one tile row -> its 16-byte chunk in each plane
+template <int R>
+__device__ __forceinline__ void x3g_put8(uint16_t* planes, int row, int chunk, const float (&v)[8]) {
+  uint32_t H[4], Mi[4], Lo[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int lrow = rbase + q;
-      const bool ok = i < 4 && lrow < M;
-      const int row = (listed && TA == 0 && ok) ? P.ridx[lrow] : lrow;      // physical row of the operands
-      pr.prow[q] = row;
-      pr.aux[q] = (need_aux && ok) ? P.act_aux[(size_t)row * ldc + gcol] : 0.f;
-      pr.res[q] = (has_res && ok) ? res_value(P.res, row, gcol) : 0.f;
-    }
-  };
-  Pre cur, nxt;
-  preload(0, cur);
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const int lrow = 4 * ((tid >> 6) + 4 * i);
-    const int rbase = m0 + lrow;
-    if (rbase >= M) break;
-    preload(i + 1, nxt);
-    Philox4 rnd = {0u, 0u, 0u, 0u};
-    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
+  for (int e = 0; e < 4; ++e) x3g_split2(v[2 * e], v[2 * e + 1], H[e], Mi[e], Lo[e]);
+  uint16_t* dst = planes + x3g_off(row, chunk);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
+  *reinterpret_cast<uint4*>(dst + R * X3K) = make_uint4(Mi[0], Mi[1], Mi[2], Mi[3]);
+  *reinterpret_cast<uint4*>(dst + 2 * R * X3K) = make_uint4(Lo[0], Lo[1], Lo[2], Lo[3]);
+}
+// One operand slab (R tile rows x 32 reduction elements) global -> registers, R / 8 floats per thread.
+//   TRANS == 0 (src[row][k]): thread = (row, 8-element chunk): q = tid + 256 u, row q >> 2, chunk q & 3: two float4
+//   TRANS == 1 (src[k][row]): wave w takes reduction elements 8 w .. 8 w + 7, lane l the R / 64 adjacent rows at (R / 64) l
+//                             (their 16-byte LDS stores are 2-way conflicts: 16 LDS-array cycles under a 13-cycle store)
+// Rows are clamped (duplicates land in outputs the epilogue never stores), reduction indices past the end too (x3g_store
+// zero-fills them); the loads are unconditional and untouched until the store (see tile_load).
+template <int TRANS, int R>
+__device__ __forceinline__ void x3g_load(const float* __restrict__ src, int ld, int row0, int nrows, int k0, int kend,
+                                         bool kmask, float (&reg)[R / 8], int tid, const float* __restrict__ seg1,
+                                         const float* __restrict__ seg2, int kseg, int pr0, int pr1, const int* kmap,
+                                         int kbase) {
+  if (TRANS == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = rbase + q;
-      if (row >= M) break;
-      float v = (Ct[lrow + q][ccol] + cbias) * alpha;
-      const size_t off = (size_t)((IDX && TA == 0) ? cur.prow[q] : row) * ldc + gcol;
-      if (P.aux_out) P.aux_out[off] = v;
-      if (act == ACT_GELU) v = gelu_tanh_f(v);
-      else if (act == ACT_TANH) v = tanh_fast(v);
-      else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(cur.aux[q]);
-      else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
-      if (dropping) {
-        const uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
-        v *= drop_word(drop, wv);
+    for (int u = 0; u < R / 64; ++u) {
+      const int q = tid + 256 * u, row = q >> 2, c = q & 3;
+      const int r = pr0 >= 0 ? (u ? pr1 : pr0) : min(row0 + row, nrows - 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int kl = min(k0 + 8 * c + 4 * j, kend - 4);              // (kend % 4 == 0: validated)
+        const float* base = src;
+        if (kseg > 0) {
+          const int sg = (kl >= kseg) + (kl >= 2 * kseg);
+          base = sg == 0 ? src : (sg == 1 ? seg1 : seg2);
+          kl -= sg * kseg;
+        }
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)r * ld + kl);
+        reg[8 * u + 4 * j + 0] = t.x; reg[8 * u + 4 * j + 1] = t.y; reg[8 * u + 4 * j + 2] = t.z; reg[8 * u + 4 * j + 3] = t.w;
       }
-      v += cur.res[q];
-      csum += v;
-      if (P.out2) P.out2[(size_t)((IDX && TA == 0) ? cur.prow[q] : row) * P.ld2 + gcol] = v + add2;
-      if (accumulate == 0) C[off] = v;
-      else if (accumulate == 1) C[off] += v;
-      else atomicAdd(&C[off], v);
     }
-    cur = nxt;
+  } else {
+    constexpr int RPT = R / 64;
+    const int w = tid >> 6;
+    const int r = min(row0 + RPT * (tid & 63), nrows - RPT);      // nrows % 4 == 0 (validated)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int kl = min(k0 + 8 * w + j, kend - 1);
+      if (kmap) kl = kmap[kl - kbase];
+      const float* base = src;
+      if (kseg > 0) {
+        const int sg = (kl >= kseg) + (kl >= 2 * kseg);
+        base = sg == 0 ? src : (sg == 1 ? seg1 : seg2);
+        kl -= sg * kseg;
+      }
+      if (RPT == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(base + (size_t)kl * ld + r);
+        reg[2 * j] = t.x; reg[2 * j + 1] = t.y;
+      } else {
+        reg[j] = base[(size_t)kl * ld + r];
+      }
+    }
   }
-  if (P.colsum_part) P.colsum_part[((size_t)(4 * tm + (tid >> 6)) * 3) * N + gcol] = csum;   // one parked row per (tile, row group)
-  else if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
+}
+template <int TRANS, int R, bool KMASK>
+__device__ __forceinline__ void x3g_store_impl(uint16_t* planes, const float (&reg)[R / 8], int tid, int k0, int kend) {
+  if (TRANS == 0) {
+#pragma unroll
+    for (int u = 0; u < R / 64; ++u) {
+      const int q = tid + 256 * u, row = q >> 2, c = q & 3;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (KMASK && k0 + 8 * c + e >= kend) ? 0.f : reg[8 * u + e];
+      x3g_put8<R>(planes, row, c, v);
+    }
+  } else {
+    constexpr int RPT = R / 64;
+    const int w = tid >> 6;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (KMASK && k0 + 8 * w + j >= kend) ? 0.f : reg[RPT * j + u];
+      x3g_put8<R>(planes, RPT * (tid & 63) + u, w, v);
+    }
+  }
+}
+// (the zero-fill of a ragged last slab as selects in the common path cost ~100 vector instructions per slab: a block-uniform branch)
+template <int TRANS, int R>
+__device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R / 8], int tid, bool kmask, int k0, int kend) {
+  if (kmask && k0 + X3K > kend) x3g_store_impl<TRANS, R, true>(planes, reg, tid, k0, kend);
+  else x3g_store_impl<TRANS, R, false>(planes, reg, tid, k0, kend);
+}
+
+template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 2>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
+  constexpr int RA = 64 * MT, RB = 64 * NT;
+  constexpr int MAIN_BYTES = 3 * (RA + RB) * X3K * 2;
+  constexpr int EPI_BYTES = FULL ? MT * NT * 64 * LDT * 4 : 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  __shared__ int kidx[IDX && TA == 1 ? KIDX_MAX : 1];
+  uint16_t* const As = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* const Bs = As + 3 * RA * X3K;
+
+  int prob, split, ftile = 0;
+  if (g.flat) {
+    const int L = blockIdx.x;
+    prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
+    const int t = L - g.flat0[prob];
+    split = t / g.flat_tiles[prob];
+    ftile = t - split * g.flat_tiles[prob];
+  } else {
+    prob = blockIdx.z / g.p[0].ksplit;
+    split = blockIdx.z - prob * g.p[0].ksplit;
+  }
+  const GemmProblem& P = g.p[prob];
+  const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
+  const int nlist = listed ? *P.rcount : 0;
+  const int M = (listed && TA == 0) ? nlist : P.M, N = P.N, K = (listed && TA == 1) ? nlist : P.K;
+  int tm, tn;                                                    // XCD-aware tile mapping as in gemm_f32_kernel
+  if (g.flat) {
+    tm = ftile % g.flat_tm[prob];
+    tn = ftile / g.flat_tm[prob];
+  } else {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int L = blockIdx.y * nx + blockIdx.x;
+    const int grp = L / (8 * nx), r = L - grp * 8 * nx;
+    const int rows_here = min(8, ny - grp * 8);
+    tm = grp * 8 + r % rows_here;
+    tn = r / rows_here;
+  }
+  const int m0 = tm * RA, n0 = tn * RB;
+  const int nslab = (K + X3K - 1) / X3K;
+  const int per = (nslab + P.ksplit - 1) / P.ksplit;
+  const int kbeg = split * per * X3K;
+  const int kend = min(K, kbeg + per * X3K);
+  if (m0 >= M || n0 >= N || kbeg >= kend) return;   // block-uniform
+  const bool kmask = (kend - kbeg) % X3K != 0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+
+  int pr0 = -1, pr1 = -1;
+  const int* kmap = nullptr;
+  if (IDX && TA == 0) {                                         // the A rows this thread loads, once
+    pr0 = min(m0 + (tid >> 2), M - 1);
+    pr1 = min(m0 + (tid >> 2) + 64, M - 1);
+    if (listed) { pr0 = P.ridx[pr0]; pr1 = P.ridx[pr1]; }
+  }
+  if (listed && TA == 1) {                                      // physical reduction rows of this split -> LDS
+    for (int i = tid; i < kend - kbeg; i += 256) kidx[i] = P.ridx[kbeg + i];
+    __syncthreads();
+    kmap = kidx;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // PF slabs in flight in registers (slot u holds slab u mod PF of the current group), every load unconditional — see gemm_f32_kernel
+  float ra[PF][RA / 8], rb[PF][RB / 8];
+  const int ldb = P.ldb;
+  const float* const bs0 = P.Bseg[0];
+  const float* const bs1 = P.Bseg[1];
+  const float* const bs2 = P.Bseg[2];
+  const int bkseg = K > P.kseg ? P.kseg : 0;          // 0: B is one segment
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int kl = kbeg + u * X3K < kend ? kbeg + u * X3K : kbeg;
+    x3g_load<TA, RA>(P.A, P.lda, m0, M, kl, kend, kmask, ra[u], tid, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);
+    x3g_load<TB, RB>(bs0, ldb, n0, N, kl, kend, kmask, rb[u], tid, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
+  }
+
+  // one slab: publish slot `ra_u / rb_u` (slab k0), refill it two slabs ahead, multiply
+  auto slab = [&](float (&ra_u)[RA / 8], float (&rb_u)[RB / 8], const int k0) __attribute__((always_inline)) {
+    x3g_store<TA, RA>(As, ra_u, tid, kmask, k0, kend);
+    x3g_store<TB, RB>(Bs, rb_u, tid, kmask, k0, kend);
+    __syncthreads();
+    const int kp = k0 + PF * X3K < kend ? k0 + PF * X3K : kbeg;
+    x3g_load<TA, RA>(P.A, P.lda, m0, M, kp, kend, kmask, ra_u, tid, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);
+    x3g_load<TB, RB>(bs0, ldb, n0, N, kp, kend, kmask, rb_u, tid, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
+#pragma unroll
+    for (int s = 0; s < X3K / 16; ++s) {
+      bf16x8 a[MT][3], b[NT][3];
+      const int cl = 2 * s + h;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+          a[mi][p] = *reinterpret_cast<const bf16x8*>(As + p * RA * X3K + x3g_off(64 * mi + 32 * wm + l31, cl));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          b[ni][p] = *reinterpret_cast<const bf16x8*>(Bs + p * RB * X3K + x3g_off(64 * ni + 32 * wn + l31, cl));
+      }
+      // small terms first; the MT x NT accumulators of one term are independent MFMAs
+#define X3G_TERM(pa, pb)                                                                                          \
+  _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)              \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][pa], b[ni][pb], acc[mi][ni], 0, 0, 0);
+      X3G_TERM(0, 2) X3G_TERM(2, 0) X3G_TERM(1, 1) X3G_TERM(0, 1) X3G_TERM(1, 0) X3G_TERM(0, 0)
+#undef X3G_TERM
+    }
+    __syncthreads();
+  };
+  // slabs go in pairs with no exit between them — a `break` inside the pair joins paths with different loads in flight
+  // and the compiler then waits for ALL of them (vmcnt(0)) at the next store; an odd last slab runs after the loop
+  static_assert(PF == 2, "two register slots");
+  const int nsl = (kend - kbeg + X3K - 1) / X3K;
+  int k0 = kbeg;
+  for (int it = 0; it < (nsl >> 1); ++it) {
+    slab(ra[0], rb[0], k0);
+    slab(ra[1], rb[1], k0 + X3K);
+    k0 += 2 * X3K;
+  }
+  if (nsl & 1) slab(ra[0], rb[0], k0);
+
+  // ------------------------------------------------------------------ epilogue, one 64x64 quadrant at a time
+  if (!FULL) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        if (m0 + 64 * mi < M && n0 + 64 * ni < N)
+          epi_plain<TA, IDX>(P, acc[mi][ni], m0 + 64 * mi, n0 + 64 * ni, split, M, N, listed, wm, wn, l31, h);
+    return;
+  }
+  float (*Ct)[64][LDT] = reinterpret_cast<float (*)[64][LDT]>(smem);       // all quadrants staged, ONE rolled body
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) epi_stage(Ct[mi * NT + ni], acc[mi][ni], wm, wn, l31, h);
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < MT * NT; ++q) {
+    const int mq = m0 + 64 * (q / NT), nq = n0 + 64 * (q % NT);
+    if (mq < M && nq < N) epi_full<TA, IDX>(P, Ct[q], mq, nq, MT * tm + q / NT, split, M, N, listed, tid);
+  }
 }
 
 static bool needs_full(const GemmProblem& p) {
@@ -356,6 +648,63 @@ static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGrou
     return;
   }
   launch_pf<FULL, BK, (BK == 32 ? 2 : 1)>(ta, tb, grid, stream, g);
+}
+
+// ---- bf16x3 form: which launches take it, and with which tile
+// PS_GEMM_X3: 0 = never, 1 (default) = wide products with enough tiles to fill the chip.  shape 2 = 128x128, 1 = 128x64,
+// 0 = 64x64 tiles; -1 = the fp32 kernel (small / latency-bound launches, where the deep-slab forms above matter more).
+// Measured at the d = 256 shard step (21,504 rows): 128x64 wins on every forward / dX product (128x128: 2 workgroups per
+// CU, 1.53 vs 1.41 ms per step), the weight gradients take 64x64 with the split counts tem.hip picks.
+static int x3_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int g_x3_mode = -2, g_x3_force = -1;           // -2: not read yet
+extern "C" int ps_gemm_x3_config(int mode, int force_shape) {   // tests / experiments: mode 0|1, force_shape -1 (rule) | 0 | 1 | 2
+  PS_REQUIRE((mode == 0 || mode == 1) && force_shape >= -1 && force_shape <= 2, "gemm x3 config %d %d", mode, force_shape);
+  g_x3_mode = mode; g_x3_force = force_shape;
+  return PS_OK;
+}
+static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
+  if (g_x3_mode == -2) { g_x3_mode = x3_env("PS_GEMM_X3", 1) ? 1 : 0; g_x3_force = x3_env("PS_GEMM_X3_SHAPE", -1); }
+  static const int t22 = x3_env("PS_GEMM_X3_T22", 4096), t21 = x3_env("PS_GEMM_X3_T21", 384), t11 = x3_env("PS_GEMM_X3_T11", 512);
+  if (!g_x3_mode) return -1;
+  if (g_x3_force >= 0) return g_x3_force > 2 ? 2 : g_x3_force;
+  const int z = g.n * g.p[0].ksplit;
+  int kmin = g.p[0].K;
+  for (int i = 1; i < g.n; ++i) kmin = g.p[i].K < kmin ? g.p[i].K : kmin;
+  // Only products of a wide model (every weight dimension >= 256: the d = 256 configuration) — at d = 128 a reduction is 4
+  // slabs deep and the fp32 kernel's deep-slab forms win; the review transformer's 78k-row launches measured 0.540 -> 0.550
+  // ms per step with this form although each is 20 % faster alone (they run beside the side stream's launches)
+  int nmin = g.p[0].N, mmin = g.p[0].M;
+  for (int i = 1; i < g.n; ++i) { nmin = g.p[i].N < nmin ? g.p[i].N : nmin; mmin = g.p[i].M < mmin ? g.p[i].M : mmin; }
+  if (kmin < 256 || nmin < 256 || kmin / g.p[0].ksplit < 256 || (g.p[0].ta && mmin < 256)) return -1;
+  if ((long)ps_cdiv(maxM, 128) * ps_cdiv(maxN, 128) * z >= t22) return 2;
+  if ((long)ps_cdiv(maxM, 128) * ps_cdiv(maxN, 64) * z >= t21) return 1;
+  if ((long)ps_cdiv(maxM, 64) * ps_cdiv(maxN, 64) * z >= t11) return 0;
+  return -1;
+}
+template <int TA, int TB, int FULL, int IDX>
+static void launch_x3(int shape, dim3 grid, hipStream_t stream, const GemmGroup& g) {
+  if (shape == 2) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 2, IDX>), grid, dim3(256), 0, stream, g);
+  else if (shape == 1) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 1, IDX>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 1, 1, IDX>), grid, dim3(256), 0, stream, g);
+}
+// false: no instantiation for this combination (the caller falls back to the fp32 kernel)
+static bool try_x3(int ta, int tb, bool full, bool listed, int shape, int maxM, int maxN, int z, hipStream_t stream, const GemmGroup& g) {
+  const dim3 grid(ps_cdiv(maxN, shape == 2 ? 128 : 64), ps_cdiv(maxM, shape >= 1 ? 128 : 64), z);
+  if (grid.y > 65535) return false;
+  if (!listed) {
+    if (ta == 0 && tb == 0 && full) launch_x3<0, 0, 1, 0>(shape, grid, stream, g);
+    else if (ta == 0 && tb == 0) launch_x3<0, 0, 0, 0>(shape, grid, stream, g);
+    else if (ta == 0 && tb == 1 && full) launch_x3<0, 1, 1, 0>(shape, grid, stream, g);
+    else if (ta == 0 && tb == 1) launch_x3<0, 1, 0, 0>(shape, grid, stream, g);
+    else if (ta == 1 && tb == 1 && !full) launch_x3<1, 1, 0, 0>(shape, grid, stream, g);
+    else return false;
+  } else {
+    if (ta == 0 && tb == 1 && full) launch_x3<0, 1, 1, 1>(shape, grid, stream, g);
+    else if (ta == 1 && tb == 1 && !full) launch_x3<1, 1, 0, 1>(shape, grid, stream, g);
+    else if (ta == 0 && tb == 0 && !full) launch_x3<0, 0, 0, 1>(shape, grid, stream, g);
+    else return false;
+  }
+  return true;
 }
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
@@ -406,6 +755,11 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
       PS_REQUIRE(p.tb == 1 && per * 32 <= KIDX_MAX, "gemm: row-list weight gradient: %d rows per split > %d", per * 32, KIDX_MAX);
     }
   }
+  const int x3 = x3_shape(g, maxM, maxN);
+  if (x3 >= 0 && try_x3(g.p[0].ta, g.p[0].tb, full, listed, x3, maxM, maxN, g.n * g.p[0].ksplit, stream, g)) {
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   if (listed) {   // row-list instantiations exist for the three shapes of the step that use them (32-deep slabs)
     const int ta = g.p[0].ta, tb = g.p[0].tb;
     // (the K/V dX product as 128-deep slabs measured slower, 0.363 vs 0.355 ms/step: its 133 KB of LDS per workgroup
@@ -449,6 +803,7 @@ extern "C" int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int
   p.C = Cm; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.alpha = alpha; p.act = ACT_NONE;
   p.accumulate = accumulate == 2 ? 2 : accumulate;
-  p.ksplit = accumulate == 2 ? 4 : 1;
+  static const int ks = getenv("PS_GEMM_KSPLIT") ? atoi(getenv("PS_GEMM_KSPLIT")) : 4;   // timing experiments
+  p.ksplit = accumulate == 2 ? ks : 1;
   return ps_launch_gemm(g, (hipStream_t)stream);
 }

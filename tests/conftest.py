@@ -22,3 +22,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def x3_restore():
+    """Tests that force a product form put the library's size rule back afterwards."""
+    yield
+    from prodsearch_amd import _lib
+    _lib.load().ps_gemm_x3_config(0 if os.environ.get('PS_GEMM_X3') == '0' else 1, -1)

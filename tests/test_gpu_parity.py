@@ -48,11 +48,15 @@ def _oracle_keep(g, step=0):
 
 # ------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (70, 132, 96), (384, 128, 128), (8064, 512, 128),
-                                   (33, 128, 512), (1, 32, 32)])
+                                   (33, 128, 512), (1, 32, 32), (132, 68, 100), (200, 260, 2048)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 1)])
-def test_mfma_gemm_layouts(M, N, K, ta, tb):
+@pytest.mark.parametrize('x3', [-1, 0, 1, 2])
+def test_mfma_gemm_layouts(M, N, K, ta, tb, x3, x3_restore):
+    """x3 = -1: the form the launch takes by itself (fp32 MFMA at these sizes); 0 / 1 / 2: the bf16x3 form (three-way exact bf16
+    split, six bf16 MFMAs per product step) forced with 64x64 / 128x64 / 128x128 tiles — same tolerance against fp64."""
     from prodsearch_amd import _lib
     lib = _lib.load()
+    lib.ps_gemm_x3_config(1, x3)
     if ta and M % 4:
         pytest.skip('ta needs M % 4 == 0')
     if tb and N % 4:
@@ -80,6 +84,33 @@ def test_mfma_gemm_layouts(M, N, K, ta, tb):
     _lib.check(rc, 'ps_gemm_f32')
     torch.cuda.synchronize()
     assert rel_err(C2.cpu(), (A.double() @ Bm.double() + 1).float()) < 2e-6
+
+
+def test_wide_products_take_the_bf16x3_form_and_match_fp64(x3_restore):
+    """The d = 256 shard's linears (21,504 rows) are picked up by the size rule: forward, dX and weight-gradient layouts
+    against fp64, and against the fp32-MFMA form of the same launch (both within the same bound of the exact product)."""
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(5)
+    for (M, N, K, ta, tb, acc) in [(21504, 256, 256, 0, 0, 0), (21504, 256, 1024, 0, 1, 0), (1024, 512, 8192, 1, 1, 2)]:
+        A = torch.randn(M, K, generator=gen)
+        Bm = torch.randn(K, N, generator=gen) * 0.1
+        Ad = (A.t().contiguous() if ta else A.contiguous()).cuda()
+        Bd = (Bm.contiguous() if tb else Bm.t().contiguous()).cuda()
+        ref = (A.double() @ Bm.double())
+        mag = (A.double().abs() @ Bm.double().abs())
+        out = []
+        for mode in (1, 0):
+            lib.ps_gemm_x3_config(mode, -1)
+            C = torch.zeros(M, N, device='cuda')
+            _lib.check(lib.ps_gemm_f32(Ad.data_ptr(), M if ta else K, ta, Bd.data_ptr(), N if tb else K, tb, C.data_ptr(), N,
+                                       M, N, K, None, 1.0, acc, st), 'ps_gemm_f32')
+            torch.cuda.synchronize()
+            out.append(C.cpu().double())
+        e3, e1 = float(((out[0] - ref).abs() / mag).max()), float(((out[1] - ref).abs() / mag).max())
+        assert e3 < 6e-7 and e1 < 6e-7, (M, N, K, e3, e1)          # |error| / sum |a b|: a few fp32 ulps, either form
+        assert not torch.equal(out[0], out[1])                     # (the two forms really are different kernels)
 
 
 # ---------------------------------------------------------------------- forward

@@ -61,8 +61,12 @@ def _device_scores(q, table, bias):
     B, d = q.shape
     N = table.shape[0]
     S = torch.empty(B, N, device='cuda')
-    _lib.check(lib.ps_gemm_f32(q.data_ptr(), d, 0, table.data_ptr(), d, 0, S.data_ptr(), N, B, N, d,
-                               _lib.ptr(bias), 1.0, 0, torch.cuda.current_stream().cuda_stream), 'gemm')
+    lib.ps_gemm_x3_config(0, -1)       # the ranking kernel multiplies with the fp32 MFMA: bitwise comparisons need the same form
+    try:
+        _lib.check(lib.ps_gemm_f32(q.data_ptr(), d, 0, table.data_ptr(), d, 0, S.data_ptr(), N, B, N, d,
+                                   _lib.ptr(bias), 1.0, 0, torch.cuda.current_stream().cuda_stream), 'gemm')
+    finally:
+        lib.ps_gemm_x3_config(1, -1)
     return S
 
 

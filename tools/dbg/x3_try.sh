@@ -1,7 +1,12 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/x3; rm -rf $O; mkdir -p $O
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_shapes.py tests/test_gpu_parity_rtm.py tests/test_gpu_fullsize_rtm.py -q -x > $O/tests.log 2>&1; tail -5 $O/tests.log
-python bench.py --steps 200 --warmup 20 --reps 0 --cpu-steps 0 > $O/c2.json 2> $O/c2.err; python -c "
-import json;d=json.load(open('$O/c2.json'));print('x3  ', d['ms_per_step'], d['roofline']['us_per_launch'])"
-PS_MLP_X3=0 python bench.py --steps 200 --warmup 20 --reps 0 --cpu-steps 0 > $O/c2o.json 2> $O/c2o.err; python -c "
-import json;d=json.load(open('$O/c2o.json'));print('f32 ', d['ms_per_step'], d['roofline']['us_per_launch'])"
+set -e
+O=gpurun_out/x3; mkdir -p $O
+for s in 0 1 2; do
+  PS_GEMM_X3=1 PS_GEMM_X3_SHAPE=$s timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -q -x -k "mfma_gemm" > $O/parity_s$s.log 2>&1 || { tail -30 $O/parity_s$s.log; exit 1; }
+  tail -1 $O/parity_s$s.log
+done
+timeout -k 10 600 python tools/gemm_x3_bench.py > $O/bench.log 2>&1 || { tail -30 $O/bench.log; exit 1; }
+cat $O/bench.log
+for ks in 8 16 32; do
+  PS_GEMM_KSPLIT=$ks timeout -k 10 300 python tools/gemm_x3_bench.py wgrad > $O/wgrad_$ks.log 2>&1 || { tail -30 $O/wgrad_$ks.log; exit 1; }
+  cat $O/wgrad_$ks.log
+done
