@@ -32,6 +32,10 @@ for B in 1024 8192; do python tools/gather_c5.py --rows 8000000 --batch $B --ite
 python tools/gather_only.py c2 2>/dev/null | tail -1 >> $O/gather_c5.log
 echo "gather done"
 python bench.py --workload c5 --items 8000000 --steps 100 --warmup 10 --cpu-steps 0 > $O/c5_bench.json 2> $O/c5_bench.err || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_prof -- python3 bench.py --workload c5 --items 8000000 --steps 30 --warmup 5 --cpu-steps 0 --no-extras > $O/c5_prof.json 2> $O/c5_prof.err
+python tools/trace_step.py $O/c5_prof > $O/c5_step_timeline.txt
+cp $(ls -t $(find $O/c5_prof -name '*kernel_stats.csv') | head -1) $O/c5_kernel_stats.csv
+PS_GEMM_X3=0 python bench.py --workload c5 --items 8000000 --steps 100 --warmup 10 --cpu-steps 0 --no-extras > $O/c5_bench_fp32_products.json 2> /dev/null || true
 rm -rf $O/pmc_mfma $O/pmc_sq $O/pmc_in $O/pmc_rf $O/pmc_rw $O/pmc_gf $O/pmc_gw
 find $O -name '*kernel_trace.csv' -delete
 find $O -name '*agent_info.csv' -delete
