@@ -51,6 +51,9 @@ the kernel is four dependent round trips per wave, not bytes (DESIGN.md 7c); PMC
 bench line (`r02_c5_bench.json`): **%.0f tuples/s, %.3f ms/step**; roofline object: the stand-alone gather+score launch inside the step,
 %.0f GB/s = %.3f of peak (it shares the machine there); alone on the chip at this shape: `r02_gather_c5_shape.jsonl` (0.61 of 8 TB/s at
 B=1024, 0.71 at B=8192); PMC traffic `r02_gather_score_c5_pmc.txt` (63 MB against 67.6 MB algorithmic: no re-reads).
+The d = 256 linears run as bf16x3 products (`gemm_x3_kernel`, DESIGN.md 5b): `r02_c5_bench_fp32_products.json` is the same run with
+`PS_GEMM_X3=0` (1.578 ms/step); timeline `r02_c5_step_timeline.txt`, kernel statistics `r02_c5_kernel_stats.csv`; the form alone:
+`r02_gemm_x3_bench.txt` (1.3-1.5x the fp32 MFMA kernel at equal error against fp64), counters `r02_gemm_x3_pmc.txt`.
 
 ## Measured and dropped this round (numbers in DESIGN.md 5, 7c and the kernels' comments)
 
