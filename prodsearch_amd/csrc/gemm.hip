@@ -456,7 +456,7 @@ __device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R
   else x3g_store_impl<TRANS, R, false>(planes, reg, tid, k0, kend);
 }
 
-template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 2>
+template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   constexpr int RA = 64 * MT, RB = 64 * NT;
   constexpr int MAIN_BYTES = 3 * (RA + RB) * X3K * 2;
@@ -571,15 +571,19 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   };
   // slabs go in pairs with no exit between them — a `break` inside the pair joins paths with different loads in flight
   // and the compiler then waits for ALL of them (vmcnt(0)) at the next store; an odd last slab runs after the loop
-  static_assert(PF == 2, "two register slots");
+  static_assert(PF == 1 || PF == 2, "one or two register slots");
   const int nsl = (kend - kbeg + X3K - 1) / X3K;
   int k0 = kbeg;
-  for (int it = 0; it < (nsl >> 1); ++it) {
-    slab(ra[0], rb[0], k0);
-    slab(ra[1], rb[1], k0 + X3K);
-    k0 += 2 * X3K;
+  if (PF == 1) {
+    for (int it = 0; it < nsl; ++it, k0 += X3K) slab(ra[0], rb[0], k0);
+  } else {
+    for (int it = 0; it < (nsl >> 1); ++it) {
+      slab(ra[0], rb[0], k0);
+      slab(ra[PF - 1], rb[PF - 1], k0 + X3K);
+      k0 += 2 * X3K;
+    }
+    if (nsl & 1) slab(ra[0], rb[0], k0);
   }
-  if (nsl & 1) slab(ra[0], rb[0], k0);
 
   // ------------------------------------------------------------------ epilogue, one 64x64 quadrant at a time
   if (!FULL) {
@@ -681,11 +685,13 @@ static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   if ((long)ps_cdiv(maxM, 64) * ps_cdiv(maxN, 64) * z >= t11) return 0;
   return -1;
 }
+// (one 32-deep slab of operands in flight in registers: two — the PF = 2 instantiation, 36 more registers — measured the same
+// in the d = 256 step, 1.41-1.43 ms either way, and 5 % slower alone: the workgroups' own count hides the latency)
 template <int TA, int TB, int FULL, int IDX>
 static void launch_x3(int shape, dim3 grid, hipStream_t stream, const GemmGroup& g) {
-  if (shape == 2) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 2, IDX>), grid, dim3(256), 0, stream, g);
-  else if (shape == 1) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 1, IDX>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 1, 1, IDX>), grid, dim3(256), 0, stream, g);
+  if (shape == 2) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 2, IDX, 1>), grid, dim3(256), 0, stream, g);
+  else if (shape == 1) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 1, IDX, 1>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 1, 1, IDX, 1>), grid, dim3(256), 0, stream, g);
 }
 // false: no instantiation for this combination (the caller falls back to the fp32 kernel)
 static bool try_x3(int ta, int tb, bool full, bool listed, int shape, int maxM, int maxN, int z, hipStream_t stream, const GemmGroup& g) {

@@ -29,4 +29,4 @@ def x3_restore():
     """Tests that force a product form put the library's size rule back afterwards."""
     yield
     from prodsearch_amd import _lib
-    _lib.load().ps_gemm_x3_config(0 if os.environ.get('PS_GEMM_X3') == '0' else 1, -1)
+    _lib.load().ps_gemm_x3_config(0 if os.environ.get('PS_GEMM_X3') == '0' else 1, int(os.environ.get('PS_GEMM_X3_SHAPE', '-1')))

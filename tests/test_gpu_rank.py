@@ -66,7 +66,7 @@ def _device_scores(q, table, bias):
         _lib.check(lib.ps_gemm_f32(q.data_ptr(), d, 0, table.data_ptr(), d, 0, S.data_ptr(), N, B, N, d,
                                    _lib.ptr(bias), 1.0, 0, torch.cuda.current_stream().cuda_stream), 'gemm')
     finally:
-        lib.ps_gemm_x3_config(1, -1)
+        lib.ps_gemm_x3_config(0 if os.environ.get('PS_GEMM_X3') == '0' else 1, int(os.environ.get('PS_GEMM_X3_SHAPE', '-1')))
     return S
 
 
