@@ -674,11 +674,16 @@ static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   const int z = g.n * g.p[0].ksplit;
   int kmin = g.p[0].K;
   for (int i = 1; i < g.n; ++i) kmin = g.p[i].K < kmin ? g.p[i].K : kmin;
-  // Only products of a wide model (every weight dimension >= 256: the d = 256 configuration) — at d = 128 a reduction is 4
-  // slabs deep and the fp32 kernel's deep-slab forms win; the review transformer's 78k-row launches measured 0.540 -> 0.550
-  // ms per step with this form although each is 20 % faster alone (they run beside the side stream's launches)
+  // Products of a wide model (every weight dimension >= 256: the d = 256 configuration) — at d = 128 a reduction is 4 slabs
+  // deep and the fp32 kernel's deep-slab forms win at C2's 8k rows (0.289 -> 0.293 ms per step with this form forced); the
+  // review transformer's 78k-row launches lose with 128x64 tiles and with their weight gradients included (0.540 -> 0.550) ...
   int nmin = g.p[0].N, mmin = g.p[0].M;
   for (int i = 1; i < g.n; ++i) { nmin = g.p[i].N < nmin ? g.p[i].N : nmin; mmin = g.p[i].M < mmin ? g.p[i].M : mmin; }
+  // ... and the forward / dX products over very many rows (the review transformer's 78k sequence positions), with 64x64 tiles:
+  // 0.544 -> 0.534 ms per step there (its weight gradients gain nothing: PS_GEMM_X3_TALL=2 adds them)
+  static const int tall = x3_env("PS_GEMM_X3_TALL", 1);
+  if (tall >= 1 && !g.p[0].ta && maxM >= 32768) return 0;
+  if (tall >= 2 && g.p[0].ta && kmin >= 32768) return 0;
   if (kmin < 256 || nmin < 256 || kmin / g.p[0].ksplit < 256 || (g.p[0].ta && mmin < 256)) return -1;
   if ((long)ps_cdiv(maxM, 128) * ps_cdiv(maxN, 128) * z >= t22) return 2;
   if ((long)ps_cdiv(maxM, 128) * ps_cdiv(maxN, 64) * z >= t21) return 1;
