@@ -666,8 +666,12 @@ extern "C" int ps_gemm_x3_config(int mode, int force_shape) {   // tests / exper
   g_x3_mode = mode; g_x3_force = force_shape;
   return PS_OK;
 }
-static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
+static bool x3_on() {
   if (g_x3_mode == -2) { g_x3_mode = x3_env("PS_GEMM_X3", 1) ? 1 : 0; g_x3_force = x3_env("PS_GEMM_X3_SHAPE", -1); }
+  return g_x3_mode != 0;
+}
+static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
+  x3_on();
   static const int t22 = x3_env("PS_GEMM_X3_T22", 4096), t21 = x3_env("PS_GEMM_X3_T21", 384), t11 = x3_env("PS_GEMM_X3_T11", 512);
   if (!g_x3_mode) return -1;
   if (g_x3_force >= 0) return g_x3_force > 2 ? 2 : g_x3_force;
@@ -737,7 +741,10 @@ int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
     }
     f.flat0[3] = total;
     for (int i = g.n; i < 3; ++i) f.flat0[i] = total + 1;      // never selected
-    launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
+    // the bf16x3 form with 64x64 tiles (the same flat tables): C2's W2 / W1 / Wo weight gradients 0.2905 -> 0.2845 ms per step
+    static const int flat_x3 = x3_env("PS_GEMM_X3_FLAT", 1);
+    if (flat_x3 && x3_on()) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
     PS_LAUNCH_CHECK();
     return PS_OK;
   }
