@@ -962,7 +962,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
       GemmProblem wgo[1] = {gp_wgrad(m.dout, d, ws + l.ctx, d, Lg.wo, d, d, M2)};
       TRY(side_fork(st));                           // fork 1: W2, W1, Wo weight gradients under the attention backward
-      if (score_on_side) {                          // ... led by the table scatter of the score backward
+      if (score_on_side) {                          // ... led by the table scatter of the score backward (behind them instead: 0.284 -> 0.293 ms/step)
         ScoreArgs t = *score_on_side;
         t.denc = nullptr;
         SideCtx* sc = side_ctx();
