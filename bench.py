@@ -343,7 +343,9 @@ def main():
                                 % ("allreduce+" if world > 1 else "")}, **extra_cfg),
         "samples_per_s": world * Bw * a.steps / elapsed, "final_loss": last_loss,
     }
-    if rank == 0 and not a.no_extras:
+    if not a.no_extras:
+        # Every rank runs these extra steps (they contain the gradient exchange: a collective only rank 0 entered would
+        # never return); rank 0 keeps the numbers.
         lib = _lib.load()
         # (1) median of single steps, each between two HIP events on the step's stream
         if a.reps > 0:

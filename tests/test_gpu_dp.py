@@ -124,3 +124,35 @@ def test_review_transformer_two_ranks_of_32_equal_one_rank_of_64(tmp_path):
         checked += 1
     assert checked >= 18
     assert abs(0.5 * (r0['__loss'] + r1['__loss']) - single['__loss']) < 2e-3 * abs(single['__loss'])
+
+
+def test_bench_contract_line_from_two_ranks_with_its_extra_legs():
+    """The N>1 launch of bench.py exactly as the driver starts it (one process per rank, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment; gloo here, both ranks on cuda:0), with the median / roofline legs on: they contain the
+    gradient exchange, so every rank has to run them — rank 0 alone would wait in its all-reduce for ever.  One JSON line,
+    from rank 0 only, whole-job value = 2 ranks' tuples."""
+    import json
+    port = _free_port()
+    bench = os.path.join(os.path.dirname(HERE), 'bench.py')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', PS_DIST_BACKEND='gloo', PS_BENCH_WATCHDOG='300')
+        procs.append(subprocess.Popen([sys.executable, bench, '--gpus', '2', '--steps', '6', '--warmup', '2', '--reps', '8'],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=360)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    lines0 = [ln for ln in outs[0].splitlines() if ln.startswith('{')]
+    assert len(lines0) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith('{')]
+    d = json.loads(lines0[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 2 * 384 * 20 * 6 / (d['ms_per_step'] * 6e-3)) < 1e-6 * d['value']
+    assert d['roofline']['launches_timed'] == 6 and 'median_ms_per_step' in d and 'cpu_baseline' not in d
