@@ -378,6 +378,9 @@ __device__ __forceinline__ void x3g_put8(uint16_t* planes, int row, int chunk, c
 //   TRANS == 0 (src[row][k]): thread = (row, 8-element chunk): q = tid + 256 u, row q >> 2, chunk q & 3: two float4
 //   TRANS == 1 (src[k][row]): wave w takes reduction elements 8 w .. 8 w + 7, lane l the R / 64 adjacent rows at (R / 64) l
 //                             (their 16-byte LDS stores are 2-way conflicts: 16 LDS-array cycles under a 13-cycle store)
+//                             (measured alternative for weight gradients: waves 0-1 fetch A, waves 2-3 B, four float4 loads of
+//                             4 rows x 4 reduction elements per thread and 8-byte LDS stores — 1024x256x21504: 120 -> 115 us,
+//                             256x256x21504: 55 -> 63 us, 128x384x78336: 164 -> 197 us, C2 step unchanged: not kept)
 // Rows are clamped (duplicates land in outputs the epilogue never stores), reduction indices past the end too (x3g_store
 // zero-fills them); the loads are unconditional and untouched until the store (see tile_load).
 template <int TRANS, int R>
