@@ -224,6 +224,7 @@ int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st) {
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_sq1_kernel(const AttnArgs a) {
+  fork_signal(a.sig, a.sigval);
   extern __shared__ float lds[];
   const int SF = a.S, LD = SF + 1, D = a.d, HF = a.H, dh = a.dh, tid = threadIdx.x, b = blockIdx.x;
   const int H = HF / (int)gridDim.y, d = D / (int)gridDim.y, h0 = (int)blockIdx.y * H, c0 = (int)blockIdx.y * d;
@@ -363,6 +364,7 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
     attr_b = true;
   }
   PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128 && hy == 2), "attention bwd(sq1): folded dQ.Wq needs d == 128 and two head groups");
+  side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
   hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in, hy), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
@@ -399,6 +401,7 @@ __device__ inline unsigned long long w1_valid(const AttnArgs& a, int b, int lane
 
 template <int LPR>
 __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int pads_unread) {
+  fork_signal(a.sig, a.sigval);
   constexpr int D = 4 * LPR, KPS = 64 / LPR;
   __shared__ int sp[4][64];
   __shared__ float pl[4][64][W1_MAXH], dpl[4][64][W1_MAXH];
@@ -711,6 +714,7 @@ __global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint
 // LDS workgroup form: 29 us.)
 template <int DH, int MAXK, int NH>   // DH = 16: d = 128 (C2); DH = 32: d = 256 (C5 shard; its dQ.Wq is a GEMM of its own: no tail)
 __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
+  fork_signal(a.sig, a.sigval);
   // keys of a lane group: i = hf * MAXK + ii, hf < NH (the key range is walked in NH parts so that only MAXK V rows and
   // d V sums are in registers at a time: d = 256 needs 11 keys per group for 21 positions)
   constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 8 * DH, NK = NH * MAXK, NV = 5 * NK, JB = 6;
@@ -875,9 +879,11 @@ int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
 int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
   PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128), "attention bwd(wf): folded dQ.Wq needs d == 128 and its output row buffer");
-  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-  else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
-  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, a, amask, pads_unread ? 1 : 0);
+  AttnArgs b = a;
+  side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
+  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
+  else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -892,8 +898,10 @@ int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(attn_w1_fits(a), "attention bwd(w1): unsupported shape");
   PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(w1): folded dQ.Wq needs its output row buffer");
   const dim3 grid(ps_cdiv(a.n_in, 4));
-  if (a.d == 128) hipLaunchKernelGGL(attn_bwd_w1_kernel<32>, grid, dim3(256), 0, st, a, pads_unread ? 1 : 0);
-  else hipLaunchKernelGGL(attn_bwd_w1_kernel<16>, grid, dim3(256), 0, st, a, pads_unread ? 1 : 0);
+  AttnArgs b = a;
+  side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
+  if (a.d == 128) hipLaunchKernelGGL(attn_bwd_w1_kernel<32>, grid, dim3(256), 0, st, b, pads_unread ? 1 : 0);
+  else hipLaunchKernelGGL(attn_bwd_w1_kernel<16>, grid, dim3(256), 0, st, b, pads_unread ? 1 : 0);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -270,6 +270,8 @@ struct GemmProblem {
 struct GemmGroup {
   GemmProblem p[3];
   int n;
+  // a fork of the side stream signalled by THIS launch: its first workgroup stores sigval to *sig as it starts (side_take_signal)
+  uint32_t* sig; uint32_t sigval;
   // flat form (weight gradients of different shapes in one launch): grid.x walks  sum_i tiles_i * ksplit_i  workgroups,
   // problem i owns [flat0[i], flat0[i+1]): split-major, then row tile, then column tile; each problem keeps its own ksplit
   int flat;
@@ -277,6 +279,18 @@ struct GemmGroup {
 };
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream);
+// Fork of the side stream without a stream operation on the main stream (tem.hip, side_fork): the side stream waits for a
+// sequence value, and the NEXT kernel launched on the main stream stores it as its first workgroup starts — every earlier
+// main-stream kernel has completed by then (in-order stream), which is all a fork promises.  A launcher that can carry the
+// signal asks for it right before its launch; side_repend_signal hands it back when the launch did not happen (the join
+// flushes an unclaimed signal with a stream write).  The write-value operation this replaces cost the main stream ~5 us
+// between two dependent kernels, twice per backward.
+bool side_take_signal(hipStream_t st, uint32_t** flag, uint32_t* val);
+void side_repend_signal(hipStream_t st, uint32_t val);
+__device__ __forceinline__ void fork_signal(uint32_t* sig, uint32_t val) {
+  if (sig && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_store(sig, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // PS_DETERMINISTIC=1 / ps_set_deterministic(1): bitwise run-to-run reproducible TEM training steps — one stream,
 // weight gradients through per-split partials + an ordered sum, table scatters by sole-owner waves walking the tasks in order.
 bool ps_deterministic();

@@ -203,6 +203,7 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
 #define KIDX_MAX PS_GEMM_KIDX_MAX
 template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
+  fork_signal(g.sig, g.sigval);
   constexpr int NLD = BK / 16;
   __shared__ float As[2][BK][LDT];
   __shared__ float Bs[2][BK][LDT];
@@ -461,6 +462,7 @@ __device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R
 
 template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
+  fork_signal(g.sig, g.sigval);
   constexpr int RA = 64 * MT, RB = 64 * NT;
   constexpr int MAIN_BYTES = 3 * (RA + RB) * X3K * 2;
   constexpr int EPI_BYTES = FULL ? MT * NT * 64 * LDT * 4 : 16;
@@ -725,7 +727,16 @@ static bool try_x3(int ta, int tb, bool full, bool listed, int shape, int maxM, 
   return true;
 }
 
-int ps_launch_gemm(const GemmGroup& g, hipStream_t stream) {
+static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
+int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
+  GemmGroup g = g0;
+  g.sig = nullptr; g.sigval = 0;
+  const bool took = side_take_signal(stream, &g.sig, &g.sigval);      // a pending fork of the side stream rides on this launch
+  const int rc = launch_gemm_impl(g, stream);
+  if (took && rc != PS_OK) side_repend_signal(stream, g.sigval);
+  return rc;
+}
+static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
   PS_REQUIRE(g.n >= 1 && g.n <= 3, "gemm: group size %d", g.n);
   if (g.flat) {
     GemmGroup f = g;

@@ -144,6 +144,7 @@ struct AttnArgs {
   // ... together with the fan-in residual of `out = dropout(context) + inputs`: the sum over the sequence's replicas of
   // fanin_src[(b*fan + j)*128 + i] (d y1), each head group adding its own 64 columns to its partial row
   const float* fanin_src;
+  uint32_t* sig; uint32_t sigval;   // backward launchers: a pending side-stream fork signalled by this launch (common.h, fork_signal)
 };
 inline void attn_finish(AttnArgs& a) {
   a.fS = make_fdiv(a.S); a.fd = make_fdiv(a.d); a.fdh = make_fdiv(a.dh); a.fd4 = make_fdiv(a.d / 4);

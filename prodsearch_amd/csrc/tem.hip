@@ -377,6 +377,8 @@ struct SideCtx {
   uint32_t* flag;            // {fork, join} sequence words for stream write / wait-value crossings (null: event pairs)
   uint32_t fork_seq, join_seq;
   bool light;                // use them for the current backward (side_set_light)
+  bool sig_pending;          // a fork whose value the next main-stream kernel stores (side_take_signal)
+  uint32_t sig_val; hipStream_t sig_stream;
 };
 // One context per device (a process drives one GPU in production; tests and tools may touch several), created under a
 // mutex.  A context serves ONE host thread at a time — the single-thread contract of the step (include/prodsearch_hip.h,
@@ -434,6 +436,7 @@ static SideCtx* side_ctx() {
       ok = ok && hipEventCreateWithFlags(&ctx.join, hipEventDisableTiming) == hipSuccess;
       ctx.next = 0; ctx.used = false;
       ctx.flag = nullptr; ctx.fork_seq = 0; ctx.join_seq = 0; ctx.light = false;
+      ctx.sig_pending = false; ctx.sig_val = 0; ctx.sig_stream = nullptr;
       // forks / joins as stream write-value / wait-value operations on a device word instead of event pairs: the waiting
       // stream loses ~3 us per crossing instead of 6-12 when the waits are SHORT (C2: 0.353 -> 0.341 ms/step), but a
       // polled wait that lasts hundreds of microseconds wakes up late (review transformer 0.924 -> 0.942 ms, C5 1.64 ->
@@ -486,6 +489,10 @@ float* ps_det_scratch(int slot, size_t floats, hipStream_t st) {
   }
   return buf[dev][slot];
 }
+static bool fork_by_kernel() {
+  static const bool on = !(getenv("PS_FORK_BY_KERNEL") && atoi(getenv("PS_FORK_BY_KERNEL")) == 0);
+  return on;
+}
 // fork: everything enqueued on the main stream so far is visible to later side-stream work.  Each fork costs the
 // main stream one event packet (~6 us before its next kernel, measured), so callers batch their weight gradients.
 int side_fork(hipStream_t main_st) {
@@ -497,10 +504,23 @@ int side_fork(hipStream_t main_st) {
   const int side_mode = side_mode_slot();   // bit 0: forks, bit 1: joins as value ops
   if (c->flag && c->light && (side_mode & 1) && !stream_capturing(main_st)) {
     ++c->fork_seq;
-    PS_CHECK_HIP(hipStreamWriteValue32(main_st, c->flag, c->fork_seq, 0));
+    // round 2, later: the value is stored by the NEXT kernel of the main stream as it starts (common.h, fork_signal) instead
+    // of by a write operation between two dependent kernels — the timeline showed 9.5 and 10.5 us between the kernels around
+    // the two forks of the C2 backward, half of it the write.  An unclaimed signal (no carrying launch follows, or one on
+    // another stream) is flushed by the join.  PS_FORK_BY_KERNEL=0: the write operation.
+    if (fork_by_kernel()) {
+      if (c->sig_pending && c->sig_stream != main_st) PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0));
+      c->sig_pending = true; c->sig_val = c->fork_seq; c->sig_stream = main_st;   // (a newer value also satisfies an older wait)
+    } else {
+      PS_CHECK_HIP(hipStreamWriteValue32(main_st, c->flag, c->fork_seq, 0));
+    }
     PS_CHECK_HIP(hipStreamWaitValue32(c->stream, c->flag, c->fork_seq, hipStreamWaitValueGte, 0xffffffffu));
     c->used = true;
     return PS_OK;
+  }
+  if (c->sig_pending) {      // an event fork behind a pending value fork: release that one first
+    PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0));
+    c->sig_pending = false;
   }
   hipEvent_t ev = c->ev[c->next];
   c->next = (c->next + 1) & 7;
@@ -528,8 +548,25 @@ int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st) {
   TRY(side_fork(main_st));
   return side_run(ps, n, main_st);
 }
+bool side_take_signal(hipStream_t st, uint32_t** flag, uint32_t* val) {
+  SideCtx* c = side_ctx();
+  if (!c || !c->sig_pending || st != c->sig_stream) return false;
+  *flag = c->flag; *val = c->sig_val;
+  c->sig_pending = false;
+  return true;
+}
+void side_repend_signal(hipStream_t st, uint32_t val) {
+  SideCtx* c = side_ctx();
+  if (!c || !c->flag) return;
+  if (!c->sig_pending || (int32_t)(val - c->sig_val) > 0) c->sig_val = val;
+  c->sig_pending = true; c->sig_stream = st;
+}
 int side_join(hipStream_t main_st) {
   SideCtx* c = side_ctx();
+  if (c && c->sig_pending) {     // nobody carried the last fork's signal: a stream write after all, or the side stream never starts
+    PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0));
+    c->sig_pending = false;
+  }
   if (!c || !c->used) return PS_OK;
   const int side_mode = side_mode_slot();
   if (c->flag && c->light && (side_mode & 2) && !stream_capturing(main_st)) {
@@ -1092,7 +1129,9 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // stream instead — one event less, and the side stream ends before the scatter does.
       // (round 2: W2 / W1 / Wo are ONE launch of ~45 us now, the side stream is free again when the attention backward
       // ends: the K / V / Q weight gradients go back to it, 0.3151 -> 0.3124 ms/step; PS_WG3_SIDE=0: main stream)
-      static const bool wg3_main_on = getenv("PS_WG3_SIDE") && atoi(getenv("PS_WG3_SIDE")) == 0;
+      // (later in round 2: with forks signalled by the next kernel the main stream lost its two bubbles and ENDED 30 us before
+      // the side stream — score scatter 28 + W2/W1/Wo 45 + these 16 us; back on the main stream: 0.2861 -> 0.2801 ms/step)
+      static const bool wg3_main_on = getenv("PS_WG3_SIDE") ? atoi(getenv("PS_WG3_SIDE")) == 0 : fork_by_kernel();
       const bool wg3_main = fused && wg3_main_on && ns <= 2 * M2;   // (review transformer: 78k K/V rows vs 1.5k replica rows -> side)
       // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the K/V
       // weight gradients (and the dX product below) run over the batch's row list instead of all n_in*S rows
