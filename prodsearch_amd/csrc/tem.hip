@@ -897,6 +897,17 @@ extern "C" int ps_set_fuse_bwd_min(int rows) {
   return old;
 }
 
+// K/V/Q weight gradients of the first layer that the caller launches on the main stream AFTER its embedding scatter
+// (PS_WG3_LAST, item transformer): the scatter (atomics) then shares the machine with the side stream's W2 / W1 / Wo
+// products, and these follow when those are nearly through, instead of slowing each other down product beside product
+static thread_local GemmProblem g_wg3_last[3];
+static thread_local int g_wg3_last_n = 0;
+static thread_local bool g_wg3_defer_ok = false;          // set by a caller that will flush them
+static int flush_wg3_last(hipStream_t st) {
+  const int n = g_wg3_last_n;
+  g_wg3_last_n = 0;
+  return n ? run_wgrads(g_wg3_last, n, st) : PS_OK;
+}
 int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTensors& G, const int64_t* ui,
                         const float* valid, float* ws, const Ws& w, hipStream_t st, ColFoldList* fold,
                         const ScoreArgs* score_on_side, bool rows_listed) {
@@ -1166,7 +1177,11 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // query row in a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
       if (listed && (q_folded || l.fan == 1)) { x.ridx = vr; x.rcount = vc; }
       TRY(run1(x, st));
-      if (wg3_main) TRY(run_wgrads(wg3, 3, st));
+      if (wg3_main) {
+        static const bool wg3_last = !(getenv("PS_WG3_LAST") && atoi(getenv("PS_WG3_LAST")) == 0);
+        if (wg3_last && g_wg3_defer_ok && i == 0) { for (int q = 0; q < 3; ++q) g_wg3_last[q] = wg3[q]; g_wg3_last_n = 3; }
+        else TRY(run_wgrads(wg3, 3, st));
+      }
       if (!qall && !q_via_res) {
         GemmProblem xq = gp(ws + w.dq, d, 0, Lp.wq, d, 1, dxn + (size_t)w.qpos * d, S * d, l.n_in, d, d);
         xq.accumulate = 1;
@@ -1228,8 +1243,11 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)
   int lddqe = d;
   if (tem) {
-    TRY(enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr,
-                            rows_list_ok(D)));
+    g_wg3_defer_ok = true; g_wg3_last_n = 0;
+    const int rc_enc = enc_layers_backward(D, P, G, batch->u_item_idxs, nullptr, ws, w, st, &fold, score_deferred ? &s : nullptr,
+                                           rows_list_ok(D));
+    g_wg3_defer_ok = false;
+    if (rc_enc != PS_OK) { g_wg3_last_n = 0; return rc_enc; }
     dqe = ws + w.dx;      // row 0 of each sequence is the query embedding
     lddqe = S * d;
   }
@@ -1262,7 +1280,9 @@ extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params
     e.dqmean_d = ws + w.dqmean;
   }
   e.fold = fold;
-  TRY(launch_embed_scatter(e, st));
+  const int rc_sc = launch_embed_scatter(e, st);
+  if (rc_sc != PS_OK) { g_wg3_last_n = 0; return rc_sc; }
+  TRY(flush_wg3_last(st));
   TRY(side_join(st));
   return PS_OK;
 }
