@@ -123,12 +123,13 @@ const char* ps_last_error(void);
  * this many replica rows upwards (default 1024, env PS_FUSE_BWD_MIN; below it five short launches are as fast).  The
  * parity tests set it to 1 to drive the fused kernel through the small golden cases.  Returns the previous value. */
 int ps_set_fuse_bwd_min(int rows);
-/* Tuning knob: how the backward's side stream crosses the main stream on short steps.  Bit 1: the join is a stream
- * write-value / wait-value pair instead of an event pair (-9 us per step at C2 in round 1); bit 0: the forks too (no gain
- * with round 1's one fork; with round 2's two forks per backward both together are worth 5-8 us).  Default 3 (env
- * PS_SIDE_MODE), 0 = event pairs only.  The wait is a spinning one-thread kernel: tools that let only one kernel run at a
- * time (counter-collecting profilers) are recognised from their environment and always get events (PS_SIDE_EVENTS=1
- * forces that).  Returns the previous value. */
+/* Tuning knob: how the backward's side stream crosses the main stream.  Bit 1: a join is a stream write-value / wait-value
+ * pair instead of an event pair; bit 0: a fork is a wait-value on the side stream whose value the NEXT kernel launched on the
+ * main stream stores as its first workgroup starts (every earlier main-stream kernel has completed by then) — the main stream
+ * itself executes nothing for a fork (round 2: -9 us per C2 step against write operations, which in turn were -5..-8 us
+ * against events).  Default 3 (env PS_SIDE_MODE), 0 = event pairs only.  The wait is a spinning one-thread kernel: tools that
+ * let only one kernel run at a time (counter-collecting profilers) are recognised from their environment and always get
+ * events (PS_SIDE_EVENTS=1 forces that).  Returns the previous value. */
 int ps_set_side_mode(int mode);
 /* Deterministic mode (env PS_DETERMINISTIC=1, no reference counterpart: the reference's CUDA index_add_ / embedding backward are
  * not deterministic either): the item-transformer training step becomes bitwise reproducible run to run — everything on one
