@@ -25,7 +25,7 @@ python3 bench.py ...` summaries.
 
 ## C2 — `python bench.py` (BASELINE configs[1]: item_transformer d=128, bs 384, 20 negatives, dropout 0.1)
 
-bench line (`r02_bench.json`): **%.0f tuples/s, %.4f ms/step**, median of 200 single steps %.4f ms (p10-p90 %.4f-%.4f), 15 kernel
+bench line (`r02_bench.json`): **%.0f tuples/s, %.4f ms/step**, median of 200 single steps %.4f ms (p10-p90 %.4f-%.4f), 13 kernel
 launches per step (+ the stream write / wait-value operations of the side stream; `r02_step_timeline.txt`: %s).
 Roofline object: `mlp_fwd_ws_kernel`, bound `mfma`, %.1f TFLOP/s of 157.3 = **%.3f** (in-step HIP-event duration %.1f µs; rocprof
 average below); PMC utilisation of the matrix pipe `r02_mfma_utilisation.md`, instruction mix `r02_inst_counters.txt`, wait / busy
