@@ -1133,6 +1133,7 @@ __device__ inline void park_cs(const float (*Cs)[4][MD], float* part, int tid) {
 }
 
 __global__ __launch_bounds__(256, 1) void mlp_bwd_fused_kernel(const MlpBwdArgs a) {
+  fork_signal(a.sig, a.sigval);
   extern __shared__ float lds_raw[];
   MlpBwdLds& L = *reinterpret_cast<MlpBwdLds*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -1309,6 +1310,7 @@ static_assert(sizeof(MlpBwdWsLds) <= 160 * 1024, "wave-specialised MLP backward:
 static_assert(3 * 8 * MD <= MBM * YLD, "column-sum scratch must fit an accumulator tile");
 
 __global__ __launch_bounds__(WS_THREADS, 2) void mlp_bwd_ws_kernel(const MlpBwdArgs a) {
+  fork_signal(a.sig, a.sigval);
   extern __shared__ float lds_raw[];
   MlpBwdWsLds& L = *reinterpret_cast<MlpBwdWsLds*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -1594,6 +1596,8 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
     attr_set = true;
   }
   KTimeScope kt("mlp_bwd", st);
+  MlpBwdArgs b = a;
+  b.sig = nullptr; b.sigval = 0;
   if (mlp_bwd_ws_enabled() && a.F >= 256) {
     static bool ws_attr = false;
     if (!ws_attr) {
@@ -1601,11 +1605,13 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpBwdWsLds)));
       ws_attr = true;
     }
-    hipLaunchKernelGGL(mlp_bwd_ws_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpBwdWsLds), st, a);
+    side_take_signal(st, &b.sig, &b.sigval);           // (every check is behind us: the launch happens)
+    hipLaunchKernelGGL(mlp_bwd_ws_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(WS_THREADS), sizeof(MlpBwdWsLds), st, b);
     PS_LAUNCH_CHECK();
     return PS_OK;
   }
-  hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, a);
+  side_take_signal(st, &b.sig, &b.sigval);
+  hipLaunchKernelGGL(mlp_bwd_fused_kernel, dim3(ps_cdiv(a.M, MBM)), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

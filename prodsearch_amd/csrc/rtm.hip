@@ -752,7 +752,8 @@ __global__ __launch_bounds__(256) void rtm_loss_kernel(const RtmK a) {
 }
 
 // ------------------------------------------------------------------ backward kernels
-__global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a, int zero_dqe) {
+__global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a, int zero_dqe, uint32_t* sig, uint32_t sigval) {
+  fork_signal(sig, sigval);
   extern __shared__ float acc[];                  // [d] partial of d wo_w, + 1 for d wo_b
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, K1 = a.K + 1;
   if (zero_dqe)                                   // d query_emb collects atomics much later (rtm_embed_bwd_kernel): no memset launch
@@ -1519,7 +1520,10 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));
   }
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k, fwd_index || !k.pvc ? 1 : 0);
+  uint32_t* sig = nullptr; uint32_t sigval = 0;
+  static const bool sbwd_carries = !(getenv("PS_RTM_SBWD_SIG") && atoi(getenv("PS_RTM_SBWD_SIG")) == 0);
+  if (sbwd_carries) side_take_signal(st, &sig, &sigval);       // the index fill's fork rides on this launch
+  hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k, fwd_index || !k.pvc ? 1 : 0, sig, sigval);
   PS_LAUNCH_CHECK();
   if (k.train_pv) {
     hipLaunchKernelGGL(rtm_pv_bwd_kernel, dim3(ps_cdiv(B * k.R, 4)), dim3(256), 0, st, k);

@@ -1007,6 +1007,9 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         c2.dst[0] = Lg.b1; c2.dst[1] = nullptr; c2.dst[2] = nullptr;
         ++fold->n;
       }
+      // (measured and dropped: the table scatter of the score backward — it needs nothing of this backward — started beside
+      // the fused kernel below, its fork carried by that kernel: starved by 252 workgroups that own their CUs' LDS it took
+      // 74 us instead of 29 and slowed the attention backward behind it, 0.278 -> 0.282 ms/step)
       TRY(launch_mlp_bwd_fused(m, st));
       GemmProblem wg[1] = {gp_wgrad(do2, d, ws + l.h1, F, Lg.w2, d, F, M2)};
       GemmProblem wg1[1] = {gp_wgrad(ws + w.da1, F, ws + l.ln1, d, Lg.w1, F, d, M2)};
