@@ -184,6 +184,7 @@ struct EmbedBwdArgs {
   const float* fsb_dqe; int fsb_lddqe; const float* fsb_qe; const float* fsb_w; float* g_fs_b;
   ColFoldList fold;              // parked column sums to add up (n = 0: none)
   float* det_dm;                 // deterministic mode + fused FS backward: [B,d] buffer for the rows' d mean (scattered by the sole-owner pass)
+  uint32_t* sig; uint32_t sigval; // a pending side-stream fork signalled by this launch (common.h, fork_signal)
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 

@@ -1244,6 +1244,7 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nq, int nfw, int nfold) {
+  fork_signal(a.sig, a.sigval);
   extern __shared__ float fsb_s[];               // fused FS backward only: [d] dqpre, [rpp][d] partials, [d] d mean
   const int tid = threadIdx.x, c = tid & 31;
   const int d = a.d, epl = d >> 5;
@@ -1468,7 +1469,9 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   const size_t lds = fsb ? sizeof(float) * (size_t)(256 / (a.d / 4) + 2) * a.d : 0;
   EmbedBwdArgs a2 = a;
   if (!det) a2.det_dm = nullptr;
+  a2.sig = nullptr; a2.sigval = 0;
   if (nq + nsb + nfw + nfold > 0) {
+    side_take_signal(st, &a2.sig, &a2.sigval);        // (every check is behind us: the launch happens)
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(nq + nsb + nfw + nfold), dim3(256), lds, st, a2, ntask, nq, nfw, nfold);
     PS_LAUNCH_CHECK();
   }

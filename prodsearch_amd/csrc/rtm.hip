@@ -1576,8 +1576,17 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     if (!fwd_index) {
       const int V = (int)D.vocab_size;
       TRY(rtm_build_index(k, r, V, true, st));
-    } else {
-      TRY(side_join(st));                           // the index (and the weight gradients queued behind it) are through
+    }
+    // The word-gradient reduce needs the index (side stream, in order there) and the slot gradients the kernel above left
+    // (main stream): with forks free it runs ON the side stream behind a fork — carried by the query scatter below — beside
+    // that scatter, and the join that used to precede it (5 us on the main stream with nothing to wait for) is gone.
+    // PS_RTM_WR_SIDE=0: joined and launched on the main stream.
+    static const bool wr_side_on = !(getenv("PS_RTM_WR_SIDE") && atoi(getenv("PS_RTM_WR_SIDE")) == 0);
+    hipStream_t wst = st;
+    if (fwd_index) {
+      hipStream_t ss = side_stream_or(st);
+      if (wr_side_on && ss != st) { TRY(side_fork(st)); wst = ss; }
+      else TRY(side_join(st));                      // the index (and the weight gradients queued behind it) are through
     }
     const int64_t max_occ = (int64_t)r.Bseq * D.R * D.WL;
     static const int wr_cap = getenv("PS_RTM_WR_WGS") ? atoi(getenv("PS_RTM_WR_WGS")) : 4096;
@@ -1586,7 +1595,7 @@ extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params
     // (measured and dropped: the columns split over the XCDs — workgroup i takes d/8 columns of every entry, so that an XCD's
     // L2 holds 1/8 of each gathered row and serves the 56 re-reads itself: 206 us against 66, each 4-lane entry stream keeps
     // too few bytes in flight; this form reads 594 MB from the Infinity Cache at 8.9 TB/s)
-    hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, wst, k);
     PS_LAUNCH_CHECK();
   }
   // query encoder backward (shared kernels) + scatter to the query word rows
