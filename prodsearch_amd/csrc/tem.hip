@@ -449,6 +449,12 @@ static SideCtx* side_ctx() {
           hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can_wait) {
         if (hipMalloc((void**)&ctx.flag, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(ctx.flag, 0, 2 * sizeof(uint32_t)) != hipSuccess)
           ctx.flag = nullptr;
+        // (tests of the wrap guard in side_fork: PS_SIDE_SEQ0 starts both sequences — and the words — at that value)
+        const char* s0 = getenv("PS_SIDE_SEQ0");
+        if (ctx.flag && s0 && *s0) {
+          const uint32_t v[2] = {(uint32_t)strtoul(s0, nullptr, 0), (uint32_t)strtoul(s0, nullptr, 0)};
+          if (hipMemcpy(ctx.flag, v, sizeof(v), hipMemcpyHostToDevice) == hipSuccess) { ctx.fork_seq = v[0]; ctx.join_seq = v[1]; }
+        }
       }
       (void)hipGetLastError();
       if (ok) state = 1;
@@ -503,6 +509,15 @@ int side_fork(hipStream_t main_st) {
   // backward, shorter kernels between them): events 0.3065, forks 0.3023, joins 0.3033, both 0.2980 -> both
   const int side_mode = side_mode_slot();   // bit 0: forks, bit 1: joins as value ops
   if (c->flag && c->light && (side_mode & 1) && !stream_capturing(main_st)) {
+    if (c->fork_seq > 0xfff00000u || c->join_seq > 0xfff00000u) {
+      // the sequence words are compared with >=: long before they wrap (2 per step: weeks of training) drain both streams
+      // and start over from zero
+      if (c->sig_pending) { PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0)); c->sig_pending = false; }
+      PS_CHECK_HIP(hipStreamSynchronize(c->stream));
+      PS_CHECK_HIP(hipStreamSynchronize(main_st));
+      PS_CHECK_HIP(hipMemset(c->flag, 0, 2 * sizeof(uint32_t)));
+      c->fork_seq = 0; c->join_seq = 0;
+    }
     ++c->fork_seq;
     // round 2, later: the value is stored by the NEXT kernel of the main stream as it starts (common.h, fork_signal) instead
     // of by a write operation between two dependent kernels — the timeline showed 9.5 and 10.5 us between the kernels around

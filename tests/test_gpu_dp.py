@@ -156,3 +156,23 @@ def test_bench_contract_line_from_two_ranks_with_its_extra_legs():
     assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 2 * 384 * 20 * 6 / (d['ms_per_step'] * 6e-3)) < 1e-6 * d['value']
     assert d['roofline']['launches_timed'] == 6 and 'median_ms_per_step' in d and 'cpu_baseline' not in d
+
+
+def test_side_stream_sequence_words_restart_before_they_wrap():
+    """Forks and joins of the side stream compare 32-bit sequence words with >=; side_fork drains both streams and restarts
+    the words long before they wrap.  PS_SIDE_SEQ0 starts them just under that threshold: the same 60 steps must give the
+    loss of a run that starts from zero (the guard is crossed about 20 steps in)."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), 'bench.py')
+    losses = []
+    for seq0 in (None, '0xffefffd8'):
+        env = dict(os.environ, PS_BENCH_WATCHDOG='240')
+        env.pop('PS_SIDE_SEQ0', None)
+        if seq0:
+            env['PS_SIDE_SEQ0'] = seq0
+        p = subprocess.run([sys.executable, bench, '--steps', '60', '--warmup', '0', '--no-extras'], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+        losses.append(d['final_loss'])
+    assert abs(losses[0] - losses[1]) <= 1e-4 * abs(losses[0]), losses
