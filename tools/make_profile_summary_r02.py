@@ -55,6 +55,18 @@ The d = 256 linears run as bf16x3 products (`gemm_x3_kernel`, DESIGN.md 5b): `r0
 `PS_GEMM_X3=0` (1.578 ms/step); timeline `r02_c5_step_timeline.txt`, kernel statistics `r02_c5_kernel_stats.csv`; the form alone:
 `r02_gemm_x3_bench.txt` (1.3-1.5x the fp32 MFMA kernel at equal error against fp64), counters `r02_gemm_x3_pmc.txt`.
 
+## Late additions of the round (DESIGN.md 5, 5b, 7c)
+
+bf16x3 product form of the GEMM kernel (exact three-way bf16 split, six bf16 MFMAs per product step, fp32-MFMA accuracy): d = 256
+linears, 78k-row products, every flat weight-gradient group — `r02_gemm_x3_bench.txt`, `r02_gemm_x3_pmc.txt`, C5 1.58 -> 1.41 ms;
+forks of the side stream signalled by the NEXT main-stream kernel (no stream operation on the main stream: the two bubbles of 9.5 and
+10.5 us around the forks of the C2 backward are gone in `r02_step_timeline.txt`), value crossings on long steps too, the backward
+tails rebalanced (K/V/Q weight gradients behind the scatter on the main stream; the review transformer's word-gradient reduce on the
+side stream beside the query scatter): C2 0.285 -> 0.276, review transformer 0.529 -> 0.502, C5 shard 1.41 -> 1.36 ms per step.
+Dropped on the way: two slabs of register prefetch in the bf16x3 kernel (same step time, 5 %% slower alone), a wide transposed fetch
+for its weight gradients (mixed), the score scatter beside the fused backward (starved: 74 us instead of 29), a four-rows-per-trip
+LayerNorm backward (no gain beside the side stream's atomics).
+
 ## Measured and dropped this round (numbers in DESIGN.md 5, 7c and the kernels' comments)
 
 bf16x3 products in the fused forward (same accuracy, 54.7 vs 59.4 µs kernel, step unchanged: opt-in `PS_MLP_X3=1`); a two-level loss ticket;
