@@ -364,6 +364,7 @@ int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st) {
     attr_b = true;
   }
   PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128 && hy == 2), "attention bwd(sq1): folded dQ.Wq needs d == 128 and two head groups");
+  b.sig = nullptr; b.sigval = 0;
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
   hipLaunchKernelGGL(attn_bwd_sq1_kernel, dim3(a.n_in, hy), dim3(256), lds, st, b);
   PS_LAUNCH_CHECK();
@@ -880,6 +881,7 @@ int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unrea
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
   PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128), "attention bwd(wf): folded dQ.Wq needs d == 128 and its output row buffer");
   AttnArgs b = a;
+  b.sig = nullptr; b.sigval = 0;
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
   if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
   else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
@@ -899,6 +901,7 @@ int launch_attn_bwd_w1(const AttnArgs& a, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(!a.wq || a.dxq_part, "attention bwd(w1): folded dQ.Wq needs its output row buffer");
   const dim3 grid(ps_cdiv(a.n_in, 4));
   AttnArgs b = a;
+  b.sig = nullptr; b.sigval = 0;
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
   if (a.d == 128) hipLaunchKernelGGL(attn_bwd_w1_kernel<32>, grid, dim3(256), 0, st, b, pads_unread ? 1 : 0);
   else hipLaunchKernelGGL(attn_bwd_w1_kernel<16>, grid, dim3(256), 0, st, b, pads_unread ? 1 : 0);
