@@ -1,7 +1,7 @@
 """Rehearsal of the N>1 bench path's RCCL calls on the one-GPU box: a world-1 'nccl' group, the flat gradient buffer through
 all_reduce, the fixed-capacity row messages through all_gather_into_tensor, barrier, and the MAX reduction of the timing."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch, torch.distributed as dist

@@ -1,6 +1,6 @@
 """Diagnostic: per-slab timeline of the wave-specialised fused MLP forward (workgroup 0: matrix wave 0, helper wave 4)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from prodsearch_amd import ItemTransformerRanker, readme_tem_args, synth, _lib
 P_, V, B = 18357, 32387, 384
