@@ -2,7 +2,11 @@
 """bench.py — train (u,q,i,neg) tuples/sec of the ranking-loss step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--workload c2|c4|c5]
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1: either the driver's form (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ..., one rank
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plain `python bench.py --gpus N`: with no
+WORLD_SIZE in the environment the script starts the N ranks itself as child processes BEFORE anything touches the GPU
+and relays rank 0's line; it exits non-zero — it never prints an `n_gpus: 1` line — if N ranks cannot be started.
 
 Workloads (BASELINE.json `configs`):
   c2 (default, configs[1], the config the metric is quoted on): item_transformer, d=128, 1 layer, 8 heads, ff 512,
@@ -16,17 +20,25 @@ One step = trainer.py:74-78: loss = model(batch); model.zero_grad(); loss.backwa
 forward, backward, gradient exchange (N>1), clip+Adam.  Inputs are synthetic and already resident in HBM.
 
 Timing: `value` / `ms_per_step` = EXACTLY --steps steps between barrier + synchronize on both sides (max over ranks).
-Then, outside that region (rank 0): `median_ms_per_step` over --reps steps timed one by one with HIP events, and
-  roofline     — the workload's dominant gather kernel: algorithmic bytes per launch / its average IN-STEP duration,
+Then, outside that region (rank 0 keeps the numbers): `median_ms_per_step` over --reps steps timed one by one with HIP
+events, and
+  roofline     — the workload's dominant kernel: algorithmic flops / bytes per launch ÷ its average IN-STEP duration,
                  measured live with one HIP event pair around every launch of it, on the stream it is launched on, over a
                  second pass of --steps steps (ps_ktimer_arm / ps_ktimer_read, include/prodsearch_hip.h)
   cpu_baseline — the oracle (op-for-op CPU restatement; for c2 incl. the B*(K+1) replicated encoder) timed on this box's
-                 host cores on a bounded sample (rank 0, N=1)
+                 host cores on a bounded sample: pools of 8, 32 and all hardware threads (rank 0, N=1)
+and, in the default c2 run at N=1 (bounded to about a minute; --no-also skips them):
+  roofline_hbm — the embedding-gather+score launch ALONE at the HBM-bound shape of configs[4] (d=256, 8 M-row item
+                 table = 8.2 GB, B=1024 and B=8192; index sets rotate so that no row is re-read out of the 256 MB
+                 Infinity Cache), event-timed per launch: the kernel the north star's 70 % target names
+  also         — the contract lines of c4 and of the c5 shard (8 M-row table), each with its own roofline object.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,69 +49,82 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32), = the fp32 vector peak
-P_ITEMS, V_WORDS = 18357, 32387
-B, K, L, Q, W, D = 384, 20, 20, 8, 1, 128
-FF = 512
-# --workload c5: one GPU's shard of BASELINE configs[4] (50 M-item table, d=256, bs=1024/GPU);
-# 51 GB table + dense gradient + Adam moments = 205 GB of HBM, row-sparse optimizer (dense Adam would stream 1.4 TB)
-C5 = dict(P_ITEMS=50_000_000, B=1024, D=256, FF=1024)
-# --workload c4: BASELINE configs[3]
-C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA; a bf16x3 product = 6 bf16 MFMAs per fp32-grade step
+V_WORDS = 32387
+# TEM workloads: c2 = BASELINE configs[1]; c5 = one GPU's shard of configs[4] (50 M-item table, d=256, bs=1024/GPU,
+# SURVEY.md §8d C5): 51 GB table + dense gradient + Adam moments = 205 GB of HBM, row-sparse optimizer
+TEM_CFG = {
+    'c2': dict(P=18357, B=384, K=20, L=20, Q=8, W=1, D=128, FF=512, row_sparse=False, config_index=1),
+    'c5': dict(P=50_000_000, B=1024, K=20, L=20, Q=8, W=1, D=256, FF=1024, row_sparse=True, config_index=4),
+}
+C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)      # BASELINE configs[3]
+ALSO_C5_ITEMS = 8_000_000                                  # the c5 line inside the default run (33 GB instead of 205)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--reps', type=int, default=200, help='steps timed one by one with HIP events for the median (0 = skip)')
     ap.add_argument('--dropout', type=float, default=0.1)
-    ap.add_argument('--cpu-steps', type=int, default=3, help='CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-steps', type=int, default=3, help='CPU-baseline steps per thread pool (0 = skip)')
     ap.add_argument('--no-extras', action='store_true', help='skip median / roofline / cpu_baseline legs')
+    ap.add_argument('--no-also', action='store_true', help='default c2 run: skip the roofline_hbm / also legs')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
                     help='c2 = BASELINE configs[1] (the metric); c4 = configs[3] (RTM); c5 = per-GPU shard of configs[4]')
     ap.add_argument('--encoder', default='pvc', choices=['pvc', 'pv'], help='c4: review encoder')
     ap.add_argument('--items', type=int, default=0, help='override the catalogue size (c5 dry runs)')
     ap.add_argument('--row-sparse', action='store_true',
                     help='touched-rows-only zero/clip/Adam/exchange (args.row_sparse_adam); always on for c5')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------ workloads
 class TemWorkload(object):
     """item_transformer (c2 / c5)."""
 
-    def __init__(self, a, rank, dev):
+    def __init__(self, a, name, rank, dev, items=0):
         from prodsearch_amd import ItemTransformerRanker, build_optim, readme_tem_args, synth
-        self.a = a
-        self.ns = readme_tem_args(dropout=a.dropout, embedding_size=D, ff_size=FF, row_sparse_adam=a.row_sparse)
+        self.a, self.name = a, name
+        c = self.c = dict(TEM_CFG[name])
+        if items:
+            c['P'] = items
+        c['row_sparse'] = c['row_sparse'] or a.row_sparse
+        self.ns = readme_tem_args(dropout=a.dropout, embedding_size=c['D'], ff_size=c['FF'], row_sparse_adam=c['row_sparse'])
         self.wd = synth.make_word_dists(V_WORDS)
         torch.manual_seed(1234)                     # identical init on every rank
-        self.model = ItemTransformerRanker(self.ns, 'cuda', V_WORDS, P_ITEMS, None, word_dists=self.wd)
+        self.model = ItemTransformerRanker(self.ns, 'cuda', V_WORDS, c['P'], None, word_dists=self.wd)
         self.optim = build_optim(self.ns, self.model, None)
-        self.batches = [synth.make_tem_batch(1000 + 97 * rank + i, B, P_ITEMS, V_WORDS, Q=Q, L=L, W=W,
+        self.batches = [synth.make_tem_batch(1000 + 97 * rank + i, c['B'], c['P'], V_WORDS, Q=c['Q'], L=c['L'], W=c['W'],
                                              word_dists=self.wd).to(dev) for i in range(8)]
-        self.B, self.K = B, K
-        self.ktag = 'gather_score'
+        self.B, self.K = c['B'], c['K']
 
     def forward(self, i):
         return self.model(self.batches[i % len(self.batches)])      # trainer.py:74 (negatives sampled on device)
 
     def describe(self):
+        c = self.c
         R = next(iter(self.model._plans.values())).layout.R
         return ("item_transformer d=%d 1 layer 8 heads ff=%d uprev=20 bs=%d/GPU 20 neg Q=8 W=1 P=%d V=32387 dropout=%.2f%s "
-                "(BASELINE configs[%d])" % (D, FF, B, P_ITEMS, self.a.dropout, " row-sparse Adam" if self.a.row_sparse else "",
-                                            4 if self.a.workload == 'c5' else 1)), {"replicas_per_row": R}
+                "(BASELINE configs[%d])" % (c['D'], c['FF'], c['B'], c['P'], self.a.dropout,
+                                            " row-sparse Adam" if c['row_sparse'] else "", c['config_index'])), {"replicas_per_row": R}
 
     def metric(self):
-        return "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (B, D)
+        return "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (self.c['B'], self.c['D'])
+
+    def dtype(self):
+        from prodsearch_amd import _lib
+        return _lib.load().ps_arith_info().decode()
 
     def roofline_spec(self):
-        """The step's dominant kernel.  With replicas at d = 128 (c2) that is the fused per-replica forward
-        (mlp_fwd_ws_kernel: Wo -> LN -> W1 -> GELU -> W2 -> LN for every one of the B*(K+1) replica rows, with the item
-        gather + score + loss in its epilogue): MFMA-bound, 2*d*d + 4*d*F flops per row.  Otherwise (c5: d = 256) the
-        stand-alone gather+score launch: HBM-bound, every table row once (4d B) + its int64 index, every distinct vector
-        it is dotted with, every score written."""
+        """The step's dominant kernel.  With replicas at d = 128 (c2) that is the fused per-replica forward (Wo -> LN -> W1
+        -> GELU -> W2 -> LN for every one of the B*(K+1) replica rows, with the item gather + score + loss in its
+        epilogue): MFMA-bound, 2*d*d + 4*d*F flops per row.  Otherwise (c5: d = 256) the stand-alone gather+score launch:
+        HBM-bound, every table row once (4d B) + its int64 index, every distinct vector it is dotted with, every score
+        written."""
+        c = self.c
+        B, K, W, D, FF = c['B'], c['K'], c['W'], c['D'], c['FF']
         R = next(iter(self.model._plans.values())).layout.R
         rows = B * (1 + K) * (1 + W)
         vecs = B * R + B                            # encoder outputs + target-item rows
@@ -107,24 +132,29 @@ class TemWorkload(object):
         if D == 128 and R > 1 and (B * R + 31) // 32 <= 256:
             flops = B * R * (2 * D * D + 4 * D * FF)
             return dict(tag='mlp_fwd', bound='mfma', work=flops, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', scale=1e12,
-                        kernel="mlp_fwd_ws_kernel (fused per-replica encoder tail, %d rows x (2*%d*%d + 4*%d*%d) flop, fp32 MFMA; "
-                               "item gather + score + loss folded into its epilogue: %d B of gathered rows and scores)"
+                        kernel="fused per-replica encoder tail (mlp_fwd), %d rows x (2*%d*%d + 4*%d*%d) flop; item gather + "
+                               "score + loss folded into its epilogue: %d B of gathered rows and scores"
                                % (B * R, D, D, D, FF, B * (1 + K) * (4 * D + 8 + 4)),
-                        traffic_key=None, extra={"gather_score_bytes_all_tasks": gather_bytes})
+                        extra={"gather_score_bytes_all_tasks": gather_bytes,
+                               "peak_note": "peak = dense fp32 MFMA; products issued as exact bf16x3 (6 bf16 MFMAs per fp32-grade "
+                                            "step) have an equivalent peak of %.0f TFLOP/s" % (MFMA_BF16_PEAK_TFLOPS / 6.0),
+                               "frac_of_bf16x3_equivalent_peak": None})
         return dict(tag='gather_score', bound='hbm', work=gather_bytes, peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
-                    traffic_key=None, extra={})
+                    extra={"traffic": 63.0e6 if (B, D) == (1024, 256) else None,
+                           "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f): FETCH_SIZE "
+                                             "31.2 MB x2 + WRITE_SIZE 0.4 MB per launch at B=1024, d=256" if (B, D) == (1024, 256) else None})
 
     def cpu_baseline(self, n_steps):
-        return cpu_baseline_tem(self.ns, n_steps)
+        return cpu_baseline_tem(self.ns, self.c, n_steps)
 
 
 class RtmWorkload(object):
     """review_transformer (c4)."""
 
-    def __init__(self, a, rank, dev):
+    def __init__(self, a, name, rank, dev, items=0):
         from prodsearch_amd import ProductRanker, build_optim, default_args, synth, rtm_data
-        self.a = a
+        self.a, self.name = a, name
         c = C4
         self.ns = default_args(model_name='review_transformer', review_encoder_name=a.encoder, embedding_size=128,
                                heads=8, ff_size=512, inter_layers=1, neg_per_pos=c['K'], dropout=a.dropout,
@@ -145,7 +175,6 @@ class RtmWorkload(object):
                                                     word_dists=self.wd) for s in range(4)]
         self.batches = [b.to(dev) for b in self.cpu_batches]
         self.B, self.K = c['B'], c['K']
-        self.ktag = 'rtm_embed'
 
     def forward(self, i):
         return self.model(self.batches[i % len(self.batches)], train_pv=False)
@@ -159,10 +188,13 @@ class RtmWorkload(object):
     def metric(self):
         return "train (u,q,i,neg) tuples/sec at bs=%d, %d neg, d=128 (review_transformer)" % (C4['B'], C4['K'])
 
+    def dtype(self):
+        return TemWorkload.dtype(self)
+
     def roofline_spec(self):
-        """rtm_embed4_kernel (review vectors, PVC.py:46-61): per valid review slot its WL int64 word ids, per word that is
-        neither padding nor dropped by the token corruption one 4d-byte row (expected count: the Philox masks are drawn
-        on the device), the rows of the encoder input it writes and the per-word ranks it leaves for the backward."""
+        """The review-vector gather (PVC.py:46-61): per valid review slot its word ids, per word that is neither padding nor
+        dropped by the token corruption one 4d-byte row (expected count: the Philox masks are drawn on the device), the
+        rows of the encoder input it writes and what it leaves for the backward's inverted index."""
         c, d = C4, 128
         b0 = self.cpu_batches[0]
         pad_r = c['RC'] - 1
@@ -180,63 +212,67 @@ class RtmWorkload(object):
             nbytes = slots * (8 + 4 * d) + out_bytes
             note = "%d review rows + %d B of x" % (slots, out_bytes)
         return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
-                    kernel="rtm_embed4_kernel (review-vector gather + mean-pool + word ranks; %s)" % note, traffic_key=None, extra={})
+                    kernel="rtm_embed4_kernel (review-vector gather + mean-pool + word ranks; %s)" % note,
+                    extra={"traffic": 123.3e6 if self.a.encoder == 'pvc' else None,
+                           "traffic_source": "committed PMC passes profiles/r02_rtm_embed_pmc.txt (commit ed4b86f): FETCH_SIZE "
+                                             "34.5 MB x2 + WRITE_SIZE 54.3 MB per launch" if self.a.encoder == 'pvc' else None})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_rtm(self, n_steps)
 
 
 # ------------------------------------------------------------------------------------------ CPU baselines
-def _best_pool(one_step, ncpu, cands=(8, 16, 32, 64)):
-    """torch's intra-op pool does not scale to every hardware thread of a 2-socket host on these small ops: a short
-    calibration picks the fastest of a few pool sizes; `cores` reports the pool that was timed."""
-    cands = sorted({min(ncpu, c) for c in cands})
+def _pools(one_step, ncpu, n_steps, cands=(8, 32, None)):
+    """torch's intra-op pool does not scale to every hardware thread of a 2-socket host on these small ops, so the same
+    step is timed on a few pool sizes — 8 (the survey probe's), 32 and ALL hardware threads — `n_steps` steps each after one
+    warm-up; the fastest pool is the reported baseline and every pool's rate is listed beside it."""
+    cands = sorted({min(ncpu, c if c else ncpu) for c in cands})
     torch.set_num_threads(cands[0])
     one_step()                                   # warm-up (allocator, first-touch)
-    trial = {}
+    per = {}
     for c in cands:
         torch.set_num_threads(c)
-        trial[c] = one_step()
-    best = min(trial, key=trial.get)
-    torch.set_num_threads(best)
-    return best, trial, cands
+        ts = [one_step() for _ in range(n_steps)]
+        per[c] = sum(ts) / len(ts)
+    best = min(per, key=per.get)
+    return best, per
 
 
-def cpu_baseline_tem(args_ns, n_steps):
+def cpu_baseline_tem(args_ns, c, n_steps):
     """The oracle as the CPU path: same shapes/flags, reference structure (replicated encoder,
     torch RNG dropout), fwd + bwd + clip/Adam on the host cores."""
     from oracle import tem as otem, optim as ooptim
     from prodsearch_amd import synth
     ncpu = os.cpu_count() or 1
+    P, B, K, L, Q, W, D = c['P'], c['B'], c['K'], c['L'], c['Q'], c['W'], c['D']
     wd = synth.make_word_dists(V_WORDS)
-    shapes = synth.tem_param_shapes(args_ns, V_WORDS, P_ITEMS)
-    Pm = {k: v.requires_grad_(True) for k, v in synth.make_state_dict(shapes, 1, {'product_emb.weight': P_ITEMS}).items()}
+    shapes = synth.tem_param_shapes(args_ns, V_WORDS, P)
+    Pm = {k: v.requires_grad_(True) for k, v in synth.make_state_dict(shapes, 1, {'product_emb.weight': P}).items()}
     opt = ooptim.ClipAdam(args_ns.lr, args_ns.max_grad_norm, args_ns.beta1, args_ns.beta2, 1e-9, args_ns.l2_lambda)
-    pad = otem.tem_pad_rows(args_ns, V_WORDS, P_ITEMS)
+    pad = otem.tem_pad_rows(args_ns, V_WORDS, P)
     drop = otem.TorchDropout(args_ns.dropout) if args_ns.dropout > 0 else None
     counter = [0]
 
     def one_step():
         s = counter[0]
         counter[0] += 1
-        batch = synth.make_tem_batch(100 + s, B, P_ITEMS, V_WORDS, Q=Q, L=L, W=W, word_dists=wd)
-        ni, nw = synth.sample_negatives(200 + s, B, K, W, P_ITEMS, wd)
+        batch = synth.make_tem_batch(100 + s, B, P, V_WORDS, Q=Q, L=L, W=W, word_dists=wd)
+        ni, nw = synth.sample_negatives(200 + s, B, K, W, P, wd)
         t0 = time.perf_counter()
-        loss, _, _ = otem.tem_forward(Pm, args_ns, batch, ni, nw, V_WORDS, P_ITEMS, training=True,
+        loss, _, _ = otem.tem_forward(Pm, args_ns, batch, ni, nw, V_WORDS, P, training=True,
                                       replicate=True, drop=drop)
         grads = otem.grads_of(loss, Pm, pad)
         with torch.no_grad():
             opt.step(Pm, grads)
         return time.perf_counter() - t0
 
-    best, trial, cands = _best_pool(one_step, ncpu)
-    times = [one_step() for _ in range(n_steps)]
-    t = sum(times) / len(times)
+    best, per = _pools(one_step, ncpu, n_steps)
+    t = per[best]
     return {"value": B * K / t, "unit": "tuples/s", "cores": best, "kind": "port",
-            "sample": "%d steps of the same B=%d,K=%d,d=%d step (fwd+bwd+clip/Adam, replicated encoder, dropout %.2f), "
-                      "%.2f s/step on %d of %d host threads (fastest of pools %s after 1 warm-up step)"
-                      % (len(times), B, K, D, args_ns.dropout, t, best, ncpu,
-                         ", ".join("%d: %.1fs" % (c, trial[c]) for c in cands))}
+            "pools_tuples_per_s": {str(k): B * K / v for k, v in sorted(per.items())},
+            "sample": "%d steps per pool of the same B=%d,K=%d,d=%d step (oracle/tem.py: fwd+bwd+clip/Adam, replicated encoder, "
+                      "dropout %.2f) on pools of %s of %d host threads after 1 warm-up step; fastest: %.2f s/step on %d threads"
+                      % (n_steps, B, K, D, args_ns.dropout, "/".join(str(k) for k in sorted(per)), ncpu, t, best)}
 
 
 def cpu_baseline_rtm(wl, n_steps):
@@ -270,37 +306,21 @@ def cpu_baseline_rtm(wl, n_steps):
             opt.step(Pm, dict(zip(names, gs)))
         return time.perf_counter() - t0
 
-    best, trial, cands = _best_pool(one_step, ncpu, cands=(8, 16, 32))
-    times = [one_step() for _ in range(n_steps)]
-    t = sum(times) / len(times)
+    best, per = _pools(one_step, ncpu, n_steps, cands=(8, 32))
+    t = per[best]
     return {"value": c['B'] * c['K'] / t, "unit": "tuples/s", "cores": best, "kind": "port",
-            "sample": "%d steps of the same B=%d,K=%d RTM step (oracle/rtm.py: fwd + autograd bwd + clip/Adam, dropout %.2f, "
-                      "token corruption 0.9), %.2f s/step on %d of %d host threads (fastest of pools %s after 1 warm-up step)"
-                      % (len(times), c['B'], c['K'], ns.dropout, t, best, ncpu,
-                         ", ".join("%d: %.1fs" % (cc, trial[cc]) for cc in cands))}
+            "pools_tuples_per_s": {str(k): c['B'] * c['K'] / v for k, v in sorted(per.items())},
+            "sample": "%d steps per pool of the same B=%d,K=%d RTM step (oracle/rtm.py: fwd + autograd bwd + clip/Adam, dropout "
+                      "%.2f, token corruption 0.9) on pools of %s of %d host threads after 1 warm-up step; fastest: %.2f s/step on "
+                      "%d threads" % (n_steps, c['B'], c['K'], ns.dropout, "/".join(str(k) for k in sorted(per)), ncpu, t, best)}
 
 
-# ------------------------------------------------------------------------------------------ main
-def main():
-    a = parse()
-    if os.environ.get('PS_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit after N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['PS_BENCH_WATCHDOG']), exit=True)
+# ------------------------------------------------------------------------------------------ one workload
+def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, items=0):
+    """Build the workload, time EXACTLY `steps` steps (barrier + synchronize on both sides, max over ranks), then the
+    extra legs; returns the contract dict."""
     from prodsearch_amd import _lib, dist as pdist
-    rank, local, world = pdist.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if a.workload == 'c5':
-        globals().update(C5)
-        a.row_sparse = True
-    if a.items:
-        globals().update(P_ITEMS=a.items)
-    wl = RtmWorkload(a, rank, dev) if a.workload == 'c4' else TemWorkload(a, rank, dev)
+    wl = (RtmWorkload if name == 'c4' else TemWorkload)(a, name, rank, dev, items)
     model, optim = wl.model, wl.optim
     model._seed = pdist.rank_seed(wl.ns.seed, rank)
     pdist.broadcast_parameters(model)
@@ -311,17 +331,17 @@ def main():
         loss = wl.forward(i)                             # trainer.py:74
         model.zero_grad()                                # :76
         loss.backward()                                  # :77
-        exchange()                                       # RCCL all-reduce of the flat gradient (N>1)
+        exchange()                                       # RCCL exchange of the flat gradient (N>1)
         optim.step()                                     # :78
         return loss
 
-    for i in range(a.warmup):
+    for i in range(warmup):
         step(i)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -332,25 +352,27 @@ def main():
 
     desc, extra_cfg = wl.describe()
     Bw, Kw = wl.B, wl.K
+    xname = type(exchange).__name__
+    xdesc = {"GradExchange": "flat all-reduce", "ShardedAdamExchange": "reduce-scatter + owner clip/Adam + all-gather",
+             "SparseGradExchange": "row-sparse all-gather exchange"}.get(xname, xname)
     out = {
         "metric": wl.metric(),
-        "value": world * Bw * Kw * a.steps / elapsed, "unit": "tuples/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value": world * Bw * Kw * steps / elapsed, "unit": "tuples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": wl.dtype(), "data": "synthetic",
         "config": dict({"workload": desc, "global_batch": world * Bw, "parallelism": "dp%d" % world,
                         "step": "sample+fwd+bwd+%sclip/Adam via nn.Module API (trainer.py:74-78)"
-                                % ("allreduce+" if world > 1 else "")}, **extra_cfg),
-        "samples_per_s": world * Bw * a.steps / elapsed, "final_loss": last_loss,
+                                % ((xdesc + "+") if world > 1 else "")}, **extra_cfg),
+        "samples_per_s": world * Bw * steps / elapsed, "final_loss": last_loss,
     }
-    if not a.no_extras:
+    if extras:
         # Every rank runs these extra steps (they contain the gradient exchange: a collective only rank 0 entered would
         # never return); rank 0 keeps the numbers.
         lib = _lib.load()
-        # (1) median of single steps, each between two HIP events on the step's stream
-        if a.reps > 0:
+        if reps > 0:     # (1) median of single steps, each between two HIP events on the step's stream
             st = torch.cuda.current_stream()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
             for i, (e0, e1) in enumerate(ev):
                 e0.record(st)
                 step(i)
@@ -358,33 +380,161 @@ def main():
             torch.cuda.synchronize()
             ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
             out["median_ms_per_step"] = ts[len(ts) // 2]
-            out["reps"] = a.reps
+            out["reps"] = reps
             out["p10_p90_ms_per_step"] = [ts[len(ts) // 10], ts[(9 * len(ts)) // 10]]
-        # (2) roofline: in-step duration of the workload's gather kernel, one event pair per launch on its own stream
+        # (2) roofline: in-step duration of the workload's dominant kernel, one event pair per launch on its own stream
         spec = wl.roofline_spec()
-        _lib.check(lib.ps_ktimer_arm(spec['tag'].encode(), a.steps), 'ps_ktimer_arm')
-        for i in range(a.steps):
+        _lib.check(lib.ps_ktimer_arm(spec['tag'].encode(), steps), 'ps_ktimer_arm')
+        for i in range(steps):
             step(i)
         avg, mn, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
         _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
-        traffic = traffic_src = None                # PMC passes cannot run inside this process
-        if spec['traffic_key']:
-            try:
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'gather_score_traffic.json')))
-                traffic, traffic_src = tj.get(spec['traffic_key']), "committed profile: " + tj.get('source', '')
-            except Exception:
-                pass
         t_k = avg.value * 1e-6
         ach = spec['work'] / t_k / spec['scale'] if t_k > 0 else 0.0
+        extra = dict(spec['extra'])
+        if 'frac_of_bf16x3_equivalent_peak' in extra:
+            extra['frac_of_bf16x3_equivalent_peak'] = ach / (MFMA_BF16_PEAK_TFLOPS / 6.0)
         out["roofline"] = dict({"bound": spec['bound'], "achieved": ach, "peak": spec['peak'], "unit": spec['unit'],
-                                "frac": ach / spec['peak'], "traffic": traffic, "traffic_source": traffic_src,
+                                "frac": ach / spec['peak'], "traffic": None, "traffic_source": None,
                                 "kernel": spec['kernel'],
                                 ("flops_per_launch" if spec['bound'] == 'mfma' else "bytes_per_launch"): spec['work'],
                                 "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
                                 "timing": "HIP event pair around every in-step launch, on the launch stream, over a second "
-                                          "pass of %d steps (ps_ktimer)" % a.steps}, **spec['extra'])
-        if world == 1 and a.cpu_steps > 0 and a.workload in ('c2', 'c4'):
-            out["cpu_baseline"] = wl.cpu_baseline(a.cpu_steps)
+                                          "pass of %d steps (ps_ktimer)" % steps}, **extra)
+        if world == 1 and cpu_steps > 0 and name in ('c2', 'c4'):
+            out["cpu_baseline"] = wl.cpu_baseline(cpu_steps)
+    del wl, model, optim, exchange
+    torch.cuda.empty_cache()
+    return out
+
+
+def gather_score_hbm_leg(dev, rows=ALSO_C5_ITEMS, iters=40):
+    """The embedding-gather+score launch alone at the C5 shape (d=256, 1-KiB rows, `rows`-row item table far beyond the
+    Infinity Cache), B=1024 and B=8192.  Every launch is bracketed by a HIP event pair on its stream (ps_ktimer); the
+    launches walk 8 different index sets in turn (8 x 67.6 MB at B=1024 > the 256 MB Infinity Cache), so a row read by
+    one launch is not served from on-die cache to the next."""
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    d, K, W, P, V = 256, 20, 1, rows, 2_000_000
+    gen = torch.Generator(device=dev).manual_seed(1)
+    table = torch.empty(P + 1, d, device=dev)
+    for i in range(0, P + 1, 1 << 22):                      # fill in slices: no table-sized temporary
+        table[i:i + (1 << 22)].normal_(generator=gen)
+    words = torch.randn(V, d, device=dev, generator=gen)
+    wbias = torch.zeros(V, device=dev)
+    res = []
+    for B in (1024, 8192):
+        desc = _lib.PsTemDesc()
+        desc.B, desc.K, desc.L, desc.Q, desc.W, desc.C = B, K, 20, 8, W, 0
+        desc.d, desc.H, desc.F, desc.n_layers = d, 8, 1024, 1
+        desc.product_size, desc.vocab_size = P, V
+        desc.use_pos_emb, desc.training, desc.dropout = 1, 1, 0.1
+        lay = _lib.PsTemWsLayout()
+        _lib.check(lib.ps_tem_workspace_layout(desc, lay), 'layout')
+        ws = torch.randn(lay.total_floats, device=dev)
+        params = _lib.PsTemTensors()
+        params.product_emb, params.word_emb, params.word_bias = table.data_ptr(), words.data_ptr(), wbias.data_ptr()
+        mk = lambda hi, *shape: torch.randint(0, hi, shape, device=dev, dtype=torch.int64, generator=gen)
+        sets = []
+        for _ in range(8):
+            idx = (mk(P, B), mk(P, B, K), mk(V - 1, B, W), mk(V - 1, B, W * K))
+            bt = _lib.PsTemBatch()
+            bt.target_prod_idxs, bt.neg_item_idxs = idx[0].data_ptr(), idx[1].data_ptr()
+            bt.pos_iword_idxs, bt.neg_word_idxs = idx[2].data_ptr(), idx[3].data_ptr()
+            sets.append((idx, bt))
+        st = torch.cuda.current_stream()
+        for i in range(8):
+            _lib.check(lib.ps_gather_score(desc, params, sets[i][1], ws.data_ptr(), st.cuda_stream), 'ps_gather_score')
+        torch.cuda.synchronize()
+        _lib.check(lib.ps_ktimer_arm(b'gather_score', iters), 'ps_ktimer_arm')
+        for i in range(iters):
+            _lib.check(lib.ps_gather_score(desc, params, sets[i % 8][1], ws.data_ptr(), st.cuda_stream), 'ps_gather_score')
+        avg, mn, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
+        _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
+        R = lay.R
+        nrows = B * (1 + K) * (1 + W)
+        nbytes = nrows * (4 * d + 8) + (B * R + B) * 4 * d + nrows * 4
+        ach = nbytes / (avg.value * 1e-6) / 1e9
+        res.append({"B": B, "bytes_per_launch": nbytes, "us_per_launch": avg.value, "us_per_launch_min": mn.value,
+                    "launches_timed": cnt.value, "achieved": ach, "frac": ach / HBM_PEAK_GBS})
+        del ws, sets
+    del table, words
+    torch.cuda.empty_cache()
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": res[0]["achieved"], "frac": res[0]["frac"],
+            "kernel": "score_fwd_wide_kernel<1,4> alone (embedding gather + score), C5 shape: d=256, %d-row item table "
+                      "(%.1f GB), K=20, W=1, R=21; 8 rotating index sets" % (rows, (rows + 1) * d * 4 / 1e9),
+            "by_batch": res, "traffic": 63.0e6,
+            "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f): FETCH_SIZE 31.2 MB x2 "
+                              "+ WRITE_SIZE 0.4 MB per launch at B=1024 against 67.6 MB algorithmic",
+            "timing": "HIP event pair around every launch on its stream (ps_ktimer), %d launches per batch size" % iters}
+
+
+# ------------------------------------------------------------------------------------------ launching N ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks as child processes of this one — nothing
+    here has touched the GPU (device_count() does not initialise it) — relay rank 0's JSON line and fail loudly otherwise."""
+    backend = os.environ.get('PS_DIST_BACKEND') or 'nccl'
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py --gpus %d: no GPU visible (no CPU fallback)" % a.gpus)
+    if ndev < a.gpus and backend != 'gloo':
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU over RCCL needs %d "
+                         "(PS_DIST_BACKEND=gloo rehearses the N-rank path on fewer devices)" % (a.gpus, ndev, a.gpus))
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PS_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    if any(rcs) or len(lines) != 1:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write("bench.py --gpus %d: rank exit codes %s, %d JSON line(s) from rank 0\n" % (a.gpus, rcs, len(lines)))
+        raise SystemExit(1)
+    d = json.loads(lines[0])
+    if d.get('n_gpus') != a.gpus:
+        sys.stderr.write("bench.py --gpus %d: rank 0 reported n_gpus=%r\n" % (a.gpus, d.get('n_gpus')))
+        raise SystemExit(1)
+    print(lines[0])
+
+
+# ------------------------------------------------------------------------------------------ main
+def main():
+    a = parse()
+    if os.environ.get('PS_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PS_BENCH_WATCHDOG']), exit=True)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(a)
+    from prodsearch_amd import dist as pdist
+    rank, local, world = pdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: refusing to report a line for a different rank count" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    out = measure(a, a.workload, rank, world, dev, a.steps, a.warmup, a.reps, not a.no_extras, a.cpu_steps, a.items)
+    if a.workload == 'c2' and world == 1 and not a.no_extras and not a.no_also:
+        out["roofline_hbm"] = gather_score_hbm_leg(dev)
+        also = []
+        for name, items in (('c4', 0), ('c5', ALSO_C5_ITEMS)):
+            also.append(measure(a, name, rank, world, dev, 100, 20, 0, True, 1 if name == 'c4' else 0, items))
+        out["also"] = also
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -119,6 +119,9 @@ typedef struct PsTemWsLayout {
 
 const char* ps_version(void);
 const char* ps_last_error(void);
+/* The arithmetic the step computes in, as text for bench.py's `dtype` field: "f32 (...)" naming the bf16x3 product form
+ * when it is enabled (ps_gemm_x3_config).  No reference counterpart (the reference is fp32 ATen throughout). */
+const char* ps_arith_info(void);
 /* Tuning knob (no reference counterpart): the last encoder layer's per-replica backward runs as one fused kernel from
  * this many replica rows upwards (default 1024, env PS_FUSE_BWD_MIN; below it five short launches are as fast).  The
  * parity tests set it to 1 to drive the fused kernel through the small golden cases.  Returns the previous value. */
@@ -131,6 +134,12 @@ int ps_set_fuse_bwd_min(int rows);
  * let only one kernel run at a time (counter-collecting profilers) are recognised from their environment and always get
  * events (PS_SIDE_EVENTS=1 forces that).  Returns the previous value. */
 int ps_set_side_mode(int mode);
+/* Error-path hygiene of the side stream: every ps_*_backward that fails releases a fork of the side stream whose
+ * signalling launch never happened, so the caller's next synchronize returns and the error surfaces (it could otherwise
+ * wait forever on hipStreamWaitValue32).  ps_side_abort() does the same on demand; ps_debug_fail_fork(n) is the test hook
+ * that makes the n-th fork from now on fail after it has parked the side stream (0 = off). */
+void ps_side_abort(void);
+void ps_debug_fail_fork(int nth);
 /* Deterministic mode (env PS_DETERMINISTIC=1, no reference counterpart: the reference's CUDA index_add_ / embedding backward are
  * not deterministic either): the item-transformer training step becomes bitwise reproducible run to run — everything on one
  * stream, weight gradients as per-split partial matrices added up in split order by a second launch, table scatters by
@@ -212,6 +221,17 @@ int32_t ps_adam_plan_chunks_host(const void* plan_host);     /* grid size; state
 int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper,
                        int64_t* state_dev, float* gnorm_out_dev /* [2]: norm, lr; may be NULL */,
                        ps_stream_t stream);
+
+/* The same step cut in two for the SHARDED data-parallel optimizer (no reference counterpart; the reference is
+ * single-process, trainer.py:64-83): after a reduce-scatter every rank owns 1/world of the flat gradient, and
+ * clip_grad_norm_ (optimizers.py:241-242) is a norm over ALL gradients, so the ranks' partial sums of squares meet in one
+ * scalar all-reduce between the two launches.  ps_adam_sumsq: out_sumsq_dev[0] = sum over the plan of (g*grad_scale)^2
+ * (fixed-order reduction) and state[0] += 1.  ps_adam_update_ext: clip + Adam exactly as ps_clip_adam_dense, with the
+ * global sum of squares read from total_sumsq_dev. */
+int ps_adam_sumsq(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
+                  float* out_sumsq_dev, ps_stream_t stream);
+int ps_adam_update_ext(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
+                       const float* total_sumsq_dev, float* gnorm_out_dev, ps_stream_t stream);
 
 /* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
 int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);

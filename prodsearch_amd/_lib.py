@@ -107,9 +107,12 @@ PS_RENC_PV, PS_RENC_PVC, PS_RENC_FS, PS_RENC_AVG = 0, 1, 2, 3
 SYMBOLS = {
     'ps_version': (C.c_char_p, []),
     'ps_last_error': (C.c_char_p, []),
+    'ps_arith_info': (C.c_char_p, []),
     'ps_set_fuse_bwd_min': (C.c_int, [C.c_int]),
     'ps_set_side_mode': (C.c_int, [C.c_int]),
     'ps_set_deterministic': (C.c_int, [C.c_int]),
+    'ps_side_abort': (None, []),
+    'ps_debug_fail_fork': (None, [C.c_int]),
     'ps_gemm_x3_config': (C.c_int, [C.c_int, C.c_int]),
     'ps_tem_workspace_layout': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemWsLayout)]),
     'ps_tem_forward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
@@ -142,6 +145,9 @@ SYMBOLS = {
     'ps_adam_plan_chunks_host': (C.c_int32, [C.c_void_p]),
     'ps_clip_adam_dense': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsAdamHyper), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    'ps_adam_sumsq': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsAdamHyper), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_adam_update_ext': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsAdamHyper), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
     'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     'ps_graph_replay_enabled': (C.c_int, []),

@@ -58,5 +58,6 @@ int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st);
 int side_fork(hipStream_t main_st);
 int side_run(GemmProblem* ps, int n, hipStream_t main_st);
 int side_join(hipStream_t main_st);
+void side_abort();                                   // error paths: release a fork nobody will signal (tem.hip)
 void side_set_light(bool light);
 hipStream_t side_stream_or(hipStream_t main_st);   // the side stream, or main_st when it is disabled

@@ -675,6 +675,7 @@ static bool x3_on() {
   if (g_x3_mode == -2) { g_x3_mode = x3_env("PS_GEMM_X3", 1) ? 1 : 0; g_x3_force = x3_env("PS_GEMM_X3_SHAPE", -1); }
   return g_x3_mode != 0;
 }
+bool gemm_x3_on() { return x3_on(); }
 static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   x3_on();
   static const int t22 = x3_env("PS_GEMM_X3_T22", 4096), t21 = x3_env("PS_GEMM_X3_T21", 384), t11 = x3_env("PS_GEMM_X3_T11", 512);

@@ -114,6 +114,54 @@ extern "C" int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const 
   return PS_OK;
 }
 
+// ---- sharded form (data parallel, prodsearch_amd/dist.py ShardedAdamExchange): every rank owns 1/world of the flat
+// gradient after a reduce-scatter, so the global clip norm (optimizers.py:241-242 is a norm over ALL gradients) needs the
+// ranks' partial sums added by one scalar all-reduce BETWEEN the two launches.  ps_adam_sumsq leaves this rank's sum of
+// squares (fixed-order reduction of the per-chunk partials) in out_sumsq_dev and bumps the step; after the all-reduce
+// ps_adam_update_ext applies clip + Adam with that external total.
+__global__ __launch_bounds__(256) void adam_total_kernel(const float* partial, int n_chunks, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_chunks; i += 256) s += partial[i];
+  const float total = block_sum_256(s, sh);
+  if (threadIdx.x == 0) out[0] = total;
+}
+__global__ __launch_bounds__(256) void adam_update_ext_kernel(const char* plan, const PsAdamHyper hp, const int64_t* state,
+                                                              const float* total_sumsq, float* gnorm_out) {
+  __shared__ float scal[4];
+  const int chunk = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float norm;
+    adam_scalars(hp, *total_sumsq, state[0], scal, &norm);
+    if (chunk == 0 && gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
+  }
+  __syncthreads();
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads};
+  adam_update_chunk(plan, chunk, a);
+}
+extern "C" int ps_adam_sumsq(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
+                             float* out_sumsq_dev, ps_stream_t stream) {
+  PS_REQUIRE(plan_dev && hyper && state_dev && out_sumsq_dev && n_chunks > 0, "adam_sumsq: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)(state_dev + 2);
+  const float gs = hyper->grad_scale == 0.f ? 1.f : hyper->grad_scale;
+  hipLaunchKernelGGL(adam_sumsq_kernel, dim3(n_chunks), dim3(256), 0, st, (const char*)plan_dev, gs, state_dev, partial);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_total_kernel, dim3(1), dim3(256), 0, st, partial, n_chunks, out_sumsq_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+extern "C" int ps_adam_update_ext(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
+                                  const float* total_sumsq_dev, float* gnorm_out_dev, ps_stream_t stream) {
+  PS_REQUIRE(plan_dev && hyper && state_dev && total_sumsq_dev && n_chunks > 0, "adam_update_ext: bad argument");
+  PsAdamHyper hp = *hyper;
+  if (hp.grad_scale == 0.f) hp.grad_scale = 1.f;
+  hipLaunchKernelGGL(adam_update_ext_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const char*)plan_dev, hp,
+                     state_dev, total_sumsq_dev, gnorm_out_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 extern "C" int32_t ps_adam_plan_chunks_host(const void* plan_host) {
   return ((const AdamPlanHeader*)plan_host)->n_chunks;
 }

@@ -1495,9 +1495,17 @@ extern "C" int ps_rtm_review_embeddings(const PsRtmDesc* desc, const PsRtmTensor
   return PS_OK;
 }
 
+static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
+                             const PsRtmTensors* grads, float loss_scale, const float* loss_scale_dev, ps_stream_t stream);
 extern "C" int ps_rtm_backward(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
                                const PsRtmTensors* grads, float loss_scale, const float* loss_scale_dev,
                                ps_stream_t stream) {
+  const int rc = rtm_backward_impl(desc, params, batch, ws, grads, loss_scale, loss_scale_dev, stream);
+  if (rc != PS_OK) side_abort();          // never leave the side stream waiting behind a failed call (tem.hip)
+  return rc;
+}
+static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, const PsRtmBatch* batch, float* ws,
+                             const PsRtmTensors* grads, float loss_scale, const float* loss_scale_dev, ps_stream_t stream) {
   PS_REQUIRE(desc && params && batch && ws && grads, "rtm backward: null argument");
   const PsRtmDesc& D = *desc;
   RtmWs r; Ws w; PsTemDesc E; RtmK k;

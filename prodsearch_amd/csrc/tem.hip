@@ -32,6 +32,15 @@ void ps_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ps_last_error(void) { return g_err; }
 extern "C" const char* ps_version(void) { return "prodsearch_hip 0.1 (gfx950, fp32 MFMA)"; }
+// what the step computes in (bench.py's `dtype`): everything is fp32 in and out; products run on the fp32 MFMA or, where the
+// bf16x3 form is enabled (ps_gemm_x3_config, the fused per-replica kernels), as exact three-way bf16 splits of both fp32
+// operands — six bf16 MFMAs per product step, fp32 accumulation, the fp32 MFMA's accuracy
+bool gemm_x3_on();
+extern "C" const char* ps_arith_info(void) {
+  return gemm_x3_on() ? "f32 (fp32 MFMA and VALU; wide products, the fused per-replica kernels and grouped weight gradients as exact "
+                        "bf16x3 products: 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per step, fp32 accumulation)"
+                      : "f32 (fp32 MFMA and VALU)";
+}
 
 // ------------------------------------------------------------------ kernel timer (common.h)
 #include <vector>
@@ -501,6 +510,7 @@ static bool fork_by_kernel() {
 }
 // fork: everything enqueued on the main stream so far is visible to later side-stream work.  Each fork costs the
 // main stream one event packet (~6 us before its next kernel, measured), so callers batch their weight gradients.
+static int side_fork_injected_failure();
 int side_fork(hipStream_t main_st) {
   SideCtx* c = side_ctx();
   if (!c) return PS_OK;
@@ -531,7 +541,7 @@ int side_fork(hipStream_t main_st) {
     }
     PS_CHECK_HIP(hipStreamWaitValue32(c->stream, c->flag, c->fork_seq, hipStreamWaitValueGte, 0xffffffffu));
     c->used = true;
-    return PS_OK;
+    return side_fork_injected_failure();
   }
   if (c->sig_pending) {      // an event fork behind a pending value fork: release that one first
     PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0));
@@ -542,7 +552,7 @@ int side_fork(hipStream_t main_st) {
   PS_CHECK_HIP(hipEventRecord(ev, main_st));
   PS_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
   c->used = true;
-  return PS_OK;
+  return side_fork_injected_failure();
 }
 // short steps cross streams with write / wait-value operations, long ones with events (see side_ctx)
 void side_set_light(bool light) {
@@ -596,6 +606,24 @@ int side_join(hipStream_t main_st) {
   PS_CHECK_HIP(hipEventRecord(c->join, c->stream));
   PS_CHECK_HIP(hipStreamWaitEvent(main_st, c->join, 0));
   c->used = false;
+  return PS_OK;
+}
+
+// A failed entry point must not leave the side stream parked on a value nobody will store (a kernel-carried fork whose
+// carrying launch never happened): release it, so that the caller's next synchronize returns and the error surfaces.
+void side_abort() {
+  SideCtx* c = side_ctx();
+  if (!c) return;
+  if (c->sig_pending && c->flag) (void)hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0);
+  c->sig_pending = false;
+  (void)hipGetLastError();
+}
+extern "C" void ps_side_abort(void) { side_abort(); }
+// test hook: the n-th side_fork from now on fails AFTER it has parked the side stream (0 = off)
+static int g_fail_fork_in = 0;
+extern "C" void ps_debug_fail_fork(int nth) { g_fail_fork_in = nth; }
+static int side_fork_injected_failure() {
+  if (g_fail_fork_in > 0 && --g_fail_fork_in == 0) { ps_set_error("injected failure behind a side-stream fork (ps_debug_fail_fork)"); return PS_ERR_ARG; }
   return PS_OK;
 }
 
@@ -1226,9 +1254,19 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
 }
 
 // --------------------------------------------------------------------- backward
+static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                             float* ws, const PsTemTensors* grads, float loss_scale, const float* loss_scale_dev,
+                             ps_stream_t stream);
 extern "C" int ps_tem_backward(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
                                float* ws, const PsTemTensors* grads, float loss_scale, const float* loss_scale_dev,
                                ps_stream_t stream) {
+  const int rc = tem_backward_impl(desc, params, batch, ws, grads, loss_scale, loss_scale_dev, stream);
+  if (rc != PS_OK) side_abort();          // never leave the side stream waiting behind a failed call
+  return rc;
+}
+static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, const PsTemBatch* batch,
+                             float* ws, const PsTemTensors* grads, float loss_scale, const float* loss_scale_dev,
+                             ps_stream_t stream) {
   PS_REQUIRE(desc && params && batch && ws && grads, "backward: null argument");
   PsTemDesc D = *desc;
   D.C = 0;
@@ -1464,6 +1502,7 @@ extern "C" int ps_tem_backward_step(const PsTemDesc* desc, const PsTemTensors* p
     }
   }
   ps_step_ptr_slot() = nullptr;
+  if (rc != PS_OK) side_abort();
   return rc;
 }
 

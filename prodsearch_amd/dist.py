@@ -59,12 +59,21 @@ class GradExchange(object):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def _all_gather_flat(out, inp, world, group):
-    """``out`` [world, ...] <- every rank's ``inp`` [...].  One collective; backends without the flat form
-    (older gloo) get the list form over views of the same buffer."""
-    try:
+def _flat_gather_supported(group=None):
+    """Chosen ONCE from the backend, never by catching an exception around a live collective (a rank that fails inside a
+    collective and then enters a different one desynchronises the group and hides the real error).  nccl (= RCCL) and
+    current gloo have ``all_gather_into_tensor``; PS_DIST_LIST_GATHER=1 forces the list form."""
+    if os.environ.get('PS_DIST_LIST_GATHER', '0') not in ('', '0'):
+        return False
+    return hasattr(dist, 'all_gather_into_tensor') and dist.get_backend(group) in ('nccl', 'gloo')
+
+
+def _all_gather_flat(out, inp, world, group, flat=True):
+    """``out`` [world, ...] <- every rank's ``inp`` [...].  One collective: the flat form where the backend has it
+    (``flat``, decided at construction), else the list form over views of the same buffer."""
+    if flat:
         dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
-    except (RuntimeError, NotImplementedError):
+    else:
         dist.all_gather([out[r].view(-1) for r in range(world)], inp.view(-1), group=group)
 
 
@@ -83,8 +92,23 @@ class SparseGradExchange(object):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._flat = _flat_gather_supported(group) if self.world > 1 else True
+        self._capacity = {}          # table -> message capacity every rank agreed on (rows)
         if optim is not None:
             optim.grad_scale = 1.0 / self.world
+
+    def _agree_capacity(self, p, bound):
+        """all_gather_into_tensor needs the SAME message size on every rank, but a rank's index count depends on its
+        batch (ragged last batch with drop_last=False, history width padded to the batch's own maximum).  The capacity is
+        therefore agreed ONCE per table, the first time the exchange runs (every rank is in that step): MAX over ranks of
+        the largest index count the rank's batch size allows under the model's flags (``model._index_cap_bound``), one
+        host sync.  Later steps never re-negotiate — a collective only some ranks enter would hang — so a step whose
+        local count exceeds the agreement raises before any collective is entered."""
+        t = torch.tensor([int(bound)], dtype=torch.int64, device=p.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        cap = max(1, min(int(t[0]), p.shape[0]))
+        self._capacity[id(p)] = cap
+        return cap
 
     def _buffers(self, info, p, cap):
         x = info.get('xchg')
@@ -110,16 +134,29 @@ class SparseGradExchange(object):
         from . import _lib
         lib = _lib.load()
         m = self.model
+        # capacities first (first step only), and the local check, BEFORE any collective of this step is entered
+        caps = []
+        for path, p, gview in m._sparse_tabs:
+            local = int(p._ps_rows['cap'])
+            cap = self._capacity.get(id(p))
+            if cap is None:
+                cap = self._agree_capacity(p, max(local, m._index_cap_bound(path)))
+            if local > cap:
+                raise RuntimeError("row-sparse exchange: this rank's step addresses up to %d rows of a table but the ranks "
+                                   "agreed on messages of %d rows at the first step; build the exchange after setting "
+                                   "args.batch_size / uprev_review_limit to the largest batch any rank will see" % (local, cap))
+            caps.append(cap)
         dist.all_reduce(m._grad_flat[:m._n_dense_grad], op=dist.ReduceOp.SUM, group=self.group)
-        for _, p, gview in m._sparse_tabs:
+        for (_, p, gview), cap in zip(m._sparse_tabs, caps):
             info = p._ps_rows
-            cap, d = int(info['cap']), p.shape[1]
+            d = p.shape[1]
             x = self._buffers(info, p, cap)
             st = torch.cuda.current_stream(p.device).cuda_stream
+            # the rank's list holds at most info['cap'] <= cap rows: the message is padded with -1 / zeros up to cap
             _lib.check(lib.ps_pack_rows(gview.data_ptr(), d, info['rows'].data_ptr(), info['count'].data_ptr(), cap,
                                         x['msg_rows'].data_ptr(), x['msg_vals'].data_ptr(), st), 'ps_pack_rows')
-            _all_gather_flat(x['all_rows'], x['msg_rows'], self.world, self.group)
-            _all_gather_flat(x['all_vals'], x['msg_vals'], self.world, self.group)
+            _all_gather_flat(x['all_rows'], x['msg_rows'], self.world, self.group, self._flat)
+            _all_gather_flat(x['all_vals'], x['msg_vals'], self.world, self.group, self._flat)
             lst = (_lib.PsIdxList * 1)()
             lst[0].idx, lst[0].n = x['all_rows'].data_ptr(), self.world * cap
             _lib.check(lib.ps_coalesce_rows(lst, 1, p.shape[0], -1, x['ws'].data_ptr(), x['urows'].data_ptr(),
@@ -131,10 +168,160 @@ class SparseGradExchange(object):
         return None
 
 
-def make_exchange(model, optim=None, group=None):
-    """The exchange matching the model's optimizer mode."""
+def flatten_parameters(model, multiple=4):
+    """Re-home every graded hot-path parameter of ``model`` into ONE flat fp32 buffer laid out exactly like the model's
+    flat gradient buffer (small tensors first, tables last, 16-byte aligned slices, total length a multiple of
+    ``multiple``).  The parameters stay ordinary ``nn.Parameter``s with the reference's names — only their storage
+    moves — and the C-ABI tensor table is refreshed.  Returns the flat parameter buffer."""
+    model.__dict__['_flat_pad_to'] = int(multiple)
+    for p in model.parameters():
+        p.grad = None
+    model._params_struct = None                 # (re)build the flat gradient buffer with the padding
+    model._grads_struct = None
+    model.__dict__['_grad_clean'] = False
+    ps, _ = model._structs()
+    gflat = model._grad_flat
+    assert gflat.numel() % multiple == 0
+    pflat = torch.zeros_like(gflat)
+    with torch.no_grad():
+        for p, v in model._grad_views:
+            o, n = v.storage_offset(), p.numel()
+            dst = pflat[o:o + n].view_as(p)
+            dst.copy_(p.data)
+            p.data = dst
+    for path, p in model._named_hot_params():    # pointers moved
+        model._set_field(ps, path, p.data_ptr())
+    model.__dict__['_param_flat'] = pflat
+    return pflat
+
+
+class ShardedAdamExchange(object):
+    """Dense data-parallel step with the optimizer SHARDED over the ranks (ZeRO-1 form; new design, the reference is
+    single-process: trainer.py:74-79, optimizers.py:241-243).
+
+        reduce-scatter(sum) of the flat gradient  ->  rank r owns slice r of the reduced gradient
+        ps_adam_sumsq on the slice  ->  ONE scalar all-reduce  =  the global clip norm over ALL gradients
+        ps_adam_update_ext: clip + dense Adam on the slice only (moments exist only for the slice: 1/world of the state)
+        all-gather of the updated parameter slices into every rank's flat parameter buffer
+
+    Same arithmetic as the replicated optimizer (every element sees the identical reduced gradient, global norm, step
+    count), so the reference's dense-Adam semantics hold exactly, but each rank streams 1/world of the optimizer's
+    8 dwords per parameter (C2, N = 8: 42 us -> ~6 us of clip+Adam per step) and the two collectives move what ONE
+    all-reduce moves (an all-reduce IS a reduce-scatter followed by an all-gather).  Replicas stay bitwise identical:
+    every parameter value is computed once, by its owner.
+
+    ``exchange()`` (between ``loss.backward()`` and ``optim.step()``) runs the reduce-scatter; ``optim.step()`` runs the
+    rest (the exchange installs itself as ``optim._sharded``), so trainer.py's call order is unchanged."""
+
+    def __init__(self, model, optim, group=None):
+        self.model, self.optim, self.group = model, optim, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lib = self._load_lib()
+        W = self.world
+        self.pflat = flatten_parameters(model, multiple=4 * W)
+        n = self.pflat.numel()
+        self.shard = n // W
+        self.lo, self.hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        dev = self.pflat.device
+        self.g_shard = torch.zeros(self.shard, device=dev, dtype=torch.float32)
+        self.m_shard = torch.zeros(self.shard, device=dev, dtype=torch.float32)
+        self.v_shard = torch.zeros(self.shard, device=dev, dtype=torch.float32)
+        self.p_shard = self.pflat[self.lo:self.hi]
+        self._build_plan(dev)
+        self.state[0] = optim._step
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.gnorm = torch.zeros(2, device=dev, dtype=torch.float32)
+        self._reduced = False
+        optim.grad_scale = 1.0 / W
+        optim._sharded = self
+        optim._plan = None
+
+    def _load_lib(self):
+        from . import _lib
+        return _lib.load()
+
+    def _build_plan(self, dev):
+        from . import _lib
+        numel = torch.tensor([self.shard], dtype=torch.int64)
+        addr = lambda t: torch.tensor([t.data_ptr()], dtype=torch.int64)
+        pa, ga, ma, va = addr(self.p_shard), addr(self.g_shard), addr(self.m_shard), addr(self.v_shard)
+        nbytes = self.lib.ps_adam_plan_bytes(1, numel.data_ptr())
+        host = torch.zeros(nbytes, dtype=torch.uint8)
+        _lib.check(self.lib.ps_adam_plan_write_host(1, pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(),
+                                                    numel.data_ptr(), host.data_ptr()), 'ps_adam_plan_write_host')
+        self.n_chunks = self.lib.ps_adam_plan_chunks_host(host.data_ptr())
+        self.plan = host.to(dev)
+        self.state = torch.zeros(2 + (self.n_chunks + 1) // 2, device=dev, dtype=torch.int64)
+
+    # the three device operations, overridable so that tests/test_dist_cpu.py can drive the collective protocol with a
+    # CPU restatement of the kernels over gloo (the product path below has no CPU form: it calls the HIP library)
+    def _k_zero(self, flat):
+        from . import _lib
+        st = torch.cuda.current_stream(flat.device).cuda_stream
+        _lib.check(self.lib.ps_zero_floats(flat.data_ptr(), flat.numel(), st), 'ps_zero_floats')
+
+    def _k_sumsq(self, hp):
+        from . import _lib
+        st = torch.cuda.current_stream(self.pflat.device).cuda_stream
+        _lib.check(self.lib.ps_adam_sumsq(self.plan.data_ptr(), self.n_chunks, hp, self.state.data_ptr(),
+                                          self.sumsq.data_ptr(), st), 'ps_adam_sumsq')
+
+    def _k_update(self, hp):
+        from . import _lib
+        st = torch.cuda.current_stream(self.pflat.device).cuda_stream
+        _lib.check(self.lib.ps_adam_update_ext(self.plan.data_ptr(), self.n_chunks, hp, self.state.data_ptr(),
+                                               self.sumsq.data_ptr(), self.gnorm.data_ptr(), st), 'ps_adam_update_ext')
+
+    def __call__(self):
+        """reduce-scatter of the step's flat gradient; leaves the flat buffer zeroed for the next backward."""
+        m = self.model
+        flat = m._grad_flat
+        if self.world > 1:
+            dist.reduce_scatter_tensor(self.g_shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.g_shard.copy_(flat[self.lo:self.hi])
+        self._k_zero(flat)
+        m.__dict__['_grad_clean'] = True
+        self._reduced = True
+        return None
+
+    def step(self, hp):
+        """The optimizer half (called by ``Optimizer.step``)."""
+        if not self._reduced:
+            raise RuntimeError("sharded optimizer: call the exchange between loss.backward() and optim.step()")
+        self._reduced = False
+        hp.zero_grads = 0
+        self._k_sumsq(hp)
+        if self.world > 1:
+            dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
+        self._k_update(hp)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.pflat, self.p_shard, group=self.group)
+
+    def full_moments(self):
+        """(exp_avg, exp_avg_sq) flat buffers gathered from every rank's shard (checkpointing: a collective)."""
+        out = []
+        for t in (self.m_shard, self.v_shard):
+            full = torch.empty_like(self.pflat)
+            if self.world > 1:
+                dist.all_gather_into_tensor(full, t, group=self.group)
+            else:
+                full.copy_(t)
+            out.append(full)
+        return out
+
+
+def make_exchange(model, optim=None, group=None, mode=None):
+    """The exchange matching the model's optimizer mode.  Dense mode: ``sharded`` (reduce-scatter -> owner clip+Adam ->
+    all-gather, the default when there is more than one rank and an optimizer to shard) or ``allreduce`` (one flat
+    all-reduce, every rank runs the whole optimizer; PS_DP_EXCHANGE=allreduce or ``mode=``)."""
     if getattr(model, '_row_sparse', lambda: False)():
         return SparseGradExchange(model, optim, group)
+    mode = mode or os.environ.get('PS_DP_EXCHANGE') or 'sharded'
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if mode == 'sharded' and optim is not None and world > 1:
+        return ShardedAdamExchange(model, optim, group)
     return GradExchange(lambda: model._grad_flat, optim, group)
 
 

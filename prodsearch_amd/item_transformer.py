@@ -27,6 +27,9 @@ import torch.nn as nn
 from . import _lib
 
 
+_DET_SET_BY_ARGS = False     # a model's args.deterministic turned the process-wide mode on
+
+
 # ------------------------------------------------------------ parameter holders
 class _Holder(nn.Module):
     def forward(self, *a, **k):     # pragma: no cover - never on the hot path
@@ -155,8 +158,16 @@ class _Plan(object):
 class ItemTransformerRanker(nn.Module):
     def __init__(self, args, device, vocab_size, product_size, vocab_words, word_dists=None):
         super(ItemTransformerRanker, self).__init__()
-        if getattr(args, 'deterministic', False):      # bitwise reproducible steps (process-wide switch, ps_set_deterministic)
+        # args.deterministic: bitwise reproducible steps.  The switch is PROCESS-WIDE (ps_set_deterministic); a model built
+        # WITHOUT the flag after one that set it through its args turns the mode off again, so it does not silently inherit
+        # the ~2.6x slower single-stream step.  Explicit ps_set_deterministic() calls / PS_DETERMINISTIC=1 are left alone.
+        global _DET_SET_BY_ARGS
+        if getattr(args, 'deterministic', False):
             _lib.load().ps_set_deterministic(1)
+            _DET_SET_BY_ARGS = True
+        elif _DET_SET_BY_ARGS:
+            _lib.load().ps_set_deterministic(0)
+            _DET_SET_BY_ARGS = False
         if args.model_name not in ('item_transformer', 'QEM'):
             raise NotImplementedError("model_name %r is outside the hot path (item_transformer/QEM only)"
                                       % args.model_name)
@@ -341,6 +352,8 @@ class ItemTransformerRanker(nn.Module):
         for _, p in graded:
             offs.append(cur)
             cur += (p.numel() + 3) // 4 * 4
+        pad = int(self.__dict__.get('_flat_pad_to', 4))       # dist.flatten_parameters: a multiple of 4 * world
+        cur = (cur + pad - 1) // pad * pad
         self._grad_flat = torch.zeros(cur, device=dev, dtype=torch.float32)
         self._grad_views = []
         for (path, p), o in zip(graded, offs):
@@ -474,6 +487,7 @@ class ItemTransformerRanker(nn.Module):
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=False)
+        self.__dict__['_last_plan'] = plan
         self._fwd_step += 1
         plan.desc.step = self._fwd_step
         loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
@@ -524,6 +538,23 @@ class ItemTransformerRanker(nn.Module):
         if path == ('hist_product_emb',):
             return ([ui] if tem else []), self.prod_pad_idx
         return [qw, pw, nw], self.word_pad_idx
+
+    def _index_cap_bound(self, path):
+        """Largest index count one step of this rank can address in ``path``'s table under the model's flags, for the
+        batch size of the latest forward: the history width is padded per batch (<= uprev_review_limit,
+        item_pv_dataloader.py:121-143) while Q is the corpus-wide padded query length.  The data-parallel row exchange
+        sizes its fixed-capacity messages with the maximum of this over the ranks (dist.SparseGradExchange)."""
+        plan = self.__dict__.get('_last_plan')
+        if plan is None:
+            return 1
+        d, a = plan.desc, self.args
+        tem = a.model_name == 'item_transformer'
+        Lmax = max(int(d.L), int(getattr(a, 'uprev_review_limit', d.L)))
+        if path == ('product_emb',):
+            return d.B * (1 + d.K + (Lmax if tem and not a.sep_prod_emb else 0))
+        if path == ('hist_product_emb',):
+            return d.B * Lmax if tem else 1
+        return d.B * (d.Q + d.W + d.W * d.K)
 
     def _coalesce_touched(self, plan):
         lib = _lib.load()

@@ -44,6 +44,7 @@ class Optimizer(object):
         self.row_sparse = bool(row_sparse)   # extension: tables updated by touched rows only
         self.params = []
         self._plan = None
+        self._sharded = None                 # dist.ShardedAdamExchange: this rank updates 1/world of the flat buffers
 
     def set_parameters(self, params):
         """``set_parameters`` (optimizers.py:165-187): every parameter that requires grad."""
@@ -129,7 +130,7 @@ class Optimizer(object):
     def step(self):
         """``Optimizer.step`` (optimizers.py:205-243)."""
         lib = _lib.load()
-        plan = self._plan if self._plan_ok() else self._build_plan()
+        plan = None if self._sharded is not None else (self._plan if self._plan_ok() else self._build_plan())
         self._step += 1
         if self.decay_method == "noam":      # host mirror of the in-kernel schedule (optimizers.py:214-219)
             self.learning_rate = self.original_lr * min(self._step ** (-0.5),
@@ -142,6 +143,8 @@ class Optimizer(object):
         hp.noam = int(self.decay_method == "noam")
         hp.warmup_steps = self.warmup_steps
         hp.grad_scale = self.grad_scale
+        if self._sharded is not None:
+            return self._sharded.step(hp)
         dev = plan['live'][0].device
         st = torch.cuda.current_stream(dev).cuda_stream
         if plan['rows']:
@@ -181,6 +184,8 @@ class Optimizer(object):
     @property
     def last_grad_norm(self):
         """Pre-clip global gradient norm of the last step (host sync when read)."""
+        if self._sharded is not None:
+            return float(self._sharded.gnorm[0])
         return float(self._plan['gnorm'][0]) if self._plan else None
 
     # ------------------------------------------------------------ checkpointing
@@ -189,6 +194,12 @@ class Optimizer(object):
         parameter index) so a reference checkpoint's ``optim.optimizer.state_dict()`` maps 1:1."""
         state = {}
         st = getattr(self, '_state_tensors', {})
+        if self._sharded is not None:        # moments live sharded over the ranks: gather them (a collective)
+            mf, vf = self._sharded.full_moments()
+            st = {}
+            for p, v in self._sharded.model._grad_views:
+                o, n = v.storage_offset(), p.numel()
+                st[id(p)] = (mf[o:o + n].view_as(p), vf[o:o + n].view_as(p))
         for i, p in enumerate(self.params):
             if id(p) in st:
                 m, v = st[id(p)]

@@ -246,6 +246,8 @@ class ProductRanker(nn.Module):
         for _, p in graded:
             offs.append(cur)
             cur += (p.numel() + 3) // 4 * 4
+        pad = int(self.__dict__.get('_flat_pad_to', 4))       # dist.flatten_parameters: a multiple of 4 * world
+        cur = (cur + pad - 1) // pad * pad
         self._grad_flat = torch.zeros(cur, device=dev, dtype=torch.float32)
         self._grad_views = []
         for (path, p), o in zip(graded, offs):

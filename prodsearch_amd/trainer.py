@@ -93,6 +93,11 @@ class Trainer(object):
                         acc = loss.detach().clone() if acc is None else acc.add_(loss.detach())
                     if step % args.steps_per_checkpoint == 0:    # the only host sync of the loop
                         n = args.steps_per_checkpoint
+                        # row-sparse mode: the kernels drop out-of-range indices / list overflows and set a status word;
+                        # it is read HERE, where the loop synchronises anyway, so such a step cannot pass silently
+                        chk = getattr(self.model, 'check_index_errors', None)
+                        if chk is not None:
+                            chk()
                         if self.rtm:
                             ps, iw, tot = 0., 0., float(acc) / n
                             acc = None

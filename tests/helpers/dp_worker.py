@@ -16,7 +16,7 @@ def global_problem(mode, Bg, seed=31):
     """Model arguments + the GLOBAL batch and negative draws, identical in every process."""
     from prodsearch_amd import readme_tem_args, synth
     P_, V, K, L, Q, W = 18357, 32387, 20, 20, 8, 1
-    a = readme_tem_args(dropout=0.0, lr=0.002, row_sparse_adam=(mode == 'sparse'))
+    a = readme_tem_args(dropout=0.0, lr=0.002, row_sparse_adam=(mode == 'sparse'))      # 'dense' / 'allreduce': dense Adam
     wd = synth.make_word_dists(V)
     batch = synth.make_tem_batch(seed, Bg, P_, V, Q=Q, L=L, W=W, word_dists=wd)
     ni, nw = synth.sample_negatives(seed + 1, Bg, K, W, P_, wd)
@@ -32,7 +32,7 @@ def slice_batch(batch, ni, nw, lo, hi):
     return b, ni[lo:hi].contiguous(), nw[lo:hi].contiguous()
 
 
-def run(mode, Bg, steps, rank, world, exchange_factory):
+def run(mode, Bg, steps, rank, world, exchange_factory, ragged=0):
     import numpy as np
     import torch
     from prodsearch_amd import ItemTransformerRanker, build_optim
@@ -42,7 +42,8 @@ def run(mode, Bg, steps, rank, world, exchange_factory):
     optim = build_optim(a, m, None)
     exchange = exchange_factory(m, optim)
     per = Bg // world
-    b, bi, bw = slice_batch(batch, ni, nw, rank * per, (rank + 1) * per)
+    # --ragged n: the LAST rank's slice is n rows short (unequal per-rank batches, e.g. a loader with drop_last=False)
+    b, bi, bw = slice_batch(batch, ni, nw, rank * per, (rank + 1) * per - (ragged if rank == world - 1 else 0))
     b, bi, bw = b.to('cuda'), bi.cuda(), bw.cuda()
     m.train()
     times = []
@@ -125,6 +126,7 @@ def main():
     ap.add_argument('--global-batch', type=int, default=384)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--out', required=True)
+    ap.add_argument('--ragged', type=int, default=0)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -133,7 +135,8 @@ def main():
     if a.model == 'rtm':
         out = run_rtm(a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o))
     else:
-        out = run(a.mode, a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o))
+        xmode = 'allreduce' if a.mode == 'allreduce' else None
+        out = run(a.mode, a.global_batch, a.steps, rank, world, lambda m, o: pdist.make_exchange(m, o, mode=xmode), ragged=a.ragged)
     np.savez(a.out + '.rank%d.npz' % rank, **out)
     if world > 1:
         torch.distributed.barrier()

@@ -81,6 +81,7 @@ def _sparse_worker(rank, world, port, q):
     n_rows, d, cap = 500, 16, 96
     gen = torch.Generator().manual_seed(7 + rank)
     out = []
+    rank_round_flat = [True]
     # ragged: rank 0 touches 37 rows, rank 1 touches 90 (some shared), plus an empty-list round
     for n_touch in ((37, 90)[rank], 0 if rank == 0 else 5):
         rows = torch.sort(torch.randperm(n_rows, generator=gen)[:n_touch]).values
@@ -93,8 +94,10 @@ def _sparse_worker(rank, world, port, q):
         msg_vals[:n_touch] = vals
         all_rows = torch.empty(world, cap, dtype=torch.int64)
         all_vals = torch.empty(world, cap, d)
-        pdist._all_gather_flat(all_rows, msg_rows, world, None)
-        pdist._all_gather_flat(all_vals, msg_vals, world, None)
+        flat = pdist._flat_gather_supported(None) and rank_round_flat[0]
+        pdist._all_gather_flat(all_rows, msg_rows, world, None, flat)
+        pdist._all_gather_flat(all_vals, msg_vals, world, None, flat)
+        rank_round_flat[0] = False                             # second round: the list form
         ar, av = all_rows.numpy(), all_vals.numpy()
         union = np.unique(ar[ar >= 0])
         merged = np.zeros((n_rows, d), np.float32)
@@ -136,3 +139,137 @@ def test_single_process_is_a_no_op():
     ex = pdist.GradExchange(lambda: flat, opt)
     assert ex() is None and opt.grad_scale == 1.0 and float(flat.sum()) == 8.0
     assert pdist.max_over_ranks(3.5, torch.device('cpu')) == 3.5
+
+
+# ------------------------------------------------------------------ sharded optimizer (reduce-scatter / owner Adam / all-gather)
+class _StubModel(torch.nn.Module):
+    """The attributes dist.flatten_parameters / ShardedAdamExchange use of the product models, on CPU tensors."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.table = torch.nn.Parameter(torch.randn(37, 8, generator=g))
+        self.w = torch.nn.Parameter(torch.randn(6, 5, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(7, generator=g))
+        self._params_struct = self._grads_struct = None
+        self._grad_flat = self._grad_views = None
+        self.fields = {}
+
+    def _named_hot_params(self):
+        return [(('table',), self.table), (('w',), self.w), (('b',), self.b)]
+
+    def _set_field(self, struct, path, value):
+        struct[path] = value
+
+    def _structs(self):
+        if self._params_struct is not None:
+            return self._params_struct, self._grads_struct
+        graded = sorted(self._named_hot_params(), key=lambda t: t[1].numel())
+        offs, cur = [], 0
+        for _, p in graded:
+            offs.append(cur)
+            cur += (p.numel() + 3) // 4 * 4
+        pad = int(self.__dict__.get('_flat_pad_to', 4))
+        cur = (cur + pad - 1) // pad * pad
+        self._grad_flat = torch.zeros(cur)
+        self._grad_views = [(p, self._grad_flat[o:o + p.numel()].view_as(p)) for (_, p), o in zip(graded, offs)]
+        self._params_struct, self._grads_struct = {}, {}
+        return self._params_struct, self._grads_struct
+
+
+class _Hyper(object):
+    lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale, zero_grads = 0.01, 0.9, 0.999, 1e-9, 0.0, 5.0, 1.0, 0
+
+
+def _sharded_worker(rank, world, port, q):
+    """ShardedAdamExchange's protocol over gloo with a CPU restatement of its three kernels (oracle/optim.py's clip+Adam
+    arithmetic): after every step all ranks hold bitwise identical parameters, and they equal a single-process
+    clip_grad_norm_ + Adam(eps=1e-9) on the MEAN of the ranks' gradients (optimizers.py:241-243)."""
+    import math
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    pdist.init_from_env(backend='gloo')
+
+    class CpuSharded(pdist.ShardedAdamExchange):
+        def _load_lib(self):
+            return None
+
+        def _build_plan(self, dev):
+            self.n_chunks, self.plan, self.state = 1, None, torch.zeros(2, dtype=torch.int64)
+
+        def _k_zero(self, flat):
+            flat.zero_()
+
+        def _k_sumsq(self, hp):
+            self.state[0] += 1
+            self.sumsq[0] = float(((self.g_shard * hp.grad_scale) ** 2).sum())
+
+        def _k_update(self, hp):
+            t = int(self.state[0])
+            norm = math.sqrt(float(self.sumsq[0]))
+            coef = min(hp.max_grad_norm / (norm + 1e-6), 1.0)
+            g = self.g_shard * (coef * hp.grad_scale)
+            self.m_shard.mul_(hp.beta1).add_(g, alpha=1 - hp.beta1)
+            self.v_shard.mul_(hp.beta2).addcmul_(g, g, value=1 - hp.beta2)
+            denom = self.v_shard.sqrt() / math.sqrt(1 - hp.beta2 ** t) + hp.eps
+            self.p_shard.addcdiv_(self.m_shard, denom, value=-hp.lr / (1 - hp.beta1 ** t))
+            self.gnorm[0] = norm
+
+    class Opt(object):
+        _step, grad_scale, _sharded, _plan = 0, 1.0, None, None
+
+    torch.manual_seed(3)                       # identical start on every rank
+    model, opt = _StubModel(), Opt()
+    ref = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ex = CpuSharded(model, opt)
+    ok_layout = model._param_flat.numel() % (4 * world) == 0 and all(
+        p.data_ptr() == model._param_flat.data_ptr() + 4 * v.storage_offset() for p, v in model._grad_views)
+    # reference: torch's own clip + Adam on the mean gradient
+    refp = [torch.nn.Parameter(ref[n].clone()) for n, _ in model.named_parameters()]
+    ropt = torch.optim.Adam(refp, lr=_Hyper.lr, betas=(0.9, 0.999), eps=1e-9)
+    ok = True
+    for step in range(3):
+        model._structs()
+        grads_all = []
+        for r in range(world):                 # every rank can restate every rank's gradient (seeded by rank and step)
+            g = torch.Generator().manual_seed(1000 * step + r)
+            grads_all.append([torch.randn(p.shape, generator=g) * 3.0 for _, p in model.named_parameters()])
+        for (p, v), gr in zip([(p, dict((id(q), w) for q, w in model._grad_views)[id(p)]) for _, p in model.named_parameters()],
+                              grads_all[rank]):
+            v.copy_(gr)
+        ex()
+        assert float(model._grad_flat.abs().sum()) == 0.0 and model._grad_clean
+        hp = _Hyper()
+        hp.grad_scale = opt.grad_scale
+        ex.step(hp)
+        for i, q_ in enumerate(refp):
+            q_.grad = sum(ga[i] for ga in grads_all) / world
+        torch.nn.utils.clip_grad_norm_(refp, 5.0)
+        ropt.step()
+        for (n, p), q_ in zip(model.named_parameters(), refp):
+            ok = ok and torch.allclose(p.detach(), q_.detach(), rtol=2e-5, atol=2e-6)
+    flats = [torch.zeros_like(model._param_flat) for _ in range(world)]
+    dist.all_gather(flats, model._param_flat)
+    same = all(torch.equal(flats[0], f) for f in flats)
+    mf, vf = ex.full_moments()
+    ok_m = all(torch.allclose(mf[v.storage_offset():v.storage_offset() + p.numel()].view_as(p),
+                              ropt.state[q_]['exp_avg'], rtol=2e-5, atol=1e-6)
+               for (p, v), q_ in zip([(p, dict((id(a), b) for a, b in model._grad_views)[id(p)]) for _, p in model.named_parameters()], refp))
+    q.put((rank, bool(ok_layout), bool(ok), bool(same), bool(ok_m), opt.grad_scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sharded_adam_protocol():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[3] and r[4] and r[5] == 0.5, r

@@ -52,7 +52,7 @@ def _run_ranks(mode, out, world=2, steps=2, extra=()):
     return [dict(np.load(out + '.rank%d.npz' % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize('mode', ['dense', 'sparse'])
+@pytest.mark.parametrize('mode', ['dense', 'allreduce', 'sparse'])      # dense = sharded optimizer (the default), allreduce = replicated
 def test_two_ranks_of_192_equal_one_rank_of_384(mode, tmp_path):
     sys.path.insert(0, os.path.join(HERE, 'helpers'))
     import dp_worker
@@ -85,6 +85,18 @@ def test_two_ranks_of_192_equal_one_rank_of_384(mode, tmp_path):
     # per-rank mean loss of the last step: the two halves average to the full batch's loss
     assert abs(0.5 * (r0['__loss'] + r1['__loss']) - single['__loss']) < 2e-3 * abs(single['__loss'])
     print("dp %s: 2-rank step %.3f ms (gloo, one GPU), single-rank %.3f ms" % (mode, r0['__ms'], single['__ms']))
+
+
+@pytest.mark.parametrize('mode', ['dense', 'sparse'])
+def test_unequal_per_rank_batches_keep_the_replicas_in_lock_step(mode, tmp_path):
+    """Ranks whose batches differ in size (192 and 150 rows: a loader with drop_last=False) address different numbers of
+    table rows; the row-sparse exchange's fixed-capacity messages are sized by the capacity the ranks agree on at the first
+    step (dist.SparseGradExchange._agree_capacity), so the collectives match and the replicas stay bitwise identical."""
+    r0, r1 = _run_ranks(mode, str(tmp_path / ('rag_' + mode)), 2, 2, extra=('--ragged', '42'))
+    for k in r0:
+        if not k.startswith('__'):
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    assert np.isfinite(r0['__loss']) and np.isfinite(r1['__loss'])
 
 
 def test_sparse_exchange_is_not_slower_than_twice_the_dense_one(tmp_path):
@@ -156,6 +168,34 @@ def test_bench_contract_line_from_two_ranks_with_its_extra_legs():
     assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 2 * 384 * 20 * 6 / (d['ms_per_step'] * 6e-3)) < 1e-6 * d['value']
     assert d['roofline']['launches_timed'] == 6 and 'median_ms_per_step' in d and 'cpu_baseline' not in d
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no torchrun environment starts the two ranks itself, before anything touches the GPU
+    (gloo here: both ranks share cuda:0), and prints ONE line with n_gpus = 2; with one visible device and the default
+    backend (RCCL: one rank per GPU) it must exit non-zero and print NO line — never a silent world-1 run."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), 'bench.py')
+    env = dict(os.environ, PS_DIST_BACKEND='gloo', PS_BENCH_WATCHDOG='300')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '6', '--warmup', '2', '--reps', '0', '--cpu-steps', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 768
+    assert 'reduce-scatter' in d['config']['step']                     # the sharded optimizer is the dense default
+    if torch.cuda.device_count() < 2:
+        env.pop('PS_DIST_BACKEND')
+        p = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '2', '--warmup', '0', '--no-extras'], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    env['WORLD_SIZE'], env['RANK'], env['LOCAL_RANK'] = '1', '0', '0'     # a launcher that started ONE rank for --gpus 2
+    p = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '2', '--warmup', '0', '--no-extras'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
 
 
 def test_side_stream_sequence_words_restart_before_they_wrap():
