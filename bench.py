@@ -227,14 +227,17 @@ def _pools(one_step, ncpu, n_steps, cands=(8, 32, None)):
     step is timed on a few pool sizes — 8 (the survey probe's), 32 and ALL hardware threads — `n_steps` steps each after one
     warm-up; the fastest pool is the reported baseline and every pool's rate is listed beside it."""
     cands = sorted({min(ncpu, c if c else ncpu) for c in cands})
+    before = torch.get_num_threads()
     torch.set_num_threads(cands[0])
     one_step()                                   # warm-up (allocator, first-touch)
     per = {}
     for c in cands:
         torch.set_num_threads(c)
-        ts = [one_step() for _ in range(n_steps)]
+        # (the all-threads pool oversubscribes these small ops ~15x on a 256-thread host: one step there bounds the run)
+        ts = [one_step() for _ in range(n_steps if c <= 64 else 1)]
         per[c] = sum(ts) / len(ts)
     best = min(per, key=per.get)
+    torch.set_num_threads(before)                # a 256-thread pool left behind slows the HOST side of the GPU steps that follow
     return best, per
 
 
@@ -401,8 +404,12 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                                 "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
                                 "timing": "HIP event pair around every in-step launch, on the launch stream, over a second "
                                           "pass of %d steps (ps_ktimer)" % steps}, **extra)
-        if world == 1 and cpu_steps > 0 and name in ('c2', 'c4'):
+        if world == 1 and cpu_steps > 0 and name == 'c4':
             out["cpu_baseline"] = wl.cpu_baseline(cpu_steps)
+        elif world == 1 and cpu_steps > 0 and name == 'c2':
+            # deferred by the caller to the very end of the run (after the GPU legs of `also`): only ns / shapes are needed
+            ns, cfg = wl.ns, dict(wl.c)
+            out["_cpu_baseline_later"] = lambda: cpu_baseline_tem(ns, cfg, cpu_steps)
     del wl, model, optim, exchange
     torch.cuda.empty_cache()
     return out
@@ -529,12 +536,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     out = measure(a, a.workload, rank, world, dev, a.steps, a.warmup, a.reps, not a.no_extras, a.cpu_steps, a.items)
+    later = out.pop("_cpu_baseline_later", None)
     if a.workload == 'c2' and world == 1 and not a.no_extras and not a.no_also:
         out["roofline_hbm"] = gather_score_hbm_leg(dev)
         also = []
-        for name, items in (('c4', 0), ('c5', ALSO_C5_ITEMS)):
-            also.append(measure(a, name, rank, world, dev, 100, 20, 0, True, 1 if name == 'c4' else 0, items))
+        for name, items in (('c5', ALSO_C5_ITEMS), ('c4', 0)):
+            also.append(measure(a, name, rank, world, dev, 200, 30, 0, True, 1 if name == 'c4' else 0, items))
         out["also"] = also
+    if later is not None:
+        out["cpu_baseline"] = later()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

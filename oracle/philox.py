@@ -4,7 +4,8 @@ The HIP kernels draw dropout from Philox4x32-10 (Salmon et al., SC'11 — the
 generator torch/curand use) keyed by ``(seed, step)``; element ``(row, col)`` of
 dropout site ``s`` uses counter ``(col, row >> 2, s, step)`` and output word
 ``row & 3``; it is kept iff ``word >= floor(p * 2**32)`` and scaled by ``1/(1-p)``
-(prodsearch_amd/csrc/common.h).  This file restates that function in numpy so
+— or, for the ctx / ff1 / ff2 sites, the 16-bit half ``col & 7`` of counter
+``(col >> 3, row, s, step)`` (``drop_mult`` below; prodsearch_amd/csrc/common.h).  This file restates that function in numpy so
 the oracle — and, through the torch dropout hooks of tests/golden/make_golden.py,
 the REFERENCE itself — can run with exactly the masks the kernels draw.
 
@@ -43,17 +44,34 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def site_is_half(site):
+    """Sites ctx / ff1 / ff2 of every layer take the 16-bit column-shared form (csrc/common.h, drop_site_is_half)."""
+    k = (site - 1) & 7
+    return 1 <= site < 0x100 and 1 <= k <= 3
+
+
 def drop_mult(rows, cols, site, step, seed, p):
-    """Multiplier array (0 or 1/(1-p), float32) for broadcastable integer arrays rows/cols."""
+    """Multiplier array (0 or 1/(1-p), float32) for broadcastable integer arrays rows/cols.
+
+    classic form: word ``row & 3`` of Philox(col, row >> 2, site, step), kept iff >= floor(p * 2**32);
+    half form (ctx / ff1 / ff2): 16-bit half ``col & 7`` of Philox(col >> 3, row, site, step) — low half of word
+    ``(col & 7) >> 1`` for even ``col``, high half for odd — kept iff >= floor(p * 2**16)."""
     rows = np.asarray(rows, dtype=np.uint64)
     cols = np.asarray(cols, dtype=np.uint64)
     rows, cols = np.broadcast_arrays(rows, cols)
+    scale = np.float32(1.0 / (1.0 - float(np.float32(p))))
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    if site_is_half(int(site)):
+        thr16 = np.uint64(int(float(np.float32(p)) * 65536.0))
+        w = philox4x32_10(cols >> np.uint64(3), rows, np.uint64(site), np.uint64(step & 0xFFFFFFFF), k0, k1)
+        e = (cols & np.uint64(7)).astype(np.int64)
+        word = np.choose(e >> 1, w)
+        hv = np.where((e & 1) == 1, word >> np.uint64(16), word & np.uint64(0xFFFF))
+        return np.where(hv >= thr16, scale, np.float32(0)).astype(np.float32)
     thr = np.uint64(int(float(np.float32(p)) * 4294967296.0))
-    w = philox4x32_10(cols, rows >> np.uint64(2), np.uint64(site), np.uint64(step & 0xFFFFFFFF),
-                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = philox4x32_10(cols, rows >> np.uint64(2), np.uint64(site), np.uint64(step & 0xFFFFFFFF), k0, k1)
     sel = (rows & np.uint64(3)).astype(np.int64)
     word = np.choose(sel, w)
-    scale = np.float32(1.0 / (1.0 - float(np.float32(p))))
     return np.where(word >= thr, scale, np.float32(0)).astype(np.float32)
 
 

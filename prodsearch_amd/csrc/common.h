@@ -44,8 +44,8 @@ struct KTimeScope {
 
 // ------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al., SC'11), the generator torch/curand use; 10 rounds.
-// Dropout element (row, col) of site s at step t:  ctr = (col, row>>2, s, t), word = row&3,
-// keep iff word >= thr(p).  The oracle restates the same function (oracle/philox.py).
+// Dropout element (row, col) of site s at step t: see DropSpec below (two forms).  The oracle restates the same function
+// (oracle/philox.py).
 struct Philox4 {
   uint32_t x, y, z, w;
 };
@@ -73,7 +73,20 @@ struct DropSpec {      // one dropout site
   float scale;         // 1/(1-p)
   uint32_t site, step, k0, k1;
   const uint32_t* step_ptr;   // if set the step lives in device memory (graph replay: kernel arguments stay constant)
+  uint32_t half;       // 1: the 16-bit column-shared form below (sites ctx / ff1 / ff2 of every layer)
+  uint32_t thr16;      // keep iff u16 >= thr16 ; thr16 = floor(p * 2^16)
 };
+// Two forms of the stream (both restated in oracle/philox.py, pinned through ps_dropout_mult_host):
+//   classic (fs, attention, review and token sites): element (row, col) = word (row & 3) of Philox(col, row >> 2, site, step)
+//     — four consecutive ROWS of a column share a call, one 32-bit word per decision;
+//   half    (ctx, ff1, ff2: the [rows, d] / [rows, F] activations of the feed-forward tail, where the Philox work was
+//     ~12 % of the fused kernels): element (row, col) = 16-bit half (col & 7) of Philox(col >> 3, row, site, step) — EIGHT
+//     consecutive COLUMNS of a row share a call (a lane of the fused kernels owns one replica row and runs of consecutive
+//     features), one 16-bit half per decision: keep probability 1 - floor(p * 65536) / 65536 (p = 0.1: 0.90001).
+__host__ __device__ inline bool drop_site_is_half(uint32_t site) {
+  const uint32_t k = (site - 1u) & 7u;
+  return site >= 1u && site < 0x100u && k >= 1u && k <= 3u;
+}
 // the step a kernel keys its Philox counters with
 __device__ inline uint32_t drop_step(const DropSpec& s) { return s.step_ptr ? *s.step_ptr : s.step; }
 // set by an entry point for the duration of its argument building (see graph.h): where the step word lives, or null
@@ -87,15 +100,27 @@ __host__ inline DropSpec make_drop(const PsTemDesc& d, uint32_t site) {
   s.scale = on ? (float)(1.0 / (1.0 - p)) : 1.f;
   s.site = site; s.step = (uint32_t)d.step; s.step_ptr = ps_step_ptr_slot();
   s.k0 = (uint32_t)(d.seed & 0xffffffffu); s.k1 = (uint32_t)(d.seed >> 32);
+  s.half = drop_site_is_half(site) ? 1u : 0u;
+  s.thr16 = on ? (uint32_t)(p * 65536.0) : 0u;
   return s;
 }
 
 __device__ inline float drop_word(const DropSpec& s, uint32_t word) {
   return word >= s.thr ? s.scale : 0.f;
 }
-// multiplier (0 or 1/(1-p)) of element (row, col)
+// half form: the call shared by columns 8*colgrp .. 8*colgrp+7 of `row`, and decision e (0..7) of it
+__host__ __device__ inline Philox4 drop_call16(const DropSpec& s, uint32_t row, uint32_t colgrp, uint32_t step) {
+  return philox4x32_10(colgrp, row, s.site, step, s.k0, s.k1);
+}
+__host__ __device__ inline float drop_half(const DropSpec& s, const Philox4& r, int e) {
+  const uint32_t w = e < 2 ? r.x : (e < 4 ? r.y : (e < 6 ? r.z : r.w));
+  const uint32_t hv = (e & 1) ? (w >> 16) : (w & 0xffffu);
+  return hv >= s.thr16 ? s.scale : 0.f;
+}
+// multiplier (0 or 1/(1-p)) of element (row, col), either form
 __device__ inline float drop_mult(const DropSpec& s, uint32_t row, uint32_t col) {
   if (s.thr == 0u) return 1.f;
+  if (s.half) return drop_half(s, drop_call16(s, row, col >> 3, drop_step(s)), (int)(col & 7u));
   Philox4 r = philox4x32_10(col, row >> 2, s.site, drop_step(s), s.k0, s.k1);
   uint32_t sel = row & 3u;
   uint32_t wv = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));

@@ -171,7 +171,26 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
     if (rbase >= M) break;
     preload(i + 1, nxt);
     Philox4 rnd = {0u, 0u, 0u, 0u};
-    if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
+    float hm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (dropping && drop.half) {
+      // half form (common.h): the 8 lanes that hold columns 8g .. 8g+7 share ONE call per row; lane j of the group draws
+      // the call of row rbase + (j & 3) and the group exchanges the words (tiles start at multiples of 64 columns, a lane's
+      // column is n0 + (tid & 63): groups are aligned)
+      const int j = tid & 7, e = gcol & 7, base = (tid & 63) & ~7;
+      if ((N & 7) == 0) {                                  // whole groups are active (lanes past N have left)
+        const Philox4 mine = drop_call16(drop, (uint32_t)(rbase + (j & 3)), (uint32_t)gcol >> 3, drop_step(drop));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Philox4 rq;
+          rq.x = __shfl(mine.x, base + q, 64); rq.y = __shfl(mine.y, base + q, 64);
+          rq.z = __shfl(mine.z, base + q, 64); rq.w = __shfl(mine.w, base + q, 64);
+          hm[q] = drop_half(drop, rq, e);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hm[q] = drop_half(drop, drop_call16(drop, (uint32_t)(rbase + q), (uint32_t)gcol >> 3, drop_step(drop)), e);
+      }
+    } else if (dropping) rnd = philox4x32_10((uint32_t)gcol, (uint32_t)rbase >> 2, drop.site, drop_step(drop), drop.k0, drop.k1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = rbase + q;
@@ -185,7 +204,7 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
       else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
       if (dropping) {
         const uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
-        v *= drop_word(drop, wv);
+        v *= drop.half ? hm[q] : drop_word(drop, wv);
       }
       v += cur.res[q];
       csum += v;

@@ -47,13 +47,22 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st);           // gather + dot ("
 int launch_loss(const ScoreArgs& a, hipStream_t st);
 int launch_score_bwd(const ScoreArgs& a, hipStream_t st);
 
-// bf16x3 weight planes of the fused per-replica kernels (mlp_fused.hip, "x3" forms): every fp32 weight is split into
-// three bf16 values w = hi + mid + lo (3 x 8 = 24 mantissa bits: exact), kept as three bf16 planes in the matrix's own
-// [rows][cols] layout (`nat`, the forward's B operands) and transposed (`tr`, the backward's).  Re-split at the start of
-// every forward (extra workgroups of the embed launch): whoever changed the weights in between is picked up.
+// bf16x3 weight FRAGMENT STREAMS of the fused per-replica kernels (mlp_fused.hip): every fp32 weight is split into three
+// bf16 values w = hi + mid + lo (3 x 8 = 24 mantissa bits: exact) and stored in the order the kernels' waves consume them —
+// one product step = 3 planes x 64 lanes x 16 bytes (a v_mfma_f32_32x32x16_bf16 A fragment per plane: lane (l31, h) holds
+// 8 reduction elements of weight row phi(l31), phi(p) = 16*((p>>2)&1) + 4*(p>>3) + (p&3): an accumulator lane then owns 16
+// CONSECUTIVE features).  Streams (step index -> content, d = 128):
+//   fwd_wo [4 nb][8 t]            rows 32nb+phi of Wo,  k = 16t + 8h + e
+//   fwd_ff [F/32 fb][16]          steps 0-7:  rows 32fb+phi of W1, k = 16t + 8h + e
+//                                 steps 8-15: (t = (s-8)>>2, nb = (s-8)&3) rows 32nb+phi of W2, k = feature 32fb + 16h + 8t + e
+//   bwd_ff [F/32 fb][16]          steps 0-7:  rows 32fb+phi of W2^T (features), k = output 16t + 8h + e
+//                                 steps 8-15: rows 32nb+phi of W1^T (inputs), k = feature 32fb + 16h + 8t + e
+//   bwd_wo [4 kb][8 t]            rows 32kb+phi of Wo^T, k = 16t + 8h + e
+// Re-split at the start of every forward (extra workgroups of the embed launch): whoever changed the weights in between
+// is picked up.
 struct WSplit {
   const float* w[3]; int rows[3], cols[3];     // final_linear [d][d], w_1 [F][d], w_2 [d][F]  (nn.Linear [out][in])
-  uint16_t* nat[3]; uint16_t* tr[3];           // plane p of matrix m: nat[m] + p*rows*cols ([rows][cols]);  tr[m] + p*rows*cols ([cols][rows])
+  uint16_t* fwd_wo; uint16_t* fwd_ff; uint16_t* bwd_ff; uint16_t* bwd_wo;
   int on;
 };
 struct EmbedArgs {
@@ -218,12 +227,13 @@ struct MlpFwdArgs {
   DropSpec drop_ctx, drop_ff1, drop_ff2;
   float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
   int fold_score; ScoreArgs sc;   // item scoring + loss in the epilogue (ScoreArgs, folded form); M = B*(K+1)
-  WSplit x3;                      // bf16x3 planes of wo / w1 / w2 (x3.on: take the bf16-MFMA form)
+  WSplit x3;                      // bf16x3 fragment streams of wo / w1 / w2
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool mlp_fwd_can_fold_score(int M, int F, int d);   // the wave-specialised kernel will serve this shape
-bool mlp_x3_enabled(int F);                          // the fused kernels will take their bf16x3 form (they then need WSplit)
-int64_t mlp_x3_floats(int d, int F);                 // workspace floats of the planes (natural + transposed)
+bool mlp_x3_enabled(int F);                          // the fused kernels serve this hidden width (F = 256, 512, 1024; they need WSplit)
+bool mlp_fused_serves(int d, int F);                 // ... and this model width (d = 128)
+int64_t mlp_x3_floats(int d, int F);                 // workspace floats of the fragment streams (forward + backward)
 bool ps_fusion_enabled();
 
 // ---- backward of the same tail as ONE kernel (mlp_fused.hip; d == 128, parked column sums):
@@ -248,7 +258,7 @@ struct MlpBwdArgs {
   float* part_f;                                       // [workgroups][3][128] {dgamma_f, dbeta_f, colsum -> b2}
   float* part_1;                                       // [workgroups][3][128] {dgamma_1, dbeta_1, colsum -> bo}
   float* part_b1;                                      // [mlp_bwd_b1_rows()][3][F] slot 0: colsum -> b1
-  WSplit x3;                                           // bf16x3 planes (transposed ones are read here)
+  WSplit x3;                                           // bf16x3 fragment streams (the bwd_* ones are read here)
   uint32_t* sig; uint32_t sigval;                      // a pending side-stream fork signalled by this launch (common.h, fork_signal)
 };
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);

@@ -142,35 +142,62 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     return;
   }
   if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs) {   // weight re-split (EmbedArgs::split)
+    // one thread = one 16-byte fragment chunk (8 reduction elements of one weight row) of one product step, all three planes
     const WSplit& W = a.split;
-    int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;   // float4 index
-    for (int m = 0; m < 3; ++m) {
-      const int n4 = W.rows[m] * W.cols[m] / 4;
-      if (q >= n4) { q -= n4; continue; }
-      const float4 v = reinterpret_cast<const float4*>(W.w[m])[q];
-      const float x[4] = {v.x, v.y, v.z, v.w};
-      const int e0 = 4 * q, row = e0 / W.cols[m], col = e0 - row * W.cols[m];
-      const size_t plane = (size_t)W.rows[m] * W.cols[m];
-      uint16_t hb[3][4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const __bf16 h = (__bf16)x[e];
-        float r = x[e] - (float)h;
-        const __bf16 md = (__bf16)r;
-        r -= (float)md;
-        const __bf16 lo = (__bf16)r;
-        hb[0][e] = __builtin_bit_cast(uint16_t, h); hb[1][e] = __builtin_bit_cast(uint16_t, md); hb[2][e] = __builtin_bit_cast(uint16_t, lo);
+    const int d = W.cols[0], F = W.rows[1];
+    const int n_wo = d * d / 8, n_ff = 2 * d * F / 8;
+    int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;
+    if (q >= 2 * (n_wo + n_ff)) return;
+    uint16_t* dst;
+    int which;                                   // 0 fwd_wo, 1 fwd_ff, 2 bwd_ff, 3 bwd_wo
+    if (q < n_wo) { which = 0; dst = W.fwd_wo; }
+    else if (q < n_wo + n_ff) { which = 1; q -= n_wo; dst = W.fwd_ff; }
+    else if (q < n_wo + 2 * n_ff) { which = 2; q -= n_wo + n_ff; dst = W.bwd_ff; }
+    else { which = 3; q -= n_wo + 2 * n_ff; dst = W.bwd_wo; }
+    const int step = q >> 6, ln = q & 63, l31 = ln & 31, hh = ln >> 5;
+    const int phi = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+    const float* src; int stride;                // element e of the chunk = src[e * stride]
+    if (which == 0) { const int nb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(32 * nb + phi) * d + 16 * t + 8 * hh; stride = 1; }
+    else if (which == 3) { const int kb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(16 * t + 8 * hh) * d + 32 * kb + phi; stride = d; }
+    else {
+      const int fb = step >> 4, r = step & 15;
+      if (r < 8) {
+        if (which == 1) { src = W.w[1] + (size_t)(32 * fb + phi) * d + 16 * r + 8 * hh; stride = 1; }          // W1 rows
+        else { src = W.w[2] + (size_t)(16 * r + 8 * hh) * F + 32 * fb + phi; stride = F; }                    // W2^T rows
+      } else {
+        const int t = (r - 8) >> 2, nb = (r - 8) & 3, kf = 32 * fb + 16 * hh + 8 * t;
+        if (which == 1) { src = W.w[2] + (size_t)(32 * nb + phi) * F + kf; stride = 1; }                      // W2 rows, k = features
+        else { src = W.w[1] + (size_t)kf * d + 32 * nb + phi; stride = d; }                                  // W1^T rows, k = features
       }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        uint16_t* nat = W.nat[m] + pl * plane + e0;
-        *reinterpret_cast<uint2*>(nat) = make_uint2((uint32_t)hb[pl][0] | ((uint32_t)hb[pl][1] << 16),
-                                                    (uint32_t)hb[pl][2] | ((uint32_t)hb[pl][3] << 16));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) W.tr[m][pl * plane + (size_t)(col + e) * W.rows[m] + row] = hb[pl][e];
-      }
-      return;
     }
+    float x[8];
+    if (stride == 1) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = src[(size_t)e * stride];
+    }
+    uint32_t wd[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint16_t hb[2][3];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float xv = x[2 * i + e];
+        const __bf16 bh = (__bf16)xv;
+        float r = xv - (float)bh;
+        const __bf16 bm = (__bf16)r;
+        r -= (float)bm;
+        const __bf16 bl = (__bf16)r;
+        hb[e][0] = __builtin_bit_cast(uint16_t, bh); hb[e][1] = __builtin_bit_cast(uint16_t, bm); hb[e][2] = __builtin_bit_cast(uint16_t, bl);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wd[pl][i] = (uint32_t)hb[0][pl] | ((uint32_t)hb[1][pl] << 16);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<uint4*>(dst + ((size_t)(step * 3 + pl) * 64 + ln) * 8) = make_uint4(wd[pl][0], wd[pl][1], wd[pl][2], wd[pl][3]);
     return;
   }
   if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs) {       // word tasks of the loss (EmbedArgs::fold_words)
@@ -333,12 +360,12 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
   b.word_wgs = a.fold_words ? a.sc.word_nblk : 0;
   b.split_wgs = 0;
   if (a.split.on) {
-    int n4 = 0;
-    for (int m = 0; m < 3; ++m) {
-      PS_REQUIRE(a.split.w[m] && a.split.nat[m] && a.split.tr[m] && a.split.cols[m] % 4 == 0, "embed: weight split: bad matrix %d", m);
-      n4 += a.split.rows[m] * a.split.cols[m] / 4;
-    }
-    b.split_wgs = ps_cdiv(n4, 256);
+    const WSplit& W = a.split;
+    PS_REQUIRE(W.w[0] && W.w[1] && W.w[2] && W.fwd_wo && W.fwd_ff && W.bwd_ff && W.bwd_wo, "embed: weight split: null pointer");
+    PS_REQUIRE(W.rows[0] == 128 && W.cols[0] == 128 && W.cols[1] == 128 && W.rows[2] == 128 && W.rows[1] == W.cols[2] &&
+               W.rows[1] % 256 == 0, "embed: weight split: shapes [%d,%d] [%d,%d] [%d,%d]", W.rows[0], W.cols[0], W.rows[1],
+               W.cols[1], W.rows[2], W.cols[2]);
+    b.split_wgs = ps_cdiv(2 * (W.cols[0] * W.cols[0] + 2 * W.cols[0] * W.rows[1]) / 8, 256);   // one thread per 16-byte chunk
   }
   PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
   b.zero_wgs = a.zero_i32 && a.zero_n > 0 ? ps_cdiv(a.zero_n, 1024) : 0;

@@ -230,9 +230,8 @@ WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const W
   s.w[1] = L.w1; s.rows[1] = F; s.cols[1] = d;
   s.w[2] = L.w2; s.rows[2] = d; s.cols[2] = F;
   uint16_t* base = reinterpret_cast<uint16_t*>(ws + w.wsplit);
-  size_t off = 0;
-  for (int m = 0; m < 3; ++m) { s.nat[m] = base + off; off += (size_t)3 * s.rows[m] * s.cols[m]; }
-  for (int m = 0; m < 3; ++m) { s.tr[m] = base + off; off += (size_t)3 * s.rows[m] * s.cols[m]; }
+  const size_t n_wo = (size_t)3 * d * d, n_ff = (size_t)3 * 2 * d * F;
+  s.fwd_wo = base; s.fwd_ff = base + n_wo; s.bwd_ff = base + n_wo + n_ff; s.bwd_wo = base + n_wo + 2 * n_ff;
   s.on = 1;
   return s;
 }
@@ -686,7 +685,7 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
     if (attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a)) TRY(launch_attn_fwd_wf(a, reinterpret_cast<uint32_t*>(ws + l.amask), st));
     else if (attn_sq1_fits(a) && attn_w1_fits(a)) TRY(launch_attn_fwd_w1(a, st));
     else TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
-    const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && d == 128 && D.F % 128 == 0 &&
+    const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && mlp_fused_serves(d, D.F) && w.wsplit &&
                       P.final_ln_g && P.final_ln_b;
     PS_REQUIRE(!fold_sc || fuse, "forward: folded scoring without the fused last layer");
     if (fuse) {   // Wo + LN + W1 + GELU + W2 + final LN of the last layer in one kernel (mlp_fused.hip)
@@ -967,8 +966,8 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   side_set_light((int64_t)B * S * d <= ((int64_t)2 << 20));   // C2: 1.03 M elements of x; review transformer 10 M; C5 5.5 M
   static const bool bwd_fuse_on = !(getenv("PS_NO_FUSE_BWD") && atoi(getenv("PS_NO_FUSE_BWD")) != 0);
   const int bwd_fuse_min = fuse_bwd_min_slot();
-  const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 && d == 128 &&
-                         F % 128 == 0 && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
+  const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 &&
+                         mlp_fused_serves(d, F) && w.wsplit && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
                          mlp_bwd_fused_blocks(w.Mf) <= 256 && fold->n + 3 <= PS_MAX_COLFOLD;
   if (score_on_side && !(fuse_last && w.R > 1)) {
     // not the fused form: d enc is needed first, so the score backward is cut in two — its d enc half leads the main
@@ -1030,6 +1029,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
         m.item_scores = sa.item_scores; m.target = sa.target; m.neg_items = sa.neg_items; m.product_emb = sa.product_emb;
         m.B = sa.B; m.K = sa.K; m.pos_weight = sa.pos_weight; m.P = sa.P; m.scale = sa.scale; m.scale_dev = sa.scale_dev;
       }
+      m.x3 = make_wsplit(D, P, ws, w);                 // the fragment streams the forward's embed launch left in the workspace
       m.do2 = const_cast<float*>(do2); m.da1 = ws + w.da1; m.dy1 = ws + w.dy1;
       m.dout = drop ? ws + w.do_ : ws + w.dy1; m.dctx = ws + w.dctx;
       const int nwg = mlp_bwd_fused_blocks(M2);
@@ -1511,6 +1511,7 @@ extern "C" float ps_dropout_mult_host(const PsTemDesc* desc, uint32_t site, uint
   D.training = 1;
   DropSpec s = make_drop(D, site);
   if (s.thr == 0u) return 1.f;
+  if (s.half) return drop_half(s, drop_call16(s, row, col >> 3, s.step), (int)(col & 7u));
   Philox4 r = philox4x32_10(col, row >> 2, s.site, s.step, s.k0, s.k1);
   uint32_t sel = row & 3u;
   uint32_t wv = sel == 0 ? r.x : (sel == 1 ? r.y : (sel == 2 ? r.z : r.w));

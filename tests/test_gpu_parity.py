@@ -243,7 +243,13 @@ def test_train_steps_match_reference(case):
                 assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 0.02 * g.args.lr, (step, n)
                 # a gradient element of the order of Adam's eps (1e-9) turns fp32 rounding noise into a few % of
                 # lr (measured up to 5.4 % on one element of f_W); a wrong sign or a missing term gives >= 1
-                assert rel_err(got - init[n], ref - init[n]) < 1e-1, (step, n)
+                # ... and ISOLATED elements whose gradient is itself of the order of eps after the clip (|g| ~ 3e-8: one element
+                # of linear_keys.weight in tem_c2s_drop) up to ~0.2 lr — the reference against its own CPU restatement differs
+                # by 0.1 lr there (tests/test_oracle_golden.py).  At most 2 in 10^4 elements, each bounded by lr per step.
+                dd = ((got - init[n]) - (ref - init[n])).abs()
+                bad = dd > 1e-1 * float((ref - init[n]).abs().max())
+                assert float(bad.float().mean()) <= 2e-4 and (int(bad.sum()) == 0 or
+                                                             float(dd[bad].max()) <= 1.01 * g.args.lr * (step + 1)), (step, n)
 
 
 # ------------------------------------------------------------------------- eval

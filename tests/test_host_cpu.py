@@ -133,10 +133,14 @@ def test_dropout_stream_matches_oracle_philox(lib):
     d.dropout, d.seed, d.step = 0.1, 666 + (5 << 32), 3
     rows = np.arange(0, 41)[:, None]
     cols = np.arange(0, 37)[None, :]
-    for site in (0, 1, 2, 12):
+    for site in (0, 1, 2, 3, 4, 12, 0x203):      # fs, attn, ctx / ff1 / ff2 (16-bit column-shared form), layer-1 ff2, a review site
         want = philox.drop_mult(rows, cols, site, 3, 666 + (5 << 32), 0.1)
         got = np.array([[lib.ps_dropout_mult_host(d, site, int(r), int(c)) for c in cols[0]] for r in rows[:, 0]],
                        dtype=np.float32)
         assert (want == got).all()
-    keep = philox.drop_mult(np.arange(4000)[:, None], np.arange(64)[None, :], 5, 1, 42, 0.1)
-    assert abs((keep > 0).mean() - 0.9) < 0.005
+    assert philox.site_is_half(2) and philox.site_is_half(3) and philox.site_is_half(4) and philox.site_is_half(12)
+    assert not philox.site_is_half(0) and not philox.site_is_half(1) and not philox.site_is_half(9) and not philox.site_is_half(0x203)
+    for site in (5, 3):                              # classic and half form: keep rate and scale
+        keep = philox.drop_mult(np.arange(4000)[:, None], np.arange(64)[None, :], site, 1, 42, 0.1)
+        assert abs((keep > 0).mean() - 0.9) < 0.005
+        assert set(np.unique(keep).tolist()) == {0.0, float(np.float32(1.0 / (1.0 - float(np.float32(0.1)))))}
