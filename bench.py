@@ -75,6 +75,8 @@ def parse(argv=None):
                     help='c2 = BASELINE configs[1] (the metric); c4 = configs[3] (RTM); c5 = per-GPU shard of configs[4]')
     ap.add_argument('--encoder', default='pvc', choices=['pvc', 'pv'], help='c4: review encoder')
     ap.add_argument('--items', type=int, default=0, help='override the catalogue size (c5 dry runs)')
+    ap.add_argument('--sharded', action='store_true',
+                    help='item table sharded by row over the ranks (args.shard_tables; implies --row-sparse): the N4 path')
     ap.add_argument('--row-sparse', action='store_true',
                     help='touched-rows-only zero/clip/Adam/exchange (args.row_sparse_adam); always on for c5')
     return ap.parse_args(argv)
@@ -91,7 +93,8 @@ class TemWorkload(object):
         if items:
             c['P'] = items
         c['row_sparse'] = c['row_sparse'] or a.row_sparse
-        self.ns = readme_tem_args(dropout=a.dropout, embedding_size=c['D'], ff_size=c['FF'], row_sparse_adam=c['row_sparse'])
+        self.ns = readme_tem_args(dropout=a.dropout, embedding_size=c['D'], ff_size=c['FF'], batch_size=c['B'],
+                                  row_sparse_adam=c['row_sparse'] or a.sharded, shard_tables=a.sharded)
         self.wd = synth.make_word_dists(V_WORDS)
         torch.manual_seed(1234)                     # identical init on every rank
         self.model = ItemTransformerRanker(self.ns, 'cuda', V_WORDS, c['P'], None, word_dists=self.wd)
@@ -108,7 +111,8 @@ class TemWorkload(object):
         R = next(iter(self.model._plans.values())).layout.R
         return ("item_transformer d=%d 1 layer 8 heads ff=%d uprev=20 bs=%d/GPU 20 neg Q=8 W=1 P=%d V=32387 dropout=%.2f%s "
                 "(BASELINE configs[%d])" % (c['D'], c['FF'], c['B'], c['P'], self.a.dropout,
-                                            " row-sparse Adam" if c['row_sparse'] else "", c['config_index'])), {"replicas_per_row": R}
+                                            (" row-sharded item table + row-sparse Adam" if self.a.sharded else
+                                             " row-sparse Adam" if c['row_sparse'] else ""), c['config_index'])), {"replicas_per_row": R}
 
     def metric(self):
         return "train (u,q,i,neg) tuples/sec at bs=%d, 20 neg, d=%d" % (self.c['B'], self.c['D'])
@@ -358,6 +362,8 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
     xname = type(exchange).__name__
     xdesc = {"GradExchange": "flat all-reduce", "ShardedAdamExchange": "reduce-scatter + owner clip/Adam + all-gather",
              "SparseGradExchange": "row-sparse all-gather exchange"}.get(xname, xname)
+    if getattr(a, 'sharded', False):
+        xdesc += " + all-to-all of the sharded item table's rows and gradients"
     out = {
         "metric": wl.metric(),
         "value": world * Bw * Kw * steps / elapsed, "unit": "tuples/s",

@@ -322,6 +322,29 @@ int64_t ps_adam_rowsparse_state_floats(int32_t n_chunks, const PsRowTable* table
 int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
                            const PsAdamHyper* hyper, int64_t* state_dev, float* gnorm_out_dev, ps_stream_t stream);
 
+/* ------------------------------------------------------------------ row-sharded tables (no reference
+ * counterpart: item_transformer.py:46,464-469 keeps the whole table on one device).  Row i lives on rank i % world at local
+ * row i / world.  Per step: ps_coalesce_rows gives the rank's sorted unique rows; ps_shard_bucket cuts that list into one
+ * fixed-capacity request per owner — send_ids[o][0..capp): local rows (id / world) of the ids with id % world == o,
+ * ascending, then -1 — and records the slot o * capp + position of every list entry (slot_of); the requests and then the
+ * rows (ps_gather_rows accepts the -1 padding: zero rows) travel by equal-split all-to-alls; ps_shard_remap rewrites an
+ * index tensor into slots (pad_in -> pad_out), so the receive buffer [world * capp + 1, d] IS the table the step reads.
+ * The gradient returns the same way; ps_coalesce_rows (pad -1) + ps_merge_rows over the received requests give the owner's
+ * touched rows and their rank-ordered sums.  *bad_dev: 1 = an index missing from the list, 2 = a request overflowed capp. */
+int ps_shard_bucket(const int64_t* rows_dev, const int32_t* count_dev, int32_t world, int64_t capp, int64_t* send_ids_dev,
+                    int32_t* slot_of_dev, int32_t* bad_dev, ps_stream_t stream);
+int ps_shard_remap(const int64_t* idx_dev, int64_t n, int64_t pad_in, const int64_t* rows_dev, const int32_t* count_dev,
+                   const int32_t* slot_of_dev, int64_t pad_out, int64_t* out_dev, int32_t* bad_dev, ps_stream_t stream);
+/* ps_clip_adam_rowsparse cut in two for sharded tables: tables [0, n_shared) and the dense plan are replicated (their sum of
+ * squares counts once), tables [n_shared, n_tables) are this rank's shards (their sums add over the ranks).  sums_dev[0] =
+ * replicated part, sums_dev[1] = owned part; the caller all-reduces sums_dev[1] between the calls; the clip norm
+ * (optimizers.py:241-242) is sqrt(sums[0] + sums[1]).  state as for ps_clip_adam_rowsparse. */
+int ps_rowsparse_sumsq(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables, int32_t n_shared,
+                       const PsAdamHyper* hyper, int64_t* state_dev, float* sums_dev, ps_stream_t stream);
+int ps_rowsparse_update_ext(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
+                            const PsAdamHyper* hyper, int64_t* state_dev, const float* sums_dev, float* gnorm_out_dev,
+                            ps_stream_t stream);
+
 /* ------------------------------------------------------------------ RTM (review_transformer)
  * ProductRanker (models/ps_model.py:53-370) with the pv (models/PV.py) / pvc (models/PVC.py) review
  * encoders.  Sequences are [query, R reviews]; K negatives per row (training) or C candidates (eval). */

@@ -155,8 +155,13 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(float* tab, const int64_
   const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (u >= n) return;
   const int lane = threadIdx.x & 31;
-  float4* t4 = (float4*)(tab + rows[u] * (int64_t)d);
+  const int64_t r = rows[u];
   float4* v4 = (float4*)(vals + u * (int64_t)d);
+  if (r < 0) {                      // padding entry of a fixed-capacity list (row-sharded tables): zeros out, nothing in
+    if (MODE == 0) for (int j = lane; j < d / 4; j += 32) v4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  float4* t4 = (float4*)(tab + r * (int64_t)d);
   for (int j = lane; j < d / 4; j += 32) {
     if (MODE == 0) v4[j] = t4[j]; else t4[j] = v4[j];
   }
@@ -418,6 +423,137 @@ extern "C" int ps_zero_rows(float* table_dev, int32_t d, const int64_t* rows_dev
   if (cap == 0) return PS_OK;
   hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((cap + 7) / 8)), dim3(256), 0, (hipStream_t)stream, table_dev,
                      rows_dev, count_dev, d);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+
+// ================================================================== row-sharded tables (prodsearch_amd/sharded.py)
+// Row i of a sharded table lives on rank i % world at local row i / world.  Per step a rank needs the rows its batch
+// addresses: its sorted unique list (ps_coalesce_rows) is cut into one FIXED-capacity request per owner (no size ever
+// crosses to the host; capacity = share of the step's index count with headroom, overflow sets the status word), the
+// requests and the rows travel by equal-split all-to-alls, and the batch's indices are remapped to the slot each row
+// arrives in, so the receive buffer itself is the table the step's kernels read.
+//   ps_shard_bucket: one workgroup per owner walks the list; request o = local rows (id / world) of the ids with
+//                    id % world == o, ascending, then -1; slot_of[u] = o * capp + position (world * capp = the pad slot)
+//   ps_shard_remap : index tensor -> slots (binary search of the id in the sorted list)
+__global__ __launch_bounds__(256) void shard_bucket_kernel(const int64_t* rows, const int32_t* count, int world, int64_t capp,
+                                                           int64_t* send_ids, int32_t* slot_of, int32_t* bad) {
+  __shared__ int wsum[4];
+  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = *count;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    const int64_t r = i < n ? rows[i] : -1;
+    const bool mine = i < n && (int)(r % world) == o;
+    const unsigned long long m = __ballot(mine);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < wv; ++k) before += wsum[k];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (mine) {
+      const int pos = base + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < capp) { send_ids[(int64_t)o * capp + pos] = r / world; slot_of[i] = (int32_t)((int64_t)o * capp + pos); }
+      else { *bad = 2; slot_of[i] = (int32_t)((int64_t)world * capp); }
+    }
+    base += total;
+    __syncthreads();
+  }
+  for (int64_t p = (base < capp ? base : capp) + tid; p < capp; p += 256) send_ids[(int64_t)o * capp + p] = -1;
+}
+__global__ __launch_bounds__(256) void shard_remap_kernel(const int64_t* idx, int64_t n, int64_t pad_in, const int64_t* rows,
+                                                          const int32_t* count, const int32_t* slot_of, int64_t pad_out,
+                                                          int64_t* out, int32_t* bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v == pad_in) { out[i] = pad_out; return; }
+  int lo = 0, hi = *count;                    // first position with rows[pos] >= v
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (rows[mid] < v) lo = mid + 1; else hi = mid; }
+  if (lo < *count && rows[lo] == v) out[i] = slot_of[lo];
+  else { out[i] = pad_out; *bad = 1; }
+}
+extern "C" int ps_shard_bucket(const int64_t* rows_dev, const int32_t* count_dev, int32_t world, int64_t capp,
+                               int64_t* send_ids_dev, int32_t* slot_of_dev, int32_t* bad_dev, ps_stream_t stream) {
+  PS_REQUIRE(rows_dev && count_dev && send_ids_dev && slot_of_dev && bad_dev && world > 0 && world <= 1024 && capp > 0 &&
+             (int64_t)world * capp < ((int64_t)1 << 31), "shard_bucket: bad argument");
+  hipLaunchKernelGGL(shard_bucket_kernel, dim3(world), dim3(256), 0, (hipStream_t)stream, rows_dev, count_dev, world, capp,
+                     send_ids_dev, slot_of_dev, bad_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+extern "C" int ps_shard_remap(const int64_t* idx_dev, int64_t n, int64_t pad_in, const int64_t* rows_dev, const int32_t* count_dev,
+                              const int32_t* slot_of_dev, int64_t pad_out, int64_t* out_dev, int32_t* bad_dev, ps_stream_t stream) {
+  PS_REQUIRE(idx_dev && rows_dev && count_dev && slot_of_dev && out_dev && bad_dev && n >= 0, "shard_remap: bad argument");
+  if (n == 0) return PS_OK;
+  hipLaunchKernelGGL(shard_remap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx_dev, n,
+                     pad_in, rows_dev, count_dev, slot_of_dev, pad_out, out_dev, bad_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
+// ---- the row-sparse clip + Adam cut in two for sharded tables: the first n_shared tables (and the dense plan) are
+// REPLICATED on every rank — their sum of squares is the same everywhere and counts once — while the remaining tables are
+// this rank's SHARDS, whose sums of squares add up over the ranks (one scalar all-reduce between the two calls).
+//   ps_rowsparse_sumsq     : sums[0] = dense plan + shared tables, sums[1] = owned shards (fixed-order reductions); step += 1
+//   ps_rowsparse_update_ext: clip coefficient from sums[0] + sums[1] (the caller has all-reduced sums[1]), then Adam on the
+//                            dense plan and the touched rows of every table; touched gradient rows come back zeroed
+__global__ __launch_bounds__(1024) void rs_two_sums_kernel(const float* partial, int n_common, int n_all, float* sums) {
+  __shared__ float sh[2][16];
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < n_common; i += 1024) s0 += partial[i];
+  for (int i = n_common + threadIdx.x; i < n_all; i += 1024) s1 += partial[i];
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int i = 0; i < 16; ++i) { t0 += sh[0][i]; t1 += sh[1][i]; }
+    sums[0] = t0; sums[1] = t1;
+  }
+}
+__global__ void rs_scalars_ext_kernel(const PsAdamHyper hp, const int64_t* state, const float* sums, float* scal, float* gnorm_out) {
+  float norm;
+  adam_scalars(hp, sums[0] + sums[1], state[0], scal, &norm);
+  if (gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
+}
+extern "C" int ps_rowsparse_sumsq(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
+                                  int32_t n_shared, const PsAdamHyper* hyper, int64_t* state_dev, float* sums_dev,
+                                  ps_stream_t stream) {
+  PS_REQUIRE(hyper && state_dev && sums_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev) && n_shared >= 0 && n_shared <= n_tables,
+             "rowsparse_sumsq: bad argument");
+  RowTables T;
+  int rc = rs_pack(tables_host, n_tables, &T);
+  if (rc != PS_OK) return rc;
+  const int n_blocks = n_chunks + T.blk0[RS_MAX_TABLES];
+  PS_REQUIRE(n_blocks > 0, "rowsparse_sumsq: nothing to update");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)(state_dev + 2) + 4;
+  const float gs = hyper->grad_scale == 0.f ? 1.f : hyper->grad_scale;
+  hipLaunchKernelGGL(rs_sumsq_kernel, dim3(n_blocks), dim3(256), 0, st, (const char*)plan_dev, n_chunks, T, gs, state_dev, partial);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rs_two_sums_kernel, dim3(1), dim3(1024), 0, st, partial, n_chunks + T.blk0[n_shared], n_blocks, sums_dev);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+extern "C" int ps_rowsparse_update_ext(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
+                                       const PsAdamHyper* hyper, int64_t* state_dev, const float* sums_dev,
+                                       float* gnorm_out_dev, ps_stream_t stream) {
+  PS_REQUIRE(hyper && state_dev && sums_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev), "rowsparse_update_ext: bad argument");
+  RowTables T;
+  int rc = rs_pack(tables_host, n_tables, &T);
+  if (rc != PS_OK) return rc;
+  const int n_blocks = n_chunks + T.blk0[RS_MAX_TABLES];
+  PS_REQUIRE(n_blocks > 0, "rowsparse_update_ext: nothing to update");
+  hipStream_t st = (hipStream_t)stream;
+  float* scal = (float*)(state_dev + 2);
+  PsAdamHyper hp = *hyper;
+  if (hp.grad_scale == 0.f) hp.grad_scale = 1.f;
+  hipLaunchKernelGGL(rs_scalars_ext_kernel, dim3(1), dim3(1), 0, st, hp, state_dev, sums_dev, scal, gnorm_out_dev);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rs_update_kernel, dim3(n_blocks), dim3(256), 0, st, (const char*)plan_dev, n_chunks, T, hp, scal);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -146,7 +146,7 @@ class SparseGradExchange(object):
                                    "agreed on messages of %d rows at the first step; build the exchange after setting "
                                    "args.batch_size / uprev_review_limit to the largest batch any rank will see" % (local, cap))
             caps.append(cap)
-        dist.all_reduce(m._grad_flat[:m._n_dense_grad], op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(m._grad_flat[:getattr(m, '_n_allreduce_grad', m._n_dense_grad)], op=dist.ReduceOp.SUM, group=self.group)
         for (_, p, gview), cap in zip(m._sparse_tabs, caps):
             info = p._ps_rows
             d = p.shape[1]

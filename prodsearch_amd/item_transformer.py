@@ -191,10 +191,25 @@ class ItemTransformerRanker(nn.Module):
         self.emb_dropout = args.dropout
         d = self.embedding_size
 
+        # args.shard_tables (extension; prodsearch_amd/sharded.py): the item table is sharded by row over
+        # the ranks; ``product_emb.weight`` is then the per-step RECEIVE buffer [slots + 1, d] the kernels read, the batch's
+        # item indices are remapped into its slots, and the owners update their shards with the row-sparse optimizer.
+        self._shard = None
+        if getattr(args, 'shard_tables', False):
+            if args.sep_prod_emb or args.sim_func == 'bias_product':
+                raise NotImplementedError("shard_tables: sep_prod_emb / bias_product are not supported with a sharded item table")
+            from .sharded import ShardedItemTable
+            tem_l = int(getattr(args, 'uprev_review_limit', 20)) if args.model_name == 'item_transformer' else 0
+            cap = int(args.batch_size) * (1 + int(args.neg_per_pos) + tem_l)
+            self._shard = ShardedItemTable(product_size, d, product_size, cap, device)
         # same registration order as the reference => same state_dict key order
         # tables above 0.5 GB (config 5: 51 GB) are created on the device, never staged through host memory
         emb_dev = device if (product_size + 1) * d > (1 << 27) else None
-        self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx, device=emb_dev)
+        if self._shard is not None:
+            self.product_emb = nn.Embedding(self._shard.slots + 1, d, padding_idx=self._shard.slots, device=device)
+            self.product_emb.weight._ps_shard_view = True       # never optimised: its gradient is routed to the owners
+        else:
+            self.product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx, device=emb_dev)
         if args.sep_prod_emb:
             self.hist_product_emb = nn.Embedding(product_size + 1, d, padding_idx=self.prod_pad_idx, device=emb_dev)
         self.product_bias = nn.Parameter(torch.zeros(product_size + 1), requires_grad=True)
@@ -211,6 +226,9 @@ class ItemTransformerRanker(nn.Module):
         self.seg_embeddings = nn.Embedding(4, d, padding_idx=self.seg_pad_idx)
         self.initialize_parameters()
         self.to(device)
+        if self._shard is not None:
+            self._shard.attach(self.product_emb.weight)
+            self._shard.init_normal(int(getattr(args, 'seed', 666)))
 
         self._plans = {}
         self._params_struct = None
@@ -249,6 +267,23 @@ class ItemTransformerRanker(nn.Module):
     def load_cp(self, pt, strict=True):
         self.load_state_dict(pt['model'], strict=strict)
 
+    def state_dict(self, *a, **k):
+        """With a sharded item table ``product_emb.weight`` is exported as the FULL [P+1, d] table, gathered from the
+        ranks' shards (a collective; for catalogue-sized tables export ``model._shard.weight`` per rank instead)."""
+        sd = super().state_dict(*a, **k)
+        if self.__dict__.get('_shard') is not None:
+            key = [q for q in sd if q.endswith('product_emb.weight')][0]
+            full = self._shard.gather_full()
+            sd[key] = torch.cat([full, full.new_zeros(1, full.shape[1])], 0)
+        return sd
+
+    def load_state_dict(self, sd, strict=True, **k):
+        if self.__dict__.get('_shard') is not None and 'product_emb.weight' in sd:
+            sd = dict(sd)
+            self._shard.load_full(sd.pop('product_emb.weight'))
+            strict = False
+        return super().load_state_dict(sd, strict=strict, **k)
+
     def forward(self, batch_data, train_pv=False, neg_item_idxs=None, neg_word_idxs=None):
         plan, loss3 = self._run_forward(batch_data, neg_item_idxs, neg_word_idxs)
         if not torch.is_grad_enabled():
@@ -258,6 +293,8 @@ class ItemTransformerRanker(nn.Module):
         return out
 
     def test(self, batch_data):
+        if self.__dict__.get('_shard') is not None:
+            raise NotImplementedError("test() with shard_tables: evaluate from an unsharded model loaded with state_dict()")
         return self._run_score(batch_data)
 
     # -------------------------------------------------------------------- plumbing
@@ -286,6 +323,9 @@ class ItemTransformerRanker(nn.Module):
         self._loss_acc = None
         self._alias = None
         self.__dict__.pop('_zg_params', None)
+        self.__dict__.pop('_param_flat', None)
+        if self.__dict__.get('_shard') is not None and self.product_emb.weight.device == self._shard.device:
+            self._shard.attach(self.product_emb.weight)          # the receive buffer moved with the parameter
         return r
 
     def _named_hot_params(self):
@@ -346,8 +386,9 @@ class ItemTransformerRanker(nn.Module):
             ps.pe = self.transformer_encoder.pos_emb.pe.data_ptr()
         # one flat gradient buffer: small tensors first, tables last; 16-byte aligned slices
         graded = [(path, p) for path, p in hot if self._has_grad(path)]
-        sparse = self._SPARSE_PATHS if self._row_sparse() else ()
-        graded.sort(key=lambda t: (t[0] in sparse, t[1].numel()))
+        sparse = self._sparse_paths()
+        # order: small dense tensors, [the sharded table's receive buffer], row-sparse tables
+        graded.sort(key=lambda t: (t[0] in sparse, self._shard is not None and t[0] == ('product_emb',), t[1].numel()))
         offs, cur = [], 0
         for _, p in graded:
             offs.append(cur)
@@ -364,6 +405,9 @@ class ItemTransformerRanker(nn.Module):
         # row-sparse mode: the flat buffer is [dense tensors | row-sparse tables]; only the first part is
         # ever memset, table rows are re-zeroed by the optimizer (or zero_grad) through their touched list
         self._n_dense_grad = sum((p.numel() + 3) // 4 * 4 for path, p in graded if path not in sparse)
+        # what a data-parallel exchange all-reduces: the small tensors only — with a sharded item table the receive buffer's
+        # gradient (the LARGEST of the non-sparse tensors, hence the last of them) travels to the owners instead
+        self._n_allreduce_grad = self._n_dense_grad - ((self.product_emb.weight.numel() + 3) // 4 * 4 if self._shard is not None else 0)
         self._sparse_tabs = [(path, p, v) for (path, p), (_, v) in zip(graded, self._grad_views) if path in sparse]
         self._params_struct, self._grads_struct = ps, gs
         self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float32)
@@ -398,7 +442,7 @@ class ItemTransformerRanker(nn.Module):
             d.B, d.K, d.L, d.Q, d.W, d.C = B, a.neg_per_pos, L, Q, W, C
             d.d, d.H, d.F = a.embedding_size, a.heads, a.ff_size
             d.n_layers = a.inter_layers if a.model_name == 'item_transformer' else 0
-            d.product_size, d.vocab_size = self.product_size, self.vocab_size
+            d.product_size, d.vocab_size = (self._shard.slots if self._shard is not None else self.product_size), self.vocab_size
             d.model = _lib.PS_MODEL_TEM if a.model_name == 'item_transformer' else _lib.PS_MODEL_QEM
             d.query_encoder = _lib.PS_QENC_FS if a.query_encoder_name == 'fs' else _lib.PS_QENC_AVG
             d.use_pos_emb, d.use_item_pos = int(a.use_pos_emb), int(a.use_item_pos)
@@ -473,6 +517,9 @@ class ItemTransformerRanker(nn.Module):
             plan.neg_items = torch.empty(d.B, d.K, device=self._dev(), dtype=torch.int64)
             plan.neg_words = torch.empty(d.B, d.W * d.K, device=self._dev(), dtype=torch.int64)
         prob, alias = self._alias_tables()
+        if self._shard is not None:                 # the plan's descriptor counts SLOTS; negatives are drawn over the catalogue
+            d = _lib.PsTemDesc.from_buffer_copy(d)
+            d.product_size = self.product_size
         _lib.check(lib.ps_sample_negatives(d, prob.data_ptr(), alias.data_ptr(), plan.neg_items.data_ptr(),
                                            plan.neg_words.data_ptr(), self._stream()), 'ps_sample_negatives')
         return plan.neg_items, plan.neg_words
@@ -491,6 +538,30 @@ class ItemTransformerRanker(nn.Module):
         self._fwd_step += 1
         plan.desc.step = self._fwd_step
         loss3 = torch.empty(3, device=self._dev(), dtype=torch.float32)
+        if self._shard is not None:
+            # sharded item table: every item id of the step must be known BEFORE the forward (the rows are fetched from their
+            # owners), so the two draws are a launch of their own; then lookup -> remapped indices -> the unchanged step
+            import copy
+            if neg_items is None or neg_words is None:
+                d = plan.desc
+                if plan.neg_items is None:
+                    plan.neg_items = torch.empty(d.B, d.K, device=self._dev(), dtype=torch.int64)
+                    plan.neg_words = torch.empty(d.B, d.W * d.K, device=self._dev(), dtype=torch.int64)
+                neg_items, neg_words = self.sample_negatives(plan)
+            tem = self.args.model_name == 'item_transformer'
+            tg = self._check_idx(batch.target_prod_idxs, 'target_prod_idxs')
+            ni = self._check_idx(neg_items, 'neg_item_idxs')
+            lists = [tg, ni] + ([self._check_idx(batch.u_item_idxs, 'u_item_idxs')] if tem else [])
+            rem = self._shard.lookup(lists)
+            b2 = copy.copy(batch)
+            b2.target_prod_idxs = rem[0]
+            if tem:
+                b2.u_item_idxs = rem[2]
+            self._fill_batch(plan, b2, False, rem[1], neg_words)
+            plan.staged = False
+            _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
+                                          self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
+            return plan, loss3
         if self._use_step_api():
             inject = neg_items is not None and neg_words is not None
             self._fill_batch(plan, batch, False, neg_items if inject else None, neg_words if inject else None,
@@ -524,9 +595,16 @@ class ItemTransformerRanker(nn.Module):
     _SPARSE_PATHS = (('product_emb',), ('word_emb',), ('hist_product_emb',))
 
     def _row_sparse(self):
-        """``args.row_sparse_adam`` (extension, default False): table gradients stay dense tensors but
-        zeroing / clip / Adam / exchange only visit the rows a step touched (BASELINE configs[4])."""
-        return bool(getattr(self.args, 'row_sparse_adam', False))
+        """``args.row_sparse_adam`` (extension, default False; implied by ``args.shard_tables``): table gradients stay dense
+        tensors but zeroing / clip / Adam / exchange only visit the rows a step touched (BASELINE configs[4])."""
+        return bool(getattr(self.args, 'row_sparse_adam', False)) or self.__dict__.get('_shard') is not None
+
+    def _sparse_paths(self):
+        """Tables handled by their touched-row lists on THIS rank (a sharded item table is not: its receive buffer is a
+        small dense tensor whose gradient goes to the owners)."""
+        if not self._row_sparse():
+            return ()
+        return tuple(p for p in self._SPARSE_PATHS if not (self._shard is not None and p == ('product_emb',)))
 
     def _index_lists(self, path, plan):
         """Index tensors of the step that address ``path``'s rows, and that table's pad row."""
@@ -605,6 +683,8 @@ class ItemTransformerRanker(nn.Module):
         the trainer calls this where it reads the loss)."""
         import ctypes
         lib = _lib.load()
+        if self.__dict__.get('_shard') is not None:
+            self._shard.check_errors()
         for name, p in self.named_parameters():
             info = getattr(p, '_ps_rows', None)
             if info is None:
@@ -695,6 +775,8 @@ class ItemTransformerRanker(nn.Module):
                                        _lib.ptr(go), st), 'ps_tem_backward')
         if self._row_sparse():
             main.wait_stream(side)
+        if self._shard is not None:
+            self._shard.pending = True           # the receive buffer's gradient waits for push_grads (Optimizer.step)
 
     def encode(self, batch):
         """Eval-mode sequence representation [B,d] that the dot-product head scores items with

@@ -45,11 +45,14 @@ class Optimizer(object):
         self.params = []
         self._plan = None
         self._sharded = None                 # dist.ShardedAdamExchange: this rank updates 1/world of the flat buffers
+        self.shard_owner = None              # weakref to a model whose item table is row-sharded (args.shard_tables)
 
     def set_parameters(self, params):
         """``set_parameters`` (optimizers.py:165-187): every parameter that requires grad."""
-        self.params = [p for _, p in params if p.requires_grad]
-        self._names = [k for k, p in params if p.requires_grad]
+        # (a sharded item table's receive buffer, ``_ps_shard_view``, is never a parameter of the optimizer: the owners
+        # update their shards — sharded.ShardedItemTable — through ``_step_rows``)
+        self.params = [p for _, p in params if p.requires_grad and not getattr(p, '_ps_shard_view', False)]
+        self._names = [k for k, p in params if p.requires_grad and not getattr(p, '_ps_shard_view', False)]
         self._plan = None
 
     # ------------------------------------------------------------------ plan
@@ -147,7 +150,7 @@ class Optimizer(object):
             return self._sharded.step(hp)
         dev = plan['live'][0].device
         st = torch.cuda.current_stream(dev).cuda_stream
-        if plan['rows']:
+        if plan['rows'] or self.shard_owner is not None:
             return self._step_rows(lib, plan, hp, dev, st)
         owner = self.zero_grads_owner() if self.zero_grads_owner is not None else None
         # only when the plan covers the model's whole flat gradient buffer (every view is the attached .grad)
@@ -168,6 +171,22 @@ class Optimizer(object):
             t.p, t.g, t.m, t.v = p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()
             rows, count, cap = info.get('active') or (info['rows'], info['count'], info['cap'])
             t.rows, t.count, t.cap, t.d = rows.data_ptr(), count.data_ptr(), cap, p.shape[1]
+        owner = self.shard_owner() if self.shard_owner is not None else None
+        shard = getattr(owner, '_shard', None) if owner is not None else None
+        if shard is not None:
+            # row-sharded item table: route the step's gradient rows to their owners, then the owned shard joins the plan as
+            # one more table whose sum of squares is added over the ranks (every row is owned once)
+            if shard.pending:
+                shard.push_grads(owner.product_emb.weight.grad)
+            n_shared = len(plan['rows'])
+            tabs2 = (_lib.PsRowTable * (n_shared + 1))()
+            for i in range(n_shared):
+                for f, _t in _lib.PsRowTable._fields_:
+                    setattr(tabs2[i], f, getattr(tabs[i], f))
+            own = shard.row_table()
+            for f, _t in _lib.PsRowTable._fields_:
+                setattr(tabs2[n_shared], f, getattr(own, f))
+            tabs = tabs2
         need = lib.ps_adam_rowsparse_state_floats(plan['n_chunks'], tabs, len(tabs))
         if need < 0:
             _lib.check(1, 'ps_adam_rowsparse_state_floats')
@@ -175,9 +194,22 @@ class Optimizer(object):
         if plan['state'].numel() < words:
             plan['state'] = torch.zeros(words, device=dev, dtype=torch.int64)
             plan['state'][0] = self._step - 1
-        _lib.check(lib.ps_clip_adam_rowsparse(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), hp,
-                                              plan['state'].data_ptr(), plan['gnorm'].data_ptr(), st),
-                   'ps_clip_adam_rowsparse')
+        if shard is not None:
+            import torch.distributed as tdist
+            sums = plan.get('sums')
+            if sums is None:
+                sums = plan['sums'] = torch.zeros(2, device=dev, dtype=torch.float32)
+            _lib.check(lib.ps_rowsparse_sumsq(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), len(tabs) - 1, hp,
+                                              plan['state'].data_ptr(), sums.data_ptr(), st), 'ps_rowsparse_sumsq')
+            if shard.world > 1:
+                tdist.all_reduce(sums[1:2], op=tdist.ReduceOp.SUM, group=shard.group)
+            _lib.check(lib.ps_rowsparse_update_ext(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), hp,
+                                                   plan['state'].data_ptr(), sums.data_ptr(), plan['gnorm'].data_ptr(), st),
+                       'ps_rowsparse_update_ext')
+        else:
+            _lib.check(lib.ps_clip_adam_rowsparse(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), hp,
+                                                  plan['state'].data_ptr(), plan['gnorm'].data_ptr(), st),
+                       'ps_clip_adam_rowsparse')
         for p, _ in plan['rows']:
             p._ps_rows['dirty'] = False
 
@@ -235,6 +267,9 @@ def build_optim(args, model, checkpoint):
     if hasattr(model, '_grad_flat') and not getattr(args, 'keep_grads_after_step', False) \
             and os.environ.get('PS_KEEP_GRADS', '0') in ('', '0'):
         optim.zero_grads_owner = weakref.ref(model)
+    if getattr(model, '_shard', None) is not None:
+        optim.row_sparse = True
+        optim.shard_owner = weakref.ref(model)
     if getattr(args, 'train_from', '') != '' and checkpoint is not None:
         optim.load_state_dict(checkpoint['optim'])
     return optim

@@ -16,7 +16,8 @@ def global_problem(mode, Bg, seed=31):
     """Model arguments + the GLOBAL batch and negative draws, identical in every process."""
     from prodsearch_amd import readme_tem_args, synth
     P_, V, K, L, Q, W = 18357, 32387, 20, 20, 8, 1
-    a = readme_tem_args(dropout=0.0, lr=0.002, row_sparse_adam=(mode == 'sparse'))      # 'dense' / 'allreduce': dense Adam
+    a = readme_tem_args(dropout=0.0, lr=0.002, row_sparse_adam=(mode in ('sparse', 'sharded')),      # 'dense' / 'allreduce': dense Adam
+                        shard_tables=(mode == 'sharded'))
     wd = synth.make_word_dists(V)
     batch = synth.make_tem_batch(seed, Bg, P_, V, Q=Q, L=L, W=W, word_dists=wd)
     ni, nw = synth.sample_negatives(seed + 1, Bg, K, W, P_, wd)
@@ -37,11 +38,16 @@ def run(mode, Bg, steps, rank, world, exchange_factory, ragged=0):
     import torch
     from prodsearch_amd import ItemTransformerRanker, build_optim
     a, wd, P_, V, batch, ni, nw = global_problem(mode, Bg)
+    from prodsearch_amd import synth
+    per = Bg // world
+    a.batch_size = per                                   # (sizes the sharded table's per-step capacity)
     torch.manual_seed(1234)
     m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    # identical weights in every mode and process (the sharded model draws a different number of random values at construction)
+    sd0 = synth.make_state_dict(synth.tem_param_shapes(a, V, P_), 123, {'product_emb.weight': P_})
+    m.load_state_dict(sd0, strict=False)
     optim = build_optim(a, m, None)
     exchange = exchange_factory(m, optim)
-    per = Bg // world
     # --ragged n: the LAST rank's slice is n rows short (unequal per-rank batches, e.g. a loader with drop_last=False)
     b, bi, bw = slice_batch(batch, ni, nw, rank * per, (rank + 1) * per - (ragged if rank == world - 1 else 0))
     b, bi, bw = b.to('cuda'), bi.cuda(), bw.cuda()
@@ -63,8 +69,9 @@ def run(mode, Bg, steps, rank, world, exchange_factory, ragged=0):
     words = np.setdiff1d(np.unique(np.concatenate([batch.query_word_idxs.numpy().ravel(), nw.numpy().ravel(),
                                                    batch.pos_iword_idxs.numpy().ravel()])), [V - 1])
     out = {'__loss': np.float32(float(loss.detach())), '__ms': np.float64(1e3 * min(times))}
+    sd_out = m.state_dict()                              # (sharded item table: gathered from the ranks' shards)
     for n, p in m.named_parameters():
-        t = p.detach()
+        t = sd_out[n].detach()
         if n == 'product_emb.weight':
             out[n] = t[torch.from_numpy(items).cuda()].cpu().numpy()
             out[n + '__sum'] = np.float64(float(t.double().sum()))

@@ -1,0 +1,103 @@
+"""Adversarial operands for the bf16x3 product form (csrc/gemm.hip, gemm_x3_kernel; the fused per-replica kernels use the
+same split): every fp32 operand is split exactly into three bf16 values and a product step is six bf16 MFMAs with fp32
+accumulation.  The claim "the fp32 MFMA's accuracy" (include/prodsearch_hip.h, ps_gemm_x3_config) is checked where it is
+hardest: a 21,504-deep reduction whose terms span 2^+-40 and cancel, non-finite operands (an Inf must come out as the fp32
+kernel's +-Inf / NaN, not as NaN everywhere: the residual of the split, Inf - Inf, is cleared), and operands so small
+that the low plane of the split is a bf16 denormal.  Reference: models/transformer.py:47-57, neural.py:30-33 run these
+products in fp32 on ATen."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def x3_restore():
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    yield lib
+    lib.ps_gemm_x3_config(1, -1)
+
+
+def _run(lib, A, Bm, ta, tb, mode, shape=-1, acc=0):
+    """C = A @ Bm through ps_gemm_f32 in the requested storage layout; mode 1 = bf16x3 form, 0 = fp32 MFMA."""
+    from prodsearch_amd import _lib
+    M, K = A.shape
+    N = Bm.shape[1]
+    Ad = (A.t().contiguous() if ta else A.contiguous()).cuda()
+    Bd = (Bm.contiguous() if tb else Bm.t().contiguous()).cuda()
+    lib.ps_gemm_x3_config(mode, shape if mode else -1)
+    C = torch.zeros(M, N, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ps_gemm_f32(Ad.data_ptr(), M if ta else K, ta, Bd.data_ptr(), N if tb else K, tb, C.data_ptr(), N,
+                               M, N, K, None, 1.0, acc, st), 'ps_gemm_f32')
+    torch.cuda.synchronize()
+    return C.cpu()
+
+
+@pytest.mark.parametrize('layout', [(0, 0, 1), (0, 1, 1), (1, 1, 0)])      # forward, dX, weight-gradient storage; forced tile
+def test_deep_cancelling_reduction_with_mixed_magnitudes(x3_restore, layout):
+    """K = 21,504 terms per output whose magnitudes span 2^-40 .. 2^+40 and whose big terms cancel in pairs: the error is
+    bounded by a few fp32 ulps of sum |a b| for BOTH forms (a product form that dropped the low plane would be off by
+    2^-16 of the largest term)."""
+    lib = x3_restore
+    ta, tb, shape = layout
+    gen = torch.Generator().manual_seed(11)
+    M, N, K = 256, 256, 21504
+    ea = torch.randint(-40, 41, (M, K), generator=gen).float()
+    A = torch.randn(M, K, generator=gen) * torch.exp2(ea)
+    Bm = torch.randn(K, N, generator=gen) * torch.exp2(-ea[0:1].t().expand(K, N) * 0.5)
+    # cancellation: the second half of the reduction repeats the first with the opposite sign, plus a small signal
+    h = K // 2
+    A[:, h:] = -A[:, :h]
+    Bm[h:] = Bm[:h] * (1.0 + 2.0 ** -12 * torch.randn(h, N, generator=gen))
+    ref = A.double() @ Bm.double()
+    mag = A.double().abs() @ Bm.double().abs()
+    e = {}
+    for mode in (1, 0):
+        C = _run(lib, A, Bm, ta, tb, mode, shape, acc=2 if ta else 0)
+        assert torch.isfinite(C).all()
+        e[mode] = float(((C.double() - ref).abs() / mag).max())
+    assert e[1] < 6e-7 and e[0] < 6e-7, e
+    assert float((ref.abs() / mag).median()) < 1e-2          # the case really cancels
+
+
+def test_non_finite_operands_propagate_like_the_fp32_kernel(x3_restore):
+    """An Inf / NaN operand poisons exactly the outputs the fp32 MFMA poisons, with the same class (+Inf, -Inf, NaN)."""
+    lib = x3_restore
+    gen = torch.Generator().manual_seed(12)
+    M, N, K = 21504, 256, 256
+    A = torch.randn(M, K, generator=gen)
+    Bm = torch.randn(K, N, generator=gen) * 0.1
+    A[3, 7] = float('inf')            # row 3: +-Inf by the sign of B[7, :]
+    A[64, 0] = float('-inf')
+    A[64, 1] = float('inf')           # row 64: Inf - Inf -> NaN wherever both hit non-zero weights
+    A[100, 5] = float('nan')          # row 100: NaN
+    Bm[9, :] = 0.0
+    A[200, 9] = float('inf')          # row 200: Inf * 0 -> NaN
+    Bm[11, 17] = float('inf')         # column 17: an Inf weight
+    outs = {mode: _run(lib, A, Bm, 0, 0, mode, 1) for mode in (1, 0)}
+    c3, c1 = outs[1], outs[0]
+    assert torch.equal(torch.isnan(c3), torch.isnan(c1))
+    assert torch.equal(torch.isposinf(c3), torch.isposinf(c1)) and torch.equal(torch.isneginf(c3), torch.isneginf(c1))
+    fin = torch.isfinite(c1)
+    assert int((~fin).sum()) >= 4 * N and float((c3[fin] - c1[fin]).abs().max()) < 1e-4
+    assert torch.isinf(c1[3]).all() and torch.isnan(c1[64]).any() and torch.isnan(c1[100]).all() and torch.isnan(c1[200]).all()
+
+
+def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore):
+    """|a| ~ 2^-112: hi / mid are normal bf16 values, the low plane falls below 2^-126.  Whatever the matrix core does with
+    a denormal bf16 input, the result must stay within the product form's bound against fp64 — if denormal inputs were
+    flushed the low plane would be lost and the error 2^-17 of a term (1e-5 relative), 20x the bound."""
+    lib = x3_restore
+    gen = torch.Generator().manual_seed(13)
+    M, N, K = 21504, 256, 256
+    A = torch.randn(M, K, generator=gen) * 2.0 ** -112
+    Bm = torch.randn(K, N, generator=gen) * 2.0 ** 90
+    ref = A.double() @ Bm.double()
+    mag = A.double().abs() @ Bm.double().abs()
+    e = {mode: float(((_run(lib, A, Bm, 0, 0, mode, 1).double() - ref).abs() / mag).max()) for mode in (1, 0)}
+    print("denormal low plane: error / sum|ab|  bf16x3 %.3g  fp32 MFMA %.3g" % (e[1], e[0]))
+    assert e[0] < 6e-7
+    assert e[1] < 6e-7, e
