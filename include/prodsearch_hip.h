@@ -134,6 +134,12 @@ int ps_set_fuse_bwd_min(int rows);
  * let only one kernel run at a time (counter-collecting profilers) are recognised from their environment and always get
  * events (PS_SIDE_EVENTS=1 forces that).  Returns the previous value. */
 int ps_set_side_mode(int mode);
+/* The value crossings are used only where a start-up self-test (once per process and device: the side stream parked on a
+ * probe word, released by a write-value on another stream, polled with a host-side timeout and, failing that, released from
+ * the host) has shown that a wait makes progress beside its producer; otherwise event pairs, which cannot hang.
+ * ps_side_values_in_use(): 1 = value waits in use, 0 = event pairs or a single stream.  PS_SIDE_SELFTEST_FAIL=1 makes the
+ * probe fail (tests). */
+int ps_side_values_in_use(void);
 /* Error-path hygiene of the side stream: every ps_*_backward that fails releases a fork of the side stream whose
  * signalling launch never happened, so the caller's next synchronize returns and the error surfaces (it could otherwise
  * wait forever on hipStreamWaitValue32).  ps_side_abort() does the same on demand; ps_debug_fail_fork(n) is the test hook

@@ -110,6 +110,7 @@ SYMBOLS = {
     'ps_arith_info': (C.c_char_p, []),
     'ps_set_fuse_bwd_min': (C.c_int, [C.c_int]),
     'ps_set_side_mode': (C.c_int, [C.c_int]),
+    'ps_side_values_in_use': (C.c_int, []),
     'ps_set_deterministic': (C.c_int, [C.c_int]),
     'ps_side_abort': (None, []),
     'ps_debug_fail_fork': (None, [C.c_int]),

@@ -371,16 +371,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int x3g_off(int row, int chunk) { return row * X3K + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
-// two adjacent reduction elements -> one packed pair per plane
+// two adjacent reduction elements -> one packed pair per plane.  Non-finite operands: hi carries the Inf / NaN and the residual
+// Inf - Inf = NaN follows it, so every output the operand reaches is NON-FINITE, as with the fp32 MFMA — but its class is NaN
+// where the fp32 kernel gives +-Inf (the form's own terms Inf * b_hi and Inf * b_mid have opposite signs: no split of b can
+// preserve the class); tests/test_gpu_gemm_x3.py pins exactly this
 __device__ __forceinline__ void x3g_split2(float x0, float x1, uint32_t& hi, uint32_t& mi, uint32_t& lo) {
   f32x2 v = {x0, x1};
   bf16x2 b = __builtin_convertvector(v, bf16x2);                         // v_cvt_pk_bf16_f32 (round to nearest even)
   hi = __builtin_bit_cast(uint32_t, b);
   v -= f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};   // v_pk_add_f32: exact
-  // a non-finite operand: hi carries it (Inf stays Inf, NaN stays NaN) and the residual Inf - Inf = NaN must not poison
-  // the other five terms — v_med3_f32(r, r, 0) returns 0 for a NaN r and r otherwise, so an Inf operand gives the fp32
-  // MFMA's result (+-Inf, or NaN against a zero / an opposite Inf) instead of NaN everywhere
-  v = f32x2{__builtin_amdgcn_fmed3f(v.x, v.x, 0.f), __builtin_amdgcn_fmed3f(v.y, v.y, 0.f)};
   b = __builtin_convertvector(v, bf16x2);
   mi = __builtin_bit_cast(uint32_t, b);
   v -= f32x2{__uint_as_float(mi << 16), __uint_as_float(mi & 0xffff0000u)};

@@ -70,7 +70,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[3]) {
       const float x = v[2 * i + e];
       const __bf16 bh = (__bf16)x;
       float r = x - (float)bh;
-      r = __builtin_amdgcn_fmed3f(r, r, 0.f);       // non-finite operand: hi carries it, the NaN residual (Inf - Inf) becomes 0 (gemm.hip)
       const __bf16 bm = (__bf16)r;
       r -= (float)bm;
       const __bf16 bl = (__bf16)r;

@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
         const float xv = x[2 * i + e];
         const __bf16 bh = (__bf16)xv;
         float r = xv - (float)bh;
-        r = __builtin_amdgcn_fmed3f(r, r, 0.f);     // non-finite weight: hi carries it, the NaN residual becomes 0 (gemm.hip, x3g_split2)
         const __bf16 bm = (__bf16)r;
         r -= (float)bm;
         const __bf16 bl = (__bf16)r;

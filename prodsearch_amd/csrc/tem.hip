@@ -419,6 +419,60 @@ static bool dispatch_may_be_serialised() {
   for (const char* n : counters) if (getenv(n)) return true;
   return !(getenv("ROCP_TOOL_LIBRARIES") && getenv("ROCPROF_KERNEL_TRACE"));
 }
+// Start-up self-test of the value crossings (once per device): park the side stream on a probe word, release it by a
+// write-value operation on ANOTHER stream, and poll — with a host-side timeout — for the side stream to drain.  Where dispatches
+// are serialised by something the environment list above does not know (a tool, a driver mode, one shared hardware queue) the
+// write never executes while the wait spins: the probe is then released from the host (a copy, not a kernel) and the value
+// crossings are switched off for this process (event pairs cannot hang).  If even the host cannot release it the side stream
+// is unusable: the step then runs on one stream and the reason is printed once.
+#include <chrono>
+#include <thread>
+static bool stream_drains_within(hipStream_t st, int ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+    if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > ms) return false;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+// 1 = value waits make progress, 0 = they do not (released from the host: use events), -1 = the side stream is stuck
+static int side_value_selftest(SideCtx& ctx) {
+  // the probe word lives in host-coherent memory: if the release by the other stream never runs, a plain host store frees the
+  // spinning wait without needing the device to execute anything
+  uint32_t* probe = nullptr;
+  if (hipHostMalloc((void**)&probe, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !probe) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  *probe = 0u;
+  hipStream_t other = nullptr;
+  if (hipStreamCreateWithFlags(&other, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(probe); return 0; }
+  int verdict = 0;
+  if (hipStreamWaitValue32(ctx.stream, probe, 1u, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess &&
+      hipStreamWriteValue32(other, probe, 1u, 0) == hipSuccess) {
+    const char* force = getenv("PS_SIDE_SELFTEST_FAIL");          // tests: pretend the write never ran
+    if (!(force && atoi(force) != 0) && stream_drains_within(ctx.stream, 500)) verdict = 1;
+    else {
+      __atomic_store_n(probe, 1u, __ATOMIC_SEQ_CST);
+      verdict = stream_drains_within(ctx.stream, 5000) ? 0 : -1;
+      fprintf(stderr, verdict == 0 ? "prodsearch_hip: stream value waits do not make progress beside their producer in this environment; "
+                                     "the side stream crosses with event pairs (PS_SIDE_EVENTS=1 skips this probe)\n"
+                                   : "prodsearch_hip: the side stream cannot be released (dispatches look serialised and blocked); "
+                                     "the step runs on ONE stream\n");
+    }
+  }
+  (void)hipGetLastError();
+  if (verdict >= 0) {                       // (a stuck stream is left alone: destroying it would wait for it)
+    (void)hipStreamSynchronize(other);
+    (void)hipStreamDestroy(other);
+    (void)hipHostFree(probe);
+  }
+  (void)hipGetLastError();
+  return verdict;
+}
+extern "C" int ps_side_values_in_use(void);
 static SideCtx* side_ctx() {
   if (ps_deterministic()) return nullptr;              // one stream: the order in which kernels add into a table is the launch order
   static SideCtx ctxs[PS_MAX_DEVICES];
@@ -457,6 +511,11 @@ static SideCtx* side_ctx() {
           hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can_wait) {
         if (hipMalloc((void**)&ctx.flag, 2 * sizeof(uint32_t)) != hipSuccess || hipMemset(ctx.flag, 0, 2 * sizeof(uint32_t)) != hipSuccess)
           ctx.flag = nullptr;
+        if (ctx.flag) {                        // the value crossings are used only where they are PROVEN to make progress
+          const int v = side_value_selftest(ctx);
+          if (v <= 0) { (void)hipFree(ctx.flag); ctx.flag = nullptr; }
+          if (v < 0) ok = false;               // unusable side stream: one stream
+        }
         // (tests of the wrap guard in side_fork: PS_SIDE_SEQ0 starts both sequences — and the words — at that value)
         const char* s0 = getenv("PS_SIDE_SEQ0");
         if (ctx.flag && s0 && *s0) {
@@ -469,6 +528,11 @@ static SideCtx* side_ctx() {
     }
   }
   return state == 1 ? &ctx : nullptr;
+}
+// 1 if this process crosses streams with value waits (the self-test passed), 0 if with event pairs / on one stream
+extern "C" int ps_side_values_in_use(void) {
+  SideCtx* c = side_ctx();
+  return c && c->flag ? 1 : 0;
 }
 static int& side_mode_slot() {
   static int v = getenv("PS_SIDE_MODE") ? atoi(getenv("PS_SIDE_MODE")) : 3;

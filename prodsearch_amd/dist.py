@@ -233,6 +233,11 @@ class ShardedAdamExchange(object):
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.gnorm = torch.zeros(2, device=dev, dtype=torch.float32)
         self._reduced = False
+        # how the reduce-scatter is issued: 'rccl' = reduce_scatter_tensor (RCCL picks the algorithm; rings are bound by ONE
+        # xGMI link); 'a2a' = equal-split all_to_all_single of the W slices + a local sum in rank order — on a fully connected
+        # node every slice travels over its own direct link (7 links busy), one hop, and the sum order is fixed
+        self.rs_mode = os.environ.get('PS_DP_RS', 'rccl')
+        self._a2a_recv = torch.empty(W, self.shard, device=dev, dtype=torch.float32) if (self.rs_mode == 'a2a' and W > 1) else None
         optim.grad_scale = 1.0 / W
         optim._sharded = self
         optim._plan = None
@@ -277,7 +282,10 @@ class ShardedAdamExchange(object):
         """reduce-scatter of the step's flat gradient; leaves the flat buffer zeroed for the next backward."""
         m = self.model
         flat = m._grad_flat
-        if self.world > 1:
+        if self.world > 1 and self._a2a_recv is not None:
+            dist.all_to_all_single(self._a2a_recv.view(-1), flat, group=self.group)
+            torch.sum(self._a2a_recv, dim=0, out=self.g_shard)
+        elif self.world > 1:
             dist.reduce_scatter_tensor(self.g_shard, flat, op=dist.ReduceOp.SUM, group=self.group)
         else:
             self.g_shard.copy_(flat[self.lo:self.hi])
