@@ -43,8 +43,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MD 128            // model width this kernel is specialised for
 #define MBM 32            // replica rows per workgroup
 #define MT_THREADS 512
+#define MLP_PF_DEFAULT 3
 #define PLD 132           // row stride (floats) of the partial tiles in LDS: [m][n], 16-byte aligned rows, +16 B per row
-#define PF 3              // weight fragments in flight per wave (product steps ahead)
 
 // Launder a value through an empty asm: stops LLVM from hoisting per-row store addresses out of unrolled code.
 __device__ inline int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -99,7 +99,11 @@ __device__ __forceinline__ void x3_mma(f32x16& acc, const uint4 (&a)[3], const u
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[0]), BF(b[0]), acc, 0, 0, 0);
 #undef BF
 }
-// one product step's weight fragment: three planes of 64 lanes x 16 bytes, contiguous (WSplit, fragment order)
+// one product step's weight fragment: three planes of 64 lanes x 16 bytes, contiguous (WSplit, fragment order).
+// The main phase is one fully unrolled basic block; left alone, hipcc's scheduler sinks these refills next to the MFMAs that
+// consume them and waits vmcnt(0..1) in front of every product step — an effective prefetch distance of ONE step whatever PF
+// says (round-3 ISA listing).  Every step therefore ends in a sched_barrier: the refill stays where it is issued, PF steps
+// ahead of its use, and the waits become the counted vmcnt(3 (PF - 1)) they should be.
 __device__ __forceinline__ void load_frag(uint4 (&f)[3], const uint16_t* __restrict__ stream, int step, int lane) {
   const uint4* q = reinterpret_cast<const uint4*>(stream) + (size_t)step * 192 + lane;
   f[0] = q[0]; f[1] = q[64]; f[2] = q[128];
@@ -126,7 +130,7 @@ __device__ __forceinline__ void dump_acc(float* slot, const f32x16& v, int l31, 
 // ====================================================================== forward
 // Lane roles.  Products: lane (l31, h) = replica row l31 of the workgroup, half h; accumulator register r = logical feature
 // 16 h + r of the 32-feature block.  LayerNorm stages: lane = (row 4*wave + (lane >> 4), columns 8c .. 8c+7 with c = lane & 15).
-template <int NBW>       // hidden-layer feature blocks per wave: F = 256 * NBW
+template <int NBW, int PF>       // hidden-layer feature blocks per wave: F = 256 * NBW; PF = weight fragments in flight per wave
 __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdArgs a) {
   extern __shared__ float lds_raw[];
   MlpTLds& L = *reinterpret_cast<MlpTLds*>(lds_raw);
@@ -270,13 +274,16 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    uint4 bq[2][3];                                                    // the B operand of step t + 1 is read under step t's MFMAs
+    read_b(bq[0], L.Xa, l31, 8 * h);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                      // a1^T block = W1[block rows] . ln1^T
       const int s = 16 * bi + t;
-      uint4 b[3];
-      read_b(b, L.Xa, l31, 16 * t + 8 * h);
-      x3_mma(acc1, ring[s % PF], b);
+      if (t + 1 < 8) read_b(bq[(t + 1) & 1], L.Xa, l31, 16 * (t + 1) + 8 * h);
+      __builtin_amdgcn_sched_barrier(0);       // (the reads of step t + 1 go out BEFORE this step's MFMAs, not behind them)
+      x3_mma(acc1, ring[s % PF], bq[t & 1]);
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
     // epilogue in registers: bias, GELU, dropout; a1 / h1 leave as one 64-byte run per lane; h1 becomes the next B operand
     float hv[16];
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       const int s = 16 * bi + 8 + u;
       x3_mma(acc2[u & 3], ring[s % PF], hf[u >> 2]);
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
   }
   // folded scoring: the item row this lane's enc elements will be dotted with (requested under the dumps and the barrier)
@@ -419,10 +427,12 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs <= 256 workgroups");
   KTimeScope kt("mlp_fwd", st);
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
-  static bool a1 = false, a2 = false, a4 = false;
-  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1>, a1)); hipLaunchKernelGGL(mlp_fwd_t_kernel<1>, grid, block, sizeof(MlpTLds), st, a); }
-  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2>, a2)); hipLaunchKernelGGL(mlp_fwd_t_kernel<2>, grid, block, sizeof(MlpTLds), st, a); }
-  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4>, a4)); hipLaunchKernelGGL(mlp_fwd_t_kernel<4>, grid, block, sizeof(MlpTLds), st, a); }
+  static bool a1 = false, a2 = false, a2b = false, a4 = false;
+  static const int pf = getenv("PS_MLP_PF") ? atoi(getenv("PS_MLP_PF")) : MLP_PF_DEFAULT;     // tuning: 3 or 5 product steps in flight
+  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, a); }
+  else if (a.F == 512 && pf >= 5) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 5>, a2b)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, a); }
+  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, a); }
+  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); hipLaunchKernelGGL((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, a); }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -436,7 +446,7 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
 //   d ctx^T = Wo^T . dout^T  (4 output blocks x 2 reduction halves over the 8 waves, halves met in LDS)
 // Writes only what the weight gradients and the fan-in residual read (do2, da1, dy1, dout, dctx) and parks the seven
 // bias / gamma / beta column sums per workgroup (fixed-order sums: bitwise reproducible).
-template <int NBW>
+template <int NBW, int PF>
 __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdArgs a) {
   fork_signal(a.sig, a.sigval);
   extern __shared__ float lds_raw[];
@@ -592,13 +602,16 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    uint4 bq[2][3];                                                    // the B operand of step t + 1 is read under step t's MFMAs
+    read_b(bq[0], L.Xa, l31, 8 * h);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                      // d h1^T block = W2^T[block rows] . do2^T
       const int s = 16 * bi + t;
-      uint4 b[3];
-      read_b(b, L.Xa, l31, 16 * t + 8 * h);
-      x3_mma(acc1, ring[s % PF], b);
+      if (t + 1 < 8) read_b(bq[(t + 1) & 1], L.Xa, l31, 16 * (t + 1) + 8 * h);
+      __builtin_amdgcn_sched_barrier(0);       // (the reads of step t + 1 go out BEFORE this step's MFMAs, not behind them)
+      x3_mma(acc1, ring[s % PF], bq[t & 1]);
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
     Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
     if (a.drop_ff1.thr) {
@@ -641,6 +654,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       const int s = 16 * bi + 8 + u;
       x3_mma(acc2[u & 3], ring[s % PF], df[u >> 2]);
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
   }
   // FF LayerNorm inputs and the Wo^T fragments, requested under the dumps and the barrier
@@ -713,14 +727,18 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   MlpBwdArgs b = a;
   b.sig = nullptr; b.sigval = 0;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
-  static bool a1 = false, a2 = false, a4 = false;
-  if (a.F == 256) TRY(set_lds_attr(mlp_bwd_t_kernel<1>, a1));
-  else if (a.F == 512) TRY(set_lds_attr(mlp_bwd_t_kernel<2>, a2));
-  else TRY(set_lds_attr(mlp_bwd_t_kernel<4>, a4));
+  static bool a1 = false, a2 = false, a2b = false, a4 = false;
+  static const int pf = getenv("PS_MLP_PF") ? atoi(getenv("PS_MLP_PF")) : MLP_PF_DEFAULT;
+  const bool deep = a.F == 512 && pf >= 5;
+  if (a.F == 256) TRY(set_lds_attr(mlp_bwd_t_kernel<1, 3>, a1));
+  else if (deep) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 5>, a2b));
+  else if (a.F == 512) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 3>, a2));
+  else TRY(set_lds_attr(mlp_bwd_t_kernel<4, 3>, a4));
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
-  if (a.F == 256) hipLaunchKernelGGL(mlp_bwd_t_kernel<1>, grid, block, sizeof(MlpTLds), st, b);
-  else if (a.F == 512) hipLaunchKernelGGL(mlp_bwd_t_kernel<2>, grid, block, sizeof(MlpTLds), st, b);
-  else hipLaunchKernelGGL(mlp_bwd_t_kernel<4>, grid, block, sizeof(MlpTLds), st, b);
+  if (a.F == 256) hipLaunchKernelGGL((mlp_bwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, b);
+  else if (deep) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, b);
+  else if (a.F == 512) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, b);
+  else hipLaunchKernelGGL((mlp_bwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, b);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

@@ -93,7 +93,7 @@ struct EmbedArgs {
   // filled by the launcher (grid = B gather + samp_wgs + list_wgs + word_wgs workgroups)
   int fold_words; ScoreArgs sc; int word_wgs, list_wgs;
   WSplit split; int split_wgs;   // optional: re-split the fused kernels' weights (WSplit); split_wgs filled by the launcher
-  uint32_t* clear_word;          // optional: TWO words (one 64-bit ticket of a later kernel) set to 0 by the launch
+  uint32_t* clear_word;          // optional: FOUR words (a 64-bit ticket of a later kernel, a list counter, one spare) set to 0 by the launch
   int32_t* zero_i32; int zero_n, zero_wgs;   // optional: int32 words to clear (the review transformer's word counters); zero_wgs filled by the launcher
 };
 int launch_embed_fwd(const EmbedArgs& a, hipStream_t st);

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     return;
   }
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (b == 0 && tid == 0 && a.clear_word) { a.clear_word[0] = 0u; a.clear_word[1] = 0u; }
+  if (b == 0 && tid == 0 && a.clear_word) { a.clear_word[0] = 0u; a.clear_word[1] = 0u; a.clear_word[2] = 0u; a.clear_word[3] = 0u; }
   const int d = a.d, nchunk = d >> 2;
   const int rpp = 256 / nchunk;
   const int rg = tid / nchunk, c = tid - rg * nchunk;

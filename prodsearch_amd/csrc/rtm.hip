@@ -26,6 +26,7 @@ struct RtmWs {
   int Bseq, S, J;
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
   int64_t loss_blk;         // the 64-bit loss / arrival word of rtm_score_kernel (cleared by the query-encoder launch)
+  int64_t glist;            // int32 list of the review-row groups that hold at least one real review (rtm_grouplist_kernel)
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
   int64_t wrank;
   int64_t wcnt, woff, wcur, wl;   // pvc backward: inverted index word -> review slots (int32 arrays; wl: int2 {slot, word})
@@ -126,7 +127,8 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.pv_terms = rtake(cur, npv);
   r.nvalid = rtake(cur, 4);
   r.seqcnt = rtake(cur, (int64_t)r.Bseq + 4);
-  r.loss_blk = rtake(cur, 4);
+  r.loss_blk = rtake(cur, 4);         // [0..1] the loss word, [2] the valid-group count of rtm_grouplist_kernel
+  r.glist = eval ? 0 : rtake(cur, (int64_t)ps_cdiv((int64_t)D.B * D.R, 4) + ps_cdiv((int64_t)D.B * D.K * D.R, 4) + 4);
   r.dvec = rtake(cur, (int64_t)D.B * D.R * d);
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
@@ -389,6 +391,48 @@ __global__ __launch_bounds__(256) void rtm_embed_kernel(const RtmK a) {
       *reinterpret_cast<float4*>(a.vec + (size_t)revrow * d + 4 * cc) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Which groups of four consecutive review rows hold at least one real review?  73 % of the review slots of a C4 batch are
+// padding, and a launch over ALL groups spends most of its workgroup slots on waves that only find that out after a
+// dependent load.  One thread per group: a group with a real review is appended to the list (wave-aggregated: one atomic
+// per wave; the order of the list does not matter — a group's outputs are its own), a group of padding only has its key-mask
+// flags and word counts written here and never reaches the gather launch (only used when padded rows of x are not read:
+// `pads_unread`).  *gcount is cleared by the query-encoder launch (EmbedArgs::clear_word).
+__global__ __launch_bounds__(256) void rtm_grouplist_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int* glist,
+                                                            int* gcount) {
+  const int g = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool in = g < npos_grp + nneg_grp;
+  const bool pos = g < npos_grp;
+  const int gg = pos ? g : g - npos_grp;
+  const int nrev = pos ? a.B * a.R : a.B * a.K * a.R;
+  const int64_t rpad = a.RC - 1;
+  bool any_ok = false;
+  if (in) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = 4 * gg + q;
+      if (rr < nrev) any_ok |= (pos ? a.pos_r : a.neg_r)[rr] != rpad;
+    }
+    if (!any_ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * gg + q;
+        if (rr >= nrev) continue;
+        const int base = fdiv(rr, fR), r = rr - base * a.R;
+        int n;
+        if (pos) n = base * a.J;
+        else { const int b = fdiv(base, fK); n = b * a.J + 1 + (base - b * a.K); }
+        a.valid[(size_t)n * a.S + r + 1] = 0.f;
+        a.cnt[(size_t)n * a.R + r] = 1.f;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(in && any_ok);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(gcount, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (in && any_ok) glist[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+}
+
 // ------------------------------------------------------------------ embed forward, pvc encoder: four reviews per wave
 // The per-slot kernel above spends most of its time in Philox: a wave (one review) evaluates the token masks of its word
 // slots and the dropout words of its output columns, and every evaluation yields four words of which it uses ONE — the
@@ -409,10 +453,21 @@ struct E4Lds {
   uint32_t dw[4][64 * NCHL][4];    // [wave][column][review]: dropout words of the output row (d = 64 * NCHL columns)
 };
 template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
-__global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread) {
+__global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread,
+                                                         const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg) {
   __shared__ E4Lds<NCHL> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = blockIdx.x * 4 + wv;
+  int g = blockIdx.x * 4 + wv;
+  if (glist) {
+    // with the valid-group list (rtm_grouplist_kernel) the launch is DENSE in real work: the first nq_wg workgroups are the
+    // query waves, the rest take groups from the list; waves past its end leave at once (no workgroup barrier in this kernel)
+    if ((int)blockIdx.x < nq_wg) g = npos_grp + nneg_grp + (int)blockIdx.x * 4 + wv;
+    else {
+      const int gi = ((int)blockIdx.x - nq_wg) * 4 + wv;
+      if (gi >= *gcount) return;
+      g = glist[gi];
+    }
+  }
   const int d = a.d;
   const int64_t rpad = a.RC - 1;
   if (g >= npos_grp + nneg_grp) {
@@ -519,6 +574,17 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
+  // occurrences of that word (a returning atomic on the word's counter, requested BEFORE the gather, in flight under it and under the rest of the kernel); the fill
+  // then places the occurrence at  segment start + rank  without another atomic
+  int rka[4] = {-1, -1, -1, -1}, rkb[4] = {-1, -1, -1, -1};
+  if (a.count_fwd && any_ok) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      rka[qq] = cwa[qq] >= 0 ? atomicAdd(&a.wcnt[cwa[qq]], 1) : -1;
+      rkb[qq] = cwb[qq] >= 0 ? atomicAdd(&a.wcnt[cwb[qq]], 1) : -1;
+    }
+  }
   // ---- 3. gather: group q = lane >> 4 walks list q
   const int q = lane >> 4, c = lane & 15;
   const int myn = q == 0 ? nlq[0] : (q == 1 ? nlq[1] : (q == 2 ? nlq[2] : nlq[3]));
@@ -551,17 +617,6 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       }
   }
 
-  // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
-  // occurrences of that word (a returning atomic on the word's counter, in flight under the rest of the kernel); the fill
-  // then places the occurrence at  segment start + rank  without another atomic
-  int rka[4] = {-1, -1, -1, -1}, rkb[4] = {-1, -1, -1, -1};
-  if (a.count_fwd && any_ok) {
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      rka[qq] = cwa[qq] >= 0 ? atomicAdd(&a.wcnt[cwa[qq]], 1) : -1;
-      rkb[qq] = cwb[qq] >= 0 ? atomicAdd(&a.wcnt[cwb[qq]], 1) : -1;
-    }
-  }
   // ---- 4. this group's review: mean, dropout, segment / user / item rows, mask, positional row
   const bool live = q == 0 ? liveq[0] : (q == 1 ? liveq[1] : (q == 2 ? liveq[2] : liveq[3]));
   if (live) {
@@ -1401,9 +1456,23 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
       static const bool keep_pads = getenv("PS_RTM_WRITE_PADS") && atoi(getenv("PS_RTM_WRITE_PADS")) != 0;
       const int pads_unread = enc_rowlist_taken(E, w, rtm_rows_listed(r, w)) && !k.raw && !keep_pads ? 1 : 0;
       const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
-      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
-      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
-      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, grid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread);
+      // the valid-group list (rtm_grouplist_kernel): only when padded rows of x are not read and the counter is cleared by
+      // the query-encoder launch (training).  PS_RTM_GROUPLIST=0: every group gets a wave, as in round 2.
+      static const bool list_on = !(getenv("PS_RTM_GROUPLIST") && atoi(getenv("PS_RTM_GROUPLIST")) == 0);
+      const int* glist = nullptr; const int* gcount = nullptr;
+      const int nq_wg = ps_cdiv(r.Bseq, 4);
+      dim3 egrid = grid;
+      if (list_on && pads_unread && !eval && r.glist && !k.train_pv) {
+        int* gl = reinterpret_cast<int*>(ws + r.glist);
+        int* gc = reinterpret_cast<int*>(ws + r.loss_blk) + 2;
+        hipLaunchKernelGGL(rtm_grouplist_kernel, dim3(ps_cdiv(npos + nneg, 256)), dim3(256), 0, st, k, npos, nneg, fR, fK, gl, gc);
+        PS_LAUNCH_CHECK();
+        glist = gl; gcount = gc;
+        egrid = dim3(nq_wg + ps_cdiv(npos + nneg, 4));
+      }
+      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
+      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
+      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
     } else {
       hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
     }

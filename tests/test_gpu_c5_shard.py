@@ -130,7 +130,9 @@ def test_c5_shard_step_matches_the_oracle_on_the_gathered_rows(P_):
         assert rel_err(top_score.cpu(), best_s.cpu()) < 2e-4
         agree = (top_idx == best_i).float().mean()
         assert float(agree) > 0.98                                   # (scores closer than the fp32 tolerance may swap places)
-        assert int((rank.long() - (ahead + 1)).abs().max()) <= 2
+        # the target sits among ~10^6 products per unit of score: a reference score that differs in its last bits (torch's
+        # summation order against the MFMA chain's) moves the count by its density times that difference
+        assert int((rank.long() - (ahead + 1)).abs().max()) <= max(2, P_ // 200_000)
     del m, optim
     torch.cuda.empty_cache()
 
