@@ -108,6 +108,10 @@ __device__ __forceinline__ void load_frag(uint4 (&f)[3], const uint16_t* __restr
   const uint4* q = reinterpret_cast<const uint4*>(stream) + (size_t)step * 192 + lane;
   f[0] = q[0]; f[1] = q[64]; f[2] = q[128];
 }
+__device__ __forceinline__ void load_frag2(uint4 (&f)[3], const uint16_t* __restrict__ stream, int step, int lane) {   // DIAG
+  const uint4* q = reinterpret_cast<const uint4*>(stream) + (size_t)step * 192 + lane;
+  f[0] = q[0]; f[1] = q[64];
+}
 __device__ __forceinline__ void read_b(uint4 (&b)[3], const uint16_t (*planes)[MBM * MD], int l31, int k0) {
   const int off = xa_off(l31, k0);
 #pragma unroll
@@ -127,10 +131,24 @@ __device__ __forceinline__ void dump_acc(float* slot, const f32x16& v, int l31, 
   for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// diagnostic timeline (tools/mlp_stamps.py): wave w of workgroup 0 stores s_memtime into stamp[16 * w + slot]
+static unsigned long long* g_mlp_stamp = nullptr;
+extern "C" void ps_debug_set_stamp_buffer(void* p) { g_mlp_stamp = (unsigned long long*)p; }
+#define MLP_STAMP(slot)                                                                              \
+  do {                                                                                               \
+    if (a.stamp && blockIdx.x == 0 && lane == 0) {                                                   \
+      unsigned long long t_;                                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+      a.stamp[16 * wave + (slot)] = t_;                                                              \
+    }                                                                                                \
+  } while (0)
+
 // ====================================================================== forward
 // Lane roles.  Products: lane (l31, h) = replica row l31 of the workgroup, half h; accumulator register r = logical feature
 // 16 h + r of the 32-feature block.  LayerNorm stages: lane = (row 4*wave + (lane >> 4), columns 8c .. 8c+7 with c = lane & 15).
-template <int NBW, int PF>       // hidden-layer feature blocks per wave: F = 256 * NBW; PF = weight fragments in flight per wave
+// DIAG (timing experiments only, results are wrong): 1 = the low weight plane is not loaded, 2 = no weight loads in the main
+// phase, 3 = a1 / h1 are not stored
+template <int NBW, int PF, int DIAG = 0>       // hidden-layer feature blocks per wave: F = 256 * NBW; PF = weight fragments in flight per wave
 __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdArgs a) {
   extern __shared__ float lds_raw[];
   MlpTLds& L = *reinterpret_cast<MlpTLds*>(lds_raw);
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
   const int mrow = 4 * wave + (lane >> 4), c8 = 8 * (lane & 15);       // LayerNorm-stage role
   const int mg = m0 + mrow;
   const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+  MLP_STAMP(0);
 
   // ---- prologue: everything with a global round trip is requested now
   // (1) the wave's four Wo fragments: output block nb = wave & 3, k half kh = wave >> 2
@@ -181,6 +200,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
 #pragma unroll
   for (int s = 0; s < PF; ++s) load_frag(ring[s], ff_stream, s, lane);
   __syncthreads();                                                     // P: ctx planes + vectors in LDS
+  MLP_STAMP(1);
 
   // ---- Wo: this wave's [32 features x 32 rows] partial over its k half
   {
@@ -195,7 +215,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     }
     dump_acc(L.Ps[kh], acc, l31, h, nbo);
   }
+  MLP_STAMP(2);
   __syncthreads();                                                     // A: Wo partials in Ps[0..1]; ctx planes consumed
+  MLP_STAMP(3);
 
   // one LayerNorm stage, all 8 waves: v = dropout(sum of partial tiles + bias) + residual ; LayerNorm
   auto ln_stage = [&](const int nslots, const int vb, const DropSpec& drop, const uint32_t dstep, const int vg, const int ve,
@@ -251,7 +273,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     ln_stage(2, 0, a.drop_ctx, step_ctx, 1, 2, true, y1r, o, mean, rstd);
     ln_store(a.y1, a.ln1, a.st1, y1r, o, mean, rstd);
   }
+  MLP_STAMP(4);
   __syncthreads();                                                     // B: ln1 planes in Xa
+  MLP_STAMP(5);
 
   // ---- the feed-forward chain of this wave's feature blocks: no barrier until every wave is through
   f32x16 acc2[4];
@@ -282,16 +306,18 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       if (t + 1 < 8) read_b(bq[(t + 1) & 1], L.Xa, l31, 16 * (t + 1) + 8 * h);
       __builtin_amdgcn_sched_barrier(0);       // (the reads of step t + 1 go out BEFORE this step's MFMAs, not behind them)
       x3_mma(acc1, ring[s % PF], bq[t & 1]);
-      load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      if (DIAG == 1) load_frag2(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      else if (DIAG != 2) load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
+    MLP_STAMP(6 + 3 * bi);
     // epilogue in registers: bias, GELU, dropout; a1 / h1 leave as one 64-byte run per lane; h1 becomes the next B operand
     float hv[16];
     float* a1p = a.a1 + (size_t)opaque(mrow_p) * F + f0;
     float* h1p = a.h1 + (size_t)opaque(mrow_p) * F + f0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] += bias[r];
-    if (row_ok) {
+    if (row_ok && DIAG != 3) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(a1p + 4 * q) = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       if (a.drop_ff1.thr) g *= drop_half(a.drop_ff1, r < 8 ? r0 : r1, r & 7);
       hv[r] = g;
     }
-    if (row_ok) {
+    if (row_ok && DIAG != 3) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(h1p + 4 * q) = make_float4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
@@ -319,14 +345,17 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       split8(lo8, hf[0]);
       split8(hi8, hf[1]);
     }
+    MLP_STAMP(7 + 3 * bi);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {                                      // y2^T += W2[:, block] . h1^T block   (k step u >> 2, rows 32 (u & 3) ..)
       const int s = 16 * bi + 8 + u;
       x3_mma(acc2[u & 3], ring[s % PF], hf[u >> 2]);
-      load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      if (DIAG == 1) load_frag2(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
+      else if (DIAG != 2) load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
   }
+  MLP_STAMP(12);
   // folded scoring: the item row this lane's enc elements will be dotted with (requested under the dumps and the barrier)
   float itr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ibias = 0.f;
@@ -344,10 +373,12 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) dump_acc(L.Ps[wave], acc2[nb], l31, h, nb);
   __syncthreads();                                                     // C: the 8 waves' y2 partials in Ps[0..7]
+  MLP_STAMP(13);
 
   // y2 = dropout(h1.W2^T + b2) + y1 ; enc = LayerNorm_final(y2)
   float o[8], mean, rstd;
   ln_stage(8, 3, a.drop_ff2, step_ff2, 4, 5, false, y1r, o, mean, rstd);
+  MLP_STAMP(14);
   if (!a.fold_score) { ln_store(a.y2, a.enc, a.stf, y1r, o, mean, rstd); return; }
 
   // ---- folded scoring: score, loss term, one loss partial per workgroup handed over by ONE returning 64-bit atomic (fixed
@@ -386,6 +417,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     L.red[8] = last;
   }
   __syncthreads();
+  MLP_STAMP(15);
   if (L.red[8] == 0.f) return;
   if (wave == 0) {      // last arriver: add the word tasks' partials in a fixed order => bitwise reproducible
     float il = 0.f;
@@ -426,13 +458,17 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   PS_REQUIRE(a.x3.on && a.x3.fwd_wo && a.x3.fwd_ff, "fused mlp: the weight fragment streams are missing (WSplit)");
   PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs <= 256 workgroups");
   KTimeScope kt("mlp_fwd", st);
+  MlpFwdArgs as = a;
+  as.stamp = g_mlp_stamp;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
-  static bool a1 = false, a2 = false, a2b = false, a4 = false;
-  static const int pf = getenv("PS_MLP_PF") ? atoi(getenv("PS_MLP_PF")) : MLP_PF_DEFAULT;     // tuning: 3 or 5 product steps in flight
-  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, a); }
-  else if (a.F == 512 && pf >= 5) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 5>, a2b)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, a); }
-  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, a); }
-  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); hipLaunchKernelGGL((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, a); }
+  static bool a1 = false, a2 = false, a4 = false, ad1 = false, ad2 = false, ad3 = false;
+  static const int diag = getenv("PS_MLP_DIAG") ? atoi(getenv("PS_MLP_DIAG")) : 0;          // timing experiments (wrong results)
+  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && diag == 1) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 1>, ad1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 1>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && diag == 2) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 2>, ad2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 2>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && diag == 3) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 3>, ad3)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); hipLaunchKernelGGL((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -727,16 +763,12 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   MlpBwdArgs b = a;
   b.sig = nullptr; b.sigval = 0;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
-  static bool a1 = false, a2 = false, a2b = false, a4 = false;
-  static const int pf = getenv("PS_MLP_PF") ? atoi(getenv("PS_MLP_PF")) : MLP_PF_DEFAULT;
-  const bool deep = a.F == 512 && pf >= 5;
+  static bool a1 = false, a2 = false, a4 = false;
   if (a.F == 256) TRY(set_lds_attr(mlp_bwd_t_kernel<1, 3>, a1));
-  else if (deep) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 5>, a2b));
   else if (a.F == 512) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 3>, a2));
   else TRY(set_lds_attr(mlp_bwd_t_kernel<4, 3>, a4));
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
   if (a.F == 256) hipLaunchKernelGGL((mlp_bwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, b);
-  else if (deep) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, b);
   else if (a.F == 512) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, b);
   else hipLaunchKernelGGL((mlp_bwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, b);
   PS_LAUNCH_CHECK();

@@ -228,6 +228,7 @@ struct MlpFwdArgs {
   float *y1, *ln1, *st1, *a1, *h1, *y2, *stf, *enc;
   int fold_score; ScoreArgs sc;   // item scoring + loss in the epilogue (ScoreArgs, folded form); M = B*(K+1)
   WSplit x3;                      // bf16x3 fragment streams of wo / w1 / w2
+  unsigned long long* stamp;      // diagnostics: workgroup 0's waves record s_memtime at their phase boundaries (ps_debug_set_stamp_buffer)
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool mlp_fwd_can_fold_score(int M, int F, int d);   // the wave-specialised kernel will serve this shape

@@ -454,7 +454,7 @@ struct E4Lds {
 };
 template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
 __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread,
-                                                         const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg) {
+                                                         const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg, int diag) {
   __shared__ E4Lds<NCHL> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int g = blockIdx.x * 4 + wv;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   if (any_ok) {
     // ---- the word slots and their token masks
     Philox4 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u};
-    if (ts.thr) {
+    if (ts.thr && !(diag & 8)) {
       t0 = philox4x32_10((uint32_t)lane, (uint32_t)gg, ts.site, drop_step(ts), ts.k0, ts.k1);
       if (a.WL > 64) t1 = philox4x32_10((uint32_t)lane + 64u, (uint32_t)gg, ts.site, drop_step(ts), ts.k0, ts.k1);
     }
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     }
   }
   // dropout words of the output row: lane evaluates columns lane, lane + 64, ... for the four reviews at once
-  if (ds.thr && any_ok)
+  if (ds.thr && any_ok && !(diag & 2))
     for (int col = lane; col < d; col += 64) {
       const Philox4 r = philox4x32_10((uint32_t)col, (uint32_t)gg, ds.site, drop_step(ds), ds.k0, ds.k1);
       L.dw[wv][col][0] = r.x; L.dw[wv][col][1] = r.y; L.dw[wv][col][2] = r.z; L.dw[wv][col][3] = r.w;
@@ -574,21 +574,10 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
-  // occurrences of that word (a returning atomic on the word's counter, requested BEFORE the gather, in flight under it and under the rest of the kernel); the fill
-  // then places the occurrence at  segment start + rank  without another atomic
-  int rka[4] = {-1, -1, -1, -1}, rkb[4] = {-1, -1, -1, -1};
-  if (a.count_fwd && any_ok) {
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      rka[qq] = cwa[qq] >= 0 ? atomicAdd(&a.wcnt[cwa[qq]], 1) : -1;
-      rkb[qq] = cwb[qq] >= 0 ? atomicAdd(&a.wcnt[cwb[qq]], 1) : -1;
-    }
-  }
   // ---- 3. gather: group q = lane >> 4 walks list q
   const int q = lane >> 4, c = lane & 15;
   const int myn = q == 0 ? nlq[0] : (q == 1 ? nlq[1] : (q == 2 ? nlq[2] : nlq[3]));
-  const int maxn = max(max(nlq[0], nlq[1]), max(nlq[2], nlq[3]));
+  const int maxn = (diag & 1) ? 0 : max(max(nlq[0], nlq[1]), max(nlq[2], nlq[3]));       // diag: timing experiments only
   float4 v[NCHL], vc[NCHL];
 #pragma unroll
   for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
@@ -617,6 +606,17 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       }
   }
 
+  // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
+  // occurrences of that word (a returning atomic on the word's counter, in flight under the rest of the kernel (issued in front of the gather instead they cost 4 us: measured)); the fill
+  // then places the occurrence at  segment start + rank  without another atomic
+  int rka[4] = {-1, -1, -1, -1}, rkb[4] = {-1, -1, -1, -1};
+  if (a.count_fwd && any_ok) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      rka[qq] = cwa[qq] >= 0 ? atomicAdd(&a.wcnt[cwa[qq]], 1) : -1;
+      rkb[qq] = cwb[qq] >= 0 ? atomicAdd(&a.wcnt[cwb[qq]], 1) : -1;
+    }
+  }
   // ---- 4. this group's review: mean, dropout, segment / user / item rows, mask, positional row
   const bool live = q == 0 ? liveq[0] : (q == 1 ? liveq[1] : (q == 2 ? liveq[2] : liveq[3]));
   if (live) {
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   const int rr = 4 * gg + q;
   const float cntf = (float)(nw > 0 ? nw : 1), inv = 1.f / cntf;
   if (c == 0) { a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f; a.cnt[(size_t)n * a.R + s - 1] = cntf; }
-  const bool skip_row = !ok && pads_unread && !need_unc;
+  const bool skip_row = (!ok && pads_unread && !need_unc) || (diag & 4);
 #pragma unroll
   for (int k = 0; k < NCHL; ++k) {
     if (skip_row) break;
@@ -1360,9 +1360,21 @@ static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) 
   static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
   return e4_on && k.pvc && !k.eval && D.WL <= 128 && (D.d == 64 || D.d == 128 || D.d == 256) && r.S <= 64;
 }
+// Round 3: the whole index (count, allocate, fill) is built on the SIDE stream, started by the forward and running beside it.
+// It depends on the batch's indices only, and timing-only variants of rtm_embed4_kernel showed that the per-occurrence returning
+// atomics the count-in-forward form issued were 45 of that kernel's 97 us (1.16 M scattered 4-byte atomics: the memory-side
+// atomic rate for one dword per lane in 64 different lines, MI355X_MICROARCH.md), hidden by nothing.  On the side stream the
+// same atomics run under the forward's ~300 us of other work; the backward finds the index ready (same stream, in order) and
+// its own side stream starts free.  PS_RTM_EARLY_INDEX=0: the round-2 form (ranks in the forward, fill in the backward).
+static bool rtm_index_early(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
+  static const bool on = !(getenv("PS_RTM_EARLY_INDEX") && atoi(getenv("PS_RTM_EARLY_INDEX")) == 0);
+  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
+  (void)D;
+  return on && !late && k.pvc && !k.eval && r.wcnt != 0;
+}
 static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
   static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
-  return !late && rtm_embed4_taken(D, k, r);
+  return !late && !rtm_index_early(D, k, r) && rtm_embed4_taken(D, k, r);
 }
 // count (unless a kernel that reads the words anyway did), allocate, fill
 static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hipStream_t st) {
@@ -1415,6 +1427,14 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   if (!eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG))
     PS_REQUIRE(k.wmask_pos && k.wmask_neg, "rtm: the fs / avg review encoders need the batch's word masks");
   if (k.train_pv) PS_REQUIRE(k.pos_words && k.pos_masks && k.neg_word_idxs, "rtm: null PV-loss tensors");
+  if (!eval && rtm_index_early(D, k, r)) {        // the backward's inverted index: side stream, beside the whole forward
+    hipStream_t ss = side_stream_or(st);
+    if (ss != st) TRY(side_fork_events(st));
+    PS_CHECK_HIP(hipMemsetAsync(k.wcnt, 0, sizeof(int) * ((size_t)D.vocab_size + 1), ss));
+    RtmK ki = k;
+    ki.count_fwd = 0;
+    TRY(rtm_build_index(ki, r, (int)D.vocab_size, true, ss));
+  }
   // query encoder (shared kernels): masked mean (+FS dropout) then tanh(f_W . + b)
   PsTemDesc dq;
   memset(&dq, 0, sizeof(dq));
@@ -1458,6 +1478,7 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
       const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
       // the valid-group list (rtm_grouplist_kernel): only when padded rows of x are not read and the counter is cleared by
       // the query-encoder launch (training).  PS_RTM_GROUPLIST=0: every group gets a wave, as in round 2.
+      static const int e4_diag = getenv("PS_RTM_DIAG") ? atoi(getenv("PS_RTM_DIAG")) : 0;      // timing experiments (wrong results)
       static const bool list_on = !(getenv("PS_RTM_GROUPLIST") && atoi(getenv("PS_RTM_GROUPLIST")) == 0);
       const int* glist = nullptr; const int* gcount = nullptr;
       const int nq_wg = ps_cdiv(r.Bseq, 4);
@@ -1470,9 +1491,9 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
         glist = gl; gcount = gc;
         egrid = dim3(nq_wg + ps_cdiv(npos + nneg, 4));
       }
-      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
-      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
-      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg);
+      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
+      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
+      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
     } else {
       hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
     }
@@ -1589,9 +1610,10 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   if (D.use_user_emb) { PS_REQUIRE(G.user_emb, "rtm backward: null user_emb gradient"); k.g_user_emb = G.user_emb; }
   if (D.use_item_emb) { PS_REQUIRE(G.product_emb, "rtm backward: null product_emb gradient"); k.g_item_emb = G.product_emb; }
   const int B = D.B, d = D.d;
-  const bool fwd_index = rtm_counts_in_forward(D, k, r);
-  k.count_fwd = fwd_index;
-  if (fwd_index) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
+  const bool early = rtm_index_early(D, k, r);    // the forward started the whole index on the side stream: nothing to build here
+  const bool fwd_index = early || rtm_counts_in_forward(D, k, r);
+  k.count_fwd = fwd_index && !early;
+  if (fwd_index && !early) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
     hipStream_t ss = side_stream_or(st);
     if (ss != st) { side_set_light(false); TRY(side_fork(st)); }
     TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));

@@ -1,0 +1,30 @@
+"""Diagnostic: phase timeline of the fused per-replica forward (mlp_fwd_t_kernel), workgroup 0, all 8 waves (s_memtime).
+    python tools/mlp_stamps.py        (on the GPU box)"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from prodsearch_amd import ItemTransformerRanker, readme_tem_args, synth, _lib
+P_, V, B = 18357, 32387, 384
+a = readme_tem_args(dropout=0.1)
+wd = synth.make_word_dists(V)
+m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+m.train()
+b = synth.make_tem_batch(1, B, P_, V, word_dists=wd).to('cuda')
+lib = ctypes.CDLL(_lib.lib_path())
+for _ in range(5):
+    m(b)
+buf = torch.zeros(128, dtype=torch.int64, device='cuda')
+lib.ps_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+with torch.no_grad():
+    m(b)
+torch.cuda.synchronize()
+lib.ps_debug_set_stamp_buffer(ctypes.c_void_p(0))
+t = buf.cpu().view(8, 16)
+names = ['start', 'P barrier', 'Wo done', 'A barrier', 'LN1 done', 'B barrier', 'blk0 W1', 'blk0 epilogue', '-', 'blk1 W1',
+         'blk1 epilogue', '-', 'chain done', 'C barrier', 'LN2 done', 'ticket']
+t0 = int(t[:, 0].min())
+print('%-14s' % 'phase' + ''.join('  wave%d' % w for w in range(8)) + '   (cycles since the first wave started)')
+for i, n in enumerate(names):
+    if n == '-':
+        continue
+    print('%-14s' % n + ''.join('%7d' % (int(t[w, i]) - t0 if int(t[w, i]) else -1) for w in range(8)))
