@@ -56,7 +56,6 @@ int run1(const GemmProblem& p, hipStream_t st);
 GemmProblem gp_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int n_out, int k_in, int rows);
 int side_wgrads(GemmProblem* ps, int n, hipStream_t main_st);
 int side_fork(hipStream_t main_st);
-int side_fork_events(hipStream_t main_st);           // the same, always as an event pair
 int side_run(GemmProblem* ps, int n, hipStream_t main_st);
 int side_join(hipStream_t main_st);
 void side_abort();                                   // error paths: release a fork nobody will signal (tem.hip)

@@ -1360,21 +1360,13 @@ static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) 
   static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
   return e4_on && k.pvc && !k.eval && D.WL <= 128 && (D.d == 64 || D.d == 128 || D.d == 256) && r.S <= 64;
 }
-// Round 3: the whole index (count, allocate, fill) is built on the SIDE stream, started by the forward and running beside it.
-// It depends on the batch's indices only, and timing-only variants of rtm_embed4_kernel showed that the per-occurrence returning
-// atomics the count-in-forward form issued were 45 of that kernel's 97 us (1.16 M scattered 4-byte atomics: the memory-side
-// atomic rate for one dword per lane in 64 different lines, MI355X_MICROARCH.md), hidden by nothing.  On the side stream the
-// same atomics run under the forward's ~300 us of other work; the backward finds the index ready (same stream, in order) and
-// its own side stream starts free.  PS_RTM_EARLY_INDEX=0: the round-2 form (ranks in the forward, fill in the backward).
-static bool rtm_index_early(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
-  static const bool on = !(getenv("PS_RTM_EARLY_INDEX") && atoi(getenv("PS_RTM_EARLY_INDEX")) == 0);
-  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
-  (void)D;
-  return on && !late && k.pvc && !k.eval && r.wcnt != 0;
-}
+// (Round 3, measured and dropped: the whole index built on the side stream BESIDE the forward, so that the forward carries no
+// atomics.  Kernels of scattered global atomics poison whatever runs next to them: the gather launch stayed at 97 us without its
+// atomics, a 3 us list kernel took 44 us, the step went 0.454 -> 0.507 ms.  Timing-only variants of rtm_embed4_kernel show the
+// rank atomics cost 45 of its 97 us — the fix is fewer global atomics, not a different place for them.)
 static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
   static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
-  return !late && !rtm_index_early(D, k, r) && rtm_embed4_taken(D, k, r);
+  return !late && rtm_embed4_taken(D, k, r);
 }
 // count (unless a kernel that reads the words anyway did), allocate, fill
 static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hipStream_t st) {
@@ -1427,14 +1419,6 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
   if (!eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG))
     PS_REQUIRE(k.wmask_pos && k.wmask_neg, "rtm: the fs / avg review encoders need the batch's word masks");
   if (k.train_pv) PS_REQUIRE(k.pos_words && k.pos_masks && k.neg_word_idxs, "rtm: null PV-loss tensors");
-  if (!eval && rtm_index_early(D, k, r)) {        // the backward's inverted index: side stream, beside the whole forward
-    hipStream_t ss = side_stream_or(st);
-    if (ss != st) TRY(side_fork_events(st));
-    PS_CHECK_HIP(hipMemsetAsync(k.wcnt, 0, sizeof(int) * ((size_t)D.vocab_size + 1), ss));
-    RtmK ki = k;
-    ki.count_fwd = 0;
-    TRY(rtm_build_index(ki, r, (int)D.vocab_size, true, ss));
-  }
   // query encoder (shared kernels): masked mean (+FS dropout) then tanh(f_W . + b)
   PsTemDesc dq;
   memset(&dq, 0, sizeof(dq));
@@ -1610,10 +1594,9 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   if (D.use_user_emb) { PS_REQUIRE(G.user_emb, "rtm backward: null user_emb gradient"); k.g_user_emb = G.user_emb; }
   if (D.use_item_emb) { PS_REQUIRE(G.product_emb, "rtm backward: null product_emb gradient"); k.g_item_emb = G.product_emb; }
   const int B = D.B, d = D.d;
-  const bool early = rtm_index_early(D, k, r);    // the forward started the whole index on the side stream: nothing to build here
-  const bool fwd_index = early || rtm_counts_in_forward(D, k, r);
-  k.count_fwd = fwd_index && !early;
-  if (fwd_index && !early) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
+  const bool fwd_index = rtm_counts_in_forward(D, k, r);
+  k.count_fwd = fwd_index;
+  if (fwd_index) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
     hipStream_t ss = side_stream_or(st);
     if (ss != st) { side_set_light(false); TRY(side_fork(st)); }
     TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));

@@ -617,22 +617,6 @@ int side_fork(hipStream_t main_st) {
   c->used = true;
   return side_fork_injected_failure();
 }
-// a fork that is always an event pair (nothing on the main stream has to carry it): the review transformer's FORWARD hands its
-// inverted-index build to the side stream this way — no main-stream kernel of the forward takes fork signals
-int side_fork_events(hipStream_t main_st) {
-  SideCtx* c = side_ctx();
-  if (!c) return PS_OK;
-  if (c->sig_pending) {
-    PS_CHECK_HIP(hipStreamWriteValue32(c->sig_stream, c->flag, c->sig_val, 0));
-    c->sig_pending = false;
-  }
-  hipEvent_t ev = c->ev[c->next];
-  c->next = (c->next + 1) & 7;
-  PS_CHECK_HIP(hipEventRecord(ev, main_st));
-  PS_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
-  c->used = true;
-  return PS_OK;
-}
 // short steps cross streams with write / wait-value operations, long ones with events (see side_ctx)
 void side_set_light(bool light) {
   static const int force = getenv("PS_SIDE_LIGHT") ? atoi(getenv("PS_SIDE_LIGHT")) : -1;   // tuning: 0 never, 1 always
