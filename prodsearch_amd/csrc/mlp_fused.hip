@@ -277,13 +277,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
   __syncthreads();                                                     // B: ln1 planes in Xa
   MLP_STAMP(5);
 
-  // (PS_MLP_TUNE experiments) stagger / priority of the younger half: the two waves of a SIMD run the same program and want
-  // the matrix pipe, then the vector ALUs, at the same moments
-  if (a.tune) {
-    if (wave >= 4) { for (int i = 0; i < (a.tune & 255); ++i) __builtin_amdgcn_s_sleep(1); }
-    if (((a.tune >> 8) & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (((a.tune >> 9) & 1) && wave < 4) __builtin_amdgcn_s_setprio(1);
-  }
   // ---- the feed-forward chain of this wave's feature blocks: no barrier until every wave is through
   f32x16 acc2[4];
 #pragma unroll
@@ -363,7 +356,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     }
   }
   MLP_STAMP(12);
-  if (a.tune) __builtin_amdgcn_s_setprio(0);
   // folded scoring: the item row this lane's enc elements will be dotted with (requested under the dumps and the barrier)
   float itr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float ibias = 0.f;
@@ -468,8 +460,6 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   KTimeScope kt("mlp_fwd", st);
   MlpFwdArgs as = a;
   as.stamp = g_mlp_stamp;
-  static const int tune = getenv("PS_MLP_TUNE") ? atoi(getenv("PS_MLP_TUNE")) : 0;
-  as.tune = tune;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
   static bool a1 = false, a2 = false, a4 = false, ad1 = false, ad2 = false, ad3 = false;
   static const int diag = getenv("PS_MLP_DIAG") ? atoi(getenv("PS_MLP_DIAG")) : 0;          // timing experiments (wrong results)
@@ -624,13 +614,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
   park(a.part_f);
   __syncthreads();                                                     // 2: column-sum scratch (partial slots 2-4) free again
 
-  // (PS_MLP_TUNE experiments) stagger / priority of the younger half: the two waves of a SIMD run the same program and want
-  // the matrix pipe, then the vector ALUs, at the same moments
-  if (a.tune) {
-    if (wave >= 4) { for (int i = 0; i < (a.tune & 255); ++i) __builtin_amdgcn_s_sleep(1); }
-    if (((a.tune >> 8) & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (((a.tune >> 9) & 1) && wave < 4) __builtin_amdgcn_s_setprio(1);
-  }
   // ---- per feature block: d h1 -> d a1 (registers) -> d ln1 partial
   f32x16 acc2[4];
 #pragma unroll
@@ -710,7 +693,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
   }
-  if (a.tune) __builtin_amdgcn_s_setprio(0);
   // FF LayerNorm inputs and the Wo^T fragments, requested under the dumps and the barrier
   float x1[8], st1v[2] = {0.f, 0.f};
   {
@@ -780,8 +762,6 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   KTimeScope kt("mlp_bwd", st);
   MlpBwdArgs b = a;
   b.sig = nullptr; b.sigval = 0;
-  static const int tune = getenv("PS_MLP_TUNE") ? atoi(getenv("PS_MLP_TUNE")) : 0;
-  b.tune = tune;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
   static bool a1 = false, a2 = false, a4 = false;
   if (a.F == 256) TRY(set_lds_attr(mlp_bwd_t_kernel<1, 3>, a1));

@@ -229,7 +229,6 @@ struct MlpFwdArgs {
   int fold_score; ScoreArgs sc;   // item scoring + loss in the epilogue (ScoreArgs, folded form); M = B*(K+1)
   WSplit x3;                      // bf16x3 fragment streams of wo / w1 / w2
   unsigned long long* stamp;      // diagnostics: workgroup 0's waves record s_memtime at their phase boundaries (ps_debug_set_stamp_buffer)
-  int tune;                       // PS_MLP_TUNE experiments: bits 0-7 s_sleep units (64 cycles) of waves 4-7 before the chain, bit 8 / 9 s_setprio 1 for waves 4-7 / 0-3
 };
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st);
 bool mlp_fwd_can_fold_score(int M, int F, int d);   // the wave-specialised kernel will serve this shape
@@ -262,7 +261,6 @@ struct MlpBwdArgs {
   float* part_b1;                                      // [mlp_bwd_b1_rows()][3][F] slot 0: colsum -> b1
   WSplit x3;                                           // bf16x3 fragment streams (the bwd_* ones are read here)
   uint32_t* sig; uint32_t sigval;                      // a pending side-stream fork signalled by this launch (common.h, fork_signal)
-  int tune;                                            // as MlpFwdArgs::tune
 };
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);
 int mlp_bwd_fused_blocks(int M);

@@ -27,6 +27,7 @@ struct RtmWs {
   int64_t qmean, query_emb, valid, vec, cnt, scores, weight, pv_scores, pv_terms, nvalid, dvec, dqe, dqpre, dqmean;
   int64_t loss_blk;         // the 64-bit loss / arrival word of rtm_score_kernel (cleared by the query-encoder launch)
   int64_t glist;            // int32 list of the review-row groups that hold at least one real review (rtm_grouplist_kernel)
+  int64_t hist;             // int32 [RTM_HIST_G][V]: per-workgroup word histograms -> exclusive prefixes (rtm_hist_kernel / rtm_hist_scan_kernel)
   int64_t seqcnt;           // int32 [Bseq]: valid positions per sequence (rtm_embed_kernel -> rtm_rowlist_kernel)
   int64_t wrank;
   int64_t wcnt, woff, wcur, wl;   // pvc backward: inverted index word -> review slots (int32 arrays; wl: int2 {slot, word})
@@ -70,6 +71,7 @@ struct RtmK {              // kernel-side view of one call
   int *wcnt, *woff, *wcur;
   int2* wl;                   // the occurrence list: {slot, word}, one 8-byte store per occurrence
   int* wrank;                 // [B*R + B*K*R][WL] rank of a counted word among its word's occurrences, -1: not counted (count_fwd)
+  int* hist; int hist_rows;   // LDS-histogram index (rtm_hist_kernel): [RTM_HIST_G][V]; review rows per histogram workgroup
 };
 
 // waves of rtm_embed_bwd_kernel: EB_GROUPS four-review groups per wave on each side, EB_QSEQ query slots per wave
@@ -81,6 +83,8 @@ static inline int rtm_eb_waves(int B, int K, int R, int* npos_w, int* nneg_w) {
   if (nneg_w) *nneg_w = nn;
   return np + nn + ps_cdiv((int64_t)B * (K + 1), EB_QSEQ);
 }
+#define RTM_HIST_G 128          // workgroups (= partitions of the review rows) of the LDS-histogram index
+#define RTM_HIST_MAXV 38000     // vocabulary sizes whose histogram fits one workgroup's LDS (4 B per word, 160 KB)
 static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
 
 static int rtm_check(const PsRtmDesc& D) {
@@ -133,7 +137,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   r.dqpre = rtake(cur, (int64_t)D.B * d);
   r.dqmean = rtake(cur, (int64_t)D.B * d);
   r.dqe = rtake(cur, (int64_t)D.B * d);          // dqe and wcnt are adjacent: the backward zeroes both with ONE memset
-  r.wcnt = r.woff = r.wcur = r.wl = r.wrank = 0;
+  r.wcnt = r.woff = r.wcur = r.wl = r.wrank = r.hist = 0;
   r.raw = r.yfs = r.dpre = r.dmean = 0;
   if (!eval && D.review_encoder != PS_RENC_PV) {
     r.wcnt = rtake(cur, D.vocab_size + 1);        // [V] occurrence counts + the segment allocator's running total
@@ -141,6 +145,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
     r.wcur = rtake(cur, D.vocab_size);
     r.wl = rtake(cur, 2 * (int64_t)r.Bseq * D.R * D.WL);
     r.wrank = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
+    if (D.vocab_size <= RTM_HIST_MAXV) r.hist = rtake(cur, (int64_t)RTM_HIST_G * D.vocab_size);
   }
   if (!eval && D.review_encoder == PS_RENC_FS) {     // (behind the index arrays: dqe .. wcnt must stay one contiguous memset)
     const int64_t nr = (int64_t)r.Bseq * D.R * d;
@@ -1097,7 +1102,8 @@ __global__ __launch_bounds__(256) void rtm_walloc_kernel(const int* cnt, int* of
 //   * the fill (and the count, when it does not ride) flattens a chunk of slots: the workgroup lists its real reviews, then
 //     its threads stride over (review, word slot) pairs, four independent reads / atomics in flight per lane.
 #define WI_CHUNK_MAX 256
-template <int FILL>     // 0: count, 1: fill (a returning atomic on the word's cursor per occurrence), 2: fill from the ranks
+template <int FILL>     // 0: count, 1: fill (a returning atomic on the word's cursor per occurrence), 2: fill from the ranks,
+                        // 3: fill from the LDS-histogram ranks (segment start + the partition's prefix + the rank inside the partition)
 __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk, FDiv fWL) {
   __shared__ int l_rev[WI_CHUNK_MAX], l_slot[WI_CHUNK_MAX];     // rev: review row on its side, ~row for a positive
   __shared__ int l_n;
@@ -1140,9 +1146,11 @@ __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk
       const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
       const size_t off = (size_t)rev * a.WL + (in ? w : 0);
       wi[u] = in ? words[off] : -1;
-      if (FILL == 2) {
-        rk[u] = in ? a.wrank[((size_t)(pos ? 0 : a.B * a.R) + rev) * a.WL + w] : -1;
+      if (FILL >= 2) {
+        const size_t grow = (size_t)(pos ? 0 : a.B * a.R) + rev;
+        rk[u] = in ? a.wrank[grow * a.WL + w] : -1;
         ok[u] = rk[u] >= 0;
+        if (FILL == 3 && ok[u]) rk[u] += a.hist[(size_t)((int)grow / a.hist_rows) * a.V + wi[u]];
       } else {
         ok[u] = in && word_ok(a, wm, off, wi[u]);
       }
@@ -1156,12 +1164,87 @@ __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk
       int at[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        at[u] = !ok[u] ? 0 : a.woff[wi[u]] + (FILL == 2 ? rk[u] : atomicAdd(&a.wcur[wi[u]], 1));
+        at[u] = !ok[u] ? 0 : a.woff[wi[u]] + (FILL >= 2 ? rk[u] : atomicAdd(&a.wcur[wi[u]], 1));
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (ok[u]) a.wl[at[u]] = make_int2(sl[u], (int)wi[u]);
     }
   }
+}
+
+// ---- the index WITHOUT global atomics (round 3).  Timing-only variants of rtm_embed4_kernel showed its per-occurrence returning
+// atomics (1.16 M scattered 4-byte atomics: the memory-side rate for one dword per lane in 64 different lines) cost 45 of its
+// 97 us, and kernels of such atomics slow whatever runs beside them.  Counting sort by word with the histogram in LDS instead:
+//   rtm_hist_kernel      RTM_HIST_G workgroups, each owns a contiguous range of review rows and the WHOLE vocabulary as an LDS
+//                        histogram (4 B x V <= 160 KB): an occurrence's rank inside its partition is a returning LDS atomic;
+//                        ranks -> wrank (-1: not counted), the partition's histogram -> hist[g][.]
+//   rtm_hist_scan_kernel per word: exclusive prefix of the partitions' counts (in place) and the word's total -> wcnt
+//   rtm_walloc_kernel    (as before) segment starts
+//   rtm_windex_kernel<3> fill: segment start + partition prefix + rank, one 8-byte store per occurrence, no atomic
+// All of it on the side stream at the start of the backward; the forward's gather carries no atomics at all.
+__global__ __launch_bounds__(1024) void rtm_hist_kernel(const RtmK a) {
+  extern __shared__ int hist_lds[];                 // [V]
+  __shared__ int l_rev[1024];                       // this partition's real reviews: global review row
+  __shared__ int l_n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = blockIdx.x, NR = a.B * a.R + a.B * a.K * a.R;
+  const int64_t rpad = a.RC - 1;
+  for (int i = tid; i < a.V; i += 1024) hist_lds[i] = 0;
+  const int row0 = g * a.hist_rows, row1 = min(row0 + a.hist_rows, NR);
+  for (int base = row0; base < row1; base += 1024) {           // lists of up to 1024 rows at a time (hist_rows <= 1024 at C4)
+    if (tid == 0) l_n = 0;
+    __syncthreads();
+    const int grow = base + tid;
+    bool real = false;
+    if (grow < row1) {
+      const bool pos = grow < a.B * a.R;
+      real = (pos ? a.pos_r[grow] : a.neg_r[grow - a.B * a.R]) != rpad;
+    }
+    const unsigned long long m = __ballot(real);
+    int at0 = 0;
+    if (lane == 0 && m) at0 = atomicAdd(&l_n, __popcll(m));
+    at0 = __shfl(at0, 0, 64);
+    if (real) l_rev[at0 + __popcll(m & ((1ull << lane) - 1ull))] = grow;
+    __syncthreads();
+    const int total = l_n * a.WL;
+    for (int i0 = tid; i0 < total; i0 += 4 * 1024) {
+      int64_t wi[4]; size_t ro[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        const bool in = i < total;
+        const int r = in ? i / a.WL : 0, w = i - r * a.WL;
+        const int gr = l_rev[r];
+        const bool pos = gr < a.B * a.R;
+        const int rev = pos ? gr : gr - a.B * a.R;
+        const int64_t* words = (pos ? (a.train_pv ? a.pos_pvc : a.pos_words) : (a.train_pv ? a.neg_pvc : a.neg_words_rev));
+        const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
+        const size_t off = (size_t)rev * a.WL + (in ? w : 0);
+        wi[u] = in ? words[off] : -1;
+        ok[u] = in && word_ok(a, wm, off, wi[u]);
+        ro[u] = (size_t)gr * a.WL + w;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        if (i < total) a.wrank[ro[u]] = ok[u] ? atomicAdd(&hist_lds[wi[u]], 1) : -1;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < a.V; i += 1024) a.hist[(size_t)g * a.V + i] = hist_lds[i];
+}
+__global__ __launch_bounds__(256) void rtm_hist_scan_kernel(int* hist, int* wcnt, int V) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= V) return;
+  int run = 0;
+#pragma unroll 8
+  for (int g = 0; g < RTM_HIST_G; ++g) {
+    const int c = hist[(size_t)g * V + w];
+    hist[(size_t)g * V + w] = run;
+    run += c;
+  }
+  wcnt[w] = run;
 }
 
 // segmented sum over the word-sorted occurrence list: a wave owns 64 consecutive entries, adds the slot rows of a
@@ -1349,6 +1432,8 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   if (r.wcnt) {
     k.wcnt = (int*)(ws + r.wcnt); k.woff = (int*)(ws + r.woff); k.wcur = (int*)(ws + r.wcur);
     k.wl = (int2*)(ws + r.wl); k.wrank = (int*)(ws + r.wrank);
+    k.hist = r.hist ? (int*)(ws + r.hist) : nullptr;
+    k.hist_rows = ps_cdiv((int64_t)r.Bseq * D.R, RTM_HIST_G);
   }
 }
 
@@ -1364,9 +1449,39 @@ static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) 
 // atomics.  Kernels of scattered global atomics poison whatever runs next to them: the gather launch stayed at 97 us without its
 // atomics, a 3 us list kernel took 44 us, the step went 0.454 -> 0.507 ms.  Timing-only variants of rtm_embed4_kernel show the
 // rank atomics cost 45 of its 97 us — the fix is fewer global atomics, not a different place for them.)
+// the LDS-histogram index (rtm_hist_kernel): the backward builds the whole index on its side stream without global atomics and
+// the forward carries none.  PS_RTM_HIST=0: the round-2 form (ranks by global atomics in the forward's gather).
+static bool rtm_hist_index(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
+  static const bool on = !(getenv("PS_RTM_HIST") && atoi(getenv("PS_RTM_HIST")) == 0);
+  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
+  return on && !late && k.pvc && !k.eval && r.hist != 0 && D.vocab_size <= RTM_HIST_MAXV &&
+         ps_cdiv((int64_t)r.Bseq * D.R, RTM_HIST_G) <= (1 << 20);
+}
 static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
   static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
-  return !late && rtm_embed4_taken(D, k, r);
+  return !late && !rtm_hist_index(D, k, r) && rtm_embed4_taken(D, k, r);
+}
+static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_t st) {
+  static const int env_chunk = getenv("PS_RTM_IDX_CHUNK") ? atoi(getenv("PS_RTM_IDX_CHUNK")) : 64;
+  const int nslots = r.Bseq * r.S;
+  const int chunk = env_chunk < 1 ? 1 : (env_chunk > 256 ? 256 : env_chunk), nwg = ps_cdiv(nslots, chunk);
+  const FDiv fWL = make_fdiv(k.WL > 0 ? k.WL : 1);
+  static bool attr = false;
+  if (!attr) {
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     RTM_HIST_MAXV * (int)sizeof(int)));
+    attr = true;
+  }
+  hipLaunchKernelGGL(rtm_hist_kernel, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.hist, k.wcnt, V);
+  PS_LAUNCH_CHECK();
+  PS_CHECK_HIP(hipMemsetAsync(k.wcnt + V, 0, sizeof(int), st));       // the allocator's running total
+  hipLaunchKernelGGL(rtm_walloc_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.wcnt, k.woff, k.wcur, k.wcnt + V, V);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rtm_windex_kernel<3>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
 }
 // count (unless a kernel that reads the words anyway did), allocate, fill
 static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hipStream_t st) {
@@ -1594,12 +1709,14 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   if (D.use_user_emb) { PS_REQUIRE(G.user_emb, "rtm backward: null user_emb gradient"); k.g_user_emb = G.user_emb; }
   if (D.use_item_emb) { PS_REQUIRE(G.product_emb, "rtm backward: null product_emb gradient"); k.g_item_emb = G.product_emb; }
   const int B = D.B, d = D.d;
-  const bool fwd_index = rtm_counts_in_forward(D, k, r);
-  k.count_fwd = fwd_index;
-  if (fwd_index) {    // allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
+  const bool hist_index = rtm_hist_index(D, k, r);
+  const bool fwd_index = hist_index || rtm_counts_in_forward(D, k, r);     // either way: built on the side stream, right here
+  k.count_fwd = fwd_index && !hist_index;
+  if (fwd_index) {    // [count +] allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
     hipStream_t ss = side_stream_or(st);
     if (ss != st) { side_set_light(false); TRY(side_fork(st)); }
-    TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));
+    if (hist_index) TRY(rtm_build_index_hist(k, r, (int)D.vocab_size, ss));
+    else TRY(rtm_build_index(k, r, (int)D.vocab_size, false, ss));
   }
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
   uint32_t* sig = nullptr; uint32_t sigval = 0;
