@@ -83,7 +83,7 @@ static inline int rtm_eb_waves(int B, int K, int R, int* npos_w, int* nneg_w) {
   if (nneg_w) *nneg_w = nn;
   return np + nn + ps_cdiv((int64_t)B * (K + 1), EB_QSEQ);
 }
-#define RTM_HIST_G 128          // workgroups (= partitions of the review rows) of the LDS-histogram index
+#define RTM_HIST_G 256          // workgroups (= partitions of the review rows) of the LDS-histogram index
 #define RTM_HIST_MAXV 38000     // vocabulary sizes whose histogram fits one workgroup's LDS (4 B per word, 160 KB)
 static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
 
@@ -1102,8 +1102,7 @@ __global__ __launch_bounds__(256) void rtm_walloc_kernel(const int* cnt, int* of
 //   * the fill (and the count, when it does not ride) flattens a chunk of slots: the workgroup lists its real reviews, then
 //     its threads stride over (review, word slot) pairs, four independent reads / atomics in flight per lane.
 #define WI_CHUNK_MAX 256
-template <int FILL>     // 0: count, 1: fill (a returning atomic on the word's cursor per occurrence), 2: fill from the ranks,
-                        // 3: fill from the LDS-histogram ranks (segment start + the partition's prefix + the rank inside the partition)
+template <int FILL>     // 0: count, 1: fill (a returning atomic on the word's cursor per occurrence), 2: fill from the ranks
 __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk, FDiv fWL) {
   __shared__ int l_rev[WI_CHUNK_MAX], l_slot[WI_CHUNK_MAX];     // rev: review row on its side, ~row for a positive
   __shared__ int l_n;
@@ -1150,7 +1149,6 @@ __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk
         const size_t grow = (size_t)(pos ? 0 : a.B * a.R) + rev;
         rk[u] = in ? a.wrank[grow * a.WL + w] : -1;
         ok[u] = rk[u] >= 0;
-        if (FILL == 3 && ok[u]) rk[u] += a.hist[(size_t)((int)grow / a.hist_rows) * a.V + wi[u]];
       } else {
         ok[u] = in && word_ok(a, wm, off, wi[u]);
       }
@@ -1178,73 +1176,127 @@ __global__ __launch_bounds__(256) void rtm_windex_kernel(const RtmK a, int chunk
 //   rtm_hist_kernel      RTM_HIST_G workgroups, each owns a contiguous range of review rows and the WHOLE vocabulary as an LDS
 //                        histogram (4 B x V <= 160 KB): an occurrence's rank inside its partition is a returning LDS atomic;
 //                        ranks -> wrank (-1: not counted), the partition's histogram -> hist[g][.]
-//   rtm_hist_scan_kernel per word: exclusive prefix of the partitions' counts (in place) and the word's total -> wcnt
-//   rtm_walloc_kernel    (as before) segment starts
-//   rtm_windex_kernel<3> fill: segment start + partition prefix + rank, one 8-byte store per occurrence, no atomic
+//   rtm_hist_scan_kernel per word: exclusive prefix of the partitions' counts, the word's total, and (folded in: the wave-sum +
+//                        one bump of the running total that rtm_walloc_kernel does) the word's segment start; hist[g][w] becomes
+//                        the list position of partition g's first occurrence of w
+//   rtm_hist_fill_kernel the partitions again, their row of positions in LDS: position + rank, one 8-byte store per occurrence
 // All of it on the side stream at the start of the backward; the forward's gather carries no atomics at all.
+// (First form, measured: 128 partitions, a one-thread-per-word scan (26 us: 128 dependent strided reads per thread) and the fill
+// as rtm_windex_kernel reading hist[g][w] per occurrence (59 us: a random 4-byte read in a 16 MB table each) — the gather fell
+// 97 -> 52 us but the step ROSE 0.449 -> 0.462 ms.)
+__device__ inline int hist_list_rows(const RtmK& a, int base, int row1, int* l_rev, int* l_n) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t rpad = a.RC - 1;
+  if (tid == 0) *l_n = 0;
+  __syncthreads();
+  const int grow = base + tid;
+  bool real = false;
+  if (grow < row1) {
+    const bool pos = grow < a.B * a.R;
+    real = (pos ? a.pos_r[grow] : a.neg_r[grow - a.B * a.R]) != rpad;
+  }
+  const unsigned long long m = __ballot(real);
+  int at0 = 0;
+  if (lane == 0 && m) at0 = atomicAdd(l_n, __popcll(m));
+  at0 = __shfl(at0, 0, 64);
+  if (real) l_rev[at0 + __popcll(m & ((1ull << lane) - 1ull))] = grow;
+  __syncthreads();
+  return *l_n;
+}
+template <int FILL>     // 0: histogram + ranks, 1: fill the list from the ranks and the partition's positions
 __global__ __launch_bounds__(1024) void rtm_hist_kernel(const RtmK a) {
-  extern __shared__ int hist_lds[];                 // [V]
+  extern __shared__ int hist_lds[];                 // [V]: FILL 0 the partition's counts, FILL 1 its list positions
   __shared__ int l_rev[1024];                       // this partition's real reviews: global review row
   __shared__ int l_n;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int g = blockIdx.x, NR = a.B * a.R + a.B * a.K * a.R;
-  const int64_t rpad = a.RC - 1;
-  for (int i = tid; i < a.V; i += 1024) hist_lds[i] = 0;
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x, NP = a.B * a.R, NR = NP + a.B * a.K * a.R;
+  for (int i = tid; i < a.V; i += 1024) hist_lds[i] = FILL ? a.hist[(size_t)g * a.V + i] : 0;
   const int row0 = g * a.hist_rows, row1 = min(row0 + a.hist_rows, NR);
-  for (int base = row0; base < row1; base += 1024) {           // lists of up to 1024 rows at a time (hist_rows <= 1024 at C4)
-    if (tid == 0) l_n = 0;
-    __syncthreads();
-    const int grow = base + tid;
-    bool real = false;
-    if (grow < row1) {
-      const bool pos = grow < a.B * a.R;
-      real = (pos ? a.pos_r[grow] : a.neg_r[grow - a.B * a.R]) != rpad;
-    }
-    const unsigned long long m = __ballot(real);
-    int at0 = 0;
-    if (lane == 0 && m) at0 = atomicAdd(&l_n, __popcll(m));
-    at0 = __shfl(at0, 0, 64);
-    if (real) l_rev[at0 + __popcll(m & ((1ull << lane) - 1ull))] = grow;
-    __syncthreads();
-    const int total = l_n * a.WL;
+  for (int base = row0; base < row1; base += 1024) {           // lists of up to 1024 rows at a time
+    const int total = hist_list_rows(a, base, row1, l_rev, &l_n) * a.WL;
     for (int i0 = tid; i0 < total; i0 += 4 * 1024) {
-      int64_t wi[4]; size_t ro[4]; bool ok[4];
+      int64_t wi[4]; size_t ro[4]; bool ok[4]; int rk[4], sl[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + 1024 * u;
         const bool in = i < total;
         const int r = in ? i / a.WL : 0, w = i - r * a.WL;
         const int gr = l_rev[r];
-        const bool pos = gr < a.B * a.R;
-        const int rev = pos ? gr : gr - a.B * a.R;
+        const bool pos = gr < NP;
+        const int rev = pos ? gr : gr - NP;
         const int64_t* words = (pos ? (a.train_pv ? a.pos_pvc : a.pos_words) : (a.train_pv ? a.neg_pvc : a.neg_words_rev));
-        const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
         const size_t off = (size_t)rev * a.WL + (in ? w : 0);
         wi[u] = in ? words[off] : -1;
-        ok[u] = in && word_ok(a, wm, off, wi[u]);
         ro[u] = (size_t)gr * a.WL + w;
+        if (FILL) {
+          rk[u] = in ? a.wrank[ro[u]] : -1;
+          ok[u] = rk[u] >= 0;
+          // the slot of review row `rev` (the inverse of seq_decode: sequence n = b*J + j, position r + 1)
+          const int seq = rev / a.R, r_in = rev - seq * a.R;
+          int n;
+          if (pos) n = seq * a.J;
+          else { const int b = seq / a.K; n = b * a.J + (seq - b * a.K) + 1; }
+          sl[u] = n * a.S + r_in + 1;
+        } else {
+          const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
+          ok[u] = in && word_ok(a, wm, off, wi[u]);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + 1024 * u;
-        if (i < total) a.wrank[ro[u]] = ok[u] ? atomicAdd(&hist_lds[wi[u]], 1) : -1;
+        if (FILL) {
+          if (ok[u]) a.wl[hist_lds[wi[u]] + rk[u]] = make_int2(sl[u], (int)wi[u]);
+        } else if (i < total) {
+          a.wrank[ro[u]] = ok[u] ? atomicAdd(&hist_lds[wi[u]], 1) : -1;
+        }
       }
     }
     __syncthreads();
   }
-  for (int i = tid; i < a.V; i += 1024) a.hist[(size_t)g * a.V + i] = hist_lds[i];
+  if (!FILL)
+    for (int i = tid; i < a.V; i += 1024) a.hist[(size_t)g * a.V + i] = hist_lds[i];
 }
-__global__ __launch_bounds__(256) void rtm_hist_scan_kernel(int* hist, int* wcnt, int V) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= V) return;
+// 64 words x 8 groups of RTM_HIST_G/8 partitions per workgroup: every lane has its group's counts in registers at once
+// (independent loads), the groups meet in LDS, wave 0 allocates the 64 segments (wave prefix + ONE bump of the running total)
+__global__ __launch_bounds__(512) void rtm_hist_scan_kernel(int* hist, int* wcnt, int* woff, int* tot, int V) {
+  __shared__ int l_tot[8][64];
+  __shared__ int l_base[64];
+  constexpr int PG = RTM_HIST_G / 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * 64 + lane;
+  const bool in = w < V;
+  int c[PG];
+#pragma unroll
+  for (int g = 0; g < PG; ++g) c[g] = in ? hist[(size_t)(wv * PG + g) * V + w] : 0;
   int run = 0;
-#pragma unroll 8
-  for (int g = 0; g < RTM_HIST_G; ++g) {
-    const int c = hist[(size_t)g * V + w];
-    hist[(size_t)g * V + w] = run;
-    run += c;
+#pragma unroll
+  for (int g = 0; g < PG; ++g) { const int t = c[g]; c[g] = run; run += t; }
+  l_tot[wv][lane] = run;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const int t = l_tot[q][lane]; before += q < wv ? t : 0; total += t; }
+  if (wv == 0) {
+    int incl = total;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const int all = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && all > 0) base = atomicAdd(tot, all);
+    base = __shfl(base, 63, 64) + incl - total;
+    l_base[lane] = base;
+    if (in) { woff[w] = base; wcnt[w] = total; }
   }
-  wcnt[w] = run;
+  __syncthreads();
+  const int start = l_base[lane] + before;
+  if (in) {
+#pragma unroll
+    for (int g = 0; g < PG; ++g) hist[(size_t)(wv * PG + g) * V + w] = start + c[g];
+  }
 }
 
 // segmented sum over the word-sorted occurrence list: a wave owns 64 consecutive entries, adds the slot rows of a
@@ -1454,7 +1506,7 @@ static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) 
 static bool rtm_hist_index(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
   static const bool on = !(getenv("PS_RTM_HIST") && atoi(getenv("PS_RTM_HIST")) == 0);
   static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
-  return on && !late && k.pvc && !k.eval && r.hist != 0 && D.vocab_size <= RTM_HIST_MAXV &&
+  return on && !late && k.pvc && !k.eval && r.hist != 0 && D.vocab_size <= RTM_HIST_MAXV && r.S == D.R + 1 &&
          ps_cdiv((int64_t)r.Bseq * D.R, RTM_HIST_G) <= (1 << 20);
 }
 static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
@@ -1462,24 +1514,21 @@ static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs
   return !late && !rtm_hist_index(D, k, r) && rtm_embed4_taken(D, k, r);
 }
 static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_t st) {
-  static const int env_chunk = getenv("PS_RTM_IDX_CHUNK") ? atoi(getenv("PS_RTM_IDX_CHUNK")) : 64;
-  const int nslots = r.Bseq * r.S;
-  const int chunk = env_chunk < 1 ? 1 : (env_chunk > 256 ? 256 : env_chunk), nwg = ps_cdiv(nslots, chunk);
-  const FDiv fWL = make_fdiv(k.WL > 0 ? k.WL : 1);
   static bool attr = false;
   if (!attr) {
-    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     RTM_HIST_MAXV * (int)sizeof(int)));
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      RTM_HIST_MAXV * (int)sizeof(int)));
     attr = true;
   }
-  hipLaunchKernelGGL(rtm_hist_kernel, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
-  PS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.hist, k.wcnt, V);
-  PS_LAUNCH_CHECK();
+  (void)r;
   PS_CHECK_HIP(hipMemsetAsync(k.wcnt + V, 0, sizeof(int), st));       // the allocator's running total
-  hipLaunchKernelGGL(rtm_walloc_kernel, dim3(ps_cdiv(V, 256)), dim3(256), 0, st, k.wcnt, k.woff, k.wcur, k.wcnt + V, V);
+  hipLaunchKernelGGL(rtm_hist_kernel<0>, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rtm_windex_kernel<3>, dim3(nwg), dim3(256), 0, st, k, chunk, fWL);
+  hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 64)), dim3(512), 0, st, k.hist, k.wcnt, k.woff, k.wcnt + V, V);
+  PS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rtm_hist_kernel<1>, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
