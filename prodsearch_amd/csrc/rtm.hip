@@ -61,6 +61,7 @@ struct RtmK {              // kernel-side view of one call
   float *query_emb, *x, *valid, *vec, *cnt, *enc, *scores, *weight, *pv_scores, *pv_terms, *nvalid;
   int32_t *seqcnt, *vrows, *vcount;   // valid-row list of x (GemmProblem::ridx): per-sequence counts, rows, length
   int count_fwd;                      // rtm_embed4_kernel counts them (the counters were cleared by the query-encoder launch)
+  int det;                            // deterministic mode (ps_deterministic): no fp32 atomic whose order could differ between runs
   float* loss3;
   // backward
   float scale; const float* scale_dev;
@@ -829,13 +830,131 @@ __global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a, int ze
     const float ds = wgt * (sigmoid_f(s) - (j == 0 ? 1.f : 0.f)) * sc;
     for (int e = lane; e < a.d; e += 64) {
       a.denc[(size_t)n * a.d + e] = ds * a.wo_w[e];
-      atomicAdd(&acc[e], ds * a.enc[(size_t)n * a.d + e]);
+      if (!a.det) atomicAdd(&acc[e], ds * a.enc[(size_t)n * a.d + e]);
     }
-    if (lane == 0) atomicAdd(&acc[a.d], ds);
+    if (lane == 0 && !a.det) atomicAdd(&acc[a.d], ds);
   }
+  if (a.det) return;                              // rtm_score_wo_det_kernel adds them up in sequence order
   __syncthreads();
   for (int e = threadIdx.x; e < a.d; e += 256) atomicAdd(&a.g_wo_w[e], acc[e]);
   if (threadIdx.x == 0) atomicAdd(&a.g_wo_b[0], acc[a.d]);
+}
+// ---- deterministic mode (ps_deterministic): the reductions of the backward whose fp32 additions could meet in a
+// different order from run to run, each as a fixed-order sum.  (The word index gets its ranks from rtm_hist_kernel<0, 64, 1>.)
+// d wo_w / d wo_b: one workgroup, a thread owns its columns and walks the sequences in order
+__global__ __launch_bounds__(256) void rtm_score_wo_det_kernel(const RtmK a) {
+  const int K1 = a.K + 1, tid = threadIdx.x;
+  const float sc = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
+  float acc0 = 0.f, acc1 = 0.f, accb = 0.f;
+  const int e0 = tid < a.d ? tid : a.d - 1, e1 = tid + 256 < a.d ? tid + 256 : a.d - 1;
+  for (int n0 = 0; n0 < a.B * K1; n0 += 8) {
+    float ds[8], x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = n0 + u < a.B * K1 ? n0 + u : n0;
+      const int b = fdiv(n, a.fK1), j = n - b * K1;
+      ds[u] = a.weight[n] * (sigmoid_f(a.scores[n]) - (j == 0 ? 1.f : 0.f)) * sc;
+      x0[u] = a.enc[(size_t)n * a.d + e0];
+      x1[u] = a.enc[(size_t)n * a.d + e1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (n0 + u < a.B * K1) { acc0 += ds[u] * x0[u]; acc1 += ds[u] * x1[u]; accb += ds[u]; }
+  }
+  if (tid < a.d) a.g_wo_w[tid] += acc0;
+  if (tid + 256 < a.d) a.g_wo_w[tid + 256] += acc1;
+  if (tid == 0) a.g_wo_b[0] += accb;
+}
+// d query_emb[b] = the query-position gradients of b's J sequences, in sequence order
+__global__ __launch_bounds__(256) void rtm_dqe_det_kernel(const RtmK a) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < a.d; e += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < a.J; ++j) acc += a.dx[(size_t)(b * a.J + j) * a.S * a.d + e];
+    a.dqe[(size_t)b * a.d + e] = acc;
+  }
+}
+// column sums of x [rows, d] in two fixed-order levels (the fs projection's bias gradient)
+__global__ __launch_bounds__(256) void rtm_colsum_det_kernel(const float* x, int rows, int d, float* part) {
+  const int per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  for (int e = threadIdx.x; e < d; e += 256) {
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += x[(size_t)r * d + e];
+    part[(size_t)blockIdx.x * d + e] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void rtm_colsum_det_fold_kernel(const float* part, int nblk, int d, float* dst) {
+  for (int e = threadIdx.x; e < d; e += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * d + e];
+    dst[e] += acc;
+  }
+}
+// The word-gradient reduce: a word's occurrences in list order (= task order, see the ranks) by ONE wave, plain add into the
+// word's row (its sole writer in this launch).  Words with more than WR_DET_LIM occurrences (Zipf heads: tens of thousands) go
+// to a list — its order does not matter — and get a 16-wave workgroup each: wave k sums the k-th sixteenth of the segment, the
+// sixteen partials are added in wave order.
+#define WR_DET_LIM 4096
+template <int NK>
+__device__ inline void wr_det_sum(const RtmK& a, int off, int n, int lane, float (&acc)[NK]) {
+  constexpr int U = NK <= 2 ? 16 : 4;
+  const int d = a.d;
+  int col[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { acc[k] = 0.f; col[k] = lane + 64 * k < d ? lane + 64 * k : d - 1; }
+  for (int i0 = 0; i0 < n; i0 += U) {
+    float r[U][NK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sl = a.wl[off + (i0 + u < n ? i0 + u : i0)].x;
+      const float* row = a.gs + (size_t)sl * d;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) r[u][k] = row[col[k]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u < n) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) acc[k] += r[u][k];
+      }
+  }
+}
+template <int NK>
+__global__ __launch_bounds__(256) void rtm_wreduce_det_kernel(const RtmK a, int* heavy, int* nheavy) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  for (int w = wave0; w < (int)a.V; w += nwave) {
+    const int n = a.wcnt[w];
+    if (n == 0) continue;
+    if (n > WR_DET_LIM) { if (lane == 0) heavy[atomicAdd(nheavy, 1)] = w; continue; }
+    float acc[NK];
+    wr_det_sum<NK>(a, a.woff[w], n, lane, acc);
+    float* grow = a.g_word_emb + (size_t)w * a.d;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (lane + 64 * k < a.d) grow[lane + 64 * k] += acc[k];
+  }
+}
+template <int NK>
+__global__ __launch_bounds__(1024) void rtm_wreduce_heavy_det_kernel(const RtmK a, const int* heavy, const int* nheavy) {
+  __shared__ float part[16][64 * NK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int h = blockIdx.x; h < *nheavy; h += gridDim.x) {
+    const int w = heavy[h], n = a.wcnt[w], per = (n + 15) / 16;
+    const int i0 = wv * per, cnt = max(0, min(n, i0 + per) - i0);
+    float acc[NK];
+    wr_det_sum<NK>(a, a.woff[w] + i0, cnt, lane, acc);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) part[wv][lane + 64 * k] = acc[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < a.d; e += 1024) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += part[q][e];
+      a.g_word_emb[(size_t)w * a.d + e] += t;
+    }
+    __syncthreads();
+  }
 }
 
 // PV backward: one wave per positive review; d vec (dense) and word-row scatter-adds
@@ -1055,7 +1174,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
             else if (segq[q] == 1) sacc[1][k] += gk[q][k];
             else sacc[2][k] += gk[q][k];
           }
-          atomicAdd(&a.dqe[(size_t)bq[q] * d + col], gk[q][k]);
+          if (!a.det) atomicAdd(&a.dqe[(size_t)bq[q] * d + col], gk[q][k]);      // det: rtm_dqe_det_kernel
         }
       }
     }
@@ -1197,28 +1316,33 @@ __device__ inline int hist_list_rows(const RtmK& a, int base, int row1, int* l_r
   }
   const unsigned long long m = __ballot(real);
   int at0 = 0;
-  if (lane == 0 && m) at0 = atomicAdd(l_n, __popcll(m));
+  if (lane == 0 && m) at0 = atomicAdd(l_n, __popcll(m));     // (one wave when the order matters: DET)
   at0 = __shfl(at0, 0, 64);
   if (real) l_rev[at0 + __popcll(m & ((1ull << lane) - 1ull))] = grow;
   __syncthreads();
   return *l_n;
 }
-template <int FILL>     // 0: histogram + ranks, 1: fill the list from the ranks and the partition's positions
-__global__ __launch_bounds__(1024) void rtm_hist_kernel(const RtmK a) {
+// FILL 0: histogram + ranks, 1: fill the list from the ranks and the partition's positions.
+// NT threads.  DET (deterministic mode, NT = 64): ONE wave walks the partition in task order and hands out the ranks without
+// atomics — per batch of 64 occurrences a lane counts the lower lanes holding its word, every lane reads the word's counter,
+// the last lane of each word adds the word's batch count — so a word's occurrences sit in its segment in task order.
+template <int FILL, int NT, int DET>
+__global__ __launch_bounds__(NT) void rtm_hist_kernel(const RtmK a) {
   extern __shared__ int hist_lds[];                 // [V]: FILL 0 the partition's counts, FILL 1 its list positions
-  __shared__ int l_rev[1024];                       // this partition's real reviews: global review row
+  __shared__ int l_rev[NT];                         // this partition's real reviews: global review row
   __shared__ int l_n;
+  static_assert(!DET || NT == 64, "the deterministic ranks are one wave's");
   const int tid = threadIdx.x;
   const int g = blockIdx.x, NP = a.B * a.R, NR = NP + a.B * a.K * a.R;
-  for (int i = tid; i < a.V; i += 1024) hist_lds[i] = FILL ? a.hist[(size_t)g * a.V + i] : 0;
+  for (int i = tid; i < a.V; i += NT) hist_lds[i] = FILL ? a.hist[(size_t)g * a.V + i] : 0;
   const int row0 = g * a.hist_rows, row1 = min(row0 + a.hist_rows, NR);
-  for (int base = row0; base < row1; base += 1024) {           // lists of up to 1024 rows at a time
+  for (int base = row0; base < row1; base += NT) {             // lists of up to NT rows at a time
     const int total = hist_list_rows(a, base, row1, l_rev, &l_n) * a.WL;
-    for (int i0 = tid; i0 < total; i0 += 4 * 1024) {
+    for (int ib = 0; ib < total; ib += 4 * NT) {               // (workgroup-uniform trip count: DET shuffles below)
       int64_t wi[4]; size_t ro[4]; bool ok[4]; int rk[4], sl[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = i0 + 1024 * u;
+        const int i = ib + NT * u + tid;
         const bool in = i < total;
         const int r = in ? i / a.WL : 0, w = i - r * a.WL;
         const int gr = l_rev[r];
@@ -1244,9 +1368,22 @@ __global__ __launch_bounds__(1024) void rtm_hist_kernel(const RtmK a) {
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = i0 + 1024 * u;
+        const int i = ib + NT * u + tid;
         if (FILL) {
           if (ok[u]) a.wl[hist_lds[wi[u]] + rk[u]] = make_int2(sl[u], (int)wi[u]);
+        } else if (DET) {
+          const int w = ok[u] ? (int)wi[u] : -1;
+          int before = 0, same = 0;
+          for (int l = 0; l < 64; ++l) {
+            const int o = __shfl(w, l, 64);
+            same += o == w ? 1 : 0;
+            before += (o == w && l < tid) ? 1 : 0;
+          }
+          const int at = ok[u] ? hist_lds[w] : 0;              // every lane reads before any lane writes (one wave, in order)
+          asm volatile("" ::: "memory");
+          if (ok[u] && before == same - 1) hist_lds[w] = at + same;
+          asm volatile("" ::: "memory");
+          if (i < total) a.wrank[ro[u]] = ok[u] ? at + before : -1;
         } else if (i < total) {
           a.wrank[ro[u]] = ok[u] ? atomicAdd(&hist_lds[wi[u]], 1) : -1;
         }
@@ -1255,7 +1392,7 @@ __global__ __launch_bounds__(1024) void rtm_hist_kernel(const RtmK a) {
     __syncthreads();
   }
   if (!FILL)
-    for (int i = tid; i < a.V; i += 1024) a.hist[(size_t)g * a.V + i] = hist_lds[i];
+    for (int i = tid; i < a.V; i += NT) a.hist[(size_t)g * a.V + i] = hist_lds[i];
 }
 // 64 words x 8 groups of RTM_HIST_G/8 partitions per workgroup: every lane has its group's counts in registers at once
 // (independent loads), the groups meet in LDS, wave 0 allocates the 64 segments (wave prefix + ONE bump of the running total)
@@ -1433,12 +1570,13 @@ __global__ __launch_bounds__(256) void rtm_fs_bwd_kernel(const RtmK a, float* dp
       if (ok) {
         const float y = a.yfs[rg * d + col];
         v = a.dx[((size_t)n * a.S + s) * d + col] * (1.f - y * y);
-        atomicAdd(&bsum[col], v);
+        if (!a.det) atomicAdd(&bsum[col], v);
       }
       dpre[rg * d + col] = v;
     }
   }
   __syncthreads();
+  if (a.det) return;                               // rtm_colsum_det_kernel over dpre
   for (int e = threadIdx.x; e < d; e += 256) atomicAdd(&g_bias[e], bsum[e]);
 }
 
@@ -1448,6 +1586,7 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   memset(&k, 0, sizeof(k));
   k.B = D.B; k.J = r.J; k.K = D.K; k.R = D.R; k.S = r.S; k.Q = D.Q; k.W = D.W > 0 ? D.W : 1; k.WL = D.WL; k.d = D.d;
   k.V = D.vocab_size; k.RC = D.review_count;
+  k.det = ps_deterministic() ? 1 : 0;
   // `pvc` = every word-mean review encoder in training (pvc, fs, avg); only pvc corrupts tokens and ignores the word masks
   k.pvc = D.review_encoder != PS_RENC_PV && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
   const bool masked_mean = !eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG);
@@ -1516,19 +1655,20 @@ static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs
 static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     RTM_HIST_MAXV * (int)sizeof(int)));
-    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     RTM_HIST_MAXV * (int)sizeof(int)));
+    const int lim = RTM_HIST_MAXV * (int)sizeof(int);
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<0, 1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<0, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rtm_hist_kernel<1, 1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     attr = true;
   }
   (void)r;
   PS_CHECK_HIP(hipMemsetAsync(k.wcnt + V, 0, sizeof(int), st));       // the allocator's running total
-  hipLaunchKernelGGL(rtm_hist_kernel<0>, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
+  if (k.det) hipLaunchKernelGGL((rtm_hist_kernel<0, 64, 1>), dim3(RTM_HIST_G), dim3(64), (size_t)V * sizeof(int), st, k);
+  else hipLaunchKernelGGL((rtm_hist_kernel<0, 1024, 0>), dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
   hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 64)), dim3(512), 0, st, k.hist, k.wcnt, k.woff, k.wcnt + V, V);
   PS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rtm_hist_kernel<1>, dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
+  hipLaunchKernelGGL((rtm_hist_kernel<1, 1024, 0>), dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
@@ -1760,6 +1900,15 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   const int B = D.B, d = D.d;
   const bool hist_index = rtm_hist_index(D, k, r);
   const bool fwd_index = hist_index || rtm_counts_in_forward(D, k, r);     // either way: built on the side stream, right here
+  if (k.det) {
+    // Deterministic mode covers the word-mean review encoders (pvc — BASELINE configs[3] —, fs, avg).  The PV encoder's review-row
+    // and PV-loss word-row scatters and the user / item embedding rows keep their fp32 atomics: refused rather than silently
+    // non-reproducible.
+    PS_REQUIRE(k.pvc && !D.use_user_emb && !D.use_item_emb && !k.train_pv,
+               "rtm backward: deterministic mode supports the pvc / fs / avg review encoders without user / item embeddings");
+    PS_REQUIRE(hist_index, "rtm backward: deterministic mode needs the LDS-histogram word index (vocabulary <= %d, PS_RTM_HIST != 0)",
+               RTM_HIST_MAXV);
+  }
   k.count_fwd = fwd_index && !hist_index;
   if (fwd_index) {    // [count +] allocate + fill on the side stream (or here, without one), under the fused kernel and the attention
     hipStream_t ss = side_stream_or(st);
@@ -1773,6 +1922,11 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   if (sbwd_carries) side_take_signal(st, &sig, &sigval);       // the index fill's fork rides on this launch
   hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k, fwd_index || !k.pvc ? 1 : 0, sig, sigval);
   PS_LAUNCH_CHECK();
+  if (k.det) {
+    PS_REQUIRE(d <= 512, "rtm backward: deterministic mode supports d <= 512");
+    hipLaunchKernelGGL(rtm_score_wo_det_kernel, dim3(1), dim3(256), 0, st, k);
+    PS_LAUNCH_CHECK();
+  }
   if (k.train_pv) {
     hipLaunchKernelGGL(rtm_pv_bwd_kernel, dim3(ps_cdiv(B * k.R, 4)), dim3(256), 0, st, k);
     PS_LAUNCH_CHECK();
@@ -1797,6 +1951,14 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     k.dx = ws + r.enc_base + w.dx;
     hipLaunchKernelGGL(rtm_fs_bwd_kernel, dim3(eb), dim3(256), (size_t)d * sizeof(float), st, k, ws + r.dpre, G.rev_fs_b);
     PS_LAUNCH_CHECK();
+    if (k.det) {
+      float* part = ps_det_scratch(1, (size_t)256 * d, st);
+      PS_REQUIRE(part, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
+      hipLaunchKernelGGL(rtm_colsum_det_kernel, dim3(256), dim3(256), 0, st, ws + r.dpre, NR, d, part);
+      PS_LAUNCH_CHECK();
+      hipLaunchKernelGGL(rtm_colsum_det_fold_kernel, dim3(1), dim3(256), 0, st, part, 256, d, G.rev_fs_b);
+      PS_LAUNCH_CHECK();
+    }
     GemmProblem wg[1] = {gp_wgrad(ws + r.dpre, d, ws + r.raw, d, G.rev_fs_w, d, d, NR)};
     TRY(side_wgrads(wg, 1, st));
     GemmProblem px = gp(ws + r.dpre, d, 0, params->rev_fs_w, d, 1, ws + r.dmean, d, NR, d, d);
@@ -1813,6 +1975,11 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
     else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
     PS_LAUNCH_CHECK();
+    if (k.det) {
+      k.dx = ws + r.enc_base + w.dx;
+      hipLaunchKernelGGL(rtm_dqe_det_kernel, dim3(B), dim3(256), 0, st, k);
+      PS_LAUNCH_CHECK();
+    }
     if (D.use_seg_emb) {
       PS_REQUIRE(fold.n < PS_MAX_COLFOLD, "rtm backward: too many parked column sums");
       ColFold& f = fold.e[fold.n++];
@@ -1843,7 +2010,23 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     // (measured and dropped: the columns split over the XCDs — workgroup i takes d/8 columns of every entry, so that an XCD's
     // L2 holds 1/8 of each gathered row and serves the 56 re-reads itself: 206 us against 66, each 4-lane entry stream keeps
     // too few bytes in flight; this form reads 594 MB from the Infinity Cache at 8.9 TB/s)
-    hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, wst, k);
+    if (k.det) {
+      const int V = (int)D.vocab_size;
+      int* heavy = reinterpret_cast<int*>(ps_det_scratch(1, (size_t)V + 8, st));
+      PS_REQUIRE(heavy, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
+      int* nheavy = heavy + V;
+      PS_CHECK_HIP(hipMemsetAsync(nheavy, 0, sizeof(int), wst));
+      const int lw = ps_cdiv(V, 4) < 2048 ? ps_cdiv(V, 4) : 2048;
+#define WR_DET_LAUNCH(NK)                                                                                              \
+  do {                                                                                                                \
+    hipLaunchKernelGGL(rtm_wreduce_det_kernel<NK>, dim3(lw), dim3(256), 0, wst, k, heavy, nheavy);                     \
+    hipLaunchKernelGGL(rtm_wreduce_heavy_det_kernel<NK>, dim3(512), dim3(1024), 0, wst, k, heavy, nheavy);             \
+  } while (0)
+      if (d <= 128) WR_DET_LAUNCH(2); else if (d <= 256) WR_DET_LAUNCH(4); else WR_DET_LAUNCH(8);
+#undef WR_DET_LAUNCH
+    } else {
+      hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, wst, k);
+    }
     PS_LAUNCH_CHECK();
   }
   // query encoder backward (shared kernels) + scatter to the query word rows
