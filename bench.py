@@ -374,6 +374,8 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                         "step": "sample+fwd+bwd+%sclip/Adam via nn.Module API (trainer.py:74-78)"
                                 % ((xdesc + "+") if world > 1 else "")}, **extra_cfg),
         "samples_per_s": world * Bw * steps / elapsed, "final_loss": last_loss,
+        # N > 1, sharded optimizer: the forms of its two collectives it timed on this node and kept (dist.ShardedAdamExchange._tune)
+        "exchange_tuning": getattr(exchange, 'tuned', None),
     }
     if extras:
         # Every rank runs these extra steps (they contain the gradient exchange: a collective only rank 0 entered would

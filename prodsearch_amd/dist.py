@@ -236,8 +236,16 @@ class ShardedAdamExchange(object):
         # how the reduce-scatter is issued: 'rccl' = reduce_scatter_tensor (RCCL picks the algorithm; rings are bound by ONE
         # xGMI link); 'a2a' = equal-split all_to_all_single of the W slices + a local sum in rank order — on a fully connected
         # node every slice travels over its own direct link (7 links busy), one hop, and the sum order is fixed
-        self.rs_mode = os.environ.get('PS_DP_RS', 'rccl')
-        self._a2a_recv = torch.empty(W, self.shard, device=dev, dtype=torch.float32) if (self.rs_mode == 'a2a' and W > 1) else None
+        # PS_DP_RS / PS_DP_AG unset on the RCCL backend: 'auto' = both forms of each collective are TIMED on this node's links
+        # inside the first exchange (a warm-up step) and the faster one is kept (`_tune`; every rank takes the max-over-ranks
+        # times, so all ranks choose alike).  The all-gather has the same two forms ('a2a': every rank sends its slice to each
+        # peer over that peer's direct link).
+        auto = 'auto' if (W > 1 and dist.is_initialized() and dist.get_backend(group) == 'nccl') else 'rccl'
+        self.rs_mode = os.environ.get('PS_DP_RS', auto)
+        self.ag_mode = os.environ.get('PS_DP_AG', auto)
+        self.tuned = None
+        self._a2a_recv = self._a2a_send = None
+        self._set_modes(self.rs_mode, self.ag_mode)
         optim.grad_scale = 1.0 / W
         optim._sharded = self
         optim._plan = None
@@ -278,15 +286,76 @@ class ShardedAdamExchange(object):
         _lib.check(self.lib.ps_adam_update_ext(self.plan.data_ptr(), self.n_chunks, hp, self.state.data_ptr(),
                                                self.sumsq.data_ptr(), self.gnorm.data_ptr(), st), 'ps_adam_update_ext')
 
+    def _set_modes(self, rs, ag):
+        W, dev = self.world, self.pflat.device
+        self.rs_mode, self.ag_mode = rs, ag
+        if W > 1 and rs in ('a2a', 'auto') and self._a2a_recv is None:
+            self._a2a_recv = torch.empty(W, self.shard, device=dev, dtype=torch.float32)
+        if W > 1 and ag in ('a2a', 'auto') and self._a2a_send is None:
+            self._a2a_send = torch.empty(W, self.shard, device=dev, dtype=torch.float32)
+
+    def _reduce_scatter(self, out, flat, mode):
+        if mode == 'a2a':
+            dist.all_to_all_single(self._a2a_recv.view(-1), flat, group=self.group)
+            torch.sum(self._a2a_recv, dim=0, out=out)          # rank order: the same sum on every run
+        else:
+            dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather(self, full, shard, mode):
+        if mode == 'a2a':
+            self._a2a_send.copy_(shard.unsqueeze(0).expand_as(self._a2a_send))
+            dist.all_to_all_single(full, self._a2a_send.view(-1), group=self.group)
+        else:
+            dist.all_gather_into_tensor(full, shard, group=self.group)
+
+    def _tune(self, flat, iters=5):
+        """Time 'rccl' and 'a2a' for each collective still on 'auto' (scratch operands of the step's own sizes) and keep the
+        faster.  Runs once, inside the first exchange; GPU backends only (events)."""
+        dev = flat.device
+        src = torch.zeros_like(flat)
+        out = torch.empty_like(self.g_shard)
+        full = torch.empty_like(self.pflat)
+        ops = {'rs': lambda mode: self._reduce_scatter(out, src, mode), 'ag': lambda mode: self._all_gather(full, out, mode)}
+        times = {}
+        for name, cur in (('rs', self.rs_mode), ('ag', self.ag_mode)):
+            if cur != 'auto':
+                continue
+            t = []
+            for mode in ('rccl', 'a2a'):
+                for _ in range(2):
+                    ops[name](mode)
+                torch.cuda.synchronize(dev)
+                dist.barrier(group=self.group)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    ops[name](mode)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                t.append(e0.elapsed_time(e1) / iters)
+            tt = torch.tensor(t, device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
+            times[name] = {'rccl_ms': float(tt[0]), 'a2a_ms': float(tt[1])}
+        rs = self.rs_mode if self.rs_mode != 'auto' else ('a2a' if times['rs']['a2a_ms'] < times['rs']['rccl_ms'] else 'rccl')
+        ag = self.ag_mode if self.ag_mode != 'auto' else ('a2a' if times['ag']['a2a_ms'] < times['ag']['rccl_ms'] else 'rccl')
+        self._set_modes(rs, ag)
+        if rs != 'a2a':
+            self._a2a_recv = None
+        if ag != 'a2a':
+            self._a2a_send = None
+        self.tuned = dict(times, reduce_scatter=rs, all_gather=ag)
+        if self.rank == 0:
+            import sys
+            print("ShardedAdamExchange: %s" % self.tuned, file=sys.stderr)
+
     def __call__(self):
         """reduce-scatter of the step's flat gradient; leaves the flat buffer zeroed for the next backward."""
         m = self.model
         flat = m._grad_flat
-        if self.world > 1 and self._a2a_recv is not None:
-            dist.all_to_all_single(self._a2a_recv.view(-1), flat, group=self.group)
-            torch.sum(self._a2a_recv, dim=0, out=self.g_shard)
-        elif self.world > 1:
-            dist.reduce_scatter_tensor(self.g_shard, flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1 and 'auto' in (self.rs_mode, self.ag_mode):
+            self._tune(flat)
+        if self.world > 1:
+            self._reduce_scatter(self.g_shard, flat, self.rs_mode)
         else:
             self.g_shard.copy_(flat[self.lo:self.hi])
         self._k_zero(flat)
@@ -305,7 +374,7 @@ class ShardedAdamExchange(object):
             dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
         self._k_update(hp)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.pflat, self.p_shard, group=self.group)
+            self._all_gather(self.pflat, self.p_shard, self.ag_mode)
 
     def full_moments(self):
         """(exp_avg, exp_avg_sq) flat buffers gathered from every rank's shard (checkpointing: a collective)."""

@@ -181,13 +181,13 @@ class _Hyper(object):
     lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale, zero_grads = 0.01, 0.9, 0.999, 1e-9, 0.0, 5.0, 1.0, 0
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, forms='rccl'):
     """ShardedAdamExchange's protocol over gloo with a CPU restatement of its three kernels (oracle/optim.py's clip+Adam
     arithmetic): after every step all ranks hold bitwise identical parameters, and they equal a single-process
     clip_grad_norm_ + Adam(eps=1e-9) on the MEAN of the ranks' gradients (optimizers.py:241-243)."""
     import math
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PS_DP_RS=forms, PS_DP_AG=forms)
     pdist.init_from_env(backend='gloo')
 
     class CpuSharded(pdist.ShardedAdamExchange):
@@ -222,6 +222,7 @@ def _sharded_worker(rank, world, port, q):
     model, opt = _StubModel(), Opt()
     ref = {n: p.detach().clone() for n, p in model.named_parameters()}
     ex = CpuSharded(model, opt)
+    assert ex.rs_mode == forms and ex.ag_mode == forms
     ok_layout = model._param_flat.numel() % (4 * world) == 0 and all(
         p.data_ptr() == model._param_flat.data_ptr() + 4 * v.storage_offset() for p, v in model._grad_views)
     # reference: torch's own clip + Adam on the mean gradient
@@ -260,11 +261,12 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gloo_world2_sharded_adam_protocol():
+@pytest.mark.parametrize('forms', ['rccl', 'a2a'])      # the library collectives / slices sent peer to peer (all_to_all_single)
+def test_gloo_world2_sharded_adam_protocol(forms):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, forms)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -99,6 +99,23 @@ def test_unequal_per_rank_batches_keep_the_replicas_in_lock_step(mode, tmp_path)
     assert np.isfinite(r0['__loss']) and np.isfinite(r1['__loss'])
 
 
+def test_timed_choice_of_the_collective_forms_changes_no_result(tmp_path, monkeypatch):
+    """dist.ShardedAdamExchange times both forms of its reduce-scatter and all-gather (the library's / slices sent peer to peer
+    with all_to_all_single) inside the first exchange and keeps the faster; on RCCL that is the default, here it is forced on
+    over gloo.  Whatever it picks, two ranks' sums are the same two addends: parameters equal the untimed run bit for bit."""
+    monkeypatch.setenv('PS_DP_RS', 'rccl'); monkeypatch.setenv('PS_DP_AG', 'rccl')
+    base = _run_ranks('dense', str(tmp_path / 'tune_base'), 2, 2)
+    monkeypatch.setenv('PS_DP_RS', 'auto'); monkeypatch.setenv('PS_DP_AG', 'auto')
+    tuned = _run_ranks('dense', str(tmp_path / 'tune_auto'), 2, 2)
+    monkeypatch.setenv('PS_DP_RS', 'a2a'); monkeypatch.setenv('PS_DP_AG', 'a2a')
+    a2a = _run_ranks('dense', str(tmp_path / 'tune_a2a'), 2, 2)
+    for other in (tuned, a2a):
+        for r in range(2):
+            for k in base[r]:
+                if not k.startswith('__'):
+                    assert np.array_equal(base[r][k], other[r][k]), k
+
+
 def test_sparse_exchange_is_not_slower_than_twice_the_dense_one(tmp_path):
     """The device-side merge (ps_pack_rows / ps_merge_rows) keeps the row-sparse exchange free of host syncs: as a 2-rank
     gloo dry run on one GPU its step must stay within 2x of the dense exchange's (it was 59 ms against 1 ms with the

@@ -1,4 +1,4 @@
-"""Copy what tools/refresh_profiles_r02.sh left under gpurun_out/refresh/ into profiles/ (tracked).
+"""Copy what tools/refresh_profiles_r02.sh / refresh_profiles_r03.sh left under gpurun_out/refresh/ into profiles/ (tracked).
     python tools/install_profiles_r02.py [r02]"""
 import os, shutil, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r02'
@@ -14,7 +14,8 @@ for a, b in (('bench_kernel_stats.csv', '_bench_kernel_stats.csv'), ('rtm_kernel
              ('sq_counters.txt', '_sq_counters.txt'), ('inst_counters.txt', '_inst_counters.txt'),
              ('rtm_embed_pmc.txt', '_rtm_embed_pmc.txt'), ('gather_score_c5_pmc.txt', '_gather_score_c5_pmc.txt'),
              ('gather_c5.log', '_gather_c5_shape.jsonl'), ('c5_step_timeline.txt', '_c5_step_timeline.txt'),
-             ('c5_kernel_stats.csv', '_c5_kernel_stats.csv')):
+             ('c5_kernel_stats.csv', '_c5_kernel_stats.csv'), ('det_step_timeline.txt', '_det_step_timeline.txt'),
+             ('det_rtm_step_timeline.txt', '_det_rtm_step_timeline.txt'), ('mlp_stamps.txt', '_mlp_stamps.txt')):
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, rnd + b))
 print(sorted(f for f in os.listdir(dst) if f.startswith(rnd)))

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse, torch
 import bench
 a = argparse.Namespace(workload='c4', encoder='pvc', dropout=0.1, row_sparse=False)
-wl = bench.RtmWorkload(a, 0, torch.device('cuda', 0))
+wl = bench.RtmWorkload(a, 'c4', 0, torch.device('cuda', 0))
 wl.model.train()
 with torch.no_grad():
     for i in range(30):
