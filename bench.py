@@ -146,7 +146,7 @@ class TemWorkload(object):
         return dict(tag='gather_score', bound='hbm', work=gather_bytes, peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
                     extra={"traffic": 63.0e6 if (B, D) == (1024, 256) else None,
-                           "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f): FETCH_SIZE "
+                           "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f; round 3 repeat: profiles/r03_gather_score_c5_pmc.txt, 31.2 MB x2 + 0.4 MB): FETCH_SIZE "
                                              "31.2 MB x2 + WRITE_SIZE 0.4 MB per launch at B=1024, d=256" if (B, D) == (1024, 256) else None})
 
     def cpu_baseline(self, n_steps):
@@ -208,18 +208,24 @@ class RtmWorkload(object):
         if self.a.encoder == 'pvc':                     # positions are neither read nor written: DESIGN.md 7c)
             words = int((b0.pos_prod_rword_idxs != V_WORDS - 1).sum() + (b0.neg_prod_rword_idxs != V_WORDS - 1).sum())
             rows = words * (1.0 - 0.9)
-            rank_bytes = slots * c['WL'] * 4            # first pass of the backward's inverted index rides in this kernel
+            # PS_RTM_HIST=0 (the round-2 form): the first pass of the backward's inverted index rides in this kernel and writes a
+            # rank per word slot; the default builds the whole index in the backward (rtm_hist_kernel), the gather writes none
+            legacy = os.environ.get('PS_RTM_HIST', '1') == '0'
+            rank_bytes = slots * c['WL'] * 4 if legacy else 0
             nbytes = slots * c['WL'] * 8 + rows * 4 * d + out_bytes + rank_bytes
-            note = "%d review slots x %d ids + %.0f surviving word rows (%.0f non-pad words x 0.1) + %d B of x + %d B of word ranks" % (
-                slots, c['WL'], rows, words, out_bytes, rank_bytes)
+            note = "%d review slots x %d ids + %.0f surviving word rows (%.0f non-pad words x 0.1) + %d B of x%s" % (
+                slots, c['WL'], rows, words, out_bytes, (" + %d B of word ranks" % rank_bytes) if legacy else "")
         else:
             nbytes = slots * (8 + 4 * d) + out_bytes
             note = "%d review rows + %d B of x" % (slots, out_bytes)
         return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
-                    kernel="rtm_embed4_kernel (review-vector gather + mean-pool + word ranks; %s)" % note,
-                    extra={"traffic": 123.3e6 if self.a.encoder == 'pvc' else None,
-                           "traffic_source": "committed PMC passes profiles/r02_rtm_embed_pmc.txt (commit ed4b86f): FETCH_SIZE "
-                                             "34.5 MB x2 + WRITE_SIZE 54.3 MB per launch" if self.a.encoder == 'pvc' else None})
+                    kernel="rtm_embed4_kernel (review-vector gather + mean-pool; %s)" % note,
+                    extra={"traffic": 77.8e6 if self.a.encoder == 'pvc' else None,
+                           "traffic_source": "committed PMC passes profiles/r03_rtm_embed_pmc.txt (round 3, the commit that added "
+                                             "it): FETCH_SIZE 33.6 MB x2 + WRITE_SIZE 10.5 MB per launch (round 2, with the rank "
+                                             "atomics in this kernel: 123.3 MB)" if self.a.encoder == 'pvc' else None,
+                           "bound_note": "the 59 MB of word rows come from a 16.6 MB table that lives in the L2s / Infinity Cache; "
+                                         "what the kernel takes from HBM is the ids and what it writes"})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_rtm(self, n_steps)
@@ -479,7 +485,7 @@ def gather_score_hbm_leg(dev, rows=ALSO_C5_ITEMS, iters=40):
             "kernel": "score_fwd_wide_kernel<1,4> alone (embedding gather + score), C5 shape: d=256, %d-row item table "
                       "(%.1f GB), K=20, W=1, R=21; 8 rotating index sets" % (rows, (rows + 1) * d * 4 / 1e9),
             "by_batch": res, "traffic": 63.0e6,
-            "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f): FETCH_SIZE 31.2 MB x2 "
+            "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f; round 3 repeat: profiles/r03_gather_score_c5_pmc.txt, 31.2 MB x2 + 0.4 MB): FETCH_SIZE 31.2 MB x2 "
                               "+ WRITE_SIZE 0.4 MB per launch at B=1024 against 67.6 MB algorithmic",
             "timing": "HIP event pair around every launch on its stream (ps_ktimer), %d launches per batch size" % iters}
 

@@ -328,6 +328,16 @@ int64_t ps_adam_rowsparse_state_floats(int32_t n_chunks, const PsRowTable* table
 int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
                            const PsAdamHyper* hyper, int64_t* state_dev, float* gnorm_out_dev, ps_stream_t stream);
 
+/* Lazy-EXACT dense Adam on the row-sparse machinery (args.lazy_exact_adam): last_dev[i][r] = optimizer steps row r of table i
+ * has had applied; the call replays, for every listed row (tables_host[i].rows / count) or every row (all_rows != 0), the
+ * steps last+1 .. state_dev[0] it missed with a ZERO gradient — the dense optimizer's arithmetic for a row without gradient
+ * (optimizers.py:186-187, 241-243: the moments decay, the row keeps moving) — and sets last = state_dev[0] (+1 with `advance`:
+ * the step in progress is about to update the row).  Called before a forward reads the rows, over the final touched list before
+ * ps_clip_adam_rowsparse, and with all_rows before evaluation / checkpointing.  tables_host[i].g is not read. */
+int ps_rowsparse_catchup(const PsRowTable* tables_host, int32_t n_tables, int32_t* const* last_dev, const int64_t* n_rows_host,
+                         const PsAdamHyper* hyper, const int64_t* state_dev, int32_t advance, int32_t all_rows,
+                         ps_stream_t stream);
+
 /* ------------------------------------------------------------------ row-sharded tables (no reference
  * counterpart: item_transformer.py:46,464-469 keeps the whole table on one device).  Row i lives on rank i % world at local
  * row i / world.  Per step: ps_coalesce_rows gives the rank's sorted unique rows; ps_shard_bucket cuts that list into one

@@ -183,6 +183,8 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'ps_rowsparse_update_ext': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(PsRowTable), C.c_int32, C.POINTER(PsAdamHyper),
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ps_rowsparse_catchup': (C.c_int, [C.POINTER(PsRowTable), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                       C.POINTER(PsAdamHyper), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'ps_ktimer_arm': (C.c_int, [C.c_char_p, C.c_int32]),
     'ps_ktimer_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     'ps_gemm_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,

@@ -12,7 +12,7 @@ from argparse import Namespace
 _DEFAULTS = dict(
     seed=666,
     row_sparse_adam=False,             # extension (no reference flag): touched-rows-only Adam/zero/exchange for huge tables
-    shard_tables=False,                # extension (no reference flag): item table sharded by row over the ranks (sharded.py; implies row_sparse_adam)
+    shard_tables=False, lazy_exact_adam=False,                # extension (no reference flag): item table sharded by row over the ranks (sharded.py; implies row_sparse_adam)
     train_from='',
     model_name='item_transformer',     # main.py:29 (default there is review_transformer)
     sep_prod_emb=False,                # main.py:31

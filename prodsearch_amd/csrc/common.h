@@ -301,7 +301,11 @@ struct GemmGroup {
   // problem i owns [flat0[i], flat0[i+1]): split-major, then row tile, then column tile; each problem keeps its own ksplit
   int flat;
   int flat0[4], flat_tm[3], flat_tiles[3];
+  // diagnostics (PS_GEMM_STAMP=1 + ps_debug_set_stamp_buffer, tools/gemm_stamps.py): the waves of one mid-grid workgroup of the
+  // bf16x3 kernel record s_memtime at their phase boundaries, 32 slots per wave
+  unsigned long long* stamp;
 };
+unsigned long long* ps_debug_stamp_ptr();
 
 int ps_launch_gemm(const GemmGroup& g, hipStream_t stream);
 // Fork of the side stream without a stream operation on the main stream (tem.hip, side_fork): the side stream waits for a

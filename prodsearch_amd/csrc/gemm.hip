@@ -482,9 +482,18 @@ __device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R
   else x3g_store_impl<TRANS, R, false>(planes, reg, tid, k0, kend);
 }
 
+#define GEMM_STAMP(slot)                                                                                             \
+  do {                                                                                                               \
+    if (g.stamp && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) {   \
+      unsigned long long t_;                                                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                     \
+      if ((slot) < 32) g.stamp[32 * (threadIdx.x >> 6) + (slot)] = t_;                                               \
+    }                                                                                                                \
+  } while (0)
 template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   fork_signal(g.sig, g.sigval);
+  GEMM_STAMP(0);
   constexpr int RA = 64 * MT, RB = 64 * NT;
   constexpr int MAIN_BYTES = 3 * (RA + RB) * X3K * 2;
   constexpr int EPI_BYTES = FULL ? MT * NT * 64 * LDT * 4 : 16;
@@ -566,11 +575,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
     x3g_load<TB, RB>(bs0, ldb, n0, N, kl, kend, kmask, rb[u], tid, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
   }
 
+  GEMM_STAMP(1);
   // one slab: publish slot `ra_u / rb_u` (slab k0), refill it two slabs ahead, multiply
   auto slab = [&](float (&ra_u)[RA / 8], float (&rb_u)[RB / 8], const int k0) __attribute__((always_inline)) {
+    const int si = (k0 - kbeg) / X3K;
     x3g_store<TA, RA>(As, ra_u, tid, kmask, k0, kend);
     x3g_store<TB, RB>(Bs, rb_u, tid, kmask, k0, kend);
+    GEMM_STAMP(2 + 4 * si);
     __syncthreads();
+    GEMM_STAMP(3 + 4 * si);
     const int kp = k0 + PF * X3K < kend ? k0 + PF * X3K : kbeg;
     x3g_load<TA, RA>(P.A, P.lda, m0, M, kp, kend, kmask, ra_u, tid, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);
     x3g_load<TB, RB>(bs0, ldb, n0, N, kp, kend, kmask, rb_u, tid, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
@@ -594,7 +607,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
       X3G_TERM(0, 2) X3G_TERM(2, 0) X3G_TERM(1, 1) X3G_TERM(0, 1) X3G_TERM(1, 0) X3G_TERM(0, 0)
 #undef X3G_TERM
     }
+    GEMM_STAMP(4 + 4 * si);
     __syncthreads();
+    GEMM_STAMP(5 + 4 * si);
   };
   // slabs go in pairs with no exit between them — a `break` inside the pair joins paths with different loads in flight
   // and the compiler then waits for ALL of them (vmcnt(0)) at the next store; an odd last slab runs after the loop
@@ -612,6 +627,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
     if (nsl & 1) slab(ra[0], rb[0], k0);
   }
 
+  GEMM_STAMP(30);
   // ------------------------------------------------------------------ epilogue, one 64x64 quadrant at a time
   if (!FULL) {
 #pragma unroll
@@ -633,6 +649,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
     const int mq = m0 + 64 * (q / NT), nq = n0 + 64 * (q % NT);
     if (mq < M && nq < N) epi_full<TA, IDX>(P, Ct[q], mq, nq, MT * tm + q / NT, split, M, N, listed, tid);
   }
+  GEMM_STAMP(31);
 }
 
 static bool needs_full(const GemmProblem& p) {
@@ -754,6 +771,8 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
 int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   GemmGroup g = g0;
   g.sig = nullptr; g.sigval = 0;
+  static const bool stamps = getenv("PS_GEMM_STAMP") && atoi(getenv("PS_GEMM_STAMP")) != 0;
+  g.stamp = stamps ? ps_debug_stamp_ptr() : nullptr;
   const bool took = side_take_signal(stream, &g.sig, &g.sigval);      // a pending fork of the side stream rides on this launch
   const int rc = launch_gemm_impl(g, stream);
   if (took && rc != PS_OK) side_repend_signal(stream, g.sigval);

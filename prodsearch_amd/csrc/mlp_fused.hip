@@ -134,6 +134,7 @@ __device__ __forceinline__ void dump_acc(float* slot, const f32x16& v, int l31, 
 // diagnostic timeline (tools/mlp_stamps.py): wave w of workgroup 0 stores s_memtime into stamp[16 * w + slot]
 static unsigned long long* g_mlp_stamp = nullptr;
 extern "C" void ps_debug_set_stamp_buffer(void* p) { g_mlp_stamp = (unsigned long long*)p; }
+unsigned long long* ps_debug_stamp_ptr() { return g_mlp_stamp; }
 #define MLP_STAMP(slot)                                                                              \
   do {                                                                                               \
     if (a.stamp && blockIdx.x == 0 && lane == 0) {                                                   \

@@ -55,31 +55,41 @@ __device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad
 }
 
 // clip coefficient, bias-corrected step size, 1/sqrt(bias_correction2), lr -> out[0..3]; one thread.
-__device__ inline void adam_scalars(const PsAdamHyper& hp, float total_sumsq, int64_t step, float* out, float* norm_out) {
-  const float norm = sqrtf(total_sumsq);
-  float coef = 1.f;
-  if (hp.max_grad_norm > 0.f) coef = fminf(hp.max_grad_norm / (norm + 1e-6f), 1.f);
+// the scalars of step `step` that do not depend on the gradients: bias-corrected step size, 1/sqrt(bias_correction2), lr.
+// ONE definition: the lazy catch-up of the row-sparse optimizer (optim_rows.hip) replays past steps with these.
+__device__ inline void adam_step_scalars(const PsAdamHyper& hp, int64_t step, float* step_size, float* inv_sbc2, float* lr_out) {
   const double t = (double)step;
   double lr = (double)hp.lr;
   if (hp.noam) lr = (double)hp.lr * fmin(pow(t, -0.5), t * pow((double)hp.warmup_steps, -1.5));
   const double bc1 = 1.0 - pow((double)hp.beta1, t);
   const double bc2 = 1.0 - pow((double)hp.beta2, t);
+  *step_size = (float)(lr / bc1);
+  *inv_sbc2 = (float)(1.0 / sqrt(bc2));
+  *lr_out = (float)lr;
+}
+__device__ inline void adam_scalars(const PsAdamHyper& hp, float total_sumsq, int64_t step, float* out, float* norm_out) {
+  const float norm = sqrtf(total_sumsq);
+  float coef = 1.f;
+  if (hp.max_grad_norm > 0.f) coef = fminf(hp.max_grad_norm / (norm + 1e-6f), 1.f);
   out[0] = coef * hp.grad_scale;
-  out[1] = (float)(lr / bc1);
-  out[2] = (float)(1.0 / sqrt(bc2));
-  out[3] = (float)lr;
+  adam_step_scalars(hp, step, &out[1], &out[2], &out[3]);
   *norm_out = norm;
 }
 
 struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; int zero_g; };
 
+// The rounding sequence is PINNED (no contraction left to the compiler, explicit fused multiply-adds where torch's kernels fuse):
+// this function is inlined into the dense chunk loop, the row-sparse row loop and the lazy replay (optim_rows.hip), and the
+// three must agree to the last bit (tests/test_gpu_lazy_exact.py) — left to the optimiser, `v*b2 + x` became an fma in one
+// context and a multiply + add in another.
 __device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& mm, float& vv) {
+#pragma clang fp contract(off)
   gg *= a.gmul;
-  if (a.wd != 0.f) gg += a.wd * pp;
-  mm = mm + (gg - mm) * (1.f - a.b1);           // exp_avg.lerp_(grad, 1-beta1)
-  vv = vv * a.b2 + ((1.f - a.b2) * gg) * gg;    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+  if (a.wd != 0.f) gg = __builtin_fmaf(a.wd, pp, gg);
+  mm = __builtin_fmaf(gg - mm, 1.f - a.b1, mm);  // exp_avg.lerp_(grad, 1-beta1): a + w (b - a), fused
+  vv = vv * a.b2 + ((1.f - a.b2) * gg) * gg;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2): two roundings
   const float denom = sqrtf(vv) * a.inv_sbc2 + a.eps;
-  pp = pp - a.step_size * (mm / denom);         // param.addcdiv_(exp_avg, denom, -step_size)
+  pp = pp - a.step_size * (mm / denom);          // param.addcdiv_(exp_avg, denom, -step_size)
 }
 
 // clip + Adam over one ADAM_CHUNK of the plan.

@@ -409,6 +409,101 @@ extern "C" int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, co
   return PS_OK;
 }
 
+// ---------------------------------------------------------------- lazy-EXACT dense Adam on a row-sparse table
+// The reference's optimizer is dense (optimizers.py:186-187, 241-243): a row whose gradient is zero this step still moves —
+// its first moment decays (m <- m + (0 - m)(1 - b1)), its second moment decays, and p <- p - step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+// — so the row-sparse rule above ("rows no step addressed stand still") is an extension, not the reference's arithmetic.
+// This pass makes the row-sparse machinery reproduce the dense result EXACTLY: last[r] = number of optimizer steps row r has
+// had applied; before a row is READ by a forward (and again, over the final touched list, before the step updates it) the
+// steps it missed are replayed one by one with a zero gradient through the same adam_elem and the same per-step scalars
+// (adam_step_scalars) as the dense kernel, so touched rows are bitwise what dense Adam would hold; everything else is stale
+// until `all_rows` flushes the table (before evaluation / state_dict).  The replay stops early once a step changes no element
+// of the row any more (m and v decay to values the multiplication maps to themselves, the update then underflows against p):
+// later steps cannot change it either — except for an element so small that a larger later step size could reach it, which
+// keeps the loop going (|p| < 1e-20 with m != 0).  Cost: the replay is sequential per row, up to ~1e5 steps for a row that
+// was last touched long ago — an exactness mode for pinning the optimizer, not the fast path.
+struct CatchTables { PsRowTable t[RS_MAX_TABLES]; int32_t* last[RS_MAX_TABLES]; int64_t n_rows[RS_MAX_TABLES]; int64_t wave0[RS_MAX_TABLES + 1]; int32_t n; };
+template <int NK>
+__device__ inline void catchup_row(const PsRowTable& tb, int32_t* last, int64_t row, const PsAdamHyper& hp, int64_t T, int advance,
+                                   float gzero, int lane) {
+  const int l0 = last[row];
+  if ((int64_t)l0 >= T) {                                // nothing missed (or already advanced for the step in progress)
+    if (advance && (int64_t)l0 == T && lane == 0) last[row] = (int32_t)(T + 1);
+    return;
+  }
+  const int d = tb.d;
+  const int64_t off = row * (int64_t)d;
+  float pp[NK], mm[NK], vv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int e = lane + 64 * k;
+    pp[k] = e < d ? tb.p[off + e] : 1.f; mm[k] = e < d ? tb.m[off + e] : 0.f; vv[k] = e < d ? tb.v[off + e] : 0.f;
+  }
+  bool done = false;
+  for (int64_t s0 = (int64_t)l0 + 1; s0 <= T && !done; s0 += 64) {
+    float my_ss = 0.f, my_is = 0.f, my_lr;                 // lane i: the scalars of step s0 + i
+    if (s0 + lane <= T) adam_step_scalars(hp, s0 + lane, &my_ss, &my_is, &my_lr);
+    const int nstep = (int)((T - s0 + 1) < 64 ? (T - s0 + 1) : 64);
+    for (int i = 0; i < nstep; ++i) {
+      AdamScal a = {1.f, __shfl(my_ss, i, 64), __shfl(my_is, i, 64), hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0};
+      bool moving = false;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float p0 = pp[k], m0 = mm[k], v0 = vv[k];
+        adam_elem(a, pp[k], gzero, mm[k], vv[k]);
+        moving |= (pp[k] != p0) || (mm[k] != m0) || (vv[k] != v0) || (mm[k] != 0.f && fabsf(pp[k]) < 1e-20f);
+      }
+      if (!__any(moving)) { done = true; break; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int e = lane + 64 * k;
+    if (e < d) { tb.p[off + e] = pp[k]; tb.m[off + e] = mm[k]; tb.v[off + e] = vv[k]; }
+  }
+  if (lane == 0) last[row] = (int32_t)(advance ? T + 1 : T);
+}
+__global__ __launch_bounds__(256) void rs_catchup_kernel(CatchTables C, const PsAdamHyper hp, const int64_t* state, int advance,
+                                                         int all_rows, float gzero) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int k = 0;
+  while (k < C.n - 1 && wave >= C.wave0[k + 1]) ++k;
+  const PsRowTable& tb = C.t[k];
+  const int64_t u = wave - C.wave0[k];
+  int64_t row;
+  if (all_rows) { if (u >= C.n_rows[k]) return; row = u; }
+  else { if (u >= (int64_t)*tb.count) return; row = tb.rows[u]; }
+  const int64_t T = state[0];
+  if (tb.d <= 128) catchup_row<2>(tb, C.last[k], row, hp, T, advance, gzero, lane);
+  else if (tb.d <= 256) catchup_row<4>(tb, C.last[k], row, hp, T, advance, gzero, lane);
+  else catchup_row<8>(tb, C.last[k], row, hp, T, advance, gzero, lane);
+}
+extern "C" int ps_rowsparse_catchup(const PsRowTable* tables_host, int32_t n_tables, int32_t* const* last_dev,
+                                    const int64_t* n_rows_host, const PsAdamHyper* hyper, const int64_t* state_dev,
+                                    int32_t advance, int32_t all_rows, ps_stream_t stream) {
+  PS_REQUIRE(tables_host && last_dev && n_rows_host && hyper && state_dev && n_tables >= 1 && n_tables <= RS_MAX_TABLES,
+             "rowsparse_catchup: bad argument");
+  CatchTables C = CatchTables();
+  C.n = n_tables;
+  int64_t w = 0;
+  for (int i = 0; i < n_tables; ++i) {
+    const PsRowTable& t = tables_host[i];
+    PS_REQUIRE(t.p && t.m && t.v && last_dev[i] && t.d > 0 && t.d <= 512 && n_rows_host[i] > 0 && n_rows_host[i] < ((int64_t)1 << 31) &&
+               (all_rows || (t.rows && t.count && t.cap >= 0)), "rowsparse_catchup: table %d bad field", i);
+    C.t[i] = t; C.last[i] = last_dev[i]; C.n_rows[i] = n_rows_host[i];
+    C.wave0[i] = w;
+    w += all_rows ? n_rows_host[i] : t.cap;
+  }
+  for (int i = n_tables; i <= RS_MAX_TABLES; ++i) C.wave0[i] = w;
+  if (w == 0) return PS_OK;
+  PS_REQUIRE((w + 3) / 4 < ((int64_t)1 << 31), "rowsparse_catchup: too many rows");
+  hipLaunchKernelGGL(rs_catchup_kernel, dim3((unsigned)((w + 3) / 4)), dim3(256), 0, (hipStream_t)stream, C, *hyper, state_dev,
+                     advance ? 1 : 0, all_rows ? 1 : 0, 0.f);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 // zero_grad() of rows a backward touched but no optimizer step consumed.
 __global__ __launch_bounds__(256) void rows_zero_kernel(float* tab, const int64_t* rows, const int32_t* count, int d) {
   const int64_t u = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);

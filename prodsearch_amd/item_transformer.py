@@ -151,7 +151,7 @@ class _LossTensor(torch.Tensor):
 
 class _Plan(object):
     """Per-shape cached call state: descriptor, batch struct, workspace."""
-    __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep', 'staged')
+    __slots__ = ('desc', 'batch', 'ws', 'layout', 'key', 'neg_items', 'neg_words', 'keep', 'staged', 'coalesced_at')
 
 
 # ------------------------------------------------------------------------ model
@@ -270,6 +270,7 @@ class ItemTransformerRanker(nn.Module):
     def state_dict(self, *a, **k):
         """With a sharded item table ``product_emb.weight`` is exported as the FULL [P+1, d] table, gathered from the
         ranks' shards (a collective; for catalogue-sized tables export ``model._shard.weight`` per rank instead)."""
+        self._lazy_flush()
         sd = super().state_dict(*a, **k)
         if self.__dict__.get('_shard') is not None:
             key = [q for q in sd if q.endswith('product_emb.weight')][0]
@@ -562,6 +563,35 @@ class ItemTransformerRanker(nn.Module):
             _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
                                           self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
             return plan, loss3
+        if self._lazy_exact():
+            # every row the step reads must be current BEFORE the forward: the draws as a launch of their own, the touched lists
+            # now (not under the backward), the optimizer's replay of the steps those rows missed, then the unchanged step
+            opt = self.__dict__.get('_lazy_optim')
+            opt = opt() if opt is not None else None
+            if opt is None:
+                raise RuntimeError("lazy_exact_adam: build_optim(args, model, ...) must run before the first training forward")
+            if neg_items is None or neg_words is None:
+                d = plan.desc
+                if plan.neg_items is None:
+                    plan.neg_items = torch.empty(d.B, d.K, device=self._dev(), dtype=torch.int64)
+                    plan.neg_words = torch.empty(d.B, d.W * d.K, device=self._dev(), dtype=torch.int64)
+                neg_items, neg_words = self.sample_negatives(plan)
+            self._fill_batch(plan, batch, False, neg_items, neg_words)
+            self._structs()
+            for path, p, gview in self._sparse_tabs:          # a backward no optimizer step consumed: its rows, before the lists change
+                info = getattr(p, '_ps_rows', None)
+                if info is not None and info['dirty'] and info.get('has_grad'):
+                    rows, count, cap = self._rows_view(info)
+                    _lib.check(lib.ps_zero_rows(gview.data_ptr(), p.shape[1], rows.data_ptr(), count.data_ptr(), cap,
+                                                self._stream()), 'ps_zero_rows')
+                    info['has_grad'] = False
+            self._coalesce_touched(plan)
+            plan.coalesced_at = self._fwd_step
+            opt.catch_up_rows()
+            plan.staged = False
+            _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
+                                          self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')
+            return plan, loss3
         if self._use_step_api():
             inject = neg_items is not None and neg_words is not None
             self._fill_batch(plan, batch, False, neg_items if inject else None, neg_words if inject else None,
@@ -597,7 +627,20 @@ class ItemTransformerRanker(nn.Module):
     def _row_sparse(self):
         """``args.row_sparse_adam`` (extension, default False; implied by ``args.shard_tables``): table gradients stay dense
         tensors but zeroing / clip / Adam / exchange only visit the rows a step touched (BASELINE configs[4])."""
-        return bool(getattr(self.args, 'row_sparse_adam', False)) or self.__dict__.get('_shard') is not None
+        return bool(getattr(self.args, 'row_sparse_adam', False)) or self._lazy_exact() or self.__dict__.get('_shard') is not None
+
+    def _lazy_exact(self):
+        """``args.lazy_exact_adam``: the row-sparse machinery with the DENSE optimizer's results (optimizers.py:241-243 moves
+        every row every step): the rows a step addresses are first brought up to date by replaying the steps they missed
+        (``Optimizer.catch_up_rows`` -> ``ps_rowsparse_catchup``), all other rows are stale until ``_lazy_flush``."""
+        return bool(getattr(self.args, 'lazy_exact_adam', False))
+
+    def _lazy_flush(self):
+        if self._lazy_exact():
+            opt = self.__dict__.get('_lazy_optim')
+            opt = opt() if opt is not None else None
+            if opt is not None:
+                opt.flush_rows()
 
     def _sparse_paths(self):
         """Tables handled by their touched-row lists on THIS rank (a sharded item table is not: its receive buffer is a
@@ -760,7 +803,8 @@ class ItemTransformerRanker(nn.Module):
         elif self._row_sparse() and any(getattr(p, '_ps_rows', {}).get('dirty') for _, p, _ in self._sparse_tabs):
             raise NotImplementedError("row_sparse_adam: gradient accumulation over several backwards is not "
                                       "supported; call model.zero_grad() (trainer.py:76) or optim.step() first")
-        if self._row_sparse():
+        pre = self._row_sparse() and getattr(plan, 'coalesced_at', None) == self._fwd_step     # lazy_exact_adam: done before the forward
+        if self._row_sparse() and not pre:
             # the touched lists only need the step's indices: built on a side stream under the backward
             main = torch.cuda.current_stream(self._dev())
             side = getattr(self, '_side_stream', None)
@@ -769,11 +813,15 @@ class ItemTransformerRanker(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._coalesce_touched(plan)
+        if self._row_sparse():
+            for _, p, _ in self._sparse_tabs:
+                if getattr(p, '_ps_rows', None) is not None:
+                    p._ps_rows['has_grad'] = True
         self.__dict__['_grad_clean'] = False
         go = None if grad_out is None else grad_out.contiguous().float()      # None: d loss / d loss = 1
         _lib.check(lib.ps_tem_backward(plan.desc, ps, batch_struct, plan.ws.data_ptr(), gs, 1.0,
                                        _lib.ptr(go), st), 'ps_tem_backward')
-        if self._row_sparse():
+        if self._row_sparse() and not pre:
             main.wait_stream(side)
         if self._shard is not None:
             self._shard.pending = True           # the receive buffer's gradient waits for push_grads (Optimizer.step)
@@ -781,6 +829,7 @@ class ItemTransformerRanker(nn.Module):
     def encode(self, batch):
         """Eval-mode sequence representation [B,d] that the dot-product head scores items with
         (item_transformer.py:118-131): one encode per (user, query) row.  Used by ``evaluate.rank_all``."""
+        self._lazy_flush()
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=True)
@@ -791,6 +840,7 @@ class ItemTransformerRanker(nn.Module):
         return enc
 
     def _run_score(self, batch):
+        self._lazy_flush()
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=True)

@@ -46,6 +46,9 @@ class Optimizer(object):
         self._plan = None
         self._sharded = None                 # dist.ShardedAdamExchange: this rank updates 1/world of the flat buffers
         self.shard_owner = None              # weakref to a model whose item table is row-sharded (args.shard_tables)
+        self.lazy_exact = False              # args.lazy_exact_adam: row-sparse machinery, the DENSE optimizer's results (catch_up_rows)
+        self._lazy_last = {}                 # id(table parameter) -> int32 [n_rows]: optimizer steps applied to each row
+        self._lazy_base = 0                  # value a new entry of _lazy_last starts from (the step of a loaded checkpoint)
 
     def set_parameters(self, params):
         """``set_parameters`` (optimizers.py:165-187): every parameter that requires grad."""
@@ -129,6 +132,56 @@ class Optimizer(object):
             pl['dead'] = [p for p in self.params if p.grad is None]
         return ok
 
+    def _hyper(self):
+        hp = _lib.PsAdamHyper()
+        hp.lr = self.original_lr if self.decay_method == "noam" else self.learning_rate
+        hp.beta1, hp.beta2, hp.eps = self.betas[0], self.betas[1], self.eps
+        hp.weight_decay = self.weight_decay
+        hp.max_grad_norm = self.max_grad_norm if self.max_grad_norm else 0.0
+        hp.noam = int(self.decay_method == "noam")
+        hp.warmup_steps = self.warmup_steps
+        hp.grad_scale = self.grad_scale
+        return hp
+
+    # ------------------------------------------------------------------ lazy-exact dense Adam (args.lazy_exact_adam)
+    def _catch_up(self, advance, all_rows, use_active):
+        """``ps_rowsparse_catchup`` over the row-sparse tables of the current plan: replay, with a zero gradient, the optimizer
+        steps a row missed (the dense optimizer moves every row every step, optimizers.py:241-243).  Before the first step there
+        is no state and nothing to replay."""
+        plan = self._plan
+        if not self.lazy_exact or plan is None or not plan['rows']:
+            return
+        import ctypes as C
+        lib = _lib.load()
+        n = len(plan['rows'])
+        tabs = (_lib.PsRowTable * n)()
+        last = (C.c_void_p * n)()
+        nrows = (C.c_int64 * n)()
+        for i, (p, (m, v)) in enumerate(plan['rows']):
+            info = p._ps_rows
+            t = tabs[i]
+            t.p, t.m, t.v = p.data_ptr(), m.data_ptr(), v.data_ptr()
+            t.g = p.grad.data_ptr() if p.grad is not None else 0
+            rows, count, cap = ((info.get('active') if use_active else None) or (info['rows'], info['count'], info['cap']))
+            t.rows, t.count, t.cap, t.d = rows.data_ptr(), count.data_ptr(), cap, p.shape[1]
+            lt = self._lazy_last.get(id(p))
+            if lt is None or lt.numel() != p.shape[0] or lt.device != p.device:
+                # fresh moments are zero: replaying from step 0 changes nothing and ends after one iteration; moments loaded
+                # from a checkpoint are current as of its step (load_state_dict sets _lazy_base)
+                lt = self._lazy_last[id(p)] = torch.full((p.shape[0],), int(self._lazy_base), device=p.device, dtype=torch.int32)
+            last[i], nrows[i] = lt.data_ptr(), p.shape[0]
+        st = torch.cuda.current_stream(plan['live'][0].device).cuda_stream
+        _lib.check(lib.ps_rowsparse_catchup(tabs, n, last, nrows, self._hyper(), plan['state'].data_ptr(), int(advance),
+                                            int(all_rows), st), 'ps_rowsparse_catchup')
+
+    def catch_up_rows(self):
+        """Before a forward READS the step's rows (the model calls this after coalescing them)."""
+        self._catch_up(True, False, False)
+
+    def flush_rows(self):
+        """Bring EVERY row up to the current step (before evaluation, ``state_dict()``, or leaving the mode)."""
+        self._catch_up(False, True, False)
+
     # ------------------------------------------------------------------ step
     def step(self):
         """``Optimizer.step`` (optimizers.py:205-243)."""
@@ -138,14 +191,7 @@ class Optimizer(object):
         if self.decay_method == "noam":      # host mirror of the in-kernel schedule (optimizers.py:214-219)
             self.learning_rate = self.original_lr * min(self._step ** (-0.5),
                                                         self._step * self.warmup_steps ** (-1.5))
-        hp = _lib.PsAdamHyper()
-        hp.lr = self.original_lr if self.decay_method == "noam" else self.learning_rate
-        hp.beta1, hp.beta2, hp.eps = self.betas[0], self.betas[1], self.eps
-        hp.weight_decay = self.weight_decay
-        hp.max_grad_norm = self.max_grad_norm if self.max_grad_norm else 0.0
-        hp.noam = int(self.decay_method == "noam")
-        hp.warmup_steps = self.warmup_steps
-        hp.grad_scale = self.grad_scale
+        hp = self._hyper()
         if self._sharded is not None:
             return self._sharded.step(hp)
         dev = plan['live'][0].device
@@ -207,6 +253,8 @@ class Optimizer(object):
                                                    plan['state'].data_ptr(), sums.data_ptr(), plan['gnorm'].data_ptr(), st),
                        'ps_rowsparse_update_ext')
         else:
+            if self.lazy_exact:          # over the FINAL touched lists (a data-parallel exchange may have widened them)
+                self._catch_up(True, False, True)
             _lib.check(lib.ps_clip_adam_rowsparse(plan['dev'].data_ptr(), plan['n_chunks'], tabs, len(tabs), hp,
                                                   plan['state'].data_ptr(), plan['gnorm'].data_ptr(), st),
                        'ps_clip_adam_rowsparse')
@@ -225,6 +273,7 @@ class Optimizer(object):
         """Adam state in ``torch.optim.Adam.state_dict()`` form (exp_avg / exp_avg_sq / step per
         parameter index) so a reference checkpoint's ``optim.optimizer.state_dict()`` maps 1:1."""
         state = {}
+        self.flush_rows()                    # (lazy_exact_adam: every row's moments current as of this step)
         st = getattr(self, '_state_tensors', {})
         if self._sharded is not None:        # moments live sharded over the ranks: gather them (a collective)
             mf, vf = self._sharded.full_moments()
@@ -249,6 +298,7 @@ class Optimizer(object):
             self._step = max(self._step, int(float(s['step'])))
         self._state_tensors = loaded
         self._plan = None
+        self._lazy_last, self._lazy_base = {}, self._step      # lazy_exact_adam: a checkpoint is written flushed (state_dict)
 
 
 def build_optim(args, model, checkpoint):
@@ -258,8 +308,14 @@ def build_optim(args, model, checkpoint):
                       decay_method=args.decay_method,
                       warmup_steps=args.warmup_steps,
                       weight_decay=args.l2_lambda,
-                      row_sparse=getattr(args, 'row_sparse_adam', False))
+                      row_sparse=getattr(args, 'row_sparse_adam', False) or getattr(args, 'lazy_exact_adam', False))
     optim.set_parameters(list(model.named_parameters()))
+    if getattr(args, 'lazy_exact_adam', False):
+        # the row-sparse machinery producing the DENSE optimizer's parameters (optimizers.py:241-243) — see catch_up_rows
+        if getattr(model, '_shard', None) is not None:
+            raise NotImplementedError("lazy_exact_adam with shard_tables")
+        optim.lazy_exact = True
+        model.__dict__['_lazy_optim'] = weakref.ref(optim)
     # The dense step leaves every gradient it consumed at zero (PsAdamHyper.zero_grads), so the memset of the next
     # zero_grad() / backward (trainer.py:76-77) costs nothing.  Visible difference: ``p.grad`` reads 0 after ``optim.step()``
     # where the reference still holds the step's gradient (nothing in it reads that).  ``args.keep_grads_after_step`` /

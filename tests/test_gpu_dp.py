@@ -103,6 +103,7 @@ def test_timed_choice_of_the_collective_forms_changes_no_result(tmp_path, monkey
     """dist.ShardedAdamExchange times both forms of its reduce-scatter and all-gather (the library's / slices sent peer to peer
     with all_to_all_single) inside the first exchange and keeps the faster; on RCCL that is the default, here it is forced on
     over gloo.  Whatever it picks, two ranks' sums are the same two addends: parameters equal the untimed run bit for bit."""
+    monkeypatch.setenv('PS_DETERMINISTIC', '1')          # (the default step's fp32 atomics differ from run to run by themselves)
     monkeypatch.setenv('PS_DP_RS', 'rccl'); monkeypatch.setenv('PS_DP_AG', 'rccl')
     base = _run_ranks('dense', str(tmp_path / 'tune_base'), 2, 2)
     monkeypatch.setenv('PS_DP_RS', 'auto'); monkeypatch.setenv('PS_DP_AG', 'auto')
