@@ -276,6 +276,14 @@ int64_t ps_rank_scratch_bytes(int32_t B, int64_t n_rows, int32_t d, int32_t topk
 int ps_rank_all(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
                 const int64_t* target, int32_t topk, int64_t* top_idx, float* top_score, int32_t* rank,
                 void* scratch, int64_t scratch_bytes, ps_stream_t stream);
+/* One rank's part of the same ranking over a ROW-SHARDED table (prodsearch_amd/sharded.py; the reference keeps
+ * the whole table on one device, item_transformer.py:46): table row i is catalogue id i * id_mul + id_add (world, rank);
+ * target[b] is a catalogue id and target_score[b] its score, computed where its row lives (+inf: not a product);
+ * ahead[b] = rows of THIS shard ranked ahead of the target under (score desc, id asc), the target's own row excluded;
+ * top_idx carries catalogue ids.  The caller adds the shards' counts (rank = 1 + sum) and merges their top-k lists. */
+int ps_rank_shard(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
+                  const int64_t* target, const float* target_score, int64_t id_mul, int64_t id_add, int32_t topk,
+                  int64_t* top_idx, float* top_score, int32_t* ahead, void* scratch, int64_t scratch_bytes, ps_stream_t stream);
 
 /* ------------------------------------------------------------------ row-sparse optimizer path
  * For tables too large to stream every step (BASELINE configs[4]: 50 M x 256).  The gradient tensors

@@ -162,6 +162,9 @@ SYMBOLS = {
     'ps_rank_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
     'ps_rank_all': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_rank_shard': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_void_p]),
     'ps_coalesce_ws_bytes': (C.c_int64, [C.c_int64]),
     'ps_coalesce_rows': (C.c_int, [C.POINTER(PsIdxList), C.c_int32, C.c_int64, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

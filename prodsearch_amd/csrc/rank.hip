@@ -42,6 +42,7 @@ struct SelArgs {
   int64_t* top_idx; float* top_score;
   const int64_t* target; const float* st; int32_t* rank;   // dense levels only (rank may be null)
   int32_t* cnt; int64_t cnt_ld;                              // [B, cnt_ld] rows ranked ahead of the target, per dense chunk
+  int64_t id_mul, id_add;                                    // catalogue id of table row i = i * id_mul + id_add (a row shard: world, rank)
 };
 
 // k-th largest of the block's keys that are >= lo (N per lane): MSB-first radix select over LDS histograms.
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
       const bool live = ok && gi >= 0;
       key[j + e] = live ? f2key(vv[e]) : 0u;
       idx[j + e] = live ? gi : -1;
-      if (count && live && gi != tgt) cnt_gt_target += (vv[e] > st) || (vv[e] == st && (int64_t)gi < tgt);
+      const int64_t gid = (int64_t)gi * a.id_mul + a.id_add;
+      if (count && live && gid != tgt) cnt_gt_target += (vv[e] > st) || (vv[e] == st && gid < tgt);
     }
   }
   if (count) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void select_kernel(const SelArgs a) {
     const uint32_t kk = (uint32_t)(v >> 32);
     const int32_t gi = (int32_t)(~(uint32_t)(v & 0xffffffffu));
     const bool live = kk != 0u && gi >= 0;
-    a.top_idx[(size_t)b * a.k + tid] = live ? (int64_t)gi : -1;
+    a.top_idx[(size_t)b * a.k + tid] = live ? (int64_t)gi * a.id_mul + a.id_add : -1;
     a.top_score[(size_t)b * a.k + tid] = live ? key2f(kk) : -INFINITY;
   }
 }
@@ -353,7 +355,7 @@ static int launch_rank_stream(const float* q, int B, int d, const float* table, 
 }
 
 // rank[b] = 1 + rows ranked ahead of the target over all dense chunks (0 stays 0: target not in the catalogue)
-__global__ __launch_bounds__(256) void rank_sum_kernel(const int32_t* cnt, int64_t ld, int32_t* rank) {
+__global__ __launch_bounds__(256) void rank_sum_kernel(const int32_t* cnt, int64_t ld, int32_t* rank, int raw) {
   __shared__ int wsum[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   int s = 0;
@@ -361,7 +363,8 @@ __global__ __launch_bounds__(256) void rank_sum_kernel(const int32_t* cnt, int64
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0 && rank[b] > 0) rank[b] = 1 + (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  if (tid == 0 && raw) rank[b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);       // a shard's count of rows ahead
+  else if (tid == 0 && rank[b] > 0) rank[b] = 1 + (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 static inline int64_t up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -406,9 +409,30 @@ extern "C" int64_t ps_rank_scratch_bytes(int32_t B, int64_t n_rows, int32_t d, i
   return p.total;
 }
 
+static int rank_all_impl(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
+                         const int64_t* target, const float* ext_score, int64_t id_mul, int64_t id_add, int32_t topk,
+                         int64_t* top_idx, float* top_score, int32_t* rank, void* scratch, int64_t scratch_bytes, ps_stream_t stream);
 extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
                            const int64_t* target, int32_t topk, int64_t* top_idx, float* top_score, int32_t* rank,
                            void* scratch, int64_t scratch_bytes, ps_stream_t stream) {
+  return rank_all_impl(q, B, d, table, n_rows, bias, target, nullptr, 1, 0, topk, top_idx, top_score, rank, scratch, scratch_bytes,
+                       stream);
+}
+// One rank's part of a full-catalogue ranking over a ROW-SHARDED table (sharded.py): table row i is catalogue id
+// i * id_mul + id_add; target_score[b] is the target's score computed where its row lives; ahead[b] = rows of THIS shard ranked
+// ahead of the target under (score desc, id asc), the target's own row excluded; top_idx carries catalogue ids.  The caller adds
+// the shards' counts and merges their top-k lists.
+extern "C" int ps_rank_shard(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
+                             const int64_t* target, const float* target_score, int64_t id_mul, int64_t id_add, int32_t topk,
+                             int64_t* top_idx, float* top_score, int32_t* ahead, void* scratch, int64_t scratch_bytes,
+                             ps_stream_t stream) {
+  PS_REQUIRE(target && target_score && ahead && id_mul >= 1 && id_add >= 0 && id_add < id_mul, "rank_shard: bad argument");
+  return rank_all_impl(q, B, d, table, n_rows, bias, target, target_score, id_mul, id_add, topk, top_idx, top_score, ahead, scratch,
+                       scratch_bytes, stream);
+}
+static int rank_all_impl(const float* q, int32_t B, int32_t d, const float* table, int64_t n_rows, const float* bias,
+                         const int64_t* target, const float* ext_score, int64_t id_mul, int64_t id_add, int32_t topk,
+                         int64_t* top_idx, float* top_score, int32_t* rank, void* scratch, int64_t scratch_bytes, ps_stream_t stream) {
   PS_REQUIRE(q && table && top_idx && top_score && scratch, "rank_all: null argument");
   PS_REQUIRE(B >= 1 && d >= 1 && n_rows >= 1 && n_rows < ((int64_t)1 << 31), "rank_all: bad sizes");
   PS_REQUIRE(topk >= 1 && topk <= SEL_KMAX, "rank_all: topk must be 1..%d", SEL_KMAX);
@@ -426,7 +450,9 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
   float* cs[2] = {(float*)(base + p.off_c0s), (float*)(base + p.off_c1s)};
   int32_t* ci[2] = {(int32_t*)(base + p.off_c0i), (int32_t*)(base + p.off_c1i)};
   int32_t* cntb = (int32_t*)(base + p.off_cnt);
-  if (target) {
+  if (ext_score) {
+    stv = const_cast<float*>(ext_score);
+  } else if (target) {
     // the target's score through the SAME GEMM (bitwise equal to its entry of the score matrix)
     hipLaunchKernelGGL(rank_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, st, table, target, n_rows, d, T, B);
     PS_LAUNCH_CHECK();
@@ -456,13 +482,14 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
     a.final = single; a.top_idx = top_idx; a.top_score = top_score;
     a.target = target; a.st = stv; a.rank = target ? rank : nullptr;
     a.cnt = cntb; a.cnt_ld = p.chunks1;
+    a.id_mul = id_mul; a.id_add = id_add;
     const int nch = (int)((w + SEL_CHUNK - 1) / SEL_CHUNK);
     hipLaunchKernelGGL(select_kernel, dim3(nch, B), dim3(256), 0, st, a);
     PS_LAUNCH_CHECK();
     chunk_off += nch;
   }
   if (target && rank) {
-    hipLaunchKernelGGL(rank_sum_kernel, dim3(B), dim3(256), 0, st, cntb, p.chunks1, rank);
+    hipLaunchKernelGGL(rank_sum_kernel, dim3(B), dim3(256), 0, st, cntb, p.chunks1, rank, ext_score ? 1 : 0);
     PS_LAUNCH_CHECK();
   }
   if (single) return PS_OK;
@@ -476,6 +503,7 @@ extern "C" int ps_rank_all(const float* q, int32_t B, int32_t d, const float* ta
     a.src_score = cs[cur]; a.src_idx = ci[cur]; a.src_ld = n; a.n = (int)n;
     a.out_score = cs[cur ^ 1]; a.out_idx = ci[cur ^ 1]; a.out_ld = (int64_t)nch * topk; a.chunk_off = 0; a.k = topk;
     a.final = nch == 1; a.top_idx = top_idx; a.top_score = top_score;
+    a.id_mul = id_mul; a.id_add = id_add;
     hipLaunchKernelGGL(select_kernel, dim3(nch, B), dim3(256), 0, st, a);
     PS_LAUNCH_CHECK();
     if (nch == 1) break;

@@ -9,8 +9,83 @@ import torch
 from . import _lib
 
 
+def _rank_all_sharded(model, batch, topk):
+    """``rank_all`` over a row-sharded item table (``args.shard_tables``, sharded.py): a COLLECTIVE — every rank calls it with a
+    batch of the same size.  Each rank encodes its own rows (the history rows come from their owners), the encodings, targets and
+    target scores are all-gathered, every rank ranks ALL rows against its shard (``ps_rank_shard``: top-k with catalogue ids and
+    the number of its rows ahead of each target), the counts are summed and the W top-k lists merged by (score desc, id asc) —
+    the order ``ps_rank_all`` uses on one table."""
+    import torch.distributed as dist
+    lib = _lib.load()
+    sh = model._shard
+    W, r = sh.world, sh.rank
+    if model.args.sim_func == 'bias_product':
+        raise NotImplementedError("rank_all over a sharded table with sim_func='bias_product'")
+    was_training = model.training
+    model.eval()
+    try:
+        enc = model.encode(batch)
+    finally:
+        model.train(was_training)
+    B, d = enc.shape
+    dev = enc.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    P = model.product_size
+    target = batch.target_prod_idxs.contiguous()
+    # the target's score through the SAME product kernel that scores the shards: q . T^T over the fetched target rows, diagonal
+    trows = sh.table_buf[model.__dict__['_shard_eval_target_slots']].contiguous()
+    tt = torch.empty(B, B, device=dev, dtype=torch.float32)
+    _lib.check(lib.ps_gemm_f32(enc.data_ptr(), d, 0, trows.data_ptr(), d, 0, tt.data_ptr(), B, B, B, d, None, 1.0, 0, st),
+               'ps_gemm_f32')
+    ok = (target >= 0) & (target < P)
+    tscore = torch.where(ok, tt.diagonal(), torch.full_like(tt.diagonal(), float('inf'))).contiguous()
+    if W > 1:
+        encs = torch.empty(W * B, d, device=dev, dtype=torch.float32)
+        tgts = torch.empty(W * B, device=dev, dtype=torch.int64)
+        tscs = torch.empty(W * B, device=dev, dtype=torch.float32)
+        dist.all_gather_into_tensor(encs, enc.contiguous(), group=sh.group)
+        dist.all_gather_into_tensor(tgts, target, group=sh.group)
+        dist.all_gather_into_tensor(tscs, tscore, group=sh.group)
+    else:
+        encs, tgts, tscs = enc.contiguous(), target, tscore
+    n_mine = (P - r + W - 1) // W                              # catalogue rows i < P with i % W == r
+    k = int(topk)
+    NB = W * B
+    nbytes = lib.ps_rank_scratch_bytes(NB, n_mine, d, k)
+    if nbytes < 0:
+        raise RuntimeError("rank_all: unsupported sizes (topk must be 1..256)")
+    scratch = model.__dict__.get('_rank_scratch')
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = model.__dict__['_rank_scratch'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    top_idx = torch.empty(NB, k, dtype=torch.int64, device=dev)
+    top_score = torch.empty(NB, k, dtype=torch.float32, device=dev)
+    ahead = torch.zeros(NB, dtype=torch.int32, device=dev)
+    _lib.check(lib.ps_rank_shard(encs.data_ptr(), NB, d, sh.weight.data_ptr(), n_mine, None, tgts.data_ptr(), tscs.data_ptr(),
+                                 W, r, k, top_idx.data_ptr(), top_score.data_ptr(), ahead.data_ptr(), scratch.data_ptr(),
+                                 scratch.numel(), st), 'ps_rank_shard')
+    if W > 1:
+        all_idx = torch.empty(W, NB, k, dtype=torch.int64, device=dev)
+        all_sc = torch.empty(W, NB, k, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(all_idx, top_idx, group=sh.group)
+        dist.all_gather_into_tensor(all_sc, top_score, group=sh.group)
+        dist.all_reduce(ahead, group=sh.group)
+        mine = slice(r * B, (r + 1) * B)
+        ci = all_idx[:, mine].permute(1, 0, 2).reshape(B, W * k)
+        cs = all_sc[:, mine].permute(1, 0, 2).reshape(B, W * k)
+        key = torch.where(ci >= 0, ci, torch.full_like(ci, P + 1))          # unfilled slots last among equal (-inf) scores
+        o1 = torch.argsort(key, dim=1, stable=True)
+        ci, cs = torch.gather(ci, 1, o1), torch.gather(cs, 1, o1)
+        o2 = torch.argsort(cs, dim=1, descending=True, stable=True)
+        top_idx, top_score = torch.gather(ci, 1, o2)[:, :k].contiguous(), torch.gather(cs, 1, o2)[:, :k].contiguous()
+        ahead = ahead[mine]
+    rank = torch.where(ok, 1 + ahead, torch.zeros_like(ahead)).to(torch.int32)
+    return top_idx, top_score, rank
+
+
 def rank_all(model, batch, topk=100):
     """-> (top_idx [B,k] int64, top_score [B,k] fp32, rank [B] int32; 1-based, 0 = target not a product), on device."""
+    if getattr(model, '_shard', None) is not None:
+        return _rank_all_sharded(model, batch, topk)
     lib = _lib.load()
     was_training = model.training
     model.eval()

@@ -295,7 +295,9 @@ class ItemTransformerRanker(nn.Module):
 
     def test(self, batch_data):
         if self.__dict__.get('_shard') is not None:
-            raise NotImplementedError("test() with shard_tables: evaluate from an unsharded model loaded with state_dict()")
+            raise NotImplementedError("test() with shard_tables scores explicit candidate lists against one table; use "
+                                      "evaluate.rank_all (full-catalogue ranking over the shards, a collective) or an unsharded "
+                                      "model loaded with state_dict()")
         return self._run_score(batch_data)
 
     # -------------------------------------------------------------------- plumbing
@@ -833,6 +835,19 @@ class ItemTransformerRanker(nn.Module):
         lib = _lib.load()
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=True)
+        if self._shard is not None:
+            # row-sharded item table: the history rows (and the targets', for evaluate.rank_all) come from their owners first —
+            # a collective, like the training forward's lookup; the encode then reads the receive buffer through remapped ids
+            import copy
+            tem = self.args.model_name == 'item_transformer'
+            tg = self._check_idx(batch.target_prod_idxs, 'target_prod_idxs')
+            lists = [tg] + ([self._check_idx(batch.u_item_idxs, 'u_item_idxs')] if tem else [])
+            rem = self._shard.lookup(lists)
+            batch = copy.copy(batch)
+            batch.target_prod_idxs = rem[0]
+            if tem:
+                batch.u_item_idxs = rem[1]
+            self.__dict__['_shard_eval_target_slots'] = rem[0]
         self._fill_batch(plan, batch, True)
         enc = torch.empty(plan.desc.B, plan.desc.d, device=self._dev(), dtype=torch.float32)
         _lib.check(lib.ps_tem_encode(plan.desc, ps, plan.batch, plan.ws.data_ptr(), enc.data_ptr(), self._stream()),

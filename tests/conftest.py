@@ -30,3 +30,16 @@ def x3_restore():
     yield
     from prodsearch_amd import _lib
     _lib.load().ps_gemm_x3_config(0 if os.environ.get('PS_GEMM_X3') == '0' else 1, int(os.environ.get('PS_GEMM_X3_SHAPE', '-1')))
+
+
+@pytest.hookimpl(wrapper=True)
+def pytest_runtest_call(item):
+    """PS_DETERMINISTIC=1 over the whole suite (tools/env_matrix.sh): the review transformer's deterministic mode REFUSES the
+    configurations it does not cover (pv encoder, PV loss, user / item embeddings: DESIGN.md 5e) — those cases are skipped, not
+    failed; tests/test_gpu_determinism_rtm.py checks the refusal itself."""
+    try:
+        return (yield)
+    except RuntimeError as e:
+        if os.environ.get('PS_DETERMINISTIC') == '1' and 'deterministic mode supports' in str(e):
+            pytest.skip("deterministic mode refuses this configuration")
+        raise
