@@ -62,6 +62,7 @@ struct RtmK {              // kernel-side view of one call
   int32_t *seqcnt, *vrows, *vcount;   // valid-row list of x (GemmProblem::ridx): per-sequence counts, rows, length
   int count_fwd;                      // rtm_embed4_kernel counts them (the counters were cleared by the query-encoder launch)
   int det;                            // deterministic mode (ps_deterministic): no fp32 atomic whose order could differ between runs
+  unsigned long long* stamp;          // diagnostics (PS_RTM_STAMP=1, tools/rtm_stamps.py): phase stamps of one workgroup of rtm_embed4_kernel
   float* loss3;
   // backward
   float scale; const float* scale_dev;
@@ -463,6 +464,15 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
                                                          const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg, int diag) {
   __shared__ E4Lds<NCHL> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#define E4_STAMP(slot)                                                                             \
+  do {                                                                                             \
+    if (a.stamp && (int)blockIdx.x == nq_wg + 8 && lane == 0) {                                    \
+      unsigned long long t_;                                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+      a.stamp[16 * wv + (slot)] = t_;                                                              \
+    }                                                                                              \
+  } while (0)
+  E4_STAMP(0);
   int g = blockIdx.x * 4 + wv;
   if (glist) {
     // with the valid-group list (rtm_grouplist_kernel) the launch is DENSE in real work: the first nq_wg workgroups are the
@@ -538,6 +548,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   // 73 % of the review slots of a C4 batch are padding: a group without a real review skips the Philox evaluations, the
   // lists and the gather (wave-uniform branch) and only writes its masked rows
   const bool any_ok = okq[0] || okq[1] || okq[2] || okq[3];
+  E4_STAMP(1);
   int cwa[4] = {-1, -1, -1, -1}, cwb[4] = {-1, -1, -1, -1};     // the counted words of slots lane / lane + 64 (-1: none)
   if (any_ok) {
     // ---- the word slots and their token masks
@@ -580,6 +591,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  E4_STAMP(2);
   // ---- 3. gather: group q = lane >> 4 walks list q
   const int q = lane >> 4, c = lane & 15;
   const int myn = q == 0 ? nlq[0] : (q == 1 ? nlq[1] : (q == 2 ? nlq[2] : nlq[3]));
@@ -612,6 +624,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       }
   }
 
+  E4_STAMP(3);
   // ---- first pass of the backward's inverted index (RtmK::count_fwd): every counted word takes its RANK among the
   // occurrences of that word (a returning atomic on the word's counter, in flight under the rest of the kernel (issued in front of the gather instead they cost 4 us: measured)); the fill
   // then places the occurrence at  segment start + rank  without another atomic
@@ -677,6 +690,8 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
         if (lane + 64 < a.WL) rk[lane + 64] = rkb[qq];
       }
   }
+  E4_STAMP(4);
+#undef E4_STAMP
 }
 
 // ------------------------------------------------------------------ scores
@@ -1587,6 +1602,8 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   k.B = D.B; k.J = r.J; k.K = D.K; k.R = D.R; k.S = r.S; k.Q = D.Q; k.W = D.W > 0 ? D.W : 1; k.WL = D.WL; k.d = D.d;
   k.V = D.vocab_size; k.RC = D.review_count;
   k.det = ps_deterministic() ? 1 : 0;
+  static const bool rtm_stamps = getenv("PS_RTM_STAMP") && atoi(getenv("PS_RTM_STAMP")) != 0;
+  k.stamp = rtm_stamps ? ps_debug_stamp_ptr() : nullptr;
   // `pvc` = every word-mean review encoder in training (pvc, fs, avg); only pvc corrupts tokens and ignores the word masks
   k.pvc = D.review_encoder != PS_RENC_PV && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
   const bool masked_mean = !eval && (D.review_encoder == PS_RENC_FS || D.review_encoder == PS_RENC_AVG);

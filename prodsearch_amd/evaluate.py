@@ -66,8 +66,8 @@ def _rank_all_sharded(model, batch, topk):
     if W > 1:
         all_idx = torch.empty(W, NB, k, dtype=torch.int64, device=dev)
         all_sc = torch.empty(W, NB, k, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(all_idx, top_idx, group=sh.group)
-        dist.all_gather_into_tensor(all_sc, top_score, group=sh.group)
+        dist.all_gather_into_tensor(all_idx.view(W * NB, k), top_idx, group=sh.group)
+        dist.all_gather_into_tensor(all_sc.view(W * NB, k), top_score, group=sh.group)
         dist.all_reduce(ahead, group=sh.group)
         mine = slice(r * B, (r + 1) * B)
         ci = all_idx[:, mine].permute(1, 0, 2).reshape(B, W * k)
