@@ -42,6 +42,7 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in device memory (prodsearch_amd/__init__.py)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
