@@ -353,7 +353,16 @@ class ShardedAdamExchange(object):
         m = self.model
         flat = m._grad_flat
         if self.world > 1 and 'auto' in (self.rs_mode, self.ag_mode):
-            self._tune(flat)
+            try:
+                self._tune(flat)
+            except Exception as e:          # (symmetric collectives: a form the backend refuses fails on every rank alike)
+                import sys
+                print("ShardedAdamExchange: timing the collective forms failed (%s: %s); using the library's" % (type(e).__name__, e),
+                      file=sys.stderr)
+                self._a2a_recv = self._a2a_send = None
+                self.rs_mode = 'rccl' if self.rs_mode == 'auto' else self.rs_mode
+                self.ag_mode = 'rccl' if self.ag_mode == 'auto' else self.ag_mode
+                self._set_modes(self.rs_mode, self.ag_mode)
         if self.world > 1:
             self._reduce_scatter(self.g_shard, flat, self.rs_mode)
         else:
