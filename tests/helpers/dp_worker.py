@@ -17,7 +17,7 @@ def global_problem(mode, Bg, seed=31):
     from prodsearch_amd import readme_tem_args, synth
     P_, V, K, L, Q, W = 18357, 32387, 20, 20, 8, 1
     a = readme_tem_args(dropout=0.0, lr=0.002, row_sparse_adam=(mode in ('sparse', 'sharded')),      # 'dense' / 'allreduce': dense Adam
-                        shard_tables=(mode == 'sharded'))
+                        shard_tables=(mode == 'sharded'), lazy_exact_adam=(mode == 'lazy'))          # 'lazy': row-sparse machinery, dense results
     wd = synth.make_word_dists(V)
     batch = synth.make_tem_batch(seed, Bg, P_, V, Q=Q, L=L, W=W, word_dists=wd)
     ni, nw = synth.sample_negatives(seed + 1, Bg, K, W, P_, wd)

@@ -99,6 +99,38 @@ def test_unequal_per_rank_batches_keep_the_replicas_in_lock_step(mode, tmp_path)
     assert np.isfinite(r0['__loss']) and np.isfinite(r1['__loss'])
 
 
+def test_two_ranks_with_lazy_exact_adam_equal_one_dense_rank(tmp_path):
+    """``args.lazy_exact_adam`` under data parallelism: the row-sparse exchange widens the touched lists to the ranks' union after
+    the backward, and the optimizer's replay runs over THOSE lists before the step, so rows only the other rank addressed are
+    brought up to date too; three steps of two ranks must equal three steps of the single-process DENSE optimizer."""
+    sys.path.insert(0, os.path.join(HERE, 'helpers'))
+    import dp_worker
+
+    class _NoExchange(object):
+        def __call__(self):
+            return None
+
+    lr, steps = 0.002, 3
+    single = dp_worker.run('dense', 384, steps, 0, 1, lambda m, o: _NoExchange())
+    r0, r1 = _run_ranks('lazy', str(tmp_path / 'dp_lazy'), 2, steps)
+    for k in r0:
+        if not k.startswith('__'):
+            assert np.array_equal(r0[k], r1[k]), "replicas diverged: " + k
+    checked = 0
+    for k, ref in single.items():
+        if k.startswith('__') or k.endswith('linear_keys.bias'):
+            continue
+        got = r0[k]
+        if k.endswith('__sum'):
+            assert abs(got - ref) < 1e-3 * max(1.0, abs(ref)) + 1.0, k          # every row of the table, flushed
+            continue
+        assert got.shape == ref.shape, k
+        tol = 2e-3 * float(np.abs(ref).max()) + 0.02 * lr * steps
+        assert float(np.abs(got - ref).max()) < tol, (k, float(np.abs(got - ref).max()), tol)
+        checked += 1
+    assert checked >= 20
+
+
 def test_timed_choice_of_the_collective_forms_changes_no_result(tmp_path, monkeypatch):
     """dist.ShardedAdamExchange times both forms of its reduce-scatter and all-gather (the library's / slices sent peer to peer
     with all_to_all_single) inside the first exchange and keeps the faster; on RCCL that is the default, here it is forced on
