@@ -87,6 +87,40 @@ def test_two_ranks_of_192_equal_one_rank_of_384(mode, tmp_path):
     print("dp %s: 2-rank step %.3f ms (gloo, one GPU), single-rank %.3f ms" % (mode, r0['__ms'], single['__ms']))
 
 
+@pytest.mark.parametrize('mode,forms', [('dense', 'rccl'), ('dense', 'a2a'), ('sparse', None), ('sharded', None)])
+def test_four_ranks_of_96_equal_one_rank_of_384(mode, forms, tmp_path, monkeypatch):
+    """World 4 (the most the one-GPU box lets share its card besides the test process): slice arithmetic of the sharded
+    optimizer's flat buffers, the peer-to-peer forms of its collectives with more than one peer, four fixed-capacity row messages,
+    four owners of a row-sharded item table — things a world of 2 cannot get wrong."""
+    sys.path.insert(0, os.path.join(HERE, 'helpers'))
+    import dp_worker
+
+    class _NoExchange(object):
+        def __call__(self):
+            return None
+
+    if forms:
+        monkeypatch.setenv('PS_DP_RS', forms); monkeypatch.setenv('PS_DP_AG', forms)
+    lr, steps = 0.002, 2
+    single = dp_worker.run('sparse' if mode == 'sharded' else mode, 384, steps, 0, 1, lambda m, o: _NoExchange())
+    ranks = _run_ranks(mode, str(tmp_path / ('dp4_' + mode)), 4, steps)
+    for r in ranks[1:]:
+        for k in ranks[0]:
+            if not k.startswith('__'):
+                assert np.array_equal(ranks[0][k], r[k]), "replicas diverged: " + k
+    checked = 0
+    for k, ref in single.items():
+        if k.startswith('__') or k.endswith('__sum') or k.endswith('linear_keys.bias'):
+            continue
+        got = ranks[0][k]
+        assert got.shape == ref.shape, k
+        tol = 2e-3 * float(np.abs(ref).max()) + 0.02 * lr * steps
+        assert float(np.abs(got - ref).max()) < tol, (k, float(np.abs(got - ref).max()), tol)
+        checked += 1
+    assert checked >= 20
+    assert abs(sum(r['__loss'] for r in ranks) / 4 - single['__loss']) < 2e-3 * abs(single['__loss'])
+
+
 @pytest.mark.parametrize('mode', ['dense', 'sparse'])
 def test_unequal_per_rank_batches_keep_the_replicas_in_lock_step(mode, tmp_path):
     """Ranks whose batches differ in size (192 and 150 rows: a loader with drop_last=False) address different numbers of
