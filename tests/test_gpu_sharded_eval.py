@@ -32,12 +32,13 @@ def test_one_process_sharded_ranking_equals_the_single_table_ranking():
     assert res['plain'][2][3] == 0                                 # the row whose target is not a product
 
 
-def test_two_ranks_rank_their_batches_over_both_shards(tmp_path):
+@pytest.mark.parametrize('world', [2, 3])      # 3: 6,001 rows in shards of 2,001 / 2,000 / 2,000
+def test_ranks_rank_their_batches_over_all_shards(world, tmp_path):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / 'shard_eval')
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, WORKER, '--out', out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
@@ -52,6 +53,6 @@ def test_two_ranks_rank_their_batches_over_both_shards(tmp_path):
         logs.append(o)
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-4000:])
-    for r in range(2):
+    for r in range(world):
         z = np.load(out + '.rank%d.npz' % r)
         _check(z['pi'], z['ps'], z['pr'], z['si'], z['ss'], z['sr'])
