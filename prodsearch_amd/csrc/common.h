@@ -76,6 +76,15 @@ struct DropSpec {      // one dropout site
   uint32_t half;       // 1: the 16-bit column-shared form below (sites ctx / ff1 / ff2 of every layer)
   uint32_t thr16;      // keep iff u16 >= thr16 ; thr16 = floor(p * 2^16)
 };
+// `c ? a : b` on two specs by VALUE, field by field: a reference to one of two structs makes the compiler keep both in scratch
+// memory and read the fields back through a pointer (rtm_embed_bwd_kernel: 56 B of scratch, loads inside its loop)
+__host__ __device__ inline DropSpec drop_select(bool c, const DropSpec& a, const DropSpec& b) {
+  DropSpec r;
+  r.thr = c ? a.thr : b.thr; r.scale = c ? a.scale : b.scale; r.site = c ? a.site : b.site; r.step = c ? a.step : b.step;
+  r.k0 = c ? a.k0 : b.k0; r.k1 = c ? a.k1 : b.k1; r.step_ptr = c ? a.step_ptr : b.step_ptr; r.half = c ? a.half : b.half;
+  r.thr16 = c ? a.thr16 : b.thr16;
+  return r;
+}
 // Two forms of the stream (both restated in oracle/philox.py, pinned through ps_dropout_mult_host):
 //   classic (fs, attention, review and token sites): element (row, col) = word (row & 3) of Philox(col, row >> 2, site, step)
 //     — four consecutive ROWS of a column share a call, one 32-bit word per decision;

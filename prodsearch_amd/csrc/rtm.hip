@@ -463,7 +463,7 @@ template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * 
 __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread,
                                                          const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg, int diag) {
   __shared__ E4Lds<NCHL> L;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #define E4_STAMP(slot)                                                                             \
   do {                                                                                             \
     if (a.stamp && (int)blockIdx.x == nq_wg + 8 && lane == 0) {                                    \
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       g = glist[gi];
     }
   }
+  g = __builtin_amdgcn_readfirstlane(g);            // wave-uniform: everything derived from it lives in scalar registers
   const int d = a.d;
   const int64_t rpad = a.RC - 1;
   if (g >= npos_grp + nneg_grp) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
   const int* wl = L.wid[wv][q];
   const float* tl = L.tm[wv][q];
-  constexpr int E4_U = NCHL <= 2 ? 8 : 4;          // word rows in flight per 16-lane group
+  constexpr int E4_U = NCHL <= 2 ? 6 : 4;          // word rows in flight per 16-lane group (6: 127 registers, four waves per SIMD)
   for (int i0 = 0; i0 < maxn; i0 += E4_U) {
     float4 rowv[E4_U][NCHL]; float mt[E4_U];
 #pragma unroll
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
     const bool pos = wave < npos_w;
     const int w0 = pos ? wave : wave - npos_w;
     const int nrev = pos ? a.B * a.R : a.B * a.K * a.R;
-    const DropSpec& ds = pos ? dpos : dneg;
+    const DropSpec ds = drop_select(pos, dpos, dneg);
     const bool wantdv = pos && a.train_pv;
     // lane i < 4 * EB_GROUPS decodes review row  4 * EB_GROUPS * w0 + i  (one coalesced read of the review ids / segment ids:
     // group after group through scalar loads the decode alone took 20 us)
