@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
   __shared__ float pl[4][64][W1_MAXH], dpl[4][64][W1_MAXH];
   __shared__ float dqs[4][D];
   __shared__ float part[256 / D][4][D];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = (int)blockIdx.x * 4 + wv;
   const int S = a.S, HF = a.H, lph = a.dh >> 2;
   const int sub = lane / LPR, cl = lane % LPR, c = 4 * cl, h = cl / lph;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w1_kernel(const AttnArgs a) {
   __shared__ int sp[4][64];
   __shared__ float sc[4][64][W1_MAXH];
   __shared__ float ls[4][W1_MAXH], mxl[4][W1_MAXH];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = (int)blockIdx.x * 4 + wv;
   if (b >= a.n_in) return;
   const int S = a.S, HF = a.H, lph = a.dh >> 2;
@@ -634,7 +634,7 @@ template <int DH, int MAXK>
 __global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint32_t* amask, int nchunk) {
   constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4;
   __shared__ int sp[4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int NHG = a.H >> 2, D = a.d, S = a.S, HF = a.H;
   // wave -> (sequence, head group, replica chunk): the replicas are independent in the forward, so `nchunk` waves share a
   // (sequence, head group) — each repeats the short softmax, each takes fan / nchunk replicas (768 waves of 21 serial
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
   __shared__ float red[4][NV][64];                            // [wave][value][lane]
   __shared__ float dqs[HC];
   __shared__ float part[128];
-  const int tid = threadIdx.x, lane = tid & 63, ch = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = a.S, HF = a.H;
   const int b = (int)blockIdx.x >> 1, hg = (int)blockIdx.x & 1;
   const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;

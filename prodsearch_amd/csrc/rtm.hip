@@ -705,8 +705,8 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
 // writes back the XCD's L2: the first form, partials + __threadfence + ticket, doubled this kernel's 6 us).
 __global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out, int fold_loss, unsigned long long* ticket) {
   __shared__ float wterm[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   float term = 0.f;
   if (n < a.B * a.J) {
     float s = 0.f;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void rtm_loss_kernel(const RtmK a) {
 __global__ __launch_bounds__(256) void rtm_score_bwd_kernel(const RtmK a, int zero_dqe, uint32_t* sig, uint32_t sigval) {
   fork_signal(sig, sigval);
   extern __shared__ float acc[];                  // [d] partial of d wo_w, + 1 for d wo_b
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, K1 = a.K + 1;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), K1 = a.K + 1;
   if (zero_dqe)                                   // d query_emb collects atomics much later (rtm_embed_bwd_kernel): no memset launch
     for (int e = blockIdx.x * 256 + threadIdx.x; e < a.B * a.d; e += gridDim.x * 256) a.dqe[e] = 0.f;
   for (int e = threadIdx.x; e <= a.d; e += 256) acc[e] = 0.f;
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(512) void rtm_hist_scan_kernel(int* hist, int* wcnt
 // run of equal words in registers and issues ONE atomic row per run (runs spanning waves meet in the atomics)
 __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
   const int lane = threadIdx.x & 63;
-  const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nwave = (gridDim.x * blockDim.x) >> 6;
   const int T = a.wcnt[a.V];                         // the allocator's total (rtm_walloc_kernel)
   const int d = a.d;                                 // lane l owns columns l, l+64, ... (< d <= 512)
   // (the list length is only known on the device: a capped grid strides over it instead of one workgroup per 256 POSSIBLE
