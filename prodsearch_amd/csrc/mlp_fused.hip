@@ -153,7 +153,7 @@ template <int NBW, int PF, int DIAG = 0>       // hidden-layer feature blocks pe
 __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdArgs a) {
   extern __shared__ float lds_raw[];
   MlpTLds& L = *reinterpret_cast<MlpTLds*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * MBM, M = a.M, F = a.F;
   const int mrow = 4 * wave + (lane >> 4), c8 = 8 * (lane & 15);       // LayerNorm-stage role
   const int mg = m0 + mrow;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
   fork_signal(a.sig, a.sigval);
   extern __shared__ float lds_raw[];
   MlpTLds& L = *reinterpret_cast<MlpTLds*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * MBM, M = a.M, F = a.F;
   const int mrow = 4 * wave + (lane >> 4), c8 = 8 * (lane & 15);
   const int mg = m0 + mrow;
