@@ -1071,8 +1071,11 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
         okq[q] = (okm >> src_lane) & 1ull;
         const int sl = okq[q] ? src_lane : 4 * gi + (__ffsll((long long)((okm >> (4 * gi)) & 0xfull)) - 1);   // a dead row repeats a live one
         rrq[q] = w0 * 4 * EB_GROUPS + sl;
-        nq[q] = __shfl(my_n, sl, 64); sq[q] = __shfl(my_s, sl, 64); segq[q] = __shfl(my_seg, sl, 64);
-        ridq[q] = __shfl((long long)my_rid, sl, 64);
+        // (the source lane is the same for the whole wave: v_readlane into scalar registers, not an LDS permute)
+        nq[q] = __builtin_amdgcn_readlane(my_n, sl); sq[q] = __builtin_amdgcn_readlane(my_s, sl);
+        segq[q] = __builtin_amdgcn_readlane(my_seg, sl);
+        ridq[q] = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)my_rid >> 32), sl) << 32) |
+                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)my_rid, sl));
         const int base = pos ? fdiv(nq[q], a.fJ) : (fdiv(nq[q], a.fJ) * a.K + (nq[q] - fdiv(nq[q], a.fJ) * a.J - 1));
         sposq[q] = (size_t)base * a.S + sq[q];
       }
@@ -1469,7 +1472,7 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int cur = __shfl(my_word, 0, 64);
+  int cur = __builtin_amdgcn_readlane(my_word, 0);
   if (d <= 128) {
     // d <= 128 (two columns per lane): 8 slot rows are requested before the first is added — one by one the loop is a
     // chain of 64 dependent L2 round trips per wave (149 us for the 594 MB of a C4 step)
@@ -1479,7 +1482,7 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
       float r0[WR_U], r1[WR_U];
 #pragma unroll
       for (int u = 0; u < WR_U; ++u) {
-        const int sl = __shfl(my_slot, (i0 + u) & 63, 64);
+        const int sl = __builtin_amdgcn_readlane(my_slot, (i0 + u) & 63);
         const bool live = i0 + u < n;
         const float* row = a.gs + (size_t)(live ? sl : 0) * d;
         r0[u] = row[c0];
@@ -1488,7 +1491,7 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
 #pragma unroll
       for (int u = 0; u < WR_U; ++u) {
         if (i0 + u < n) {                            // wave-uniform
-          const int w = __shfl(my_word, (i0 + u) & 63, 64);
+          const int w = __builtin_amdgcn_readlane(my_word, (i0 + u) & 63);
           if (w != cur) {
             float* grow = a.g_word_emb + (size_t)cur * d;
             if (lane < d) { atomicAdd(&grow[lane], acc[0]); acc[0] = 0.f; }
