@@ -1019,12 +1019,17 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
 // The segment-embedding gradient (3 rows fed by EVERY slot) is summed in registers, combined over the workgroup's waves
 // in LDS and PARKED as one [3][d] partial per workgroup (`seg_part`, folded by the step's last launch, ColFoldList)
 // instead of 3d same-address atomics per workgroup.
-template <int NK>      // columns per lane: d <= 64 * NK
+// PL (the pvc encoder without the PV loss, the feature-selection layer and the user / item embeddings — configs[3]): those
+// switches are compile-time off, which takes their pointers and flags out of the scalar registers (the general form reloads 34
+// spilled scalars per group from VGPR lanes)
+template <int NK, int PL>      // columns per lane: d <= 64 * NK
 __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float* seg_part, int npos_w, int nneg_w, FDiv fR, FDiv fK) {
   __shared__ float segs[4][3][64 * NK];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = (int)blockIdx.x * 4 + wv;
   const int d = a.d;
+  const bool pvc = PL ? true : (bool)a.pvc, has_ui = !PL && (a.g_user_emb || a.g_item_emb);
+  const float* const dmean = PL ? nullptr : a.dmean;
   const int64_t rpad = a.RC - 1;
   DropSpec dpos = a.d_pos, dneg = a.d_neg, dpv = a.d_pv;      // the step word is read once, not per element
   dpos.step = drop_step(a.d_pos); dpos.step_ptr = nullptr;
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
     const int w0 = pos ? wave : wave - npos_w;
     const int nrev = pos ? a.B * a.R : a.B * a.K * a.R;
     const DropSpec ds = drop_select(pos, dpos, dneg);
-    const bool wantdv = pos && a.train_pv;
+    const bool wantdv = !PL && pos && a.train_pv;
     // lane i < 4 * EB_GROUPS decodes review row  4 * EB_GROUPS * w0 + i  (one coalesced read of the review ids / segment ids:
     // group after group through scalar loads the decode alone took 20 us)
     int my_n = 0, my_s = 1, my_seg = 3; int64_t my_rid = rpad; bool my_ok = false;
@@ -1093,16 +1098,16 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
       for (int q = 0; q < 4; ++q) {
         const float* g = a.dx + ((size_t)nq[q] * a.S + sq[q]) * d;
         // fs: the review vector reached x through tanh(f_W . raw + b); its input gradient d raw was left in a.dmean
-        const float* gm = a.dmean ? a.dmean + ((pos ? (size_t)0 : (size_t)a.B * a.R) + rrq[q]) * d : g;
+        const float* gm = dmean ? dmean + ((pos ? (size_t)0 : (size_t)a.B * a.R) + rrq[q]) * d : g;
         const float* dvp = wantdv ? a.dvec + (size_t)rrq[q] * d : g;
 #pragma unroll
         for (int k = 0; k < NK; ++k) { gk[q][k] = g[colc[k]]; src[q][k] = gm[colc[k]]; dvv[q][k] = dvp[colc[k]]; }
-        cntv[q] = a.pvc ? a.cnt[(size_t)nq[q] * a.R + sq[q] - 1] : 1.f;
+        cntv[q] = pvc ? a.cnt[(size_t)nq[q] * a.R + sq[q] - 1] : 1.f;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (!okq[q]) continue;                             // wave-uniform
-        if (a.g_user_emb || a.g_item_emb) {                // user / item embedding rows of this position
+        if (has_ui) {                // user / item embedding rows of this position
           const int64_t uid = a.g_user_emb ? (pos ? a.pos_u : a.neg_u)[sposq[q]] : -1;
           const int64_t iid = a.g_item_emb ? (pos ? a.pos_i : a.neg_i)[sposq[q]] : -1;
 #pragma unroll
@@ -1130,11 +1135,11 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
           float v = src[q][k] * (ds.thr ? drop_word(ds, dw[k][q]) : 1.f);
           if (wantdv) {
             v += dvv[q][k];
-            if (!a.pvc) v *= drop_mult(dpv, (uint32_t)rrq[q], (uint32_t)(lane + 64 * k));
+            if (!pvc) v *= drop_mult(dpv, (uint32_t)rrq[q], (uint32_t)(lane + 64 * k));
           }
           t[k] = v;
         }
-        if (!a.pvc) {
+        if (!pvc) {
           float* grow = a.g_table + (size_t)rclamp(ridq[q], rpad) * d;
 #pragma unroll
           for (int k = 0; k < NK; ++k)
@@ -1172,7 +1177,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (!on[q]) continue;
-        if (a.g_user_emb || a.g_item_emb) {
+        if (has_ui) {
           const int64_t uid = a.g_user_emb ? (posq[q] ? a.pos_u : a.neg_u)[sposq[q]] : -1;
           const int64_t iid = a.g_item_emb ? (posq[q] ? a.pos_i : a.neg_i)[sposq[q]] : -1;
 #pragma unroll
@@ -1991,10 +1996,17 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     const int nwg = ps_cdiv(rtm_eb_waves(B, D.K, D.R, &npw, &nnw), 4);
     const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
     float* sp = ws + r.segpart;
-    if (d <= 64) hipLaunchKernelGGL(rtm_embed_bwd_kernel<1>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
-    else if (d <= 128) hipLaunchKernelGGL(rtm_embed_bwd_kernel<2>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
-    else if (d <= 256) hipLaunchKernelGGL(rtm_embed_bwd_kernel<4>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
-    else hipLaunchKernelGGL(rtm_embed_bwd_kernel<8>, dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);
+    const bool plain = k.pvc && !k.dmean && !k.g_user_emb && !k.g_item_emb && !k.train_pv;
+#define EB_LAUNCH(NK_)                                                                                             \
+  do {                                                                                                             \
+    if (plain) hipLaunchKernelGGL((rtm_embed_bwd_kernel<NK_, 1>), dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK); \
+    else hipLaunchKernelGGL((rtm_embed_bwd_kernel<NK_, 0>), dim3(nwg), dim3(256), 0, st, k, sp, npw, nnw, fR, fK);       \
+  } while (0)
+    if (d <= 64) EB_LAUNCH(1);
+    else if (d <= 128) EB_LAUNCH(2);
+    else if (d <= 256) EB_LAUNCH(4);
+    else EB_LAUNCH(8);
+#undef EB_LAUNCH
     PS_LAUNCH_CHECK();
     if (k.det) {
       k.dx = ws + r.enc_base + w.dx;
