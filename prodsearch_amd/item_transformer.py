@@ -295,10 +295,40 @@ class ItemTransformerRanker(nn.Module):
 
     def test(self, batch_data):
         if self.__dict__.get('_shard') is not None:
-            raise NotImplementedError("test() with shard_tables scores explicit candidate lists against one table; use "
-                                      "evaluate.rank_all (full-catalogue ranking over the shards, a collective) or an unsharded "
-                                      "model loaded with state_dict()")
+            return self._run_score_sharded(batch_data)
         return self._run_score(batch_data)
+
+    def _run_score_sharded(self, batch):
+        """``test()`` over a row-sharded item table: the candidates' (and the history's) rows come from their owners first, like
+        the training forward's lookup (a COLLECTIVE: every rank calls test() the same number of times with batches of the same
+        shape, each with its own candidates), then the ordinary score launch reads the receive buffer through remapped ids.
+        The buffer holds ``shard.cap`` indices (a function of the training batch shape), so a wide candidate list goes through in
+        column chunks; scores are per (row, candidate), so the chunks concatenate (item_transformer.py:87-131)."""
+        import copy
+        sh = self._shard
+        tem = self.args.model_name == 'item_transformer'
+        if getattr(batch, 'candi_prod_idxs', None) is None:
+            raise RuntimeError("test(): batch.candi_prod_idxs [B,C] is required")
+        cand = self._check_idx(batch.candi_prod_idxs, 'candi_prod_idxs')
+        hist = self._check_idx(batch.u_item_idxs, 'u_item_idxs') if tem else None
+        Bn, C = int(cand.shape[0]), int(cand.shape[1])
+        room = sh.cap - (hist.numel() if tem else 0)
+        per = min(C, room // max(Bn, 1))
+        if per < 1:
+            raise RuntimeError("test(): %d rows x (history + 1 candidate) do not fit the shard exchange's %d indices per step "
+                               "(sized from args.batch_size x (1 + neg_per_pos + history)); use a smaller test batch" % (Bn, sh.cap))
+        outs = []
+        for c0 in range(0, C, per):
+            cc = cand[:, c0:c0 + per].contiguous()
+            rem = sh.lookup(([hist] if tem else []) + [cc])
+            b2 = copy.copy(batch)
+            if tem:
+                b2.u_item_idxs = rem[0]
+            b2.candi_prod_idxs = rem[-1].view(Bn, -1)
+            if getattr(b2, 'target_prod_idxs', None) is not None:      # not read by the score launch; keep it inside the buffer
+                b2.target_prod_idxs = torch.full_like(b2.target_prod_idxs, sh.slots)
+            outs.append(self._run_score(b2))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
     # -------------------------------------------------------------------- plumbing
     def _dev(self):

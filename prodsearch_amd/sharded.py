@@ -141,6 +141,9 @@ class ShardedItemTable(object):
     def lookup(self, index_tensors):
         """Fetch the rows the index tensors address into the receive buffer; -> the tensors remapped into its slots."""
         W = self.world
+        if self.pending:
+            raise RuntimeError("ShardedItemTable.lookup: the last backward's gradient still sits in the receive buffer (slots are "
+                               "per lookup): call optimizer.step() before the next forward / encode / test")
         total = sum(t.numel() for t in index_tensors)
         if total > self.cap and self.cap < self.n_rows:
             raise RuntimeError("ShardedItemTable.lookup: %d indices but the table was built for %d per step "

@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-P_, V, B, L = 6001, 3000, 24, 12
+P_, V, B, L, C_ = 6001, 3000, 24, 12, 100
 
 
 def run(rank, world, out=None, topk=50):
@@ -28,13 +28,21 @@ def run(rank, world, out=None, topk=50):
         if rank == 0:
             batch.target_prod_idxs[3] = P_          # a row whose target is not a product: rank 0, never ahead of anything
         ti, ts, rk = evaluate.rank_all(m, batch, topk)
+        # test() with explicit candidate lists (trainer.py:125-160): C = 100 columns do not fit the exchange's 984 indices beside
+        # the 288 history ids, so the sharded model scores them in column chunks of 29
+        g = torch.Generator().manual_seed(900 + rank)
+        batch.candi_prod_idxs = torch.randint(0, P_, (B, C_), generator=g).cuda()
+        batch.candi_prod_idxs[:, -3:] = P_           # padded tails, as the loader's ragged candidate lists have
+        batch.candi_prod_idxs[5, 40:] = P_
+        sc = m.test(batch)
         torch.cuda.synchronize()
-        res[mode] = (ti.cpu().numpy(), ts.cpu().numpy(), rk.cpu().numpy())
+        res[mode] = (ti.cpu().numpy(), ts.cpu().numpy(), rk.cpu().numpy(), sc.cpu().numpy())
         if mode == 'sharded':
             m.check_index_errors()
     if out:
         np.savez(out + '.rank%d.npz' % rank, pi=res['plain'][0], ps=res['plain'][1], pr=res['plain'][2],
-                 si=res['sharded'][0], ss=res['sharded'][1], sr=res['sharded'][2])
+                 si=res['sharded'][0], ss=res['sharded'][1], sr=res['sharded'][2],
+                 pc=res['plain'][3], sc=res['sharded'][3])
     return res
 
 
