@@ -293,6 +293,7 @@ struct GemmProblem {
   // optional row list (IDX instantiations of the kernel): only the *rcount rows ridx[0..] of the operands exist as
   // far as the product is concerned — the valid (non-pad) positions of the batch's sequences.
   //   ta == 0:            logical row i of A / C / residual is physical row ridx[i]; M is the list length on the device
+  //                       (the host's M bounds it, and ridx has room for that many entries: the kernel may read past the length)
   //   ta == 1 && tb == 1: logical reduction row k of A and B is physical row ridx[k]; K is the list length
   const int32_t* ridx; const int32_t* rcount;
   int64_t split_stride;                 // split s of a split reduction writes at C + s * split_stride (deterministic mode: every split

@@ -107,7 +107,7 @@ __device__ inline void tile_store(float (*T)[LDT], const float4 (&reg)[BK / 16],
 // One 64x64 tile whose four 32x32 accumulators sit in the workgroup's four waves (wave (wm, wn), MFMA 32x32 C layout).
 template <int TA, int IDX>
 __device__ __forceinline__ void epi_plain(const GemmProblem& P, const f32x16& acc, int m0, int n0, int split, int M, int N,
-                                          bool listed, int wm, int wn, int l31, int h) {
+                                          bool listed, int wm, int wn, int l31, int h, const int* rows_s = nullptr) {
   const int col = n0 + wn * 32 + l31;
   const bool col_ok = col < N;
   const float bias = (P.bias && col_ok && split == 0) ? P.bias[col] : 0.f;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void epi_plain(const GemmProblem& P, const f32x16& ac
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     if (col_ok && row < M) {
       const float v = (acc[r] + bias) * alpha;
-      const size_t off = (size_t)((listed && TA == 0) ? P.ridx[row] : row) * ldc + col;
+      const size_t off = (size_t)((listed && TA == 0) ? (rows_s ? rows_s[row - m0] : P.ridx[row]) : row) * ldc + col;
       if (accumulate == 0) C[off] = v;
       else if (accumulate == 1) C[off] += v;
       else atomicAdd(&C[off], v);
@@ -134,7 +134,7 @@ __device__ __forceinline__ void epi_stage(float (*Ct)[LDT], const f32x16& acc, i
 
 template <int TA, int IDX>
 __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)[LDT], int m0, int n0, int tm, int split,
-                                         int M, int N, bool listed, int tid) {
+                                         int M, int N, bool listed, int tid, const int* rows_s = nullptr) {
   float* const C = P.C + (size_t)split * P.split_stride;
   const float alpha = P.alpha;
   const int ldc = P.ldc, accumulate = P.accumulate;
@@ -146,30 +146,74 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
   const bool dropping = drop.thr != 0u, has_res = P.res.mode != RES_NONE;
   const float add2 = (P.out2 && P.add2) ? P.add2[gcol] : 0.f;
   float csum = 0.f;
-  // global operands of the epilogue (activation aux, residual) for row group i; fetched one group
-  // AHEAD of its use so the rolled loop does not serialise four global-latency round trips
+  // global operands of the epilogue (activation aux, residual) of ALL 16 rows of this thread, fetched up front by loads that
+  // are unconditional inside their (kernel-uniform) switch: a load under a per-row condition makes the compiler wait for
+  // everything in flight at the join, and the rolled loop this used to be — one row group fetched ahead under `ok ? load : 0`
+  // selects — was sixteen dependent round trips (11 us of the 24 us dX product over the step's row list,
+  // tools/gemm_f32_stamps.py).  Rows past M repeat row M - 1, so every address is a real one; their values are never used.
   const bool need_aux = act == ACT_GELU_BWD || act == ACT_TANH_BWD;
-  struct Pre { float aux[4], res[4]; int prow[4]; };
-  auto preload = [&](int i, Pre& pr) {
-    const int rbase = m0 + 4 * ((tid >> 6) + 4 * i);
+  float paux[4][4], pres[4][4];
+  int prow[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int lrow = rbase + q;
-      const bool ok = i < 4 && lrow < M;
-      const int row = (listed && TA == 0 && ok) ? P.ridx[lrow] : lrow;      // physical row of the operands
-      pr.prow[q] = row;
-      pr.aux[q] = (need_aux && ok) ? P.act_aux[(size_t)row * ldc + gcol] : 0.f;
-      pr.res[q] = (has_res && ok) ? res_value(P.res, row, gcol) : 0.f;
+      const int lrow = min(m0 + 4 * ((tid >> 6) + 4 * i) + q, M - 1);
+      // physical row of the operands (rows_s: the tile's 64 list entries, put in LDS by the prologue)
+      prow[i][q] = (listed && TA == 0) ? (rows_s ? rows_s[lrow - m0] : P.ridx[lrow]) : lrow;
+      paux[i][q] = 0.f; pres[i][q] = 0.f;
     }
-  };
-  Pre cur, nxt;
-  preload(0, cur);
-#pragma unroll 1
+  if (need_aux) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) paux[i][q] = P.act_aux[(size_t)prow[i][q] * ldc + gcol];
+  }
+  if (has_res) {
+    const ResMap& R = P.res;
+    if (R.mode == RES_DIRECT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pres[i][q] = R.ptr[(size_t)prow[i][q] * R.ld + gcol];
+    } else if (R.mode == RES_FANIN && !R.ptr && R.extra) {   // the fan-in sums already sit in extra (+ extra2): one row per sequence
+      const float* const e2 = R.extra2 ? R.extra2 : R.extra;
+      const float w2 = R.extra2 ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nin = fdiv(prow[i][q], R.dS), pos = prow[i][q] - nin * R.S;
+          const float v1 = R.extra[(size_t)nin * R.extra_ld + gcol], v2 = e2[(size_t)nin * R.extra_ld + gcol];
+          pres[i][q] = (R.Sq == R.S || pos == R.qpos) ? v1 + w2 * v2 : 0.f;
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pres[i][q] = res_value(R, prow[i][q], gcol);
+    }
+  }
+  // lean form (bias / scale / residual only — the step's dX products): straight-line, nothing re-read from the argument
+  // segment per row (the general body below is so large that the compiler keeps none of P's fields in scalar registers: it
+  // fetched three of them again for EVERY row, each a scalar-cache round trip in front of the row's store)
+  if (!dropping && act == ACT_NONE && !P.aux_out && !P.out2 && !P.colsum && !P.colsum_part && accumulate == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // (no branch per row: a row past M repeats row M - 1 — same address, same value — because a store under a per-row
+        // condition made the compiler wait for the previous row's store to be acknowledged before the next LDS read)
+        const int lrow = min(4 * ((tid >> 6) + 4 * i) + q, M - 1 - m0);
+        C[(size_t)((IDX && TA == 0) ? prow[i][q] : m0 + lrow) * ldc + gcol] = (Ct[lrow][ccol] + cbias) * alpha + pres[i][q];
+      }
+    return;
+  }
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int lrow = 4 * ((tid >> 6) + 4 * i);
     const int rbase = m0 + lrow;
     if (rbase >= M) break;
-    preload(i + 1, nxt);
     Philox4 rnd = {0u, 0u, 0u, 0u};
     float hm[4] = {1.f, 1.f, 1.f, 1.f};
     if (dropping && drop.half) {
@@ -196,37 +240,48 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
       const int row = rbase + q;
       if (row >= M) break;
       float v = (Ct[lrow + q][ccol] + cbias) * alpha;
-      const size_t off = (size_t)((IDX && TA == 0) ? cur.prow[q] : row) * ldc + gcol;
+      const size_t off = (size_t)((IDX && TA == 0) ? prow[i][q] : row) * ldc + gcol;
       if (P.aux_out) P.aux_out[off] = v;
       if (act == ACT_GELU) v = gelu_tanh_f(v);
       else if (act == ACT_TANH) v = tanh_fast(v);
-      else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(cur.aux[q]);
-      else if (act == ACT_TANH_BWD) v *= (1.f - cur.aux[q] * cur.aux[q]);
+      else if (act == ACT_GELU_BWD) v *= gelu_tanh_grad(paux[i][q]);
+      else if (act == ACT_TANH_BWD) v *= (1.f - paux[i][q] * paux[i][q]);
       if (dropping) {
         const uint32_t wv = q == 0 ? rnd.x : (q == 1 ? rnd.y : (q == 2 ? rnd.z : rnd.w));
         v *= drop.half ? hm[q] : drop_word(drop, wv);
       }
-      v += cur.res[q];
+      v += pres[i][q];
       csum += v;
-      if (P.out2) P.out2[(size_t)((IDX && TA == 0) ? cur.prow[q] : row) * P.ld2 + gcol] = v + add2;
+      if (P.out2) P.out2[(size_t)((IDX && TA == 0) ? prow[i][q] : row) * P.ld2 + gcol] = v + add2;
       if (accumulate == 0) C[off] = v;
       else if (accumulate == 1) C[off] += v;
       else atomicAdd(&C[off], v);
     }
-    cur = nxt;
   }
   if (P.colsum_part) P.colsum_part[((size_t)(4 * tm + (tid >> 6)) * 3) * N + gcol] = csum;   // one parked row per (tile, row group)
   else if (P.colsum) atomicAdd(&P.colsum[gcol], csum);
 }
 
 #define KIDX_MAX PS_GEMM_KIDX_MAX
+// diagnostics (PS_GEMM_STAMP=2 / 3, tools/gemm_f32_stamps.py): s_memtime of the four waves of workgroup (0, 8, 0) at the phase
+// boundaries of the fp32 kernel — the step's own dX product over the row list (2) or its K/V projection (3)
+#define F32_STAMP(slot)                                                                                              \
+  do {                                                                                                               \
+    if (g.stamp && blockIdx.x == 0 && blockIdx.y == 8 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) {               \
+      unsigned long long t_;                                                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                     \
+      if ((slot) < 32) g.stamp[32 * (threadIdx.x >> 6) + (slot)] = t_;                                               \
+    }                                                                                                                \
+  } while (0)
 template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   fork_signal(g.sig, g.sigval);
+  F32_STAMP(0);
   constexpr int NLD = BK / 16;
   __shared__ float As[2][BK][LDT];
   __shared__ float Bs[2][BK][LDT];
   __shared__ int kidx[IDX && TA == 1 ? KIDX_MAX : 1];
+  __shared__ int rows_s[IDX && TA == 0 ? BM : 1];
 
   int prob, split, ftile = 0;
   if (g.flat) {
@@ -241,8 +296,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   }
   const GemmProblem& P = g.p[prob];
   const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
-  const int nlist = listed ? *P.rcount : 0;
-  const int M = (listed && TA == 0) ? nlist : P.M, N = P.N, K = (listed && TA == 1) ? nlist : P.K;
   // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
   // so give every XCD whole ROW tiles: all column tiles that re-read one A row-tile share an L2.
   int tm = blockIdx.y, tn = blockIdx.x;
@@ -258,11 +311,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     tn = r / rows_here;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  // row list, ta == 0: the tile's 64 list entries are fetched NOW, beside the list length (the list has room for P.M
+  // entries, common.h; what lies past the length is never used), and kept in LDS for the operand loads and the epilogue
+  // — after the length they were a second dependent round trip here and a third in front of every epilogue row group
+  int my_row = 0;
+  if (IDX && TA == 0 && listed && threadIdx.x < BM) my_row = P.ridx[min(m0 + (int)threadIdx.x, P.M - 1)];
+  const int nlist = listed ? *P.rcount : 0;
+  const int M = (listed && TA == 0) ? nlist : P.M, N = P.N, K = (listed && TA == 1) ? nlist : P.K;
   const int nslab = (K + BK - 1) / BK;
   const int per = (nslab + P.ksplit - 1) / P.ksplit;
   const int kbeg = split * per * BK;
   const int kend = min(K, kbeg + per * BK);
   if (m0 >= M || n0 >= N || kbeg >= kend) return;   // block-uniform
+  F32_STAMP(1);
   const bool kmask = (kend - kbeg) % BK != 0;       // ragged reduction tail (never on the hot shapes)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,13 +334,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   if (IDX && TA == 0) {                                         // the two A rows this thread loads, once (plain
     pr0 = min(m0 + (tid >> 3), M - 1);                          // problems of a row-list launch: the natural rows)
     pr1 = min(m0 + (tid >> 3) + 32, M - 1);
-    if (listed) { pr0 = P.ridx[pr0]; pr1 = P.ridx[pr1]; }
+    if (listed) {
+      if (tid < BM) rows_s[tid] = my_row;
+      __syncthreads();
+      pr0 = rows_s[pr0 - m0]; pr1 = rows_s[pr1 - m0];
+    }
   }
   if (listed && TA == 1) {                                      // physical reduction rows of this split -> LDS
     for (int i = tid; i < kend - kbeg; i += 256) kidx[i] = P.ridx[kbeg + i];
     __syncthreads();
     kmap = kidx;
   }
+  const int* const rows_l = (IDX && TA == 0 && listed) ? rows_s : nullptr;
+  F32_STAMP(2);
 
   f32x16 acc;
 #pragma unroll
@@ -303,9 +370,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     tile_load<TA, BK>(P.A, P.lda, m0, M, kl, kend, ra[u], tid, kmask, nullptr, nullptr, 0, pr0, pr1, kmap, kbeg);
     tile_load<TB, BK>(bs0, ldb, n0, N, kl, kend, rb[u], tid, kmask, bs1, bs2, bkseg, -1, -1, TA == 1 ? kmap : nullptr, kbeg);
   }
+  F32_STAMP(3);
   tile_store<TA, BK>(As[0], ra[0], tid, kmask, kbeg, kend);
   tile_store<TB, BK>(Bs[0], rb[0], tid, kmask, kbeg, kend);
   __syncthreads();
+  F32_STAMP(4);
 
   int buf = 0;
   for (int kg = kbeg; kg < kend; kg += PF * BK) {
@@ -335,13 +404,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
         tile_store<TB, BK>(Bs[buf ^ 1], rb[nx], tid, kmask, k0 + BK, kend);
       }
       __syncthreads();
+      F32_STAMP(5 + (k0 - kbeg) / BK);
       buf ^= 1;
     }
   }
 
   // ------------------------------------------------------------------ epilogue
   if (!FULL) {
-    epi_plain<TA, IDX>(P, acc, m0, n0, split, M, N, listed, wm, wn, l31, h);
+    epi_plain<TA, IDX>(P, acc, m0, n0, split, M, N, listed, wm, wn, l31, h, rows_l);
+    F32_STAMP(31);
     return;
   }
   // FULL: stage the 64x64 tile through LDS so that the (large) epilogue body exists ONCE in the
@@ -350,7 +421,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   float (*Ct)[LDT] = reinterpret_cast<float (*)[LDT]>(&As[0][0][0]);   // 64x65 floats fit As for BK >= 32
   epi_stage(Ct, acc, wm, wn, l31, h);
   __syncthreads();
-  epi_full<TA, IDX>(P, Ct, m0, n0, tm, split, M, N, listed, tid);
+  F32_STAMP(30);
+  epi_full<TA, IDX>(P, Ct, m0, n0, tm, split, M, N, listed, tid, rows_l);
+  F32_STAMP(31);
 }
 
 // ====================================================================== bf16x3 product form
@@ -771,8 +844,10 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
 int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   GemmGroup g = g0;
   g.sig = nullptr; g.sigval = 0;
-  static const bool stamps = getenv("PS_GEMM_STAMP") && atoi(getenv("PS_GEMM_STAMP")) != 0;
-  g.stamp = stamps ? ps_debug_stamp_ptr() : nullptr;
+  static const int stamps = getenv("PS_GEMM_STAMP") ? atoi(getenv("PS_GEMM_STAMP")) : 0;
+  const bool stamp_this = stamps == 1 || (stamps == 2 && g0.p[0].ridx && g0.p[0].res.mode == RES_FANIN) ||
+                          (stamps == 3 && g0.p[0].ridx && !g0.p[0].ta && g0.p[0].res.mode == RES_NONE);
+  g.stamp = stamp_this ? ps_debug_stamp_ptr() : nullptr;
   const bool took = side_take_signal(stream, &g.sig, &g.sigval);      // a pending fork of the side stream rides on this launch
   const int rc = launch_gemm_impl(g, stream);
   if (took && rc != PS_OK) side_repend_signal(stream, g.sigval);
