@@ -944,10 +944,16 @@ int launch_loss(const ScoreArgs& a, hipStream_t st) {
 // With replicas (R > 1) the item tasks are independent of one another (every task owns its d enc row), so they get
 // workgroups of their own behind the B per-row workgroups: SB_RG tasks each, one round, instead of two dependent
 // rounds inside the row's workgroup — the launch is a chain of memory round trips, not bandwidth.
+// EPL = 32-column groups per row (d = 32 * EPL exactly; EPL = 16 also serves every other d <= 512, with the columns past d
+// masked by VALUE).  Every task is "fetch, then add": all of a task's operand loads are issued unconditionally, then all of its
+// atomics, with pad rows adding 0.f to a real address instead of branching — a load or an atomic under a per-group condition
+// (the `k < epl` form this replaces) made the compiler wait for everything in flight at every join, i.e. for the previous
+// group's ATOMICS to be acknowledged before the next group's loads were even issued: four dependent round trips per task.
+template <int EPL>
 __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a) {
   extern __shared__ float red[];                 // [SB_RG][d]
   const int tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
-  const int d = a.d, epl = d >> 5, K1 = a.K + 1;
+  const int d = a.d, K1 = a.K + 1;
   const bool split = a.R > 1;
   const bool item_wg = split && (int)blockIdx.x >= 2 * a.B;
   int b = blockIdx.x, j0 = rg, j1 = K1;
@@ -966,33 +972,47 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
   const float invB = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / (float)a.B;
   const float wpos = a.pos_weight ? (float)a.K : 1.f;
   const int64_t tb = clamp_idx(a.target[b], a.P);
-  float acc[BW_MAXE];
+  int col[EPL]; bool cok[EPL];                   // this lane's columns (clamped: every address is a real one)
 #pragma unroll
-  for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
+  for (int k = 0; k < EPL; ++k) { cok[k] = c + 32 * k < d; col[k] = cok[k] ? c + 32 * k : c; }
+  float acc[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) acc[k] = 0.f;
+  const bool scatter = a.part != 1, want_denc = a.denc && a.part != 2;
   // ---- item tasks
   for (int j = j0; j < j1; j += SB_RG) {
-    int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
-    float s = a.item_scores[(size_t)b * K1 + j];
-    float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
+    const int64_t idx = clamp_idx(j == 0 ? a.target[b] : a.neg_items[(size_t)b * a.K + j - 1], a.P);
+    const float s = a.item_scores[(size_t)b * K1 + j];
+    const float ds = (j == 0 ? wpos * (sigmoid_f(s) - 1.f) : sigmoid_f(s)) * invB;
     const float* encr = a.enc + ((size_t)b * a.R + (a.R > 1 ? j : 0)) * d;
     const float* row = a.product_emb + (size_t)idx * d;
     float* grow = a.g_product_emb + (size_t)idx * d;
+    float rv[EPL], ev[EPL];
 #pragma unroll
-    for (int k = 0; k < BW_MAXE; ++k) {
-      if (k < epl) {
-        int e = c + 32 * k;
-        float rv = row[e], ev = encr[e];
-        if (idx != a.P && a.part != 1) atomicAdd(&grow[e], ds * ev);
-        if (a.R > 1) { if (a.denc && a.part != 2) a.denc[((size_t)b * a.R + j) * d + e] = ds * rv; }
-        else acc[k] += ds * rv;
+    for (int k = 0; k < EPL; ++k) { rv[k] = row[col[k]]; ev[k] = encr[col[k]]; }
+    if (a.R > 1) {
+      if (want_denc) {
+        float* de = a.denc + ((size_t)b * a.R + j) * d;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+          if (EPL < 16 || cok[k]) de[col[k]] = ds * rv[k];
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPL; ++k) acc[k] += ds * rv[k];
     }
-    if (a.bias_product && c == 0 && a.part != 1) atomicAdd(&a.g_product_bias[idx], ds);
+    if (scatter) {
+      const bool live = idx != a.P;              // the padding row takes +0.f (its gradient stays exactly zero)
+#pragma unroll
+      for (int k = 0; k < EPL; ++k)
+        if (EPL < 16 || cok[k]) atomicAdd(&grow[col[k]], live ? ds * ev[k] : 0.f);
+      if (a.bias_product && c == 0) atomicAdd(&a.g_product_bias[idx], ds);
+    }
   }
   if (a.R == 1) {
 #pragma unroll
-    for (int k = 0; k < BW_MAXE; ++k)
-      if (k < epl) red[rg * d + c + 32 * k] = acc[k];
+    for (int k = 0; k < EPL; ++k)
+      if (EPL < 16 || cok[k]) red[rg * d + col[k]] = acc[k];
     __syncthreads();
     for (int e = tid; e < d; e += 32 * SB_RG) {
       float s = 0.f;
@@ -1004,33 +1024,37 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
   if (item_wg || a.part == 1) return;
   // ---- word tasks
 #pragma unroll
-  for (int k = 0; k < BW_MAXE; ++k) acc[k] = 0.f;
+  for (int k = 0; k < EPL; ++k) acc[k] = 0.f;
   int cnt = 0;
   for (int w = 0; w < a.W; ++w) cnt += (a.pos_words[(size_t)b * a.W + w] != a.V - 1);
   const float cf = invB / (float)(cnt > 0 ? cnt : 1);
   const float* prow = a.product_emb + (size_t)tb * d;
+  float pv[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) pv[k] = prow[col[k]];
   for (int t = wt0; t < a.W * K1; t += wstride) {
-    int w = t / K1, j = t - w * K1;
-    int64_t pw = a.pos_words[(size_t)b * a.W + w];
+    const int w = t / K1, j = t - w * K1;
+    const int64_t pw = a.pos_words[(size_t)b * a.W + w];
     if (pw == a.V - 1) continue;                                  // masked window slot (get_vector_mean)
-    int64_t idx = clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
-    float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
-    float ds = (j == 0 ? sigmoid_f(s) - 1.f : sigmoid_f(s)) * cf;
+    const int64_t idx = clamp_idx(j == 0 ? pw : a.neg_words[(size_t)b * a.W * a.K + (size_t)w * a.K + j - 1], a.V - 1);
+    const float s = a.word_scores[((size_t)b * a.W + w) * K1 + j];
+    const float ds = (j == 0 ? sigmoid_f(s) - 1.f : sigmoid_f(s)) * cf;
     const float* wrow = a.word_emb + (size_t)idx * d;
     float* grow = a.g_word_emb + (size_t)idx * d;
+    float wv[EPL];
 #pragma unroll
-    for (int k = 0; k < BW_MAXE; ++k) {
-      if (k < epl) {
-        int e = c + 32 * k;
-        if (idx != a.V - 1) atomicAdd(&grow[e], ds * prow[e]);
-        acc[k] += ds * wrow[e];
-      }
+    for (int k = 0; k < EPL; ++k) wv[k] = wrow[col[k]];
+    const bool live = idx != a.V - 1;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      if (EPL < 16 || cok[k]) atomicAdd(&grow[col[k]], live ? ds * pv[k] : 0.f);
+      acc[k] += ds * wv[k];
     }
     if (c == 0) atomicAdd(&a.g_word_bias[idx], ds);
   }
 #pragma unroll
-  for (int k = 0; k < BW_MAXE; ++k)
-    if (k < epl) red[rg * d + c + 32 * k] = acc[k];
+  for (int k = 0; k < EPL; ++k)
+    if (EPL < 16 || cok[k]) red[rg * d + col[k]] = acc[k];
   __syncthreads();
   if (tb != a.P)
     for (int e = tid; e < d; e += 32 * SB_RG) {
@@ -1038,6 +1062,14 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
       for (int r = 0; r < SB_RG; ++r) s += red[r * d + e];
       atomicAdd(&a.g_product_emb[(size_t)tb * d + e], s);
     }
+}
+static void launch_score_bwd_kernel(const ScoreArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = (size_t)SB_RG * a.d * sizeof(float);
+  if (a.d == 32) hipLaunchKernelGGL(score_bwd_kernel<1>, dim3(blocks), dim3(32 * SB_RG), lds, st, a);
+  else if (a.d == 64) hipLaunchKernelGGL(score_bwd_kernel<2>, dim3(blocks), dim3(32 * SB_RG), lds, st, a);
+  else if (a.d == 128) hipLaunchKernelGGL(score_bwd_kernel<4>, dim3(blocks), dim3(32 * SB_RG), lds, st, a);
+  else if (a.d == 256) hipLaunchKernelGGL(score_bwd_kernel<8>, dim3(blocks), dim3(32 * SB_RG), lds, st, a);
+  else hipLaunchKernelGGL(score_bwd_kernel<16>, dim3(blocks), dim3(32 * SB_RG), lds, st, a);
 }
 
 // Deterministic form of the table scatter above (ps_deterministic): every gradient row has ONE owner — half-wave
@@ -1244,7 +1276,7 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
       ScoreArgs e = a;
       e.part = 1;
       const int iw = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
-      hipLaunchKernelGGL(score_bwd_kernel, dim3((a.R > 1 ? 2 : 1) * a.B + iw), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, e);
+      launch_score_bwd_kernel(e, (a.R > 1 ? 2 : 1) * a.B + iw, st);
       PS_LAUNCH_CHECK();
     }
     if (a.part != 1) {
@@ -1262,12 +1294,20 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
     return PS_OK;
   }
   const int item_wgs = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
-  hipLaunchKernelGGL(score_bwd_kernel, dim3((a.R > 1 ? 2 : 1) * a.B + item_wgs), dim3(32 * SB_RG), (size_t)SB_RG * a.d * sizeof(float), st, a);
+  launch_score_bwd_kernel(a, (a.R > 1 ? 2 : 1) * a.B + item_wgs, st);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
 
 // ========================================================== embedding scatter-add
+template <int EPL>
+__device__ __forceinline__ void row_fetch_add(float* dst, const float* src, int c, float scale) {
+  float v[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) v[k] = src[c + 32 * k];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) atomicAdd(&dst[c + 32 * k], scale == 1.f ? v[k] : v[k] * scale);
+}
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nq, int nfw, int nfold) {
@@ -1413,20 +1453,47 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     if (idx == a.P || idx < 0 || idx > a.P) return;
     const float* src = a.dx + ((size_t)b * a.S + 1 + l) * d;
     float* dst = a.g_hist_tab + (size_t)idx * d;
-    for (int k = 0; k < epl; ++k) atomicAdd(&dst[c + 32 * k], src[c + 32 * k]);
+    // fetch the whole row, then add it: in a `load, add` loop every load waits for the previous group's ATOMIC to be
+    // acknowledged (one in-order counter tracks both) — epl dependent round trips per row instead of one
+    switch (epl) {
+      case 1: row_fetch_add<1>(dst, src, c, 1.f); break;
+      case 2: row_fetch_add<2>(dst, src, c, 1.f); break;
+      case 4: row_fetch_add<4>(dst, src, c, 1.f); break;
+      case 8: row_fetch_add<8>(dst, src, c, 1.f); break;
+      default: for (int k = 0; k < epl; ++k) atomicAdd(&dst[c + 32 * k], src[c + 32 * k]);
+    }
   } else {
     int u = t - nitem;
     int b = u / a.Q;
     int64_t idx = a.qw[u];
     if (idx == a.V - 1 || idx < 0 || idx >= a.V) return;
+    // non-pad words of the query: lane q of the half-wave tests word q (one round trip; a counting loop was Q of them)
     int cnt = 0;
-    for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+    for (int q0 = 0; q0 < a.Q; q0 += 32) {
+      const bool w = q0 + c < a.Q && a.qw[(size_t)b * a.Q + min(q0 + c, a.Q - 1)] != a.V - 1;
+      cnt += __popc((uint32_t)(__ballot(w) >> (tid & 32)));
+    }
     const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
     const float* src = a.dqmean_d + (size_t)b * d;
     float* dst = a.g_word_emb + (size_t)idx * d;
-    for (int k = 0; k < epl; ++k) {
-      int e = c + 32 * k;
-      atomicAdd(&dst[e], src[e] * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)e) * inv);
+    if (a.drop_fs.thr == 0u && (epl == 4 || epl == 1 || epl == 2 || epl == 8)) {
+      switch (epl) {
+        case 1: row_fetch_add<1>(dst, src, c, inv); break;
+        case 2: row_fetch_add<2>(dst, src, c, inv); break;
+        case 4: row_fetch_add<4>(dst, src, c, inv); break;
+        default: row_fetch_add<8>(dst, src, c, inv); break;
+      }
+    } else if (epl == 4) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = src[c + 32 * k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(&dst[c + 32 * k], v[k] * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)(c + 32 * k)) * inv);
+    } else {
+      for (int k = 0; k < epl; ++k) {
+        int e = c + 32 * k;
+        atomicAdd(&dst[e], src[e] * drop_mult(a.drop_fs, (uint32_t)b, (uint32_t)e) * inv);
+      }
     }
   }
 }
