@@ -846,7 +846,8 @@ int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   g.sig = nullptr; g.sigval = 0;
   static const int stamps = getenv("PS_GEMM_STAMP") ? atoi(getenv("PS_GEMM_STAMP")) : 0;
   const bool stamp_this = stamps == 1 || (stamps == 2 && g0.p[0].ridx && g0.p[0].res.mode == RES_FANIN) ||
-                          (stamps == 3 && g0.p[0].ridx && !g0.p[0].ta && g0.p[0].res.mode == RES_NONE);
+                          (stamps == 3 && g0.p[0].ridx && !g0.p[0].ta && g0.p[0].res.mode == RES_NONE) ||
+                          (stamps == 4 && g0.n == 3 && g0.p[0].ta && !g0.p[0].ridx);      // 4: the grouped FF / Wo weight gradients
   g.stamp = stamp_this ? ps_debug_stamp_ptr() : nullptr;
   const bool took = side_take_signal(stream, &g.sig, &g.sigval);      // a pending fork of the side stream rides on this launch
   const int rc = launch_gemm_impl(g, stream);

@@ -1,6 +1,7 @@
 """Diagnostic: phase timeline of one workgroup of the fp32 GEMM kernel INSIDE the C2 training step (s_memtime per wave).
     python tools/gemm_f32_stamps.py 2      the backward's dX product over the valid-row list (dK.Wk + dV.Wv + fan-in)
-    python tools/gemm_f32_stamps.py 3      the forward K/V projection over the valid-row list                   (on the GPU box)"""
+    python tools/gemm_f32_stamps.py 3      the forward K/V projection over the valid-row list
+    python tools/gemm_f32_stamps.py 4      the grouped FF / Wo weight gradients (bf16x3 kernel: use tools/gemm_stamps.py's phase names)   (on the GPU box)"""
 import argparse, ctypes, os, sys
 which = sys.argv[1] if len(sys.argv) > 1 else '2'
 os.environ['PS_GEMM_STAMP'] = which
@@ -39,6 +40,10 @@ names = {0: 'start', 1: 'list length known', 2: 'row indices in LDS', 3: 'first 
          30: 'tile staged for the epilogue', 31: 'end'}
 for s in range(16):
     names[5 + s] = 'slab %d done' % s
+if which == '4':
+    names = {0: 'start', 1: 'prologue loads issued', 30: 'main loop done', 31: 'end'}
+    for sl in range(7):
+        names.update({2 + 4 * sl: 'slab %d stored' % sl, 3 + 4 * sl: 'slab %d barrier' % sl, 4 + 4 * sl: 'slab %d products' % sl, 5 + 4 * sl: 'slab %d barrier 2' % sl})
 print('%-30s' % 'phase' + ''.join('   wave%d' % w for w in range(4)) + '   (s_memtime ticks since the first wave started; 1 tick = 10 ns)')
 for i in range(32):
     if i in names and any(int(t[w, i]) for w in range(4)):
