@@ -546,6 +546,24 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     if (a.item_emb) { iidq[q] = (pos ? a.pos_i : a.neg_i)[spos]; if (iidq[q] < 0 || iidq[q] > a.PI) iidq[q] = -1; }
     nwq[q] = 0; nlq[q] = 0;
   }
+  // The word slots of the four reviews depend on the group number only, not on what the review ids turn out to be: they are
+  // requested HERE, beside the ids and segments, by unconditional loads (slot clamped to the review's last) — one round trip
+  // for both.  Fetched under `ok && lane < WL` selects, each of the eight loads sat behind its own branch, the compiler
+  // waited for everything in flight at every join, and the whole block came a round trip after the ids.
+  const uint8_t* const wm = pos ? a.wmask_pos : a.wmask_neg;
+  const int la = min(lane, a.WL - 1), lb = min(lane + 64, a.WL - 1);
+  int64_t waq[4], wbq[4];
+  uint8_t mka[4] = {1, 1, 1, 1}, mkb[4] = {1, 1, 1, 1};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t* words = wsrc + (size_t)rrq[q] * a.WL;
+    waq[q] = words[la];
+    wbq[q] = words[lb];
+  }
+  if (wm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mka[q] = wm[(size_t)rrq[q] * a.WL + la]; mkb[q] = wm[(size_t)rrq[q] * a.WL + lb]; }
+  }
   // 73 % of the review slots of a C4 batch are padding: a group without a real review skips the Philox evaluations, the
   // lists and the gather (wave-uniform branch) and only writes its masked rows
   const bool any_ok = okq[0] || okq[1] || okq[2] || okq[3];
@@ -561,13 +579,10 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // word slots lane and lane + 64 of review q
-      const int64_t* words = wsrc + (size_t)rrq[q] * a.WL;
-      const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
-      const size_t woff = (size_t)rrq[q] * a.WL;
-      const int64_t wa64 = (okq[q] && lane < a.WL) ? words[lane] : a.V - 1;
-      const int64_t wb64 = (okq[q] && lane + 64 < a.WL) ? words[lane + 64] : a.V - 1;
-      const bool va = okq[q] && lane < a.WL && word_ok(a, wm, woff + lane, wa64);
-      const bool vb = okq[q] && lane + 64 < a.WL && word_ok(a, wm, woff + lane + 64, wb64);
+      const int64_t wa64 = (okq[q] && lane < a.WL) ? waq[q] : a.V - 1;
+      const int64_t wb64 = (okq[q] && lane + 64 < a.WL) ? wbq[q] : a.V - 1;
+      const bool va = okq[q] && lane < a.WL && (wm ? mka[q] != 0 : wa64 != a.V - 1) && wa64 >= 0 && wa64 < a.V;      // = word_ok
+      const bool vb = okq[q] && lane + 64 < a.WL && (wm ? mkb[q] != 0 : wb64 != a.V - 1) && wb64 >= 0 && wb64 < a.V;
       const uint32_t w0 = q == 0 ? t0.x : (q == 1 ? t0.y : (q == 2 ? t0.z : t0.w));
       const uint32_t w1 = q == 0 ? t1.x : (q == 1 ? t1.y : (q == 2 ? t1.z : t1.w));
       const float tm0 = ts.thr ? drop_word(ts, w0) : 1.f, tm1 = ts.thr ? drop_word(ts, w1) : 1.f;
@@ -602,24 +617,26 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
   const int* wl = L.wid[wv][q];
   const float* tl = L.tm[wv][q];
-  constexpr int E4_U = NCHL <= 2 ? 6 : 4;          // word rows in flight per 16-lane group (6: 127 registers, four waves per SIMD)
+  constexpr int E4_U = NCHL <= 2 ? 2 : 2;          // word rows REALLY in flight per 16-lane group now that their loads are unconditional (registers: four waves per SIMD at d = 128)
   for (int i0 = 0; i0 < maxn; i0 += E4_U) {
-    float4 rowv[E4_U][NCHL]; float mt[E4_U];
+    float4 rowv[E4_U][NCHL]; float mt[E4_U], mo[E4_U];
 #pragma unroll
     for (int u = 0; u < E4_U; ++u) {
       const bool on = i0 + u < myn;
       const int wi = on ? wl[i0 + u] : 0;
       mt[u] = on ? tl[i0 + u] : 0.f;
+      mo[u] = on ? 1.f : 0.f;
       const float* row = a.word_emb + (size_t)wi * d + 4 * c;
+      // (unconditional: an entry past this list reads row 0 and is weighted 0 — under `on ? load : 0` every one of the
+      // E4_U x NCHL loads was its own branch and the compiler waited for all loads in flight at each join)
 #pragma unroll
-      for (int k = 0; k < NCHL; ++k)
-        rowv[u][k] = on ? *reinterpret_cast<const float4*>(row + 64 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < NCHL; ++k) rowv[u][k] = *reinterpret_cast<const float4*>(row + 64 * k);
     }
 #pragma unroll
     for (int u = 0; u < E4_U; ++u)
 #pragma unroll
       for (int k = 0; k < NCHL; ++k) {
-        v[k].x += rowv[u][k].x; v[k].y += rowv[u][k].y; v[k].z += rowv[u][k].z; v[k].w += rowv[u][k].w;
+        v[k].x += rowv[u][k].x * mo[u]; v[k].y += rowv[u][k].y * mo[u]; v[k].z += rowv[u][k].z * mo[u]; v[k].w += rowv[u][k].w * mo[u];
         vc[k].x += rowv[u][k].x * mt[u]; vc[k].y += rowv[u][k].y * mt[u];
         vc[k].z += rowv[u][k].z * mt[u]; vc[k].w += rowv[u][k].w * mt[u];
       }
@@ -651,10 +668,26 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   const float cntf = (float)(nw > 0 ? nw : 1), inv = 1.f / cntf;
   if (c == 0) { a.valid[(size_t)n * a.S + s] = ok ? 1.f : 0.f; a.cnt[(size_t)n * a.R + s - 1] = cntf; }
   const bool skip_row = (!ok && pads_unread && !need_unc) || (diag & 4);
+  // segment / positional (/ user / item) rows of this position, all chunks at once (each behind its own per-element test
+  // before: a round trip per element)
+  float4 addv[NCHL], pev[NCHL];       // addv: segment + user + item rows (summed in that order, as the per-element form did)
+#pragma unroll
+  for (int k = 0; k < NCHL; ++k) { addv[k] = make_float4(0.f, 0.f, 0.f, 0.f); pev[k] = addv[k]; }
+  if (!skip_row && !a.raw) {
+    if (a.use_seg) {
+#pragma unroll
+      for (int k = 0; k < NCHL; ++k) addv[k] = *reinterpret_cast<const float4*>(a.seg_emb + (size_t)seg * d + 4 * c + 64 * k);
+    }
+    if (a.use_pos) {
+#pragma unroll
+      for (int k = 0; k < NCHL; ++k) pev[k] = *reinterpret_cast<const float4*>(a.pe + (size_t)s * d + 4 * c + 64 * k);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NCHL; ++k) {
     if (skip_row) break;
     const int col0 = 4 * c + 64 * k;
+    const float sg4[4] = {addv[k].x, addv[k].y, addv[k].z, addv[k].w}, pe4[4] = {pev[k].x, pev[k].y, pev[k].z, pev[k].w};
     const float unc[4] = {v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv};
     const float cor[4] = {vc[k].x * inv, vc[k].y * inv, vc[k].z * inv, vc[k].w * inv};
     float o[4];
@@ -664,11 +697,11 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       float val = need_unc ? unc[e] : cor[e];        // the sequence gets the UNcorrupted mean under train_pv (PVC.py:76,95)
       if (ds.thr && ok) val *= drop_word(ds, L.dw[wv][col][q]);                   // dropout_layer (ps_model.py:303-304)
       if (a.raw) { o[e] = ok ? val : 0.f; continue; }                             // fs: rtm_fs_finish_kernel does the rest
-      if (a.use_seg) val += a.seg_emb[(size_t)seg * d + col];
-      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];
+      if (a.use_seg) val += sg4[e];
+      if (uid >= 0) val += a.user_emb[(size_t)uid * d + col];       // (user / item rows: not in configs[3]; per element as before)
       if (iid >= 0) val += a.item_emb[(size_t)iid * d + col];
       val = ok ? val : 0.f;
-      if (a.use_pos) val += a.pe[(size_t)s * d + col];
+      if (a.use_pos) val += pe4[e];
       o[e] = val;
     }
     if (a.raw) {
