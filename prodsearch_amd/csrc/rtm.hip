@@ -473,6 +473,21 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     }                                                                                              \
   } while (0)
   E4_STAMP(0);
+  // PS_RTM_STAMP=1 PS_RTM_DIAG=64 (tools/rtm_wg_times.py): start / end time (s_memrealtime: the 100 MHz counter all CUs share —
+  // s_memtime is per CU) and XCC of EVERY workgroup's wave 0, behind the phase slots
+  const bool wg_times = a.stamp && diag == 64 && threadIdx.x == 0;
+  if (wg_times) {
+    unsigned long long t_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    a.stamp[64 + 3 * blockIdx.x] = t_;
+    a.stamp[64 + 3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID bits 3:0
+  }
+  struct WgEnd {
+    unsigned long long* p; bool on;
+    __device__ ~WgEnd() {
+      if (on) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); *p = t_; }
+    }
+  } wg_end = {wg_times ? a.stamp + 64 + 3 * blockIdx.x + 1 : nullptr, wg_times};
   int g = blockIdx.x * 4 + wv;
   if (glist) {
     // with the valid-group list (rtm_grouplist_kernel) the launch is DENSE in real work: the first nq_wg workgroups are the
@@ -480,8 +495,9 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     if ((int)blockIdx.x < nq_wg) g = npos_grp + nneg_grp + (int)blockIdx.x * 4 + wv;
     else {
       const int gi = ((int)blockIdx.x - nq_wg) * 4 + wv;
+      const int gsp = glist[gi];                     // requested WITH the count (the list has room for every group: in bounds)
       if (gi >= *gcount) return;
-      g = glist[gi];
+      g = gsp;
     }
   }
   g = __builtin_amdgcn_readfirstlane(g);            // wave-uniform: everything derived from it lives in scalar registers
@@ -526,6 +542,18 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   int nq[4], sq[4], segq[4], nwq[4], nlq[4], rrq[4];
   bool okq[4], liveq[4];
   int64_t uidq[4], iidq[4];
+  // lane l reads the id and the segment of review l & 3 (two wave-instructions, one round trip; the values then go to
+  // scalar registers by v_readlane).  Review after review through wave-uniform loads — each followed by its own wait — the
+  // decode was eight dependent round trips: 6.1 k of a workgroup's 10.7 k cycles (profiles/r03_rtm_embed4_stamps.txt)
+  int my_rid_lo, my_rid_hi, my_seg;
+  {
+    const int rr = 4 * gg + (lane & 3);
+    const int rrc = rr < nrev ? rr : 0;
+    const int base = fdiv(rrc, fR), r = rrc - base * a.R;
+    const int64_t rid = (pos ? a.pos_r : a.neg_r)[rrc];
+    my_seg = (int)(pos ? a.pos_seg : a.neg_seg)[(size_t)base * a.S + r + 1];
+    my_rid_lo = (int)(unsigned long long)rid; my_rid_hi = (int)((unsigned long long)rid >> 32);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int rr = 4 * gg + q;
@@ -533,14 +561,14 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
     const int rrc = liveq[q] ? rr : 0;
     rrq[q] = rrc;
     const int base = fdiv(rrc, fR), r = rrc - base * a.R;
-    int b, n;
-    if (pos) { b = base; n = b * a.J; }
-    else { b = fdiv(base, fK); n = b * a.J + 1 + (base - b * a.K); }
+    const int bn = fdiv(base, fK);
+    const int n = pos ? base * a.J : bn * a.J + 1 + (base - bn * a.K);
     nq[q] = n; sq[q] = r + 1;
-    const int64_t ridx = (pos ? a.pos_r : a.neg_r)[rrc];
+    const int64_t ridx = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(my_rid_hi, q) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane(my_rid_lo, q));
     okq[q] = liveq[q] && ridx != rpad;
     const size_t spos = (size_t)base * a.S + r + 1;
-    segq[q] = (int)(pos ? a.pos_seg : a.neg_seg)[spos];
+    segq[q] = __builtin_amdgcn_readlane(my_seg, q);
     uidq[q] = -1; iidq[q] = -1;
     if (a.user_emb) { uidq[q] = (pos ? a.pos_u : a.neg_u)[spos]; if (uidq[q] < 0 || uidq[q] > a.U) uidq[q] = -1; }
     if (a.item_emb) { iidq[q] = (pos ? a.pos_i : a.neg_i)[spos]; if (iidq[q] < 0 || iidq[q] > a.PI) iidq[q] = -1; }
@@ -617,7 +645,7 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
   for (int k = 0; k < NCHL; ++k) { v[k] = make_float4(0.f, 0.f, 0.f, 0.f); vc[k] = v[k]; }
   const int* wl = L.wid[wv][q];
   const float* tl = L.tm[wv][q];
-  constexpr int E4_U = NCHL <= 2 ? 2 : 2;          // word rows REALLY in flight per 16-lane group now that their loads are unconditional (registers: four waves per SIMD at d = 128)
+  constexpr int E4_U = 2;          // word rows REALLY in flight per 16-lane group now that their loads are unconditional (d = 128: 95 registers, five waves per SIMD; 3 measured the same, 4 costs a wave)
   for (int i0 = 0; i0 < maxn; i0 += E4_U) {
     float4 rowv[E4_U][NCHL]; float mt[E4_U], mo[E4_U];
 #pragma unroll
