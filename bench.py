@@ -221,10 +221,10 @@ class RtmWorkload(object):
             note = "%d review rows + %d B of x" % (slots, out_bytes)
         return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="rtm_embed4_kernel (review-vector gather + mean-pool; %s)" % note,
-                    extra={"traffic": 77.8e6 if self.a.encoder == 'pvc' else None,
+                    extra={"traffic": 79.5e6 if self.a.encoder == 'pvc' else None,
                            "traffic_source": "committed PMC passes profiles/r03_rtm_embed_pmc.txt (round 3, the commit that added "
-                                             "it): FETCH_SIZE 33.6 MB x2 + WRITE_SIZE 10.5 MB per launch (round 2, with the rank "
-                                             "atomics in this kernel: 123.3 MB)" if self.a.encoder == 'pvc' else None,
+                                             "it; refreshed on the final round-3 kernel): FETCH_SIZE 34.5 MB x2 + WRITE_SIZE 10.6 MB "
+                                             "per launch (round 2, with the rank atomics in this kernel: 123.3 MB)" if self.a.encoder == 'pvc' else None,
                            "bound_note": "the 59 MB of word rows come from a 16.6 MB table that lives in the L2s / Infinity Cache; "
                                          "what the kernel takes from HBM is the ids and what it writes"})
 

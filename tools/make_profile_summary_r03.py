@@ -47,9 +47,9 @@ Kernel statistics (`r03_bench_kernel_stats.csv`, the timed steps plus the roofli
 
 bench line (`r03_rtm_bench.json`): **%.0f tuples/s, %.4f ms/step** (median %.4f); round 2: 0.502 ms; round 1: 0.733 ms.
 Roofline object: `rtm_embed4_kernel`, bound `hbm`, %.0f GB/s of 8000 = **%.3f** on %.1f MB of algorithmic bytes (in-step %.1f µs; round
-2: 100.9 µs with the word-rank atomics in it).  PMC `r03_rtm_embed_pmc.txt`: FETCH 33.6 MB x2 + WRITE 10.5 MB = 77.8 MB per launch
+2: 100.9 µs with the word-rank atomics in it).  PMC `r03_rtm_embed_pmc.txt`: FETCH 34.5 MB x2 + WRITE 10.6 MB = 79.5 MB per launch
 against 84.5 MB algorithmic (round 2: 123.3 MB against 91.9): nothing is re-read; the 59 MB of word rows come out of the L2s / Infinity
-Cache (a 16.6 MB table), and the kernel stays a chain of dependent round trips (DESIGN.md 7c).  Timeline `r03_rtm_step_timeline.txt`
+Cache (a 16.6 MB table), and the kernel's loads are no longer one round trip per element (DESIGN.md 5f: 55.5 -> 37.4 µs; per-workgroup lives `r03_rtm_embed4_wg_times.txt`).  Timeline `r03_rtm_step_timeline.txt`
 (%s); kernel statistics (`r03_rtm_kernel_stats.csv`):
 
 %s
