@@ -400,6 +400,12 @@ __device__ inline unsigned long long w1_valid(const AttnArgs& a, int b, int lane
   return vm;
 }
 
+// A wave of these two kernels is alone on its SIMD (1,536 sequences on 1,024 SIMDs at configs[3]): its time is the number of
+// dependent memory round trips.  W1_U key steps are loaded together — 16 keys per round whatever the row width — and PIN4 makes
+// every loaded row arrive BEFORE the first conditional store of the round: behind such a store's join the compiler can name a
+// later row's arrival only by a count that also covers the store, i.e. it waited for each store's acknowledgement in turn.
+// (Two key steps per round and no pins: 13 + 13 rounds per sequence of 51 positions, 19.7 / 44 us.)
+#define PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 template <int LPR>
 __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int pads_unread) {
   fork_signal(a.sig, a.sigval);
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
     drop.step = drop_step(a.drop); drop.step_ptr = nullptr;
     // (an idle lane group repeats key 0 — always a real row: the query position is valid — so every load is
     // unconditional; W1_U steps of loads are in flight together)
-    constexpr int W1_U = 2;
+    constexpr int W1_U = 16 / KPS;
     for (int k0 = 0; k0 < Sv; k0 += KPS * W1_U) {
       int kk[W1_U], pp[W1_U]; bool on[W1_U]; float4 v4[W1_U]; float Pv[W1_U];
 #pragma unroll
@@ -436,6 +442,8 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
         v4[u] = f4_ld(a.vp + row * D + c);
         Pv[u] = a.attn[((size_t)b * HF + h) * S + pp[u]];
       }
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) { PIN4(v4[u]); asm volatile("" : "+v"(Pv[u])); }
 #pragma unroll
       for (int u = 0; u < W1_U; ++u) {
         const size_t row = (size_t)b * S + pp[u];
@@ -467,6 +475,8 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
         pp[u] = sp[wv][on[u] ? kk[u] : 0];
         k4[u] = f4_ld(a.kp + ((size_t)b * S + pp[u]) * D + c);
       }
+#pragma unroll
+      for (int u = 0; u < W1_U; ++u) PIN4(k4[u]);
 #pragma unroll
       for (int u = 0; u < W1_U; ++u) {
         const float g = on[u] ? pl[wv][kk[u]][h] * (dpl[wv][kk[u]][h] - th) : 0.f;        // softmax backward
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_bwd_w1_kernel(const AttnArgs a, int 
 // all S positions (0 at the masked ones) for the backward
 template <int LPR>
 __global__ __launch_bounds__(256) void attn_fwd_w1_kernel(const AttnArgs a) {
-  constexpr int D = 4 * LPR, KPS = 64 / LPR, W1_U = 2;
+  constexpr int D = 4 * LPR, KPS = 64 / LPR, W1_U = 16 / KPS;       // 16 keys per round (see PIN4 above)
   __shared__ int sp[4][64];
   __shared__ float sc[4][64][W1_MAXH];
   __shared__ float ls[4][W1_MAXH], mxl[4][W1_MAXH];
