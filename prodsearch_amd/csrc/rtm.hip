@@ -1424,21 +1424,24 @@ __global__ __launch_bounds__(NT) void rtm_hist_kernel(const RtmK a) {
   for (int base = row0; base < row1; base += NT) {             // lists of up to NT rows at a time
     const int total = hist_list_rows(a, base, row1, l_rev, &l_n) * a.WL;
     for (int ib = 0; ib < total; ib += 4 * NT) {               // (workgroup-uniform trip count: DET shuffles below)
-      int64_t wi[4]; size_t ro[4]; bool ok[4]; int rk[4], sl[4];
+      int64_t wi[4]; size_t ro[4]; bool ok[4]; int rk[4], sl[4]; const uint8_t* wmo[4] = {nullptr, nullptr, nullptr, nullptr};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = ib + NT * u + tid;
         const bool in = i < total;
-        const int r = in ? i / a.WL : 0, w = i - r * a.WL;
-        const int gr = l_rev[r];
+        const int ic = in ? i : 0;                             // (a slot past the end repeats slot 0: every load below is
+        const int r = ic / a.WL, w = ic - r * a.WL;            // unconditional — under `in ? load : -1` each was its own branch
+        const int gr = l_rev[r];                               // and the four, or eight, round trips of a pass ran one by one)
         const bool pos = gr < NP;
         const int rev = pos ? gr : gr - NP;
         const int64_t* words = (pos ? (a.train_pv ? a.pos_pvc : a.pos_words) : (a.train_pv ? a.neg_pvc : a.neg_words_rev));
-        const size_t off = (size_t)rev * a.WL + (in ? w : 0);
-        wi[u] = in ? words[off] : -1;
+        const size_t off = (size_t)rev * a.WL + w;
+        wi[u] = words[off];
+        if (!in) wi[u] = -1;
         ro[u] = (size_t)gr * a.WL + w;
         if (FILL) {
-          rk[u] = in ? a.wrank[ro[u]] : -1;
+          rk[u] = a.wrank[ro[u]];
+          if (!in) rk[u] = -1;
           ok[u] = rk[u] >= 0;
           // the slot of review row `rev` (the inverse of seq_decode: sequence n = b*J + j, position r + 1)
           const int seq = rev / a.R, r_in = rev - seq * a.R;
@@ -1447,9 +1450,19 @@ __global__ __launch_bounds__(NT) void rtm_hist_kernel(const RtmK a) {
           else { const int b = seq / a.K; n = b * a.J + (seq - b * a.K) + 1; }
           sl[u] = n * a.S + r_in + 1;
         } else {
-          const uint8_t* wm = pos ? a.wmask_pos : a.wmask_neg;
-          ok[u] = in && word_ok(a, wm, off, wi[u]);
+          wmo[u] = (pos ? a.wmask_pos : a.wmask_neg) + off;
+          ok[u] = in;
         }
+      }
+      if (!FILL) {                                             // word_ok, the mask bytes (if the batch has any) in one request
+        uint8_t mk[4] = {1, 1, 1, 1};
+        if (a.wmask_pos && a.wmask_neg) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) mk[u] = *wmo[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          ok[u] = ok[u] && ((a.wmask_pos && a.wmask_neg) ? mk[u] != 0 : wi[u] != a.V - 1) && wi[u] >= 0 && wi[u] < a.V;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
