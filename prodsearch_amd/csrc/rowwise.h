@@ -196,6 +196,8 @@ struct EmbedBwdArgs {
   uint32_t* sig; uint32_t sigval; // a pending side-stream fork signalled by this launch (common.h, fork_signal)
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
+// deterministic  table[keys[t]] += src[t * ld .. + d)  (keys[t] < 0: no task): one owner half-wave per table row, tasks in order
+int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, int64_t ld, int d, float* table, hipStream_t st);
 
 // dqpre = dqe * (1 - qe^2), dfb += colsum(dqpre)
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,

@@ -14,6 +14,7 @@
 //   rtm_loss       weighted BCE over products (ps_model.py:341-356) + PV loss (:277-280), one block
 //   *_bwd          their backward: fp32-atomic scatter-adds into the dense table gradients
 #include "encoder.h"
+#include "rowwise.h"
 #include <string.h>
 
 #define SITE_REV_PV 0x200u
@@ -1072,6 +1073,28 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
     }
 }
 
+// deterministic mode: the user / item row of every sequence position as a scatter key (-1: no gradient — a padded review
+// position, the embedding's padding row, an id out of range), position-major like d x
+__global__ __launch_bounds__(256) void rtm_ui_keys_kernel(const RtmK a, int32_t* ukeys, int32_t* ikeys, int npos) {
+  const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (t >= npos) return;
+  const int n = t / a.S, s = t - n * a.S;
+  const int b = fdiv(n, a.fJ), j = n - b * a.J;
+  const bool pos = j == 0;
+  const size_t base = pos ? (size_t)b : (size_t)b * a.K + (j - 1);
+  bool ok = true;
+  if (s > 0) ok = (pos ? a.pos_r : a.neg_r)[base * a.R + s - 1] != a.RC - 1;
+  const size_t spos = base * a.S + s;
+  if (ukeys) {
+    const int64_t uid = ok ? (pos ? a.pos_u : a.neg_u)[spos] : -1;
+    ukeys[t] = (uid >= 0 && uid < a.U) ? (int32_t)uid : -1;
+  }
+  if (ikeys) {
+    const int64_t iid = ok ? (pos ? a.pos_i : a.neg_i)[spos] : -1;
+    ikeys[t] = (iid >= 0 && iid < a.PI) ? (int32_t)iid : -1;
+  }
+}
+
 // Backward of rtm_embed.  Like rtm_embed4_kernel it works on groups of the four review rows 4g .. 4g+3 of one side, which
 // share one Philox counter row: a lane evaluates the dropout words of its columns once for the four reviews, and the
 // (unconditional, all-real-address) loads of the four rows are in flight together — the wave's dependent chain is one round
@@ -1089,7 +1112,7 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = (int)blockIdx.x * 4 + wv;
   const int d = a.d;
-  const bool pvc = PL ? true : (bool)a.pvc, has_ui = !PL && (a.g_user_emb || a.g_item_emb);
+  const bool pvc = PL ? true : (bool)a.pvc, has_ui = !PL && !a.det && (a.g_user_emb || a.g_item_emb);   // det: rtm_ui_keys_kernel + launch_rows_scatter_det
   const float* const dmean = PL ? nullptr : a.dmean;
   const int64_t rpad = a.RC - 1;
   DropSpec dpos = a.d_pos, dneg = a.d_neg, dpv = a.d_pv;      // the step word is read once, not per element
@@ -2004,8 +2027,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     // Deterministic mode covers the word-mean review encoders (pvc — BASELINE configs[3] —, fs, avg).  The PV encoder's review-row
     // and PV-loss word-row scatters and the user / item embedding rows keep their fp32 atomics: refused rather than silently
     // non-reproducible.
-    PS_REQUIRE(k.pvc && !D.use_user_emb && !D.use_item_emb && !k.train_pv,
-               "rtm backward: deterministic mode supports the pvc / fs / avg review encoders without user / item embeddings");
+    PS_REQUIRE(k.pvc && !k.train_pv, "rtm backward: deterministic mode supports the pvc / fs / avg review encoders without the PV loss");
     PS_REQUIRE(hist_index, "rtm backward: deterministic mode needs the LDS-histogram word index (vocabulary <= %d, PS_RTM_HIST != 0)",
                RTM_HIST_MAXV);
   }
@@ -2070,6 +2092,20 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     const int nwg = ps_cdiv(rtm_eb_waves(B, D.K, D.R, &npw, &nnw), 4);
     const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
     float* sp = ws + r.segpart;
+    if (k.det && (k.g_user_emb || k.g_item_emb)) {
+      // user / item embedding rows, deterministic mode: a sole-owner scatter of d x by position — BEFORE the kernel below, which
+      // rewrites the review positions' rows of d x in place (pvc: RtmK::gs)
+      const int npos = r.Bseq * r.S;
+      const float* dxp = ws + r.enc_base + w.dx;
+      int32_t* keys = reinterpret_cast<int32_t*>(ps_det_scratch(1, (size_t)2 * npos + 8, st));
+      PS_REQUIRE(keys, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
+      int32_t* uk = k.g_user_emb ? keys : nullptr;
+      int32_t* ik = k.g_item_emb ? keys + npos : nullptr;
+      hipLaunchKernelGGL(rtm_ui_keys_kernel, dim3(ps_cdiv(npos, 256)), dim3(256), 0, st, k, uk, ik, npos);
+      PS_LAUNCH_CHECK();
+      if (uk) TRY(launch_rows_scatter_det(uk, npos, dxp, d, d, k.g_user_emb, st));
+      if (ik) TRY(launch_rows_scatter_det(ik, npos, dxp, d, d, k.g_item_emb, st));
+    }
     const bool plain = k.pvc && !k.dmean && !k.g_user_emb && !k.g_item_emb && !k.train_pv;
 #define EB_LAUNCH(NK_)                                                                                             \
   do {                                                                                                             \

@@ -3,7 +3,8 @@ of ``ProductRanker`` with a word-mean review encoder (pvc = BASELINE configs[3],
 index hands out its ranks in task order (one wave per partition, no atomics), a word's occurrences are summed in list order by
 one wave (sixteen fixed slices for the Zipf heads), d wo / d query_emb / the fs bias as fixed-order sums, weight gradients as
 per-split partials added in split order, one stream.  The default path differs from it only by the order of fp32 additions.
-The encoders whose scatters keep fp32 atomics (pv; user / item embeddings) are refused, not silently non-reproducible.
+The user / item embedding rows go through the sole-owner row scatter of the item transformer (one owner half-wave per table row,
+tasks in order).  What keeps fp32 atomics (the pv encoder, the PV loss) is refused, not silently non-reproducible.
 Reference semantics: models/ps_model.py:241-358, models/PVC.py:46-61 (its own CUDA embedding backward is not deterministic)."""
 import numpy as np
 import pytest
@@ -16,14 +17,15 @@ pytestmark = pytest.mark.gpu
 V, RC, K, WL, U_LIM, I_LIM, D = 32387, 60000, 5, 100, 20, 30, 128
 
 
-def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9):
+def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9, ui=False):
     from prodsearch_amd import ProductRanker, _lib, build_optim, default_args, synth, rtm_data
     lib = _lib.load()
     old = lib.ps_set_deterministic(1 if det else 0)
     try:
         a = default_args(model_name='review_transformer', review_encoder_name=encoder, embedding_size=D, heads=8,
                          ff_size=512, inter_layers=1, neg_per_pos=K, dropout=dropout, corrupt_rate=corrupt, lr=0.0005,
-                         review_word_limit=WL, uprev_review_limit=U_LIM, iprev_review_limit=I_LIM)
+                         review_word_limit=WL, uprev_review_limit=U_LIM, iprev_review_limit=I_LIM,
+                         use_user_emb=ui, use_item_emb=ui)
         wd = synth.make_word_dists(V)
         rng = synth.rng_for(3)
         # Zipf-distributed review words: the head words collect far more than WR_DET_LIM occurrences at B = 256
@@ -38,7 +40,8 @@ def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9):
         losses = []
         for s in range(steps):
             batch = rtm_data.make_rtm_batch(300 + s, B, K, RC, V, rw, Q=8, u_lim=U_LIM, i_lim=I_LIM, W=1, train_pv=False,
-                                            encoder=encoder, word_dists=wd)
+                                            encoder=encoder, word_dists=wd, user_size=1000 if ui else None,
+                                            product_size=1000 if ui else None)
             loss = m(batch.to('cuda'), train_pv=False)
             m.zero_grad()
             loss.backward()
@@ -57,16 +60,19 @@ def _zipf(n):
     return p / p.sum()
 
 
-@pytest.mark.parametrize('encoder,B,corrupt', [('pvc', 256, 0.9), ('pvc', 64, 0.0), ('fs', 32, 0.0), ('avg', 32, 0.0)])
-def test_rtm_deterministic_mode_repeats_bit_for_bit_and_agrees_with_the_default_path(encoder, B, corrupt):
-    l1, g1, p1 = _train(True, encoder, B, corrupt=corrupt)
-    l2, g2, p2 = _train(True, encoder, B, corrupt=corrupt)
+@pytest.mark.parametrize('encoder,B,corrupt,ui', [('pvc', 256, 0.9, False), ('pvc', 64, 0.0, False), ('fs', 32, 0.0, False),
+                                                    ('avg', 32, 0.0, False), ('pvc', 64, 0.9, True), ('fs', 32, 0.0, True)])
+def test_rtm_deterministic_mode_repeats_bit_for_bit_and_agrees_with_the_default_path(encoder, B, corrupt, ui):
+    l1, g1, p1 = _train(True, encoder, B, corrupt=corrupt, ui=ui)
+    l2, g2, p2 = _train(True, encoder, B, corrupt=corrupt, ui=ui)
     assert l1 == l2
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n                                     # every gradient of the first step, bitwise
     for n in p1:
         assert torch.equal(p1[n], p2[n]), n                                     # every parameter after two clip+Adam steps
-    l0, g0, p0 = _train(False, encoder, B, corrupt=corrupt)
+    l0, g0, p0 = _train(False, encoder, B, corrupt=corrupt, ui=ui)
+    if ui:
+        assert 'user_emb.weight' in g1 and 'product_emb.weight' in g1 and float(g1['user_emb.weight'].abs().max()) > 0
     assert np.allclose(l0, l1, rtol=1e-5)
     assert sorted(g0) == sorted(g1)
     for n in g1:                                                                # the same sums in another order
