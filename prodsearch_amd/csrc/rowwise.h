@@ -197,7 +197,8 @@ struct EmbedBwdArgs {
 };
 int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st);
 // deterministic  table[keys[t]] += src[t * ld .. + d)  (keys[t] < 0: no task): one owner half-wave per table row, tasks in order
-int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, int64_t ld, int d, float* table, hipStream_t st);
+int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, int64_t ld, int d, float* table, hipStream_t st,
+                            const float* scale = nullptr, const int32_t* rowidx = nullptr);   // task t: scale[t] * row rowidx[t] of src
 
 // dqpre = dqe * (1 - qe^2), dfb += colsum(dqpre)
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,

@@ -1611,12 +1611,13 @@ __global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void embed_scatter_det_kern
     });
 }
 
-// table[keys[t]] += src[t * ld .. + d)  for t < ntask (keys[t] < 0: no task), deterministically: every table row has one
+// table[keys[t]] += [scale[t] *] src[(rowidx ? rowidx[t] : t) * ld .. + d)  for t < ntask (keys[t] < 0: no task), deterministically: every table row has one
 // owner half-wave, which walks the tasks in task order (det_owner_walk) — the review transformer's user / item embedding
 // gradients in deterministic mode (rtm.hip)
 template <int EPL>
 __global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void rows_scatter_det_kernel(const int32_t* keys, int ntask, const float* src,
-                                                                                 int64_t ld, int d, float* table) {
+                                                                                 int64_t ld, int d, float* table, const float* scale,
+                                                                                 const int32_t* rowidx) {
   typedef DetItemT<EPL> DetItem;
   const int tid = threadIdx.x, hl = tid & 31, c = hl;
   const int owner = (int)blockIdx.x * SBD_OWNERS_PER_WG + (tid >> 5), nown = (int)gridDim.x * SBD_OWNERS_PER_WG;
@@ -1625,17 +1626,19 @@ __global__ __launch_bounds__(32 * SBD_OWNERS_PER_WG) void rows_scatter_det_kerne
     [&](int t, DetItem& it) {
       it.row = keys[t];
       it.bias = 0.f;
-      const float* s = src + (size_t)t * ld;
+      const float* s = src + (size_t)(rowidx ? rowidx[t] : t) * ld;
+      const float sc = scale ? scale[t] : 1.f;
 #pragma unroll
-      for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? s[c + 32 * k] : 0.f;
+      for (int k = 0; k < EPL; ++k) it.v[k] = k < epl ? (scale ? sc * s[c + 32 * k] : s[c + 32 * k]) : 0.f;
     });
 }
-int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, int64_t ld, int d, float* table, hipStream_t st) {
+int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, int64_t ld, int d, float* table, hipStream_t st,
+                            const float* scale, const int32_t* rowidx) {
   PS_REQUIRE(d % 32 == 0 && d <= 32 * BW_MAXE, "deterministic row scatter: d=%d unsupported", d);
   if (ntask <= 0) return PS_OK;
-  if (d <= 128) hipLaunchKernelGGL(rows_scatter_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table);
-  else if (d <= 256) hipLaunchKernelGGL(rows_scatter_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table);
-  else hipLaunchKernelGGL(rows_scatter_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table);
+  if (d <= 128) hipLaunchKernelGGL(rows_scatter_det_kernel<4>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table, scale, rowidx);
+  else if (d <= 256) hipLaunchKernelGGL(rows_scatter_det_kernel<8>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table, scale, rowidx);
+  else hipLaunchKernelGGL(rows_scatter_det_kernel<16>, dim3(256), dim3(32 * SBD_OWNERS_PER_WG), 0, st, keys, ntask, src, ld, d, table, scale, rowidx);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

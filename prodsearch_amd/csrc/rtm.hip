@@ -1035,6 +1035,27 @@ __global__ __launch_bounds__(1024) void rtm_wreduce_heavy_det_kernel(const RtmK 
   }
 }
 
+// deterministic mode: the PV loss's word-row tasks (review, window slot, 1 + K words) as scatter keys with their scalar — the
+// task's row is  ds * vec[review]  (the same arithmetic as rtm_pv_bwd_kernel below)
+__global__ __launch_bounds__(256) void rtm_pv_keys_kernel(const RtmK a, int32_t* keys, float* scale, int32_t* rowidx, int ntask) {
+  const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (t >= ntask) return;
+  const int K1 = a.K + 1, per = a.W * K1;
+  const int rev = t / per, rem = t - rev * per, w = rem / K1, j = rem - w * K1;
+  int cnt = 0;
+  for (int w2 = 0; w2 < a.W; ++w2) cnt += a.pos_masks[(size_t)rev * a.W + w2] ? 1 : 0;
+  const float sc = a.scale * (a.scale_dev ? *a.scale_dev : 1.f) / ((float)(cnt > 0 ? cnt : 1) * a.nvalid[0]);
+  int32_t key = -1; float ds = 0.f;
+  if (a.pos_masks[(size_t)rev * a.W + w]) {
+    int64_t idx = j == 0 ? a.pos_words[(size_t)rev * a.W + w] : a.neg_word_idxs[(size_t)rev * a.W * a.K + (size_t)w * a.K + j - 1];
+    idx = rclamp(idx, a.V - 1);
+    const float s = a.pv_scores[((size_t)rev * a.W + w) * K1 + j];
+    ds = (sigmoid_f(s) - (j == 0 ? 1.f : 0.f)) * sc;
+    key = idx != a.V - 1 ? (int32_t)idx : -1;
+  }
+  keys[t] = key; scale[t] = ds; rowidx[t] = rev;
+}
+
 // PV backward: one wave per positive review; d vec (dense) and word-row scatter-adds
 __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
   const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
@@ -1061,7 +1082,7 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
     for (int k = 0; k < 16; ++k)
       if (k < epl) {
         const int e = c + 32 * k;
-        if (idx != a.V - 1) atomicAdd(&grow[e], ds * vec[e]);
+        if (idx != a.V - 1 && !a.det) atomicAdd(&grow[e], ds * vec[e]);      // det: rtm_pv_keys_kernel + launch_rows_scatter_det
         dv[k] += ds * wrow[e];
       }
   }
@@ -1075,7 +1096,7 @@ __global__ __launch_bounds__(256) void rtm_pv_bwd_kernel(const RtmK a) {
 
 // deterministic mode: the user / item row of every sequence position as a scatter key (-1: no gradient — a padded review
 // position, the embedding's padding row, an id out of range), position-major like d x
-__global__ __launch_bounds__(256) void rtm_ui_keys_kernel(const RtmK a, int32_t* ukeys, int32_t* ikeys, int npos) {
+__global__ __launch_bounds__(256) void rtm_ui_keys_kernel(const RtmK a, int32_t* ukeys, int32_t* ikeys, int32_t* rkeys, int npos) {
   const int t = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (t >= npos) return;
   const int n = t / a.S, s = t - n * a.S;
@@ -1083,7 +1104,9 @@ __global__ __launch_bounds__(256) void rtm_ui_keys_kernel(const RtmK a, int32_t*
   const bool pos = j == 0;
   const size_t base = pos ? (size_t)b : (size_t)b * a.K + (j - 1);
   bool ok = true;
-  if (s > 0) ok = (pos ? a.pos_r : a.neg_r)[base * a.R + s - 1] != a.RC - 1;
+  int64_t rid = -1;
+  if (s > 0) { rid = (pos ? a.pos_r : a.neg_r)[base * a.R + s - 1]; ok = rid != a.RC - 1; }
+  if (rkeys) rkeys[t] = (s > 0 && rid >= 0 && rid < a.RC - 1) ? (int32_t)rid : -1;      // pv encoder: the review's table row
   const size_t spos = base * a.S + s;
   if (ukeys) {
     const int64_t uid = ok ? (pos ? a.pos_u : a.neg_u)[spos] : -1;
@@ -1223,11 +1246,18 @@ __global__ __launch_bounds__(256) void rtm_embed_bwd_kernel(const RtmK a, float*
           }
           t[k] = v;
         }
-        if (!pvc) {
+        if (!pvc && !a.det) {
           float* grow = a.g_table + (size_t)rclamp(ridq[q], rpad) * d;
 #pragma unroll
           for (int k = 0; k < NK; ++k)
             if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], t[k]);
+        } else if (!pvc) {
+          // deterministic mode: the review row's gradient parked in place of d x (like the pvc rows below); rtm_ui_keys_kernel's
+          // review keys + launch_rows_scatter_det add the rows up, one owner per table row, in position order
+          float* gw = a.gs + ((size_t)nq[q] * a.S + sq[q]) * d;
+#pragma unroll
+          for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < d) gw[lane + 64 * k] = t[k];
         } else {
           // mean backward: every non-pad word row of the review gets g / cnt (token corruption bypasses autograd, PVC.py:53)
           // 1.2 M word occurrences x 512 B of fp32 atomics per step ran at 0.7 TB/s; instead the row is rewritten in
@@ -2024,11 +2054,9 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   const bool hist_index = rtm_hist_index(D, k, r);
   const bool fwd_index = hist_index || rtm_counts_in_forward(D, k, r);     // either way: built on the side stream, right here
   if (k.det) {
-    // Deterministic mode covers the word-mean review encoders (pvc — BASELINE configs[3] —, fs, avg).  The PV encoder's review-row
-    // and PV-loss word-row scatters and the user / item embedding rows keep their fp32 atomics: refused rather than silently
-    // non-reproducible.
-    PS_REQUIRE(k.pvc && !k.train_pv, "rtm backward: deterministic mode supports the pvc / fs / avg review encoders without the PV loss");
-    PS_REQUIRE(hist_index, "rtm backward: deterministic mode needs the LDS-histogram word index (vocabulary <= %d, PS_RTM_HIST != 0)",
+    // Deterministic mode covers every review encoder (pvc — BASELINE configs[3] —, fs, avg: the word index + ordered reduce; pv:
+    // the review rows through the sole-owner row scatter), the user / item embedding rows and the PV loss's word rows.
+    PS_REQUIRE(!k.pvc || hist_index, "rtm backward: deterministic mode needs the LDS-histogram word index (vocabulary <= %d, PS_RTM_HIST != 0)",
                RTM_HIST_MAXV);
   }
   k.count_fwd = fwd_index && !hist_index;
@@ -2052,6 +2080,17 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   if (k.train_pv) {
     hipLaunchKernelGGL(rtm_pv_bwd_kernel, dim3(ps_cdiv(B * k.R, 4)), dim3(256), 0, st, k);
     PS_LAUNCH_CHECK();
+    if (k.det) {                                     // the PV loss's word rows: sole-owner scatter of ds * vec[review]
+      const int ntask = B * k.R * k.W * (k.K + 1);
+      float* scr = ps_det_scratch(1, (size_t)3 * ntask + 8, st);
+      PS_REQUIRE(scr, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
+      int32_t* pk = reinterpret_cast<int32_t*>(scr);
+      float* psc = scr + ntask;
+      int32_t* pri = reinterpret_cast<int32_t*>(scr + 2 * (size_t)ntask);
+      hipLaunchKernelGGL(rtm_pv_keys_kernel, dim3(ps_cdiv(ntask, 256)), dim3(256), 0, st, k, pk, psc, pri, ntask);
+      PS_LAUNCH_CHECK();
+      TRY(launch_rows_scatter_det(pk, ntask, k.vec, d, d, k.g_word_emb, st, psc, pri));
+    }
   }
   PsTemTensors T, TG;
   to_tem_tensors(*params, T);
@@ -2064,7 +2103,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     PS_CHECK_HIP(hipMemsetAsync(ws + r.dqe, 0, sizeof(float) * (size_t)(zend - r.dqe), st));
   }
   const int eb = rtm_slot_blocks(r);
-  if (k.pvc) k.gs = ws + r.enc_base + w.dx;
+  if (k.pvc || k.det) k.gs = ws + r.enc_base + w.dx;     // (det + pv encoder: the review rows' gradients are parked in place, scattered below)
   TRY(enc_layers_backward(E, T, TG, nullptr, ws + r.valid, ws + r.enc_base, w, st, &fold, nullptr, rtm_rows_listed(r, w)));
   if (D.review_encoder == PS_RENC_FS) {
     // through the review projection: d pre = dx * tanh', bias gradient, weight gradient, d raw = d pre . f_W
@@ -2101,7 +2140,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
       PS_REQUIRE(keys, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
       int32_t* uk = k.g_user_emb ? keys : nullptr;
       int32_t* ik = k.g_item_emb ? keys + npos : nullptr;
-      hipLaunchKernelGGL(rtm_ui_keys_kernel, dim3(ps_cdiv(npos, 256)), dim3(256), 0, st, k, uk, ik, npos);
+      hipLaunchKernelGGL(rtm_ui_keys_kernel, dim3(ps_cdiv(npos, 256)), dim3(256), 0, st, k, uk, ik, (int32_t*)nullptr, npos);
       PS_LAUNCH_CHECK();
       if (uk) TRY(launch_rows_scatter_det(uk, npos, dxp, d, d, k.g_user_emb, st));
       if (ik) TRY(launch_rows_scatter_det(ik, npos, dxp, d, d, k.g_item_emb, st));
@@ -2118,6 +2157,14 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     else EB_LAUNCH(8);
 #undef EB_LAUNCH
     PS_LAUNCH_CHECK();
+    if (k.det && !k.pvc) {                           // pv encoder: the parked review-row gradients -> review_emb, by review id
+      const int npos = r.Bseq * r.S;
+      int32_t* rk = reinterpret_cast<int32_t*>(ps_det_scratch(1, (size_t)npos + 8, st));
+      PS_REQUIRE(rk, "rtm backward: deterministic mode has no scratch (allocation failed or stream capture)");
+      hipLaunchKernelGGL(rtm_ui_keys_kernel, dim3(ps_cdiv(npos, 256)), dim3(256), 0, st, k, (int32_t*)nullptr, (int32_t*)nullptr, rk, npos);
+      PS_LAUNCH_CHECK();
+      TRY(launch_rows_scatter_det(rk, npos, k.gs, d, d, k.g_table, st));
+    }
     if (k.det) {
       k.dx = ws + r.enc_base + w.dx;
       hipLaunchKernelGGL(rtm_dqe_det_kernel, dim3(B), dim3(256), 0, st, k);

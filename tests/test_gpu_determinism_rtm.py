@@ -3,8 +3,8 @@ of ``ProductRanker`` with a word-mean review encoder (pvc = BASELINE configs[3],
 index hands out its ranks in task order (one wave per partition, no atomics), a word's occurrences are summed in list order by
 one wave (sixteen fixed slices for the Zipf heads), d wo / d query_emb / the fs bias as fixed-order sums, weight gradients as
 per-split partials added in split order, one stream.  The default path differs from it only by the order of fp32 additions.
-The user / item embedding rows go through the sole-owner row scatter of the item transformer (one owner half-wave per table row,
-tasks in order).  What keeps fp32 atomics (the pv encoder, the PV loss) is refused, not silently non-reproducible.
+The user / item embedding rows, the pv encoder's review rows and the PV loss's word rows go through the sole-owner row scatter of
+the item transformer (one owner half-wave per table row, tasks in order).
 Reference semantics: models/ps_model.py:241-358, models/PVC.py:46-61 (its own CUDA embedding backward is not deterministic)."""
 import numpy as np
 import pytest
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 V, RC, K, WL, U_LIM, I_LIM, D = 32387, 60000, 5, 100, 20, 30, 128
 
 
-def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9, ui=False):
+def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9, ui=False, train_pv=False):
     from prodsearch_amd import ProductRanker, _lib, build_optim, default_args, synth, rtm_data
     lib = _lib.load()
     old = lib.ps_set_deterministic(1 if det else 0)
@@ -39,10 +39,10 @@ def _train(det, encoder, B, steps=2, dropout=0.1, corrupt=0.9, ui=False):
         m.train()
         losses = []
         for s in range(steps):
-            batch = rtm_data.make_rtm_batch(300 + s, B, K, RC, V, rw, Q=8, u_lim=U_LIM, i_lim=I_LIM, W=1, train_pv=False,
+            batch = rtm_data.make_rtm_batch(300 + s, B, K, RC, V, rw, Q=8, u_lim=U_LIM, i_lim=I_LIM, W=1, train_pv=train_pv,
                                             encoder=encoder, word_dists=wd, user_size=1000 if ui else None,
                                             product_size=1000 if ui else None)
-            loss = m(batch.to('cuda'), train_pv=False)
+            loss = m(batch.to('cuda'), train_pv=train_pv)
             m.zero_grad()
             loss.backward()
             if s == 0:
@@ -60,17 +60,20 @@ def _zipf(n):
     return p / p.sum()
 
 
-@pytest.mark.parametrize('encoder,B,corrupt,ui', [('pvc', 256, 0.9, False), ('pvc', 64, 0.0, False), ('fs', 32, 0.0, False),
-                                                    ('avg', 32, 0.0, False), ('pvc', 64, 0.9, True), ('fs', 32, 0.0, True)])
-def test_rtm_deterministic_mode_repeats_bit_for_bit_and_agrees_with_the_default_path(encoder, B, corrupt, ui):
-    l1, g1, p1 = _train(True, encoder, B, corrupt=corrupt, ui=ui)
-    l2, g2, p2 = _train(True, encoder, B, corrupt=corrupt, ui=ui)
+@pytest.mark.parametrize('encoder,B,corrupt,ui,tp', [
+    ('pvc', 256, 0.9, False, False), ('pvc', 64, 0.0, False, False), ('fs', 32, 0.0, False, False), ('avg', 32, 0.0, False, False),
+    ('pvc', 64, 0.9, True, False), ('fs', 32, 0.0, True, False),            # + user / item embedding rows
+    ('pv', 48, 0.0, False, False), ('pv', 32, 0.0, True, False),            # the pv encoder's review rows
+    ('pv', 32, 0.0, False, True), ('pvc', 32, 0.9, True, True)])            # + the PV loss (train_pv): its word rows
+def test_rtm_deterministic_mode_repeats_bit_for_bit_and_agrees_with_the_default_path(encoder, B, corrupt, ui, tp):
+    l1, g1, p1 = _train(True, encoder, B, corrupt=corrupt, ui=ui, train_pv=tp)
+    l2, g2, p2 = _train(True, encoder, B, corrupt=corrupt, ui=ui, train_pv=tp)
     assert l1 == l2
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n                                     # every gradient of the first step, bitwise
     for n in p1:
         assert torch.equal(p1[n], p2[n]), n                                     # every parameter after two clip+Adam steps
-    l0, g0, p0 = _train(False, encoder, B, corrupt=corrupt, ui=ui)
+    l0, g0, p0 = _train(False, encoder, B, corrupt=corrupt, ui=ui, train_pv=tp)
     if ui:
         assert 'user_emb.weight' in g1 and 'product_emb.weight' in g1 and float(g1['user_emb.weight'].abs().max()) > 0
     assert np.allclose(l0, l1, rtol=1e-5)
@@ -80,5 +83,10 @@ def test_rtm_deterministic_mode_repeats_bit_for_bit_and_agrees_with_the_default_
 
 
 def test_rtm_deterministic_mode_refuses_what_it_does_not_cover():
+    """Nothing of the review transformer is refused any more (round 3: the pv encoder, the PV loss and the user / item rows go
+    through the sole-owner row scatter); what IS still refused is a configuration whose word index cannot be the LDS histogram."""
+    import os
+    if os.environ.get('PS_RTM_HIST', '1') != '0':
+        pytest.skip("the LDS-histogram index is on: every configuration is covered")
     with pytest.raises(RuntimeError, match='deterministic mode'):
-        _train(True, 'pv', 16, steps=1)
+        _train(True, 'pvc', 16, steps=1)
