@@ -31,7 +31,8 @@ and, in the default c2 run at N=1 (bounded to about a minute; --no-also skips th
   roofline_hbm — the embedding-gather+score launch ALONE at the HBM-bound shape of configs[4] (d=256, 8 M-row item
                  table = 8.2 GB, B=1024 and B=8192; index sets rotate so that no row is re-read out of the 256 MB
                  Infinity Cache), event-timed per launch: the kernel the north star's 70 % target names
-  also         — the contract lines of c4 and of the c5 shard (8 M-row table), each with its own roofline object.
+  also         — the contract lines of c4 and of the c5 shard (the stated 50 M-row table: 205 GB resident), each with its own
+                 roofline object.
 """
 import argparse
 import ctypes
@@ -59,7 +60,8 @@ TEM_CFG = {
     'c5': dict(P=50_000_000, B=1024, K=20, L=20, Q=8, W=1, D=256, FF=1024, row_sparse=True, config_index=4),
 }
 C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)      # BASELINE configs[3]
-ALSO_C5_ITEMS = 8_000_000                                  # the c5 line inside the default run (33 GB instead of 205)
+ALSO_C5_ITEMS = 50_000_000                                 # the c5 line inside the default run: the STATED table of configs[4] (205 GB resident)
+GATHER_LEG_ITEMS = 8_000_000                               # the stand-alone gather+score leg: an 8.2 GB table is 32x the Infinity Cache already
 
 
 def parse(argv=None):
@@ -384,6 +386,26 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
         # N > 1, sharded optimizer: the forms of its two collectives it timed on this node and kept (dist.ShardedAdamExchange._tune)
         "exchange_tuning": getattr(exchange, 'tuned', None),
     }
+    if world > 1:
+        # comm / compute split (every rank runs it; rank 0 keeps the numbers): a HIP event pair around every collective of the
+        # step on the stream it is issued from (dist.comm_timing) and around each whole step, over a further `steps` steps
+        pdist.comm_timing(True)
+        stc = torch.cuda.current_stream()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for i, (e0, e1) in enumerate(evs):
+            e0.record(stc)
+            step(i)
+            e1.record(stc)
+        spans = pdist.comm_timing_read()
+        pdist.comm_timing(False)
+        tot = sum(e0.elapsed_time(e1) for e0, e1 in evs) / steps
+        comm = {k: v / steps for k, v in spans.items()}
+        out["step_ms_event_timed"] = tot
+        out["comm_ms"] = sum(comm.values())
+        out["compute_ms"] = tot - out["comm_ms"]
+        out["comm_breakdown_ms"] = comm
+        out["comm_note"] = ("per step, rank 0, HIP events on the step's stream around every collective call (the stream waits for the "
+                            "collective when the call returns); compute_ms = event-timed step - comm_ms (includes pack / merge kernels)")
     if extras:
         # Every rank runs these extra steps (they contain the gradient exchange: a collective only rank 0 entered would
         # never return); rank 0 keeps the numbers.
@@ -430,7 +452,7 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
     return out
 
 
-def gather_score_hbm_leg(dev, rows=ALSO_C5_ITEMS, iters=40):
+def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
     """The embedding-gather+score launch alone at the C5 shape (d=256, 1-KiB rows, `rows`-row item table far beyond the
     Infinity Cache), B=1024 and B=8192.  Every launch is bracketed by a HIP event pair on its stream (ps_ktimer); the
     launches walk 8 different index sets in turn (8 x 67.6 MB at B=1024 > the 256 MB Infinity Cache), so a row read by

@@ -151,13 +151,14 @@ void ps_debug_fail_fork(int nth);
  * stream, weight gradients as per-split partial matrices added up in split order by a second launch, table scatters by
  * sole-owner half-waves that walk the task lists in order.  ~2.6x the default step time (0.78 ms at C2: a
  * popular row's additions are one chain); allocates scratch buffers on first use; process-wide.  The review transformer runs
- * in this mode too but keeps its own fp32-atomic reductions.  Returns the previous value. */
+ * in this mode too.  Returns the previous value; a negative argument only queries. */
 int ps_set_deterministic(int on);
 /* Product form of the large linears (no reference counterpart).  mode 1: launches with enough tiles to fill the chip take
  * the bf16x3 kernel — every fp32 operand split exactly into three bf16 values, six v_mfma_f32_32x32x16_bf16 per product step,
  * fp32 accumulation: as accurate as the fp32 MFMA (1.1e-7 of sum|a b|) at a third of its cycles; mode 0: the fp32 MFMA
  * everywhere.  force_shape -1: tile chosen by the launch's size; 0 / 1 / 2: 64x64 / 128x64 / 128x128 for every launch that
- * has an instantiation (tests).  Env PS_GEMM_X3 / PS_GEMM_X3_SHAPE set the initial values.  Process-wide. */
+ * has an instantiation (tests); 3: the direct-to-LDS form (fp32 slabs by global_load_lds, split on the fragments in registers,
+ * 128x128 tiles) wherever it applies.  Env PS_GEMM_X3 / PS_GEMM_X3_SHAPE set the initial values.  Process-wide. */
 int ps_gemm_x3_config(int mode, int force_shape);
 
 /* Workspace the caller allocates once per shape (bytes) and its layout. */
@@ -238,6 +239,12 @@ int ps_adam_sumsq(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyp
                   float* out_sumsq_dev, ps_stream_t stream);
 int ps_adam_update_ext(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
                        const float* total_sumsq_dev, float* gnorm_out_dev, ps_stream_t stream);
+
+/* Peer-to-peer reduce-scatter, local half (no reference counterpart: trainer.py:64-83 is single-process): recv [world][n] =
+ * every rank's copy of this rank's slice of the flat gradient (after an equal-split all-to-all); out[i] = sum over ranks in
+ * rank order; the same launch clears `zero_n` floats at `zero` (the flat gradient buffer the all-to-all has consumed).
+ * n and zero_n multiples of 4, buffers 16-byte aligned. */
+int ps_sum_slices(const float* recv, int32_t world, int64_t n, float* out, float* zero, int64_t zero_n, ps_stream_t stream);
 
 /* model.zero_grad() helper (trainer.py:76): async memset of a float buffer. */
 int ps_zero_floats(float* p, int64_t n, ps_stream_t stream);

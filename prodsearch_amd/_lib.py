@@ -151,6 +151,7 @@ SYMBOLS = {
                                      C.c_void_p]),
     'ps_dropout_mult_host': (C.c_float, [C.POINTER(PsTemDesc), C.c_uint32, C.c_uint32, C.c_uint32]),
     'ps_zero_floats': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    'ps_sum_slices': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'ps_graph_replay_enabled': (C.c_int, []),
     'ps_tem_staged_batch': (C.c_int, [C.POINTER(PsTemDesc), C.c_void_p, C.POINTER(PsTemBatch)]),
     'ps_tem_forward_step': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch), C.c_void_p,
@@ -274,7 +275,9 @@ def check_data(rc, what):
 
 
 def lib_path():
-    return _build.LIB
+    """The shipped library; with PS_DIAG_LIB=1 the diagnostic build (`python -m prodsearch_amd.build --diag`: the same sources
+    with -DPS_DIAG, which alone contains the tuning knobs, in-kernel stamps and timing-only kernel variants — tools/ only)."""
+    return _build.DIAG_LIB if os.environ.get('PS_DIAG_LIB') == '1' else _build.LIB
 
 
 def load():

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprodsearch_hip.so')
+DIAG_LIB = os.path.join(LIBDIR, 'libprodsearch_hip_diag.so')      # -DPS_DIAG: tuning knobs, stamps, timing-only variants (tools/)
 SOURCES = ['gemm.hip', 'rowwise.hip', 'attn_sq1.hip', 'mlp_fused.hip', 'optim.hip', 'optim_rows.hip', 'rank.hip', 'tem.hip', 'rtm.hip']
 HEADERS = ['common.h', 'rowwise.h', 'encoder.h', 'optim_core.h', 'graph.h', os.path.join('..', '..', 'include', 'prodsearch_hip.h')]
 
@@ -46,16 +47,19 @@ def _newer(path, deps):
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def _stale():
+def _stale(lib):
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return _newer(LIB, deps)
+    return _newer(lib, deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, diag=False):
     """Compile every HIP source for gfx950 — one object per source, in parallel, only the stale ones — and link
-    them into one shared library (plus the host batch builder); returns its path."""
+    them into one shared library (plus the host batch builder); returns its path.  diag=True builds the diagnostic
+    library beside it (same sources, -DPS_DIAG; see csrc/common.h, ps_diag_int) — never loaded unless PS_DIAG_LIB=1."""
     build_data(force, verbose)
-    if not force and not _stale():
+    LIB = DIAG_LIB if diag else globals()['LIB']
+    OBJDIR = globals()['OBJDIR'] + ('_diag' if diag else '')
+    if not force and not _stale(LIB):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -68,7 +72,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJDIR, src.replace('.hip', '.o'))
         objs.append(obj)
         if force or _newer(obj, [os.path.join(CSRC, src)] + hdrs):
-            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-o', obj, os.path.join(CSRC, src)]
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + (['-DPS_DIAG'] if diag else []) + \
+                  ['-c', '-o', obj, os.path.join(CSRC, src)]
             if verbose:
                 print(' '.join(cmd), file=sys.stderr)
             jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -89,4 +94,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, diag='--diag' in sys.argv))

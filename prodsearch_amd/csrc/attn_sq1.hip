@@ -192,7 +192,7 @@ bool attn_sq1_fits(const AttnArgs& a) {
 // head groups per sequence (grid.y): heads are independent, so a sequence's work can be cut into workgroups that each
 // walk the same latency chain over fewer columns; groups of 4 heads keep the shared Philox call of sq1_masks intact
 static inline int sq1_pick_split(const AttnArgs& a) {
-  static const int env = getenv("PS_ATTN_SPLIT") ? atoi(getenv("PS_ATTN_SPLIT")) : 0;     // tuning experiments
+  static const int env = ps_diag_int("PS_ATTN_SPLIT", 0);     // tuning experiments
   int hy = env > 0 ? env : 2;
   while (hy > 1 && (a.H % hy != 0 || (a.H / hy) % 4 != 0 || (a.d / hy) % 4 != 0)) hy >>= 1;
   return hy < 1 ? 1 : hy;
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
 // or 32 (d = 256, <= 24 positions) columns, keys
 // within the register budget and their keep bits within one word, the replicas of a chunk within the backward's row batch
 static bool attn_wf4_fits(const AttnArgs& a) {
-  static const bool on = !(getenv("PS_ATTN_WF") && atoi(getenv("PS_ATTN_WF")) == 0);
+  static const bool on = ps_env_int("PS_ATTN_WF", 1) != 0;
   return on && a.Sq == 1 && a.H == 8 && ((a.d == 128 && a.dh == 16 && a.S <= 32) || (a.d == 256 && a.dh == 32 && a.S <= 24)) &&
          a.fan >= 4 && a.fan <= 24;
 }
@@ -877,7 +877,7 @@ bool attn_wf_fits(const AttnArgs& a) { return attn_wf4_fits(a); }
 bool attn_bwd_wf_two_partials(const AttnArgs& a) { return attn_wf4_fits(a); }
 int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention(wf): unsupported shape");
-  static const int env_ch = getenv("PS_ATTN_WF_CHUNKS") ? atoi(getenv("PS_ATTN_WF_CHUNKS")) : 0;
+  static const int env_ch = ps_diag_int("PS_ATTN_WF_CHUNKS", 0);
   int nch = env_ch > 0 ? env_ch : (a.fan >= 12 ? 4 : 2);
   if (nch > a.fan) nch = a.fan;
   const dim3 grid(ps_cdiv(a.n_in * (a.H / 4) * nch, 4));
@@ -901,7 +901,7 @@ int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unrea
 }
 
 bool attn_w1_fits(const AttnArgs& a) {
-  static const bool on = !(getenv("PS_ATTN_W1") && atoi(getenv("PS_ATTN_W1")) == 0);
+  static const bool on = ps_env_int("PS_ATTN_W1", 1) != 0;
   const int lph = a.dh / 4;
   return on && a.Sq == 1 && a.fan == 1 && a.S <= 64 && (a.d == 128 || a.d == 64) && a.H <= W1_MAXH && a.dh % 4 == 0 &&
          lph >= 1 && (lph & (lph - 1)) == 0 && a.dh * a.H == a.d;

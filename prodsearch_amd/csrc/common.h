@@ -27,6 +27,23 @@ void ps_set_error(const char* fmt, ...);
 
 static inline int ps_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------ environment switches
+// ps_env_int: the SUPPORTED switches ("Switches"): alternative code paths with results of their own, every one
+// covered by tools/env_matrix.sh or a test.  ps_diag_int: launch-shape tuning and timing-experiment knobs (some of the latter
+// compute WRONG results on purpose: PS_MLP_DIAG, PS_RTM_DIAG, PS_X3D_DIAG) — they exist only in the diagnostic build
+// (hipcc -DPS_DIAG: `python -m prodsearch_amd.build --diag` -> lib/libprodsearch_hip_diag.so, which prodsearch_amd._lib
+// loads when PS_DIAG_LIB=1); in the shipped library the call folds to its default and a stray variable in a training
+// environment changes nothing.
+#include <stdlib.h>
+static inline int ps_env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+#ifdef PS_DIAG
+static inline int ps_diag_int(const char* name, int dflt) { return ps_env_int(name, dflt); }
+#define PS_DIAG_ON 1
+#else
+static inline int ps_diag_int(const char*, int dflt) { return dflt; }
+#define PS_DIAG_ON 0
+#endif
+
 // ------------------------------------------------------------------ kernel timer (measurement only)
 // ps_ktimer_arm("tag", n) makes the launch sites of ONE tagged kernel bracket their launch with a HIP event pair recorded
 // on the launch stream (bench.py's roofline: the kernel's in-step duration, measured live on its own stream);

@@ -265,6 +265,7 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
 #define KIDX_MAX PS_GEMM_KIDX_MAX
 // diagnostics (PS_GEMM_STAMP=2 / 3, tools/gemm_f32_stamps.py): s_memtime of the four waves of workgroup (0, 8, 0) at the phase
 // boundaries of the fp32 kernel — the step's own dX product over the row list (2) or its K/V projection (3)
+#if PS_DIAG_ON      // in-kernel phase stamps: diagnostic build only
 #define F32_STAMP(slot)                                                                                              \
   do {                                                                                                               \
     if (g.stamp && blockIdx.x == 0 && blockIdx.y == 8 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) {               \
@@ -273,6 +274,9 @@ __device__ __forceinline__ void epi_full(const GemmProblem& P, const float (*Ct)
       if ((slot) < 32) g.stamp[32 * (threadIdx.x >> 6) + (slot)] = t_;                                               \
     }                                                                                                                \
   } while (0)
+#else
+#define F32_STAMP(slot) do { } while (0)
+#endif
 template <int TA, int TB, int FULL, int BK, int PF, int IDX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   fork_signal(g.sig, g.sigval);
@@ -555,6 +559,7 @@ __device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R
   else x3g_store_impl<TRANS, R, false>(planes, reg, tid, k0, kend);
 }
 
+#if PS_DIAG_ON      // in-kernel phase stamps: diagnostic build only
 #define GEMM_STAMP(slot)                                                                                             \
   do {                                                                                                               \
     if (g.stamp && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) {   \
@@ -563,6 +568,9 @@ __device__ __forceinline__ void x3g_store(uint16_t* planes, const float (&reg)[R
       if ((slot) < 32) g.stamp[32 * (threadIdx.x >> 6) + (slot)] = t_;                                               \
     }                                                                                                                \
   } while (0)
+#else
+#define GEMM_STAMP(slot) do { } while (0)
+#endif
 template <int TA, int TB, int FULL, int MT, int NT, int IDX, int PF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   fork_signal(g.sig, g.sigval);
@@ -725,6 +733,258 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   GEMM_STAMP(31);
 }
 
+// ====================================================================== bf16x3 product form, operands straight into LDS (round 4)
+// gemm_x3_kernel above spends as long moving a slab VGPR -> split -> ds_write_b128 as multiplying it, and the two phases ADD
+// (profiles/r03_gemm_notes.md: fixed 31 + products 36 + loads / split / LDS stores 41 of the FF1 product's 100 us).  This form has
+// no store phase at all:
+//   * the fp32 operand slabs go global -> LDS by global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no ds_write); the LDS image
+//     is the DMA's lane-linear one, the bank swizzle sits on the per-lane SOURCE address (k contiguous: 128-byte rows, 16-byte
+//     chunk c of row r is stored at chunk c ^ ((r >> 1) & 7), so the ds_read_b128 lane groups of a fragment read hit 16
+//     different 16-byte slots; row contiguous: [k][128 rows], a fragment is eight conflict-free ds_read_b32);
+//   * a wave reads the fp32 fragments of a WHOLE 32-deep slab into registers (64 VGPRs), then the workgroup's loads of the
+//     next slab are issued into the other LDS stage and fly under the slab's products: one barrier per slab, and hipcc's
+//     forced vmcnt(0) in front of a ds_read that follows an LDS-DMA (SIInsertWaitcnts cannot tell the stages apart) falls
+//     where the loop has to wait anyway;
+//   * the three-way split happens on the fragments in registers, between the MFMAs (a wave pays it for the operands of its own
+//     64x64 accumulator only): tile 128x128, 4 waves, each wave the (wm, wn) 32x32 block of every 64x64 quadrant as above — so
+//     the epilogues serve unchanged — = 0.5 ds_read_b128 per MFMA; 64 KB of LDS per workgroup, two workgroups per CU, the other
+//     workgroup's wave on the SIMD multiplies while this one splits.
+// Takes what the kernel above takes except a ragged reduction tail and K-concatenated B operands (the caller falls back).
+#define X3D_BK 32
+#define X3D_T 128
+#define X3D_STAGE (2 * X3D_T * X3D_BK * 4)          // bytes of one stage: A slab + B slab
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// the four 16-byte pieces this thread fetches of one operand's slab (wave w issues instructions 4 w .. 4 w + 3, each 1 KB)
+template <int TRANS>
+__device__ __forceinline__ void x3d_issue(const float* const (&p)[4], size_t step, unsigned char* stage, int wave) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(p[j] + step), (lds_ptr_t)(stage + (4 * wave + j) * 1024), 16, 0, 0);
+}
+
+// fragment (8 reduction elements of one tile row per lane) of k-step s from a stage image, fp32
+template <int TRANS>
+__device__ __forceinline__ void x3d_frag(const unsigned char* img, int row, int s, int h, int swz, float (&f)[8]) {
+  if (TRANS == 0) {
+    const int c = 4 * s + 2 * h;
+    const float4 u = *reinterpret_cast<const float4*>(img + row * 128 + ((c ^ swz) << 4));
+    const float4 v = *reinterpret_cast<const float4*>(img + row * 128 + (((c + 1) ^ swz) << 4));
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+  } else {
+    const float* t = reinterpret_cast<const float*>(img) + (16 * s + 8 * h) * X3D_T + row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = t[j * X3D_T];
+  }
+}
+__device__ __forceinline__ void x3d_split8(const float (&f)[8], bf16x8 (&pl)[3]) {
+  uint32_t H[4], Mi[4], Lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x3g_split2(f[2 * e], f[2 * e + 1], H[e], Mi[e], Lo[e]);
+  pl[0] = __builtin_bit_cast(bf16x8, make_uint4(H[0], H[1], H[2], H[3]));
+  pl[1] = __builtin_bit_cast(bf16x8, make_uint4(Mi[0], Mi[1], Mi[2], Mi[3]));
+  pl[2] = __builtin_bit_cast(bf16x8, make_uint4(Lo[0], Lo[1], Lo[2], Lo[3]));
+}
+
+// DIAG (diagnostic build only, PS_X3D_DIAG; WRONG results): 1 no split (raw bits as planes), 2 no MFMAs, 3 no slab loads in the loop
+template <int TA, int TB, int FULL, int IDX, int DIAG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_x3d_kernel(const GemmGroup g) {
+  fork_signal(g.sig, g.sigval);
+  constexpr int MT = 2, NT = 2;
+  constexpr int MAIN_BYTES = 2 * X3D_STAGE;
+  constexpr int EPI_BYTES = FULL ? MT * NT * 64 * LDT * 4 : 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  __shared__ int kidx[IDX && TA == 1 ? KIDX_MAX : 1];
+
+  int prob, split, ftile = 0;
+  if (g.flat) {
+    const int L = blockIdx.x;
+    prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
+    const int t = L - g.flat0[prob];
+    split = t / g.flat_tiles[prob];
+    ftile = t - split * g.flat_tiles[prob];
+  } else {
+    prob = blockIdx.z / g.p[0].ksplit;
+    split = blockIdx.z - prob * g.p[0].ksplit;
+  }
+  const GemmProblem& P = g.p[prob];
+  const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
+  const int nlist = listed ? *P.rcount : 0;
+  const int M = (listed && TA == 0) ? nlist : P.M, N = P.N, K = (listed && TA == 1) ? nlist : P.K;
+  int tm, tn;                                                    // XCD-aware tile mapping as in gemm_f32_kernel
+  if (g.flat) {
+    tm = ftile % g.flat_tm[prob];
+    tn = ftile / g.flat_tm[prob];
+  } else {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int L = blockIdx.y * nx + blockIdx.x;
+    const int grp = L / (8 * nx), r = L - grp * 8 * nx;
+    const int rows_here = min(8, ny - grp * 8);
+    tm = grp * 8 + r % rows_here;
+    tn = r / rows_here;
+  }
+  const int m0 = tm * X3D_T, n0 = tn * X3D_T;
+  const int nslab = (K + X3D_BK - 1) / X3D_BK;
+  const int per = (nslab + P.ksplit - 1) / P.ksplit;
+  const int kbeg = split * per * X3D_BK;
+  const int kend = min(K, kbeg + per * X3D_BK);
+  if (m0 >= M || n0 >= N || kbeg >= kend) return;   // block-uniform
+  const int nsl = (kend - kbeg + X3D_BK - 1) / X3D_BK;      // listed weight gradients: a ragged last slab repeats the list's last row ...
+  const int ktail = kend - kbeg - (nsl - 1) * X3D_BK;       // ... and the fragments of the repeated rows are zeroed (below)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+
+  // ---- per-thread sources of the slab loads
+  const float* pa[4];
+  const float* pb[4];
+  size_t stepa, stepb;                                           // floats per slab
+  if (listed && TA == 1) {                                       // physical reduction rows of this split -> LDS (padded by the last one)
+    for (int i = tid; i < nsl * X3D_BK; i += 256) kidx[i] = P.ridx[min(kbeg + i, kend - 1)];
+    __syncthreads();
+  }
+  if (TA == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 32 * wave + 8 * j + (lane >> 3);
+      int row = min(m0 + r, M - 1);
+      if (listed) row = P.ridx[row];
+      pa[j] = P.A + (size_t)row * P.lda + kbeg + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    stepa = X3D_BK;
+  } else {
+    const int col = min(m0 + 4 * (lane & 31), M - 4);          // M % 4 == 0 (validated)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pa[j] = P.A + (size_t)(listed ? 0 : kbeg + 8 * wave + 2 * j + (lane >> 5)) * P.lda + col;
+    stepa = (size_t)X3D_BK * P.lda;
+  }
+  if (TB == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 32 * wave + 8 * j + (lane >> 3);
+      pb[j] = P.Bseg[0] + (size_t)min(n0 + r, N - 1) * P.ldb + kbeg + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+    stepb = X3D_BK;
+  } else {
+    const int col = min(n0 + 4 * (lane & 31), N - 4);          // N % 4 == 0 (validated)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pb[j] = P.Bseg[0] + (size_t)((listed && TA == 1) ? 0 : kbeg + 8 * wave + 2 * j + (lane >> 5)) * P.ldb + col;
+    stepb = (size_t)X3D_BK * P.ldb;
+  }
+  auto issue = [&](int it) __attribute__((always_inline)) {
+    unsigned char* const stage = smem + (it & 1) * X3D_STAGE;
+    if (listed && TA == 1) {                                     // reduction rows through the list
+      const float* qa[4];
+      const float* qb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t kr = (size_t)kidx[it * X3D_BK + 8 * wave + 2 * j + (lane >> 5)];
+        qa[j] = pa[j] + kr * P.lda;
+        qb[j] = pb[j] + kr * P.ldb;
+      }
+      x3d_issue<TA>(qa, 0, stage, wave);
+      x3d_issue<TB>(qb, 0, stage + X3D_STAGE / 2, wave);
+    } else {
+      x3d_issue<TA>(pa, it * stepa, stage, wave);
+      x3d_issue<TB>(pb, it * stepb, stage + X3D_STAGE / 2, wave);
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int swz = (l31 >> 1) & 7;
+  issue(0);
+  for (int it = 0; it < nsl; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's pieces of slab `it` have landed
+    __syncthreads();                                             // everybody's; and everybody is done with the other stage
+    const unsigned char* const sa = smem + (it & 1) * X3D_STAGE;
+    const unsigned char* const sb = sa + X3D_STAGE / 2;
+    float fa[2][MT][8], fb[2][NT][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) x3d_frag<TA>(sa, 64 * mi + 32 * wm + l31, s, h, swz, fa[s][mi]);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) x3d_frag<TB>(sb, 64 * ni + 32 * wn + l31, s, h, swz, fb[s][ni]);
+    }
+    if (it + 1 < nsl && DIAG != 3) issue(it + 1);                // block-uniform; flies under the products below
+    if (IDX && TA == 1 && it == nsl - 1 && ktail < X3D_BK) {     // ragged tail of a listed reduction: zero A's repeated rows
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (16 * s + 8 * h + j >= ktail) fa[s][mi][j] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[MT][3], b[NT][3];
+      if (DIAG == 1) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          a[mi][0] = a[mi][2] = __builtin_bit_cast(bf16x8, make_float4(fa[s][mi][0], fa[s][mi][1], fa[s][mi][2], fa[s][mi][3]));
+          a[mi][1] = __builtin_bit_cast(bf16x8, make_float4(fa[s][mi][4], fa[s][mi][5], fa[s][mi][6], fa[s][mi][7]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          b[ni][0] = b[ni][2] = __builtin_bit_cast(bf16x8, make_float4(fb[s][ni][0], fb[s][ni][1], fb[s][ni][2], fb[s][ni][3]));
+          b[ni][1] = __builtin_bit_cast(bf16x8, make_float4(fb[s][ni][4], fb[s][ni][5], fb[s][ni][6], fb[s][ni][7]));
+        }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) x3d_split8(fa[s][mi], a[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) x3d_split8(fb[s][ni], b[ni]);
+      }
+      if (DIAG == 2) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(a[mi][p])); asm volatile("" ::"v"(b[mi][p])); }
+        continue;
+      }
+#define X3D_TERM(pa_, pb_)                                                                                        \
+  _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)              \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][pa_], b[ni][pb_], acc[mi][ni], 0, 0, 0);
+      X3D_TERM(0, 2) X3D_TERM(2, 0) X3D_TERM(1, 1) X3D_TERM(0, 1) X3D_TERM(1, 0) X3D_TERM(0, 0)
+#undef X3D_TERM
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue, one 64x64 quadrant at a time (as gemm_x3_kernel)
+  if (!FULL) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        if (m0 + 64 * mi < M && n0 + 64 * ni < N)
+          epi_plain<TA, IDX>(P, acc[mi][ni], m0 + 64 * mi, n0 + 64 * ni, split, M, N, listed, wm, wn, l31, h);
+    return;
+  }
+  __syncthreads();                                               // the last slab's fragments have left LDS in every wave
+  float (*Ct)[64][LDT] = reinterpret_cast<float (*)[64][LDT]>(smem);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) epi_stage(Ct[mi * NT + ni], acc[mi][ni], wm, wn, l31, h);
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < MT * NT; ++q) {
+    const int mq = m0 + 64 * (q / NT), nq = n0 + 64 * (q % NT);
+    if (mq < M && nq < N) epi_full<TA, IDX>(P, Ct[q], mq, nq, MT * tm + q / NT, split, M, N, listed, tid);
+  }
+}
+
 static bool needs_full(const GemmProblem& p) {
   return p.act != ACT_NONE || p.drop.thr != 0u || p.res.mode != RES_NONE || p.aux_out || p.out2 || p.colsum;
 }
@@ -759,7 +1019,7 @@ template <int FULL, int BK>
 static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGroup& g) {
   // two 32-deep slabs in flight (measured on MI355X: 1 -> 2 takes the 8064x128x512 product from 24.4 to 20.5 us and
   // 4096^3 from 104 to 112 TFLOP/s; 3 and 4 give nothing more); a 128-deep slab is a whole reduction already
-  static const int wg_pf = getenv("PS_WGRAD_PF") ? atoi(getenv("PS_WGRAD_PF")) : 2;   // tuning experiments
+  static const int wg_pf = ps_diag_int("PS_WGRAD_PF", 2);   // tuning experiments
   if (BK == 32 && !FULL && ta == 1 && tb == 1 && wg_pf == 4) {
     hipLaunchKernelGGL((gemm_f32_kernel<1, 1, 0, 32, 4>), grid, dim3(256), 0, stream, g);
     return;
@@ -776,23 +1036,22 @@ static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGrou
 // 0 = 64x64 tiles; -1 = the fp32 kernel (small / latency-bound launches, where the deep-slab forms above matter more).
 // Measured at the d = 256 shard step (21,504 rows): 128x64 wins on every forward / dX product (128x128: 2 workgroups per
 // CU, 1.53 vs 1.41 ms per step), the weight gradients take 64x64 with the split counts tem.hip picks.
-static int x3_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int g_x3_mode = -2, g_x3_force = -1;           // -2: not read yet
 extern "C" int ps_gemm_x3_config(int mode, int force_shape) {   // tests / experiments: mode 0|1, force_shape -1 (rule) | 0 | 1 | 2
-  PS_REQUIRE((mode == 0 || mode == 1) && force_shape >= -1 && force_shape <= 2, "gemm x3 config %d %d", mode, force_shape);
+  PS_REQUIRE((mode == 0 || mode == 1) && force_shape >= -1 && force_shape <= 3, "gemm x3 config %d %d", mode, force_shape);
   g_x3_mode = mode; g_x3_force = force_shape;
   return PS_OK;
 }
 static bool x3_on() {
-  if (g_x3_mode == -2) { g_x3_mode = x3_env("PS_GEMM_X3", 1) ? 1 : 0; g_x3_force = x3_env("PS_GEMM_X3_SHAPE", -1); }
+  if (g_x3_mode == -2) { g_x3_mode = ps_env_int("PS_GEMM_X3", 1) ? 1 : 0; g_x3_force = ps_env_int("PS_GEMM_X3_SHAPE", -1); }
   return g_x3_mode != 0;
 }
 bool gemm_x3_on() { return x3_on(); }
 static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   x3_on();
-  static const int t22 = x3_env("PS_GEMM_X3_T22", 4096), t21 = x3_env("PS_GEMM_X3_T21", 384), t11 = x3_env("PS_GEMM_X3_T11", 512);
+  static const int t22 = ps_diag_int("PS_GEMM_X3_T22", 4096), t21 = ps_diag_int("PS_GEMM_X3_T21", 384), t11 = ps_diag_int("PS_GEMM_X3_T11", 512);
   if (!g_x3_mode) return -1;
-  if (g_x3_force >= 0) return g_x3_force > 2 ? 2 : g_x3_force;
+  if (g_x3_force >= 0) return g_x3_force > 3 ? 3 : g_x3_force;
   const int z = g.n * g.p[0].ksplit;
   int kmin = g.p[0].K;
   for (int i = 1; i < g.n; ++i) kmin = g.p[i].K < kmin ? g.p[i].K : kmin;
@@ -803,7 +1062,7 @@ static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   for (int i = 1; i < g.n; ++i) { nmin = g.p[i].N < nmin ? g.p[i].N : nmin; mmin = g.p[i].M < mmin ? g.p[i].M : mmin; }
   // ... and the forward / dX products over very many rows (the review transformer's 78k sequence positions), with 64x64 tiles:
   // 0.544 -> 0.534 ms per step there (its weight gradients gain nothing: PS_GEMM_X3_TALL=2 adds them)
-  static const int tall = x3_env("PS_GEMM_X3_TALL", 1);
+  static const int tall = ps_diag_int("PS_GEMM_X3_TALL", 1);
   if (tall >= 1 && !g.p[0].ta && maxM >= 32768) return 0;
   if (tall >= 2 && g.p[0].ta && kmin >= 32768) return 0;
   if (kmin < 256 || nmin < 256 || kmin / g.p[0].ksplit < 256 || (g.p[0].ta && mmin < 256)) return -1;
@@ -820,8 +1079,62 @@ static void launch_x3(int shape, dim3 grid, hipStream_t stream, const GemmGroup&
   else if (shape == 1) hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 2, 1, IDX, 1>), grid, dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_x3_kernel<TA, TB, FULL, 1, 1, IDX, 1>), grid, dim3(256), 0, stream, g);
 }
+// flat weight-gradient groups: which tile (false: 64x64 of gemm_x3_kernel, true: 128x128 of gemm_x3d_kernel)
+static bool x3_flat_d(const GemmGroup& g) {
+  x3_on();
+  (void)g;
+  return g_x3_force == 3;
+}
+// the direct-to-LDS form (gemm_x3d_kernel) takes single-segment operands and whole 32-deep slabs (a listed weight gradient pads
+// its reduction list itself)
+static bool x3d_takes(const GemmGroup& g) {
+  for (int i = 0; i < g.n; ++i) {
+    const GemmProblem& p = g.p[i];
+    if (p.K > p.kseg) return false;
+    if (p.K % X3D_BK != 0 && !(p.ridx && p.ta)) return false;
+    if (((uintptr_t)p.Bseg[0] & 15) || ((uintptr_t)p.A & 15)) return false;
+  }
+  return true;
+}
+template <int TA, int TB, int FULL, int IDX>
+static void launch_x3d(dim3 grid, hipStream_t stream, const GemmGroup& g) {
+  hipLaunchKernelGGL((gemm_x3d_kernel<TA, TB, FULL, IDX>), grid, dim3(256), 0, stream, g);
+}
+static bool try_x3d(int ta, int tb, bool full, bool listed, int maxM, int maxN, int z, hipStream_t stream, const GemmGroup& g) {
+  if (!x3d_takes(g)) return false;
+  const dim3 grid(ps_cdiv(maxN, X3D_T), ps_cdiv(maxM, X3D_T), z);
+  if (grid.y > 65535) return false;
+#ifdef PS_DIAG
+  static const int diag = ps_diag_int("PS_X3D_DIAG", 0), pad = ps_diag_int("PS_X3D_LDSPAD", 0);   // pad: dynamic LDS bytes (96 KB total = one workgroup per CU)
+  if (!listed && ta == 0 && tb == 0 && !full && (diag || pad)) {
+    if (diag == 1) hipLaunchKernelGGL((gemm_x3d_kernel<0, 0, 0, 0, 1>), grid, dim3(256), pad, stream, g);
+    else if (diag == 2) hipLaunchKernelGGL((gemm_x3d_kernel<0, 0, 0, 0, 2>), grid, dim3(256), pad, stream, g);
+    else if (diag == 3) hipLaunchKernelGGL((gemm_x3d_kernel<0, 0, 0, 0, 3>), grid, dim3(256), pad, stream, g);
+    else hipLaunchKernelGGL((gemm_x3d_kernel<0, 0, 0, 0, 0>), grid, dim3(256), pad, stream, g);
+    return true;
+  }
+#endif
+  if (!listed) {
+    if (ta == 0 && tb == 0 && full) launch_x3d<0, 0, 1, 0>(grid, stream, g);
+    else if (ta == 0 && tb == 0) launch_x3d<0, 0, 0, 0>(grid, stream, g);
+    else if (ta == 0 && tb == 1 && full) launch_x3d<0, 1, 1, 0>(grid, stream, g);
+    else if (ta == 0 && tb == 1) launch_x3d<0, 1, 0, 0>(grid, stream, g);
+    else if (ta == 1 && tb == 1 && !full) launch_x3d<1, 1, 0, 0>(grid, stream, g);
+    else return false;
+  } else {
+    if (ta == 0 && tb == 1 && full) launch_x3d<0, 1, 1, 1>(grid, stream, g);
+    else if (ta == 1 && tb == 1 && !full) launch_x3d<1, 1, 0, 1>(grid, stream, g);
+    else if (ta == 0 && tb == 0 && !full) launch_x3d<0, 0, 0, 1>(grid, stream, g);
+    else return false;
+  }
+  return true;
+}
 // false: no instantiation for this combination (the caller falls back to the fp32 kernel)
 static bool try_x3(int ta, int tb, bool full, bool listed, int shape, int maxM, int maxN, int z, hipStream_t stream, const GemmGroup& g) {
+  if (shape == 3) {
+    if (try_x3d(ta, tb, full, listed, maxM, maxN, z, stream, g)) return true;
+    shape = 1;                                                   // what the rule picked before this form existed
+  }
   const dim3 grid(ps_cdiv(maxN, shape == 2 ? 128 : 64), ps_cdiv(maxM, shape >= 1 ? 128 : 64), z);
   if (grid.y > 65535) return false;
   if (!listed) {
@@ -844,7 +1157,7 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
 int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   GemmGroup g = g0;
   g.sig = nullptr; g.sigval = 0;
-  static const int stamps = getenv("PS_GEMM_STAMP") ? atoi(getenv("PS_GEMM_STAMP")) : 0;
+  static const int stamps = ps_diag_int("PS_GEMM_STAMP", 0);
   const bool stamp_this = stamps == 1 || (stamps == 2 && g0.p[0].ridx && g0.p[0].res.mode == RES_FANIN) ||
                           (stamps == 3 && g0.p[0].ridx && !g0.p[0].ta && g0.p[0].res.mode == RES_NONE) ||
                           (stamps == 4 && g0.n == 3 && g0.p[0].ta && !g0.p[0].ridx);      // 4: the grouped FF / Wo weight gradients
@@ -857,25 +1170,32 @@ int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
 static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
   PS_REQUIRE(g.n >= 1 && g.n <= 3, "gemm: group size %d", g.n);
   if (g.flat) {
-    GemmGroup f = g;
-    int total = 0;
-    for (int i = 0; i < 3; ++i) {
-      f.flat0[i] = total;
-      if (i >= g.n) { f.flat_tm[i] = 1; f.flat_tiles[i] = 1; continue; }
+    for (int i = 0; i < g.n; ++i) {
       int rc = validate(g.p[i]);
       if (rc) return rc;
       PS_REQUIRE(g.p[i].ta == 1 && g.p[i].tb == 1 && !needs_full(g.p[i]) && !g.p[i].ridx && g.p[i].ksplit >= 1 &&
                  (g.p[i].accumulate == 2 || (g.p[i].accumulate == 0 && g.p[i].split_stride > 0)),
                  "gemm: the flat group form takes plain weight-gradient problems");
-      f.flat_tm[i] = ps_cdiv(g.p[i].M, BM);
-      f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, BN);
+    }
+    // the bf16x3 forms (the same flat tables): C2's W2 / W1 / Wo weight gradients 0.2905 -> 0.2845 ms per step with 64x64 tiles
+    // (round 2); 128x128 tiles of the direct-to-LDS form where x3_flat_shape() says so
+    static const int flat_x3 = ps_diag_int("PS_GEMM_X3_FLAT", 1);
+    const bool x3 = flat_x3 && x3_on();
+    const bool x3d = x3 && x3_flat_d(g) && x3d_takes(g);
+    const int T = x3d ? X3D_T : BM;
+    GemmGroup f = g;
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+      f.flat0[i] = total;
+      if (i >= g.n) { f.flat_tm[i] = 1; f.flat_tiles[i] = 1; continue; }
+      f.flat_tm[i] = ps_cdiv(g.p[i].M, T);
+      f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, T);
       total += f.flat_tiles[i] * g.p[i].ksplit;
     }
     f.flat0[3] = total;
     for (int i = g.n; i < 3; ++i) f.flat0[i] = total + 1;      // never selected
-    // the bf16x3 form with 64x64 tiles (the same flat tables): C2's W2 / W1 / Wo weight gradients 0.2905 -> 0.2845 ms per step
-    static const int flat_x3 = x3_env("PS_GEMM_X3_FLAT", 1);
-    if (flat_x3 && x3_on()) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    if (x3d) hipLaunchKernelGGL((gemm_x3d_kernel<1, 1, 0, 0>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
     PS_LAUNCH_CHECK();
     return PS_OK;
@@ -919,7 +1239,7 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     else if (ta == 0 && tb == 0 && !full) {
       // small launches whose whole reduction is one 128-deep slab (the K/V projection at C2: ~240 live workgroups):
       // one global round trip instead of four shallow slabs (0.3615 -> 0.3564 ms/step); big grids keep 4 workgroups per CU
-      static const int deep_kv = getenv("PS_KV_DEEP") ? atoi(getenv("PS_KV_DEEP")) : 1;   // tuning experiment
+      static const int deep_kv = ps_diag_int("PS_KV_DEEP", 1);   // tuning experiment
       if (deep_kv && g.p[0].K <= 128 && (size_t)grid.x * grid.y * grid.z <= 1024)
         hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 128, 1, 1>), grid, dim3(256), 0, stream, g);
       else hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 0, 32, 2, 1>), grid, dim3(256), 0, stream, g);
@@ -928,10 +1248,10 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     PS_LAUNCH_CHECK();
     return PS_OK;
   }
-  static const int repeat = getenv("PS_DEBUG_REPEAT") ? atoi(getenv("PS_DEBUG_REPEAT")) : 1;   // timing experiments only
+  static const int repeat = ps_diag_int("PS_DEBUG_REPEAT", 1);   // timing experiments only
   for (int r = 0; r < repeat; ++r) {
     // few workgroups (latency-bound chain): one deep slab per round trip; many: shallow slabs, 4 wgs per CU
-    static const int deep_max = getenv("PS_GEMM_DEEP_MAX") ? atoi(getenv("PS_GEMM_DEEP_MAX")) : 64;         // tuning experiments
+    static const int deep_max = ps_diag_int("PS_GEMM_DEEP_MAX", 64);         // tuning experiments
     const bool deep = (size_t)grid.x * grid.y * grid.z <= (size_t)deep_max && !g.p[0].no_deep;
     if (full && deep) launch<1, 128>(g.p[0].ta, g.p[0].tb, grid, stream, g);
     else if (full) launch<1, 32>(g.p[0].ta, g.p[0].tb, grid, stream, g);
@@ -953,7 +1273,7 @@ extern "C" int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int
   p.C = Cm; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
   p.bias = bias; p.alpha = alpha; p.act = ACT_NONE;
   p.accumulate = accumulate == 2 ? 2 : accumulate;
-  static const int ks = getenv("PS_GEMM_KSPLIT") ? atoi(getenv("PS_GEMM_KSPLIT")) : 4;   // timing experiments
+  static const int ks = ps_diag_int("PS_GEMM_KSPLIT", 4);   // timing experiments
   p.ksplit = accumulate == 2 ? ks : 1;
   return ps_launch_gemm(g, (hipStream_t)stream);
 }

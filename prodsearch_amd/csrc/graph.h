@@ -33,7 +33,7 @@ struct PsGraphEntry {
 };
 
 inline bool ps_graphs_enabled() {
-  static const bool on = getenv("PS_GRAPHS") && atoi(getenv("PS_GRAPHS")) != 0;
+  static const bool on = ps_env_int("PS_GRAPHS", 0) != 0;
   return on;
 }
 
@@ -74,7 +74,7 @@ inline hipStream_t ps_graph_begin() {
 // Ends the capture on `st`; on success the entry holds an instantiated graph.  `patch_funcs`: kernels (device function
 // addresses) whose nodes the caller will re-parameterise before each replay, located here once.
 inline bool ps_graph_debug() {
-  static const bool on = getenv("PS_GRAPH_DEBUG") && atoi(getenv("PS_GRAPH_DEBUG")) != 0;
+  static const bool on = ps_diag_int("PS_GRAPH_DEBUG", 0) != 0;
   return on;
 }
 inline int ps_graph_end(hipStream_t st, PsGraphEntry* e, const void* const* patch_funcs, int n_patch) {

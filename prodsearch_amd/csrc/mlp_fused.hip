@@ -33,7 +33,7 @@
 #endif
 
 bool ps_fusion_enabled() {
-  static const bool on = !(getenv("PS_NO_FUSE") && atoi(getenv("PS_NO_FUSE")) != 0);
+  static const bool on = ps_env_int("PS_NO_FUSE", 0) == 0;
   return on;
 }
 
@@ -135,6 +135,7 @@ __device__ __forceinline__ void dump_acc(float* slot, const f32x16& v, int l31, 
 static unsigned long long* g_mlp_stamp = nullptr;
 extern "C" void ps_debug_set_stamp_buffer(void* p) { g_mlp_stamp = (unsigned long long*)p; }
 unsigned long long* ps_debug_stamp_ptr() { return g_mlp_stamp; }
+#if PS_DIAG_ON      // in-kernel phase stamps: diagnostic build only
 #define MLP_STAMP(slot)                                                                              \
   do {                                                                                               \
     if (a.stamp && blockIdx.x == 0 && lane == 0) {                                                   \
@@ -143,6 +144,9 @@ unsigned long long* ps_debug_stamp_ptr() { return g_mlp_stamp; }
       a.stamp[16 * wave + (slot)] = t_;                                                              \
     }                                                                                                \
   } while (0)
+#else
+#define MLP_STAMP(slot) do { } while (0)
+#endif
 
 // ====================================================================== forward
 // Lane roles.  Products: lane (l31, h) = replica row l31 of the workgroup, half h; accumulator register r = logical feature
@@ -439,7 +443,7 @@ int64_t mlp_x3_floats(int d, int F) {      // forward + backward fragment stream
   return ((int64_t)2 * 3 * ((int64_t)d * d + 2 * (int64_t)d * F) * 2 + 3) / 4 + 16;
 }
 bool mlp_fwd_can_fold_score(int M, int F, int d) {
-  static const bool fold_on = !(getenv("PS_NO_FOLD_SCORE") && atoi(getenv("PS_NO_FOLD_SCORE")) != 0);
+  static const bool fold_on = ps_env_int("PS_NO_FOLD_SCORE", 0) == 0;
   return fold_on && d == MD && mlp_x3_enabled(F) && M > 0 &&
          ps_cdiv(M, MBM) <= 256;               // one workgroup per CU, all resident: the ticket hand-off's measured regime
 }
@@ -462,12 +466,16 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   MlpFwdArgs as = a;
   as.stamp = g_mlp_stamp;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
-  static bool a1 = false, a2 = false, a4 = false, ad1 = false, ad2 = false, ad3 = false;
-  static const int diag = getenv("PS_MLP_DIAG") ? atoi(getenv("PS_MLP_DIAG")) : 0;          // timing experiments (wrong results)
-  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && diag == 1) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 1>, ad1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 1>), grid, block, sizeof(MlpTLds), st, as); }
+  static bool a1 = false, a2 = false, a4 = false;
+#ifdef PS_DIAG                                                     // timing experiments (WRONG results): diagnostic build only
+  static bool ad1 = false, ad2 = false, ad3 = false;
+  static const int diag = ps_diag_int("PS_MLP_DIAG", 0);
+  if (a.F == 512 && diag == 1) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 1>, ad1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 1>), grid, block, sizeof(MlpTLds), st, as); }
   else if (a.F == 512 && diag == 2) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 2>, ad2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 2>), grid, block, sizeof(MlpTLds), st, as); }
   else if (a.F == 512 && diag == 3) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 3>, ad3)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else
+#endif
+  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
   else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
   else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); hipLaunchKernelGGL((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
   PS_LAUNCH_CHECK();

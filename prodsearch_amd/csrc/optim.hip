@@ -166,6 +166,38 @@ extern "C" int32_t ps_adam_plan_chunks_host(const void* plan_host) {
   return ((const AdamPlanHeader*)plan_host)->n_chunks;
 }
 
+// Data-parallel reduce-scatter in its peer-to-peer form (dist.ShardedAdamExchange, rs 'a2a'): after the equal-split all-to-all
+// recv[r][0..n) is rank r's copy of THIS rank's slice of the flat gradient; out[i] = sum_r recv[r][i] added in rank order (the
+// same bits on every run), and — the all-to-all has consumed it — the flat gradient buffer is cleared by the same launch, so
+// the step path has no torch kernel and no separate memset.  float4 grid-stride; n % 4 == 0 (slices are cut that way).
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float4* __restrict__ recv, int W, int64_t n4, float4* __restrict__ out,
+                                                         float4* __restrict__ zero, int64_t zero4) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 s = recv[i];
+    for (int r = 1; r < W; ++r) {
+      const float4 v = recv[(int64_t)r * n4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[i] = s;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < zero4; i += stride) zero[i] = z;
+}
+extern "C" int ps_sum_slices(const float* recv, int32_t world, int64_t n, float* out, float* zero, int64_t zero_n,
+                             ps_stream_t stream) {
+  PS_REQUIRE(recv && out && world >= 1 && n >= 0 && n % 4 == 0 && zero_n >= 0 && zero_n % 4 == 0 && (zero || zero_n == 0),
+             "sum_slices: bad argument (n %lld, zero_n %lld)", (long long)n, (long long)zero_n);
+  PS_REQUIRE((((uintptr_t)recv | (uintptr_t)out | (uintptr_t)zero) & 15) == 0, "sum_slices: buffers must be 16-byte aligned");
+  const int64_t work = (n > zero_n ? n : zero_n) / 4;
+  if (work == 0) return PS_OK;
+  const int grid = (int)(work / 256 + 1 < 2048 ? work / 256 + 1 : 2048);
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)recv, world, n / 4, (float4*)out,
+                     (float4*)zero, zero_n / 4);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 extern "C" int ps_zero_floats(float* p, int64_t n, ps_stream_t stream) {
   PS_REQUIRE(p && n >= 0, "zero: bad argument");
   PS_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(float), (hipStream_t)stream));

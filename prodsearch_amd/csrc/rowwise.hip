@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
 // Measured (MI355X): C5 shape B=1024 22.6 -> 13.6 us (4.99 TB/s), B=8192 167 -> 95.7 us (5.65 TB/s = 0.71 of the HBM
 // peak); the latency-bound C2 launch 5.03 -> 4.23 us back to back (floor of an empty launch: 3.8 us).
 static int score_wide_ch(const ScoreArgs& a, int ntask) {
-  static const int env = getenv("PS_SCORE_CH") ? atoi(getenv("PS_SCORE_CH")) : -1;   // tuning: 0 off, 2 / 4 / 8 force
+  static const int env = ps_diag_int("PS_SCORE_CH", -1);   // tuning: 0 off, 2 / 4 / 8 force
   const int nch = a.d / 4;
   int ch;
   if (env >= 0) ch = env;
@@ -928,14 +928,14 @@ static int score_wide_ch(const ScoreArgs& a, int ntask) {
   return (ch == 2 || ch == 4 || ch == 8) && nch / ch <= 64 ? ch : 0;
 }
 static int score_wide_u() {
-  static const int env = getenv("PS_SCORE_WIDE_U") ? atoi(getenv("PS_SCORE_WIDE_U")) : 1;
-  static const int ch = getenv("PS_SCORE_CH") ? atoi(getenv("PS_SCORE_CH")) : 0;
+  static const int env = ps_diag_int("PS_SCORE_WIDE_U", 1);
+  static const int ch = ps_diag_int("PS_SCORE_CH", 0);
   return env == 2 && ch != 8 ? 2 : 1;
 }
 
 // one-chunk fallback: one task per row group below 64 MB of rows per launch, two above
 static int score_one_chunk_u(const ScoreArgs& a, int ntask) {
-  static const int Uenv = getenv("PS_SCORE_U") ? atoi(getenv("PS_SCORE_U")) : 0;     // tuning experiments (1 or 2)
+  static const int Uenv = ps_diag_int("PS_SCORE_U", 0);     // tuning experiments (1 or 2)
   if (Uenv == 1 || Uenv == 2) return Uenv;
   return (size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2;
 }

@@ -462,9 +462,11 @@ struct E4Lds {
 };
 template <int NCHL>     // 16-byte chunks per lane of a 16-lane group: d = 64 * NCHL
 __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_grp, int nneg_grp, FDiv fR, FDiv fK, int pads_unread,
-                                                         const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg, int diag) {
+                                                         const int* __restrict__ glist, const int* __restrict__ gcount, int nq_wg, int diag_arg) {
+  const int diag = PS_DIAG_ON ? diag_arg : 0;      // timing-only variants (WRONG results) exist in the diagnostic build only
   __shared__ E4Lds<NCHL> L;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if PS_DIAG_ON      // in-kernel phase stamps: diagnostic build only
 #define E4_STAMP(slot)                                                                             \
   do {                                                                                             \
     if (a.stamp && (int)blockIdx.x == nq_wg + 8 && lane == 0) {                                    \
@@ -473,6 +475,9 @@ __global__ __launch_bounds__(256) void rtm_embed4_kernel(const RtmK a, int npos_
       a.stamp[16 * wv + (slot)] = t_;                                                              \
     }                                                                                              \
   } while (0)
+#else
+#define E4_STAMP(slot) do { } while (0)
+#endif
   E4_STAMP(0);
   // PS_RTM_STAMP=1 PS_RTM_DIAG=64 (tools/rtm_wg_times.py): start / end time (s_memrealtime: the 100 MHz counter all CUs share —
   // s_memtime is per CU) and XCC of EVERY workgroup's wave 0, behind the phase slots
@@ -1738,7 +1743,7 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
   k.B = D.B; k.J = r.J; k.K = D.K; k.R = D.R; k.S = r.S; k.Q = D.Q; k.W = D.W > 0 ? D.W : 1; k.WL = D.WL; k.d = D.d;
   k.V = D.vocab_size; k.RC = D.review_count;
   k.det = ps_deterministic() ? 1 : 0;
-  static const bool rtm_stamps = getenv("PS_RTM_STAMP") && atoi(getenv("PS_RTM_STAMP")) != 0;
+  static const bool rtm_stamps = ps_diag_int("PS_RTM_STAMP", 0) != 0;
   k.stamp = rtm_stamps ? ps_debug_stamp_ptr() : nullptr;
   // `pvc` = every word-mean review encoder in training (pvc, fs, avg); only pvc corrupts tokens and ignores the word masks
   k.pvc = D.review_encoder != PS_RENC_PV && !eval; k.use_pos = D.use_pos_emb; k.use_seg = D.use_seg_emb;
@@ -1786,7 +1791,7 @@ static void fill_k(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatch& 
 // embeds through rtm_embed4_kernel, which holds every word id in registers; the backward then only allocates and fills,
 // on the side stream under its first kernels.
 static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
-  static const bool e4_on = !(getenv("PS_RTM_EMBED4") && atoi(getenv("PS_RTM_EMBED4")) == 0);
+  static const bool e4_on = ps_diag_int("PS_RTM_EMBED4", 1) != 0;
   return e4_on && k.pvc && !k.eval && D.WL <= 128 && (D.d == 64 || D.d == 128 || D.d == 256) && r.S <= 64;
 }
 // (Round 3, measured and dropped: the whole index built on the side stream BESIDE the forward, so that the forward carries no
@@ -1796,13 +1801,13 @@ static bool rtm_embed4_taken(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) 
 // the LDS-histogram index (rtm_hist_kernel): the backward builds the whole index on its side stream without global atomics and
 // the forward carries none.  PS_RTM_HIST=0: the round-2 form (ranks by global atomics in the forward's gather).
 static bool rtm_hist_index(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
-  static const bool on = !(getenv("PS_RTM_HIST") && atoi(getenv("PS_RTM_HIST")) == 0);
-  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
+  static const bool on = ps_env_int("PS_RTM_HIST", 1) != 0;
+  static const bool late = ps_diag_int("PS_RTM_LATE_INDEX", 0) != 0;
   return on && !late && k.pvc && !k.eval && r.hist != 0 && D.vocab_size <= RTM_HIST_MAXV && r.S == D.R + 1 &&
          ps_cdiv((int64_t)r.Bseq * D.R, RTM_HIST_G) <= (1 << 20);
 }
 static bool rtm_counts_in_forward(const PsRtmDesc& D, const RtmK& k, const RtmWs& r) {
-  static const bool late = getenv("PS_RTM_LATE_INDEX") && atoi(getenv("PS_RTM_LATE_INDEX")) != 0;
+  static const bool late = ps_diag_int("PS_RTM_LATE_INDEX", 0) != 0;
   return !late && !rtm_hist_index(D, k, r) && rtm_embed4_taken(D, k, r);
 }
 static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_t st) {
@@ -1827,7 +1832,7 @@ static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_
 }
 // count (unless a kernel that reads the words anyway did), allocate, fill
 static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hipStream_t st) {
-  static const int env_chunk = getenv("PS_RTM_IDX_CHUNK") ? atoi(getenv("PS_RTM_IDX_CHUNK")) : 64;
+  static const int env_chunk = ps_diag_int("PS_RTM_IDX_CHUNK", 64);
   const int nslots = r.Bseq * r.S;
   const int chunk = env_chunk < 1 ? 1 : (env_chunk > WI_CHUNK_MAX ? WI_CHUNK_MAX : env_chunk), nwg = ps_cdiv(nslots, chunk);
   const FDiv fWL = make_fdiv(k.WL > 0 ? k.WL : 1);
@@ -1848,7 +1853,7 @@ static int rtm_build_index(const RtmK& k, const RtmWs& r, int V, bool count, hip
 // workgroups of the slot-walking kernels (measured, ms/step: 128 0.850, 256 0.764, 384 0.762, 512 0.734, 1024 0.749,
 // 2048 0.784, 4096 0.837)
 static int rtm_slot_blocks(const RtmWs& r) {
-  static const int eb_cap = getenv("PS_RTM_EB") ? atoi(getenv("PS_RTM_EB")) : 512;
+  static const int eb_cap = ps_diag_int("PS_RTM_EB", 512);
   int eb = ps_cdiv(r.Bseq * r.S, 4);
   return eb > eb_cap ? eb_cap : eb;
 }
@@ -1914,13 +1919,13 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
       const dim3 grid(ps_cdiv(npos + nneg + r.Bseq, 4));
       // x rows of padded positions: with the valid-row list nothing downstream reads them (the projections, the attention and
       // the backward all walk the list), so they are not written either (18 us of the launch at C4, 73 % padding)
-      static const bool keep_pads = getenv("PS_RTM_WRITE_PADS") && atoi(getenv("PS_RTM_WRITE_PADS")) != 0;
+      static const bool keep_pads = ps_diag_int("PS_RTM_WRITE_PADS", 0) != 0;
       const int pads_unread = enc_rowlist_taken(E, w, rtm_rows_listed(r, w)) && !k.raw && !keep_pads ? 1 : 0;
       const FDiv fR = make_fdiv(D.R), fK = make_fdiv(D.K > 0 ? D.K : 1);
       // the valid-group list (rtm_grouplist_kernel): only when padded rows of x are not read and the counter is cleared by
       // the query-encoder launch (training).  PS_RTM_GROUPLIST=0: every group gets a wave, as in round 2.
-      static const int e4_diag = getenv("PS_RTM_DIAG") ? atoi(getenv("PS_RTM_DIAG")) : 0;      // timing experiments (wrong results)
-      static const bool list_on = !(getenv("PS_RTM_GROUPLIST") && atoi(getenv("PS_RTM_GROUPLIST")) == 0);
+      static const int e4_diag = ps_diag_int("PS_RTM_DIAG", 0);      // timing experiments (wrong results)
+      static const bool list_on = ps_env_int("PS_RTM_GROUPLIST", 1) != 0;
       const int* glist = nullptr; const int* gcount = nullptr;
       const int nq_wg = ps_cdiv(r.Bseq, 4);
       dim3 egrid = grid;
@@ -2068,7 +2073,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
   }
   int blocks = ps_cdiv(r.Bseq, 4); if (blocks > 256) blocks = 256;
   uint32_t* sig = nullptr; uint32_t sigval = 0;
-  static const bool sbwd_carries = !(getenv("PS_RTM_SBWD_SIG") && atoi(getenv("PS_RTM_SBWD_SIG")) == 0);
+  static const bool sbwd_carries = ps_diag_int("PS_RTM_SBWD_SIG", 1) != 0;
   if (sbwd_carries) side_take_signal(st, &sig, &sigval);       // the index fill's fork rides on this launch
   hipLaunchKernelGGL(rtm_score_bwd_kernel, dim3(blocks), dim3(256), (size_t)(d + 1) * sizeof(float), st, k, fwd_index || !k.pvc ? 1 : 0, sig, sigval);
   PS_LAUNCH_CHECK();
@@ -2186,7 +2191,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
     // (main stream): with forks free it runs ON the side stream behind a fork — carried by the query scatter below — beside
     // that scatter, and the join that used to precede it (5 us on the main stream with nothing to wait for) is gone.
     // PS_RTM_WR_SIDE=0: joined and launched on the main stream.
-    static const bool wr_side_on = !(getenv("PS_RTM_WR_SIDE") && atoi(getenv("PS_RTM_WR_SIDE")) == 0);
+    static const bool wr_side_on = ps_diag_int("PS_RTM_WR_SIDE", 1) != 0;
     hipStream_t wst = st;
     if (fwd_index) {
       hipStream_t ss = side_stream_or(st);
@@ -2194,7 +2199,7 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
       else TRY(side_join(st));                      // the index (and the weight gradients queued behind it) are through
     }
     const int64_t max_occ = (int64_t)r.Bseq * D.R * D.WL;
-    static const int wr_cap = getenv("PS_RTM_WR_WGS") ? atoi(getenv("PS_RTM_WR_WGS")) : 4096;
+    static const int wr_cap = ps_diag_int("PS_RTM_WR_WGS", 4096);
     int64_t wr = (max_occ + 255) / 256;
     if (wr > wr_cap) wr = wr_cap;
     // (measured and dropped: the columns split over the XCDs — workgroup i takes d/8 columns of every entry, so that an XCD's

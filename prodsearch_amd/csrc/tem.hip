@@ -264,8 +264,8 @@ static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, but at 
   // Every split adds a 64x64 tile of fp32 atomics onto the same weight-gradient addresses.  Measured: C2 (8,064 rows; step
   // time by blocks per launch: 512 0.380 ms, 256 0.375, 224 0.373, 192 0.372-0.377, 128 0.392) wants ~15 splits of ~540
   // rows; the review transformer (78k rows, 4 tiles) wants its 128 splits of ~610 rows (1.146 ms vs 1.193 with 56).
-  static const int target = getenv("PS_WGRAD_BLOCKS") ? atoi(getenv("PS_WGRAD_BLOCKS")) : 512;   // tuning experiments
-  static const int min_rows = getenv("PS_WGRAD_ROWS") ? atoi(getenv("PS_WGRAD_ROWS")) : 512;
+  static const int target = ps_env_int("PS_WGRAD_BLOCKS", 512);   // tuning experiments
+  static const int min_rows = ps_env_int("PS_WGRAD_ROWS", 512);
   const int nt = tiles > 0 ? tiles : 1;
   const int want = target / nt;
   int ks = (rows + min_rows - 1) / min_rows;                 // >= ~512 rows per split ...
@@ -276,13 +276,13 @@ static int pick_ksplit(int tiles, int rows) {   // ~2 workgroups per CU, but at 
 }
 // ---- deterministic mode (PS_DETERMINISTIC=1 or ps_set_deterministic): see common.h / DESIGN.md 5e
 static int& det_slot() {
-  static int v = getenv("PS_DETERMINISTIC") ? atoi(getenv("PS_DETERMINISTIC")) : 0;
+  static int v = ps_env_int("PS_DETERMINISTIC", 0);
   return v;
 }
 bool ps_deterministic() { return det_slot() != 0; }
 extern "C" int ps_set_deterministic(int on) {
   const int old = det_slot();
-  det_slot() = on ? 1 : 0;
+  if (on >= 0) det_slot() = on ? 1 : 0;          // negative: query only
   return old;
 }
 // scratch of the ordered split reduction: per device, grow-only, allocated outside any stream capture
@@ -488,7 +488,7 @@ static SideCtx* side_ctx() {
     if (!env_on("PS_NO_SIDE")) {
       // the side stream carries filler (weight gradients, table scatters): LOWEST priority, so that when both streams have
       // workgroups ready the dependent chain of the main stream is dispatched first (PS_SIDE_PRIO=0: default priority)
-      static const bool low_prio = !(getenv("PS_SIDE_PRIO") && atoi(getenv("PS_SIDE_PRIO")) == 0);
+      static const bool low_prio = ps_diag_int("PS_SIDE_PRIO", 1) != 0;
       int prio_lo = 0, prio_hi = 0;
       bool ok = false;
       if (low_prio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_lo != prio_hi)
@@ -535,7 +535,7 @@ extern "C" int ps_side_values_in_use(void) {
   return c && c->flag ? 1 : 0;
 }
 static int& side_mode_slot() {
-  static int v = getenv("PS_SIDE_MODE") ? atoi(getenv("PS_SIDE_MODE")) : 3;
+  static int v = ps_env_int("PS_SIDE_MODE", 3);
   return v;
 }
 extern "C" int ps_set_side_mode(int mode) {
@@ -568,7 +568,7 @@ float* ps_det_scratch(int slot, size_t floats, hipStream_t st) {
   return buf[dev][slot];
 }
 static bool fork_by_kernel() {
-  static const bool on = !(getenv("PS_FORK_BY_KERNEL") && atoi(getenv("PS_FORK_BY_KERNEL")) == 0);
+  static const bool on = ps_diag_int("PS_FORK_BY_KERNEL", 1) != 0;
   return on;
 }
 // fork: everything enqueued on the main stream so far is visible to later side-stream work.  Each fork costs the
@@ -619,7 +619,7 @@ int side_fork(hipStream_t main_st) {
 }
 // short steps cross streams with write / wait-value operations, long ones with events (see side_ctx)
 void side_set_light(bool light) {
-  static const int force = getenv("PS_SIDE_LIGHT") ? atoi(getenv("PS_SIDE_LIGHT")) : -1;   // tuning: 0 never, 1 always
+  static const int force = ps_diag_int("PS_SIDE_LIGHT", -1);   // tuning: 0 never, 1 always
   SideCtx* c = side_ctx();
   // (with forks signalled by the next kernel the value crossings win on the long steps too: review transformer 0.531 -> 0.527,
   // C5 shard 1.41 -> 1.38 ms per step; PS_SIDE_LIGHT=0 / PS_FORK_BY_KERNEL=0 restore the per-step choice)
@@ -693,7 +693,7 @@ static int side_fork_injected_failure() {
 // does the (one-layer) encoder walk the valid-row list?  Then the rows of x at padded positions are never read, forward
 // or backward (K / V products, attention and their gradients all go through the list), and need not be written.
 bool enc_rowlist_taken(const PsTemDesc& D, const Ws& w, bool rows_listed) {
-  static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+  static const bool rows_on = ps_env_int("PS_NO_ROWLIST", 0) == 0;
   if (!(rows_on && rows_listed && D.n_layers == 1 && w.qpos == 0 && w.vrows != 0 && w.S <= 64)) return false;
   const LayerWs& l = w.layer[0];
   if (l.Sq != 1 || l.n_in != D.B) return false;
@@ -994,7 +994,7 @@ static void park_colsums(LnBwdArgs& a, float* ws, const Ws& w, ColFoldList* fold
 }
 
 static int& fuse_bwd_min_slot() {
-  static int v = getenv("PS_FUSE_BWD_MIN") ? atoi(getenv("PS_FUSE_BWD_MIN")) : 1024;
+  static int v = ps_env_int("PS_FUSE_BWD_MIN", 1024);
   return v;
 }
 extern "C" int ps_set_fuse_bwd_min(int rows) {
@@ -1028,7 +1028,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   // The last layer's whole per-replica backward (final LN, FFN, FF LN, Wo) as one kernel (mlp_fused.hip) when the
   // forward took the fused form too; needs parked column sums (fold) and one parked row per workgroup (<= 256).
   side_set_light((int64_t)B * S * d <= ((int64_t)2 << 20));   // C2: 1.03 M elements of x; review transformer 10 M; C5 5.5 M
-  static const bool bwd_fuse_on = !(getenv("PS_NO_FUSE_BWD") && atoi(getenv("PS_NO_FUSE_BWD")) != 0);
+  static const bool bwd_fuse_on = ps_env_int("PS_NO_FUSE_BWD", 0) == 0;
   const int bwd_fuse_min = fuse_bwd_min_slot();
   const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 &&
                          mlp_fused_serves(d, F) && w.wsplit && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
@@ -1078,7 +1078,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
     const int ns = l.n_in * S, M2 = l.M2;
     const float* do2 = drop ? ws + w.do2 : ws + w.dy2;
     const bool fused = fuse_last && i == NL - 1;
-    static const bool wgrad_early = !(getenv("PS_WGRAD_LATE") && atoi(getenv("PS_WGRAD_LATE")) != 0);
+    static const bool wgrad_early = ps_diag_int("PS_WGRAD_LATE", 0) == 0;
     if (fused) {
       MlpBwdArgs m;
       memset(&m, 0, sizeof(m));
@@ -1132,7 +1132,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // one launch for the three (the flat group form: every member keeps its own split count; three launches of ~250
       // latency-bound workgroups one after the other took 86 us at C2; review transformer 0.563 -> 0.543 ms/step, C2 0.3156 ->
       // 0.3144).  PS_WGRAD_GROUP_ROWS=0 restores the separate launches.
-      static const int wg_group_rows = getenv("PS_WGRAD_GROUP_ROWS") ? atoi(getenv("PS_WGRAD_GROUP_ROWS")) : (1 << 30);
+      static const int wg_group_rows = ps_diag_int("PS_WGRAD_GROUP_ROWS", (1 << 30));
       if (M2 <= wg_group_rows) {
         GemmProblem all3[3] = {wg[0], wg1[0], wgo[0]};
         TRY(side_run(all3, 3, st));
@@ -1226,7 +1226,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
                                 : d == 128 && attn_sq1_split(a) == 2 && (size_t)2 * l.n_in <= (size_t)M2);
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
       // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
-      static const bool rows_on0 = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      static const bool rows_on0 = ps_env_int("PS_NO_ROWLIST", 0) == 0;
       const bool listed0 = rows_on0 && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
       if (wf) TRY(launch_attn_bwd_wf(a, reinterpret_cast<const uint32_t*>(ws + l.amask), listed0 && (q_folded || l.fan == 1), st));
       else if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1), st));
@@ -1254,11 +1254,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // ends: the K / V / Q weight gradients go back to it, 0.3151 -> 0.3124 ms/step; PS_WG3_SIDE=0: main stream)
       // (later in round 2: with forks signalled by the next kernel the main stream lost its two bubbles and ENDED 30 us before
       // the side stream — score scatter 28 + W2/W1/Wo 45 + these 16 us; back on the main stream: 0.2861 -> 0.2801 ms/step)
-      static const bool wg3_main_on = getenv("PS_WG3_SIDE") ? atoi(getenv("PS_WG3_SIDE")) == 0 : fork_by_kernel();
+      static const int wg3_side = ps_diag_int("PS_WG3_SIDE", -1);
+      static const bool wg3_main_on = wg3_side >= 0 ? wg3_side == 0 : fork_by_kernel();
       const bool wg3_main = fused && wg3_main_on && ns <= 2 * M2;   // (review transformer: 78k K/V rows vs 1.5k replica rows -> side)
       // valid rows only: padded positions have exactly-zero dK / dV rows (their attention weights are 0), so the K/V
       // weight gradients (and the dX product below) run over the batch's row list instead of all n_in*S rows
-      static const bool rows_on = !(getenv("PS_NO_ROWLIST") && atoi(getenv("PS_NO_ROWLIST")) != 0);
+      static const bool rows_on = ps_env_int("PS_NO_ROWLIST", 0) == 0;
       const bool listed = rows_on && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
       const int32_t* vr = reinterpret_cast<const int32_t*>(ws + w.vrows);
       const int32_t* vc = reinterpret_cast<const int32_t*>(ws + w.vcount);
@@ -1288,7 +1289,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       if (listed && (q_folded || l.fan == 1)) { x.ridx = vr; x.rcount = vc; }
       TRY(run1(x, st));
       if (wg3_main) {
-        static const bool wg3_last = !(getenv("PS_WG3_LAST") && atoi(getenv("PS_WG3_LAST")) == 0);
+        static const bool wg3_last = ps_diag_int("PS_WG3_LAST", 1) != 0;
         if (wg3_last && g_wg3_defer_ok && i == 0) { for (int q = 0; q < 3; ++q) g_wg3_last[q] = wg3[q]; g_wg3_last_n = 3; }
         else TRY(run_wgrads(wg3, 3, st));
       }
@@ -1354,7 +1355,7 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
   s.g_product_emb = G.product_emb; s.g_word_emb = G.word_emb; s.g_product_bias = G.product_bias;
   s.g_word_bias = G.word_bias;
   // TEM with replicas: the encoder backward decides where the score backward runs (enc_layers_backward, score_on_side)
-  static const bool score_side_on = !(getenv("PS_SCORE_BWD_MAIN") && atoi(getenv("PS_SCORE_BWD_MAIN")) != 0);
+  static const bool score_side_on = ps_diag_int("PS_SCORE_BWD_MAIN", 0) == 0;
   const bool score_deferred = tem && NL > 0 && w.R > 1 && score_side_on;
   if (!score_deferred) TRY(launch_score_bwd(s, st));
 

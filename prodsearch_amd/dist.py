@@ -34,6 +34,52 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+# ------------------------------------------------------------------ communication clock (measurement only)
+# bench.py --gpus N: a HIP event pair around every collective of the step, recorded on the stream the collective is issued
+# from (torch's process group makes that stream wait for the collective's own stream when the call returns), so that the
+# step's communication time can be reported beside its compute time.  Off (the default) the context manager is one
+# attribute test.
+class _CommClock(object):
+    enabled = False
+    spans = []
+
+
+def comm_timing(on):
+    _CommClock.enabled = bool(on) and torch.cuda.is_available()
+    _CommClock.spans = []
+
+
+class _comm(object):
+    __slots__ = ('name', 'e0')
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _CommClock.enabled:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _CommClock.enabled:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _CommClock.spans.append((self.name, self.e0, e1))
+        return False
+
+
+def comm_timing_read():
+    """{collective name: total ms since comm_timing(True)} (synchronises); clears the spans."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in _CommClock.spans:
+        out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+    _CommClock.spans = []
+    return out
+
+
 def rank_seed(base_seed, rank):
     """Per-rank Philox key: negatives and dropout masks are independent across ranks."""
     return (int(base_seed) & 0xFFFFFFFF) | ((int(rank) + 1) << 32) if rank else int(base_seed)
@@ -56,7 +102,8 @@ class GradExchange(object):
         if self.world == 1:
             return None
         flat = self.flat_getter()
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        with _comm('all_reduce(flat gradient)'):
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
 def _flat_gather_supported(group=None):
@@ -146,7 +193,8 @@ class SparseGradExchange(object):
                                    "agreed on messages of %d rows at the first step; build the exchange after setting "
                                    "args.batch_size / uprev_review_limit to the largest batch any rank will see" % (local, cap))
             caps.append(cap)
-        dist.all_reduce(m._grad_flat[:getattr(m, '_n_allreduce_grad', m._n_dense_grad)], op=dist.ReduceOp.SUM, group=self.group)
+        with _comm('all_reduce(small tensors)'):
+            dist.all_reduce(m._grad_flat[:getattr(m, '_n_allreduce_grad', m._n_dense_grad)], op=dist.ReduceOp.SUM, group=self.group)
         for (_, p, gview), cap in zip(m._sparse_tabs, caps):
             info = p._ps_rows
             d = p.shape[1]
@@ -155,8 +203,9 @@ class SparseGradExchange(object):
             # the rank's list holds at most info['cap'] <= cap rows: the message is padded with -1 / zeros up to cap
             _lib.check(lib.ps_pack_rows(gview.data_ptr(), d, info['rows'].data_ptr(), info['count'].data_ptr(), cap,
                                         x['msg_rows'].data_ptr(), x['msg_vals'].data_ptr(), st), 'ps_pack_rows')
-            _all_gather_flat(x['all_rows'], x['msg_rows'], self.world, self.group, self._flat)
-            _all_gather_flat(x['all_vals'], x['msg_vals'], self.world, self.group, self._flat)
+            with _comm('all_gather(row ids + rows)'):
+                _all_gather_flat(x['all_rows'], x['msg_rows'], self.world, self.group, self._flat)
+                _all_gather_flat(x['all_vals'], x['msg_vals'], self.world, self.group, self._flat)
             lst = (_lib.PsIdxList * 1)()
             lst[0].idx, lst[0].n = x['all_rows'].data_ptr(), self.world * cap
             _lib.check(lib.ps_coalesce_rows(lst, 1, p.shape[0], -1, x['ws'].data_ptr(), x['urows'].data_ptr(),
@@ -230,6 +279,8 @@ class ShardedAdamExchange(object):
         self.p_shard = self.pflat[self.lo:self.hi]
         self._build_plan(dev)
         self.state[0] = optim._step
+        if getattr(optim, '_state_tensors', None):       # build_optim(train_from) loaded a checkpoint before the exchange existed
+            self.load_moments(optim._state_tensors, optim._step)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.gnorm = torch.zeros(2, device=dev, dtype=torch.float32)
         self._reduced = False
@@ -241,11 +292,16 @@ class ShardedAdamExchange(object):
         # times, so all ranks choose alike).  The all-gather has the same two forms ('a2a': every rank sends its slice to each
         # peer over that peer's direct link).
         auto = 'auto' if (W > 1 and dist.is_initialized() and dist.get_backend(group) == 'nccl') else 'rccl'
+        if auto == 'auto' and self.lib.ps_set_deterministic(-1) != 0:
+            auto = 'a2a'         # PS_DETERMINISTIC: no timing-dependent choice; the a2a form sums the slices in rank order
         self.rs_mode = os.environ.get('PS_DP_RS', auto)
         self.ag_mode = os.environ.get('PS_DP_AG', auto)
         self.tuned = None
-        self._a2a_recv = self._a2a_send = None
+        self._a2a_recv = None
         self._set_modes(self.rs_mode, self.ag_mode)
+        self._tune_scratch = None
+        if 'auto' in (self.rs_mode, self.ag_mode):       # _tune's operands, allocated HERE (an out-of-memory error surfaces at
+            self._tune_scratch = (torch.zeros_like(self.pflat), torch.empty_like(self.g_shard), torch.empty_like(self.pflat))   # construction, on every rank alike, not between live collectives)
         optim.grad_scale = 1.0 / W
         optim._sharded = self
         optim._plan = None
@@ -286,25 +342,48 @@ class ShardedAdamExchange(object):
         _lib.check(self.lib.ps_adam_update_ext(self.plan.data_ptr(), self.n_chunks, hp, self.state.data_ptr(),
                                                self.sumsq.data_ptr(), self.gnorm.data_ptr(), st), 'ps_adam_update_ext')
 
+    def _k_sum_slices(self, recv, out, zero):
+        """out = sum over ranks of recv[r] in rank order; clears ``zero`` (or nothing) in the same launch (ps_sum_slices)."""
+        from . import _lib
+        st = torch.cuda.current_stream(out.device).cuda_stream
+        _lib.check(self.lib.ps_sum_slices(recv.data_ptr(), self.world, out.numel(), out.data_ptr(),
+                                          zero.data_ptr() if zero is not None else None,
+                                          zero.numel() if zero is not None else 0, st), 'ps_sum_slices')
+
     def _set_modes(self, rs, ag):
         W, dev = self.world, self.pflat.device
         self.rs_mode, self.ag_mode = rs, ag
         if W > 1 and rs in ('a2a', 'auto') and self._a2a_recv is None:
             self._a2a_recv = torch.empty(W, self.shard, device=dev, dtype=torch.float32)
-        if W > 1 and ag in ('a2a', 'auto') and self._a2a_send is None:
-            self._a2a_send = torch.empty(W, self.shard, device=dev, dtype=torch.float32)
 
-    def _reduce_scatter(self, out, flat, mode):
+    def _reduce_scatter(self, out, flat, mode, zero=None):
+        """``out`` <- this rank's slice of the sum of ``flat`` over the ranks.  ``zero``: a buffer the caller wants cleared once
+        the collective has consumed ``flat`` (the flat gradient itself on the step path): the a2a form clears it inside its
+        summing launch and returns True, otherwise the caller clears it."""
         if mode == 'a2a':
             dist.all_to_all_single(self._a2a_recv.view(-1), flat, group=self.group)
-            torch.sum(self._a2a_recv, dim=0, out=out)          # rank order: the same sum on every run
-        else:
-            dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._k_sum_slices(self._a2a_recv, out, zero)      # rank order: the same sum on every run
+            return zero is not None
+        dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM, group=self.group)
+        return False
 
     def _all_gather(self, full, shard, mode):
+        """``full`` [world * shard] <- every rank's ``shard``.  'a2a': one send of the slice to each peer and one receive from
+        each, batched (ncclSend / ncclRecv pairs: on a fully connected xGMI node every pair has its own direct link) straight
+        from the slice into its place — no staging copy (round 3 expanded the slice W times for all_to_all_single: a 27 MB
+        torch copy per step at C2).  When ``shard`` IS the rank's slice of ``full`` (the step path) nothing is copied at all."""
         if mode == 'a2a':
-            self._a2a_send.copy_(shard.unsqueeze(0).expand_as(self._a2a_send))
-            dist.all_to_all_single(full, self._a2a_send.view(-1), group=self.group)
+            W, r, n = self.world, self.rank, shard.numel()
+            mine = full[r * n:(r + 1) * n]
+            if mine.data_ptr() != shard.data_ptr():
+                mine.copy_(shard)
+            ops = []
+            for k in range(1, W):                # ring-shifted order: in every round each rank sends to a different peer
+                dst, src = (r + k) % W, (r - k) % W
+                ops.append(dist.P2POp(dist.isend, shard, dst, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, full[src * n:(src + 1) * n], src, group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         else:
             dist.all_gather_into_tensor(full, shard, group=self.group)
 
@@ -312,9 +391,7 @@ class ShardedAdamExchange(object):
         """Time 'rccl' and 'a2a' for each collective still on 'auto' (scratch operands of the step's own sizes) and keep the
         faster.  Runs once, inside the first exchange; GPU backends only (events)."""
         dev = flat.device
-        src = torch.zeros_like(flat)
-        out = torch.empty_like(self.g_shard)
-        full = torch.empty_like(self.pflat)
+        src, out, full = self._tune_scratch
         ops = {'rs': lambda mode: self._reduce_scatter(out, src, mode), 'ag': lambda mode: self._all_gather(full, out, mode)}
         times = {}
         for name, cur in (('rs', self.rs_mode), ('ag', self.ag_mode)):
@@ -341,9 +418,8 @@ class ShardedAdamExchange(object):
         self._set_modes(rs, ag)
         if rs != 'a2a':
             self._a2a_recv = None
-        if ag != 'a2a':
-            self._a2a_send = None
         self.tuned = dict(times, reduce_scatter=rs, all_gather=ag)
+        self._tune_scratch = None
         if self.rank == 0:
             import sys
             print("ShardedAdamExchange: %s" % self.tuned, file=sys.stderr)
@@ -353,21 +429,18 @@ class ShardedAdamExchange(object):
         m = self.model
         flat = m._grad_flat
         if self.world > 1 and 'auto' in (self.rs_mode, self.ag_mode):
-            try:
-                self._tune(flat)
-            except Exception as e:          # (symmetric collectives: a form the backend refuses fails on every rank alike)
-                import sys
-                print("ShardedAdamExchange: timing the collective forms failed (%s: %s); using the library's" % (type(e).__name__, e),
-                      file=sys.stderr)
-                self._a2a_recv = self._a2a_send = None
-                self.rs_mode = 'rccl' if self.rs_mode == 'auto' else self.rs_mode
-                self.ag_mode = 'rccl' if self.ag_mode == 'auto' else self.ag_mode
-                self._set_modes(self.rs_mode, self.ag_mode)
+            # no try / except here: _tune issues live collectives, and a rank that caught a local failure between two of them
+            # would enter the step's reduce-scatter while its peers still sit in the tuning all-to-all.  Its scratch operands
+            # were allocated at construction; a collective that fails, fails the step on this rank (and the peers' timeout).
+            self._tune(flat)
+        zeroed = False
         if self.world > 1:
-            self._reduce_scatter(self.g_shard, flat, self.rs_mode)
+            with _comm('reduce_scatter(flat gradient)'):
+                zeroed = self._reduce_scatter(self.g_shard, flat, self.rs_mode, zero=flat)
         else:
             self.g_shard.copy_(flat[self.lo:self.hi])
-        self._k_zero(flat)
+        if not zeroed:
+            self._k_zero(flat)
         m.__dict__['_grad_clean'] = True
         self._reduced = True
         return None
@@ -380,10 +453,32 @@ class ShardedAdamExchange(object):
         hp.zero_grads = 0
         self._k_sumsq(hp)
         if self.world > 1:
-            dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
+            with _comm('all_reduce(clip norm scalar)'):
+                dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
         self._k_update(hp)
         if self.world > 1:
-            self._all_gather(self.pflat, self.p_shard, self.ag_mode)
+            with _comm('all_gather(parameter slices)'):
+                self._all_gather(self.pflat, self.p_shard, self.ag_mode)
+
+    def load_moments(self, state_tensors, step):
+        """Adam moments of a checkpoint — ``{id(parameter): (exp_avg, exp_avg_sq)}`` as ``Optimizer.load_state_dict`` keeps them —
+        laid out like the flat buffers; this rank keeps its slice.  Also sets the step the bias corrections continue from.
+        Resuming is then the reference's Adam resume (optimizers.py:186-187 + ps_model.py:39-51) under data parallelism too."""
+        mfull, vfull = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
+        with torch.no_grad():
+            for p, view in self.model._grad_views:
+                st = state_tensors.get(id(p))
+                if st is None:
+                    continue
+                o, n = view.storage_offset(), p.numel()
+                if tuple(st[0].shape) != tuple(p.shape) or tuple(st[1].shape) != tuple(p.shape):
+                    raise RuntimeError("sharded optimizer: a loaded moment has shape %s, its parameter %s"
+                                       % (tuple(st[0].shape), tuple(p.shape)))
+                mfull[o:o + n].copy_(st[0].reshape(-1))
+                vfull[o:o + n].copy_(st[1].reshape(-1))
+            self.m_shard.copy_(mfull[self.lo:self.hi])
+            self.v_shard.copy_(vfull[self.lo:self.hi])
+            self.state[0] = int(step)
 
     def full_moments(self):
         """(exp_avg, exp_avg_sq) flat buffers gathered from every rank's shard (checkpointing: a collective)."""

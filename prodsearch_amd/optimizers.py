@@ -56,6 +56,9 @@ class Optimizer(object):
         # update their shards — sharded.ShardedItemTable — through ``_step_rows``)
         self.params = [p for _, p in params if p.requires_grad and not getattr(p, '_ps_shard_view', False)]
         self._names = [k for k, p in params if p.requires_grad and not getattr(p, '_ps_shard_view', False)]
+        # checkpoint indices follow the REFERENCE's parameter order (optimizers.py:165-187 enumerates named_parameters): a
+        # row-sharded table keeps its slot there although its owners, not this list, update it
+        self._ref_params = [p for _, p in params if p.requires_grad]
         self._plan = None
 
     # ------------------------------------------------------------------ plan
@@ -269,9 +272,16 @@ class Optimizer(object):
         return float(self._plan['gnorm'][0]) if self._plan else None
 
     # ------------------------------------------------------------ checkpointing
+    def _shard(self):
+        owner = self.shard_owner() if self.shard_owner is not None else None
+        return getattr(owner, '_shard', None) if owner is not None else None
+
     def state_dict(self):
-        """Adam state in ``torch.optim.Adam.state_dict()`` form (exp_avg / exp_avg_sq / step per
-        parameter index) so a reference checkpoint's ``optim.optimizer.state_dict()`` maps 1:1."""
+        """Adam state in ``torch.optim.Adam.state_dict()`` form (exp_avg / exp_avg_sq / step per parameter index, indices
+        in the reference's ``named_parameters`` order) so a reference checkpoint's ``optim.optimizer.state_dict()`` maps
+        1:1.  A row-sharded item table (``args.shard_tables``) exports its moments gathered from the owners in the full
+        table's shape, like ``model.state_dict()`` does for the weight; under the sharded optimizer the moment slices are
+        gathered from the ranks.  Both are collectives: every rank calls this."""
         state = {}
         self.flush_rows()                    # (lazy_exact_adam: every row's moments current as of this step)
         st = getattr(self, '_state_tensors', {})
@@ -281,24 +291,55 @@ class Optimizer(object):
             for p, v in self._sharded.model._grad_views:
                 o, n = v.storage_offset(), p.numel()
                 st[id(p)] = (mf[o:o + n].view_as(p), vf[o:o + n].view_as(p))
-        for i, p in enumerate(self.params):
-            if id(p) in st:
+        shard = self._shard()
+        ref = getattr(self, '_ref_params', self.params)
+        for i, p in enumerate(ref):
+            if getattr(p, '_ps_shard_view', False):
+                if shard is None or self._step == 0:
+                    continue
+                pad = torch.zeros(1, shard.d, device=shard.device)      # the reference's table has its padding row last
+                state[i] = {'step': torch.tensor(float(self._step)),
+                            'exp_avg': torch.cat([shard.gather_full('m'), pad]),
+                            'exp_avg_sq': torch.cat([shard.gather_full('v'), pad])}
+            elif id(p) in st:
                 m, v = st[id(p)]
                 state[i] = {'step': torch.tensor(float(self._step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
         return {'state': state, 'param_groups': [{'lr': self.learning_rate, 'betas': tuple(self.betas),
                                                   'eps': self.eps, 'weight_decay': self.weight_decay,
-                                                  'params': list(range(len(self.params)))}], '_step': self._step}
+                                                  'params': list(range(len(ref)))}], '_step': self._step}
 
     def load_state_dict(self, sd):
+        """Restore ``state_dict()``'s (or the reference optimizer's) Adam state.  Indices are positions in the reference's
+        parameter order; every moment must have its parameter's shape (a dense checkpoint loaded into a run with another
+        table layout raises instead of assigning moments to the wrong tensors)."""
         self._step = int(sd.get('_step', 0))
         loaded = {}
+        shard = self._shard()
+        ref = getattr(self, '_ref_params', self.params)
         for i, s in sd['state'].items():
-            p = self.params[int(i)]
-            loaded[id(p)] = (s['exp_avg'].to(p.device), s['exp_avg_sq'].to(p.device))
+            p = ref[int(i)]
             self._step = max(self._step, int(float(s['step'])))
+            if getattr(p, '_ps_shard_view', False):
+                if shard is None:
+                    raise RuntimeError("optimizer state for a row-sharded table but the model has no shard")
+                want = (shard.n_rows, shard.d)
+                for which, key in (('m', 'exp_avg'), ('v', 'exp_avg_sq')):
+                    t = s[key]
+                    if tuple(t.shape) not in (want, (want[0] + 1, want[1])):
+                        raise RuntimeError("optimizer state %d (%s): shape %s, the sharded table is %s (+ padding row)"
+                                           % (int(i), key, tuple(t.shape), want))
+                    shard.load_full(t, which)
+                continue
+            for key in ('exp_avg', 'exp_avg_sq'):
+                if tuple(s[key].shape) != tuple(p.shape):
+                    raise RuntimeError("optimizer state %d (%s): shape %s does not match its parameter's %s — the checkpoint "
+                                       "was written for a different parameter list" % (int(i), key, tuple(s[key].shape), tuple(p.shape)))
+            loaded[id(p)] = (s['exp_avg'].to(p.device), s['exp_avg_sq'].to(p.device))
         self._state_tensors = loaded
         self._plan = None
         self._lazy_last, self._lazy_base = {}, self._step      # lazy_exact_adam: a checkpoint is written flushed (state_dict)
+        if self._sharded is not None:        # sharded optimizer: the moments live in its slices, not in _state_tensors
+            self._sharded.load_moments(loaded, self._step)
 
 
 def build_optim(args, model, checkpoint):

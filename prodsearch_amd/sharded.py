@@ -89,10 +89,11 @@ class ShardedItemTable(object):
         for i in range(0, self.local_rows, 1 << 22):
             self.weight[i:i + (1 << 22)].normal_(generator=g)
 
-    def load_full(self, full):
-        """Take this rank's rows of a full ``[n_rows(+pad), d]`` table (tests / checkpoint import)."""
+    def load_full(self, full, which='weight'):
+        """Take this rank's rows of a full ``[n_rows(+pad), d]`` tensor (tests / checkpoint import); ``which``: ``weight``, or
+        ``m`` / ``v`` for the Adam moments of an optimizer checkpoint."""
         rows = torch.arange(self.rank, self.n_rows, self.world, device=full.device)
-        self.weight[:rows.numel()].copy_(full[rows].to(self.device))
+        getattr(self, which)[:rows.numel()].copy_(full[rows].to(self.device))
 
     def gather_full(self, which='weight'):
         """The full ``[n_rows, d]`` tensor on every rank (tests / checkpoint export of small tables; a collective)."""
@@ -151,9 +152,12 @@ class ShardedItemTable(object):
         self._k_coalesce(index_tensors, self.n_rows, self.pad_row, self.co_ws, self.rows, self.cap, self.count)
         self._k_bucket()
         if W > 1:
-            dist.all_to_all_single(self.asked.view(-1), self.send_ids.view(-1), group=self.group)
+            from .dist import _comm
+            with _comm('all_to_all(row requests)'):
+                dist.all_to_all_single(self.asked.view(-1), self.send_ids.view(-1), group=self.group)
             self._k_gather(self.send_rows)                  # owners gather the requested rows (-1 entries give zero rows)
-            dist.all_to_all_single(self.table_buf[:self.slots].view(-1), self.send_rows.view(-1), group=self.group)
+            with _comm('all_to_all(rows)'):
+                dist.all_to_all_single(self.table_buf[:self.slots].view(-1), self.send_rows.view(-1), group=self.group)
         else:                                               # nobody to exchange with: straight into the receive buffer
             self.asked.copy_(self.send_ids)
             self._k_gather(self.table_buf)
@@ -170,7 +174,9 @@ class ShardedItemTable(object):
         """Route the receive buffer's gradient rows (``[slots + 1, d]``) to their owners and merge them into ``self.grad``;
         ``urows[:ucount]`` = the shard's touched local rows (sorted)."""
         if self.world > 1:
-            dist.all_to_all_single(self.ggot.view(-1), grad_buf[:self.slots].reshape(-1), group=self.group)
+            from .dist import _comm
+            with _comm('all_to_all(gradient rows)'):
+                dist.all_to_all_single(self.ggot.view(-1), grad_buf[:self.slots].reshape(-1), group=self.group)
             got = self.ggot
         else:
             got = grad_buf[:self.slots]

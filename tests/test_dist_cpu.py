@@ -181,14 +181,8 @@ class _Hyper(object):
     lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale, zero_grads = 0.01, 0.9, 0.999, 1e-9, 0.0, 5.0, 1.0, 0
 
 
-def _sharded_worker(rank, world, port, q, forms='rccl'):
-    """ShardedAdamExchange's protocol over gloo with a CPU restatement of its three kernels (oracle/optim.py's clip+Adam
-    arithmetic): after every step all ranks hold bitwise identical parameters, and they equal a single-process
-    clip_grad_norm_ + Adam(eps=1e-9) on the MEAN of the ranks' gradients (optimizers.py:241-243)."""
+def _cpu_sharded_class():
     import math
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PS_DP_RS=forms, PS_DP_AG=forms)
-    pdist.init_from_env(backend='gloo')
 
     class CpuSharded(pdist.ShardedAdamExchange):
         def _load_lib(self):
@@ -199,6 +193,14 @@ def _sharded_worker(rank, world, port, q, forms='rccl'):
 
         def _k_zero(self, flat):
             flat.zero_()
+
+        def _k_sum_slices(self, recv, out, zero):          # ps_sum_slices restated: rank-ordered sum + clear
+            acc = recv[0].clone()
+            for r in range(1, recv.shape[0]):
+                acc += recv[r]
+            out.copy_(acc)
+            if zero is not None:
+                zero.zero_()
 
         def _k_sumsq(self, hp):
             self.state[0] += 1
@@ -214,6 +216,20 @@ def _sharded_worker(rank, world, port, q, forms='rccl'):
             denom = self.v_shard.sqrt() / math.sqrt(1 - hp.beta2 ** t) + hp.eps
             self.p_shard.addcdiv_(self.m_shard, denom, value=-hp.lr / (1 - hp.beta1 ** t))
             self.gnorm[0] = norm
+
+    return CpuSharded
+
+
+def _sharded_worker(rank, world, port, q, forms='rccl'):
+    """ShardedAdamExchange's protocol over gloo with a CPU restatement of its three kernels (oracle/optim.py's clip+Adam
+    arithmetic): after every step all ranks hold bitwise identical parameters, and they equal a single-process
+    clip_grad_norm_ + Adam(eps=1e-9) on the MEAN of the ranks' gradients (optimizers.py:241-243)."""
+    import math
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PS_DP_RS=forms, PS_DP_AG=forms)
+    pdist.init_from_env(backend='gloo')
+
+    CpuSharded = _cpu_sharded_class()
 
     class Opt(object):
         _step, grad_scale, _sharded, _plan = 0, 1.0, None, None
@@ -261,9 +277,9 @@ def _sharded_worker(rank, world, port, q, forms='rccl'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('forms', ['rccl', 'a2a'])      # the library collectives / slices sent peer to peer (all_to_all_single)
-def test_gloo_world2_sharded_adam_protocol(forms):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize('world,forms', [(2, 'rccl'), (2, 'a2a'), (8, 'a2a')])      # the library collectives / slices sent peer to
+def test_gloo_sharded_adam_protocol(world, forms):                                   # peer (all-to-all + batched send / recv); 8 = a node's rank count
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, forms)) for r in range(world)]
@@ -274,4 +290,88 @@ def test_gloo_world2_sharded_adam_protocol(forms):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in res:
-        assert r[1] and r[2] and r[3] and r[4] and r[5] == 0.5, r
+        assert r[1] and r[2] and r[3] and r[4] and r[5] == 1.0 / world, r
+
+
+def _resume_worker(rank, world, port, q):
+    """Save / resume under the sharded optimizer: three steps, then the moments and the step count go through
+    ``Optimizer.state_dict()`` / ``load_state_dict()`` semantics — ``full_moments()`` -> per-parameter tensors ->
+    ``load_moments()`` of a FRESH exchange over a fresh copy of the model — and step four of the resumed pair must equal step
+    four of the uninterrupted pair bit for bit (it used to restart from zero moments with the old step count)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PS_DP_RS='rccl', PS_DP_AG='rccl')
+    pdist.init_from_env(backend='gloo')
+    CpuSharded = _cpu_sharded_class()
+
+    class Opt(object):
+        _step, grad_scale, _sharded, _plan, _state_tensors = 0, 1.0, None, None, None
+
+    def grads_into(model, step):
+        model._structs()
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        views = dict((id(a), b) for a, b in model._grad_views)
+        for _, p in model.named_parameters():
+            views[id(p)].copy_(torch.randn(p.shape, generator=g) * 3.0)
+
+    def run_step(model, opt, ex, step):
+        grads_into(model, step)
+        ex()
+        opt._step += 1
+        hp = _Hyper()
+        hp.grad_scale = opt.grad_scale
+        ex.step(hp)
+
+    torch.manual_seed(3)
+    model, opt = _StubModel(), Opt()
+    ex = CpuSharded(model, opt)
+    for step in range(3):
+        run_step(model, opt, ex, step)
+    # "checkpoint": parameters, per-parameter moments (what Optimizer.state_dict() builds from full_moments()), the step
+    mf, vf = ex.full_moments()
+    ck_params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ck_m = {n: (mf[v.storage_offset():v.storage_offset() + p.numel()].view_as(p).clone(),
+                vf[v.storage_offset():v.storage_offset() + p.numel()].view_as(p).clone())
+            for (n, p), v in zip(model.named_parameters(),
+                                 [dict((id(a), b) for a, b in model._grad_views)[id(p)] for _, p in model.named_parameters()])}
+    run_step(model, opt, ex, 3)                        # the uninterrupted fourth step
+    # resume: a fresh model and optimizer whose state was loaded BEFORE the exchange is built (build_optim(train_from)) ...
+    torch.manual_seed(3)
+    model2, opt2 = _StubModel(), Opt()
+    with torch.no_grad():
+        for n, p in model2.named_parameters():
+            p.copy_(ck_params[n])
+    opt2._step = 3
+    opt2._state_tensors = {id(p): ck_m[n] for n, p in model2.named_parameters()}
+    ex2 = CpuSharded(model2, opt2)
+    ok_loaded = int(ex2.state[0]) == 3 and float(ex2.m_shard.abs().sum()) > 0
+    run_step(model2, opt2, ex2, 3)
+    same = all(torch.equal(p.detach(), q_.detach()) for (_, p), (_, q_) in zip(model.named_parameters(), model2.named_parameters()))
+    # ... and load_moments() called on a LIVE exchange (Optimizer.load_state_dict after make_exchange) does the same
+    torch.manual_seed(3)
+    model3, opt3 = _StubModel(), Opt()
+    with torch.no_grad():
+        for n, p in model3.named_parameters():
+            p.copy_(ck_params[n])
+    ex3 = CpuSharded(model3, opt3)
+    ex3.load_moments({id(p): ck_m[n] for n, p in model3.named_parameters()}, 3)
+    opt3._step = 3
+    run_step(model3, opt3, ex3, 3)
+    same3 = all(torch.equal(p.detach(), q_.detach()) for (_, p), (_, q_) in zip(model.named_parameters(), model3.named_parameters()))
+    q.put((rank, bool(ok_loaded), bool(same), bool(same3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sharded_adam_resume_keeps_moments_and_step():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_resume_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[3], r

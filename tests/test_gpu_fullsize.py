@@ -86,3 +86,40 @@ def test_full_size_scorer_is_permutation_equivariant_and_ranking_is_sorted():
     inside = hit.any(1)
     assert torch.equal(rank[inside].long(), pos[inside])
     assert bool((rank[~inside] > 100).all())
+
+
+def test_full_size_dropout_step_matches_the_replicated_oracle():
+    """THE benched configuration (BASELINE configs[1] with the reference's default dropout 0.1: B = 384, K = 20, d = 128,
+    ff = 512, R = 21 replicas = 8,064 replica rows, folded scoring at 252 workgroups) against the oracle in the reference's
+    own replicated structure (item_transformer.py:471-494: the encoder runs on B and on B*K expanded copies), with the
+    product's Philox masks injected: loss / ps / item loss and the [384, 21] logits <= 1e-4, the gradient of every tensor
+    <= 5e-4 of its max, the touched rows of both tables bit-exact.  This is mlp_fwd_t_kernel<2, 3> with the loss hand-off
+    at full grid and mlp_bwd_t_kernel<2, 3> unforced — the kernels BENCH times."""
+    from oracle import tem as otem, philox
+    a, wd, sd, m, batch, ni, nw = _setup(0.1)
+    m.train()
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(m._plans.values()))
+    assert plan.layout.R == K + 1                                   # the replicas really are computed
+    scores = m.workspace_view(plan, 'item_scores', (B, K + 1)).cpu()
+    Pm = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    keep = {}
+    drop = philox.PhiloxDropout(0.1, m._seed, m._fwd_step, B, K, a.heads, L + 1, 1, L if a.use_item_pos else 0)
+    oloss, ops, oil = otem.tem_forward(Pm, a, batch, ni, nw, V, P_, training=True, replicate=True, drop=drop, keep=keep)
+    assert rel_err(loss.detach().cpu(), oloss.detach()) < 1e-4
+    assert abs(m.ps_loss - float(ops)) < 1e-4 * abs(float(ops)) and abs(m.item_loss - float(oil)) < 1e-4 * abs(float(oil))
+    ref_scores = torch.cat([keep['pos_scores'].detach()[:, None], keep['neg_scores'].detach()], 1)
+    assert rel_err(scores, ref_scores) < 1e-4
+    grads = otem.grads_of(oloss, Pm, otem.tem_pad_rows(a, V, P_))
+    for n, p in m.named_parameters():
+        ref = grads.get(n)
+        assert (p.grad is None) == (ref is None), n
+        if ref is None or n.endswith('linear_keys.bias'):          # (exactly-zero true gradient: rounding noise on both sides)
+            continue
+        got = p.grad.cpu()
+        assert rel_err(got, ref) < 5e-4, (n, rel_err(got, ref))
+        if ref.dim() == 2 and ref.shape[0] > 256:
+            assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n

@@ -37,7 +37,7 @@ def _run(lib, A, Bm, ta, tb, mode, shape=-1, acc=0):
     return C.cpu()
 
 
-@pytest.mark.parametrize('layout', [(0, 0, 1), (0, 1, 1), (1, 1, 0)])      # forward, dX, weight-gradient storage; forced tile
+@pytest.mark.parametrize('layout', [(0, 0, 1), (0, 1, 1), (1, 1, 0), (0, 0, 3), (0, 1, 3), (1, 1, 3)])      # forward, dX, weight-gradient storage; forced tile (3: direct-to-LDS form)
 def test_deep_cancelling_reduction_with_mixed_magnitudes(x3_restore, layout):
     """K = 21,504 terms per output whose magnitudes span 2^-40 .. 2^+40 and whose big terms cancel in pairs: the error is
     bounded by a few fp32 ulps of sum |a b| for BOTH forms (a product form that dropped the low plane would be off by
@@ -66,7 +66,8 @@ def test_deep_cancelling_reduction_with_mixed_magnitudes(x3_restore, layout):
     assert float((ref.abs() / mag).median()) < 1e-2          # the case really cancels
 
 
-def test_non_finite_operands_poison_exactly_the_outputs_the_fp32_kernel_poisons(x3_restore):
+@pytest.mark.parametrize('shape', [1, 3])
+def test_non_finite_operands_poison_exactly_the_outputs_the_fp32_kernel_poisons(x3_restore, shape):
     """An Inf / NaN operand makes exactly the outputs non-finite that the fp32 MFMA makes non-finite (never a silently finite
     value, never a poisoned neighbour); NaN operands give NaN in both forms; an Inf operand gives +-Inf in the fp32 form and
     may give NaN in the bf16x3 form (see the module docstring)."""
@@ -82,7 +83,7 @@ def test_non_finite_operands_poison_exactly_the_outputs_the_fp32_kernel_poisons(
     Bm[9, :] = 0.0
     A[200, 9] = float('inf')          # row 200: Inf * 0 -> NaN
     Bm[11, 17] = float('inf')         # column 17: an Inf weight
-    outs = {mode: _run(lib, A, Bm, 0, 0, mode, 1) for mode in (1, 0)}
+    outs = {mode: _run(lib, A, Bm, 0, 0, mode, shape) for mode in (1, 0)}
     c3, c1 = outs[1], outs[0]
     assert torch.equal(torch.isfinite(c3), torch.isfinite(c1))
     assert bool((torch.isnan(c3) | ~torch.isnan(c1)).all())                      # NaN in the fp32 form => NaN in the bf16x3 form
@@ -91,7 +92,8 @@ def test_non_finite_operands_poison_exactly_the_outputs_the_fp32_kernel_poisons(
     assert torch.isinf(c1[3]).all() and torch.isnan(c1[64]).any() and torch.isnan(c1[100]).all() and torch.isnan(c1[200]).all()
 
 
-def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore):
+@pytest.mark.parametrize('shape', [1, 3])
+def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore, shape):
     """|a| ~ 2^-112: hi / mid are normal bf16 values, the low plane falls below 2^-126.  Whatever the matrix core does with
     a denormal bf16 input, the result must stay within the product form's bound against fp64 — if denormal inputs were
     flushed the low plane would be lost and the error 2^-17 of a term (1e-5 relative), 20x the bound."""
@@ -102,7 +104,7 @@ def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore):
     Bm = torch.randn(K, N, generator=gen) * 2.0 ** 90
     ref = A.double() @ Bm.double()
     mag = A.double().abs() @ Bm.double().abs()
-    e = {mode: float(((_run(lib, A, Bm, 0, 0, mode, 1).double() - ref).abs() / mag).max()) for mode in (1, 0)}
+    e = {mode: float(((_run(lib, A, Bm, 0, 0, mode, shape).double() - ref).abs() / mag).max()) for mode in (1, 0)}
     print("denormal low plane: error / sum|ab|  bf16x3 %.3g  fp32 MFMA %.3g" % (e[1], e[0]))
     assert e[0] < 6e-7
     assert e[1] < 6e-7, e

@@ -50,10 +50,11 @@ def _oracle_keep(g, step=0):
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (70, 132, 96), (384, 128, 128), (8064, 512, 128),
                                    (33, 128, 512), (1, 32, 32), (132, 68, 100), (200, 260, 2048)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize('x3', [-1, 0, 1, 2])
+@pytest.mark.parametrize('x3', [-1, 0, 1, 2, 3])
 def test_mfma_gemm_layouts(M, N, K, ta, tb, x3, x3_restore):
     """x3 = -1: the form the launch takes by itself (fp32 MFMA at these sizes); 0 / 1 / 2: the bf16x3 form (three-way exact bf16
-    split, six bf16 MFMAs per product step) forced with 64x64 / 128x64 / 128x128 tiles — same tolerance against fp64."""
+    split, six bf16 MFMAs per product step) forced with 64x64 / 128x64 / 128x128 tiles, 3: its direct-to-LDS form (gemm_x3d_kernel, 128x128; shapes with a ragged reduction
+    tail fall back to 128x64) — same tolerance against fp64."""
     from prodsearch_amd import _lib
     lib = _lib.load()
     lib.ps_gemm_x3_config(1, x3)

@@ -51,7 +51,7 @@ if __name__ == '__main__':
         t0, e0 = one(M, N, K, ta, tb, acc, 0, -1)
         line = "M=%6d N=%5d K=%6d ta=%d tb=%d acc=%d | fp32 %7.1f us %6.1f TF err %.1e |" % (
             M, N, K, ta, tb, acc, t0, 2.0 * M * N * K / t0 / 1e6, e0)
-        for shp in (0, 1, 2):
+        for shp in (0, 1, 2, 3):
             t, e = one(M, N, K, ta, tb, acc, 1, shp)
             line += " x3[%d] %7.1f us %6.1f TF err %.1e |" % (shp, t, 2.0 * M * N * K / t / 1e6, e)
         print(line, flush=True)
