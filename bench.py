@@ -495,12 +495,24 @@ def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
             _lib.check(lib.ps_gather_score(desc, params, sets[i % 8][1], ws.data_ptr(), st.cuda_stream), 'ps_gather_score')
         avg, mn, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
         _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
+        # the same launches back to back between ONE event pair: an event pair around every launch adds its own packets to
+        # what it brackets (17.5 us where rocprofv3's kernel trace reads 14-15, profiles/r04_gather_score_kernel_stats.csv);
+        # the loop average (kernel + the gap to the next launch) is the duration `achieved` is computed from
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(st)
+        for i in range(iters):
+            lib.ps_gather_score(desc, params, sets[i % 8][1], ws.data_ptr(), st.cuda_stream)
+        e1.record(st)
+        torch.cuda.synchronize()
+        loop_us = e0.elapsed_time(e1) * 1e3 / iters
         R = lay.R
         nrows = B * (1 + K) * (1 + W)
         nbytes = nrows * (4 * d + 8) + (B * R + B) * 4 * d + nrows * 4
-        ach = nbytes / (avg.value * 1e-6) / 1e9
-        res.append({"B": B, "bytes_per_launch": nbytes, "us_per_launch": avg.value, "us_per_launch_min": mn.value,
-                    "launches_timed": cnt.value, "achieved": ach, "frac": ach / HBM_PEAK_GBS})
+        ach = nbytes / (loop_us * 1e-6) / 1e9
+        res.append({"B": B, "bytes_per_launch": nbytes, "us_per_launch": loop_us, "us_per_launch_event_pairs": avg.value,
+                    "us_per_launch_event_pairs_min": mn.value, "launches_timed": cnt.value, "achieved": ach,
+                    "frac": ach / HBM_PEAK_GBS, "frac_event_pairs": nbytes / (avg.value * 1e-6) / 1e9 / HBM_PEAK_GBS})
         del ws, sets
     del table, words
     torch.cuda.empty_cache()
@@ -510,7 +522,8 @@ def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
             "by_batch": res, "traffic": 63.0e6,
             "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f; round 3 repeat: profiles/r03_gather_score_c5_pmc.txt, 31.2 MB x2 + 0.4 MB): FETCH_SIZE 31.2 MB x2 "
                               "+ WRITE_SIZE 0.4 MB per launch at B=1024 against 67.6 MB algorithmic",
-            "timing": "HIP event pair around every launch on its stream (ps_ktimer), %d launches per batch size" % iters}
+            "timing": "%d launches per batch size, back to back on their stream between one HIP event pair (us_per_launch); and "
+                      "one event pair around every launch (ps_ktimer; us_per_launch_event_pairs, which includes the pairs' own packets)" % iters}
 
 
 # ------------------------------------------------------------------------------------------ launching N ranks

@@ -158,8 +158,15 @@ int ps_set_deterministic(int on);
  * fp32 accumulation: as accurate as the fp32 MFMA (1.1e-7 of sum|a b|) at a third of its cycles; mode 0: the fp32 MFMA
  * everywhere.  force_shape -1: tile chosen by the launch's size; 0 / 1 / 2: 64x64 / 128x64 / 128x128 for every launch that
  * has an instantiation (tests); 3: the direct-to-LDS form (fp32 slabs by global_load_lds, split on the fragments in registers,
- * 128x128 tiles) wherever it applies.  Env PS_GEMM_X3 / PS_GEMM_X3_SHAPE set the initial values.  Process-wide. */
+ * 128x128 tiles) wherever it applies; 4: weights pre-split once per call into bf16 plane images (ps_gemm_f32_weight; the d >= 256
+ * step's forward / dX products), the size rule elsewhere.  3 and 4 are measured alternatives (profiles/r04_gemm_notes.md), not defaults.  Env PS_GEMM_X3 / PS_GEMM_X3_SHAPE set the initial values.  Process-wide. */
 int ps_gemm_x3_config(int mode, int force_shape);
+/* C = (A . op(W) + bias) * alpha with W declared a WEIGHT — [N][K] (tb 0, nn.Linear, models/neural.py:20-21, 86-96) or [K][N]
+ * (tb 1: the input-gradient product of the same linear) with dense rows: W is split once into bf16 plane images for the
+ * duration of the call and the product runs on the pre-split-weight kernel (gemm_x3w_kernel) where it applies
+ * (ps_gemm_x3_config(1, 4), M >= 4096, N / K multiples of 32), otherwise as ps_gemm_f32 would.  What the d >= 256 step's forward / dX products do. */
+int ps_gemm_f32_weight(const float* A, int lda, const float* W, int tb, float* C, int ldc, int M, int N, int K,
+                       const float* bias, float alpha, ps_stream_t stream);
 
 /* Workspace the caller allocates once per shape (bytes) and its layout. */
 int ps_tem_workspace_layout(const PsTemDesc* desc, PsTemWsLayout* out);

@@ -115,6 +115,8 @@ SYMBOLS = {
     'ps_side_abort': (None, []),
     'ps_debug_fail_fork': (None, [C.c_int]),
     'ps_gemm_x3_config': (C.c_int, [C.c_int, C.c_int]),
+    'ps_gemm_f32_weight': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_float, C.c_void_p]),
     'ps_tem_workspace_layout': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemWsLayout)]),
     'ps_tem_forward': (C.c_int, [C.POINTER(PsTemDesc), C.POINTER(PsTemTensors), C.POINTER(PsTemBatch),
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -287,6 +287,7 @@ __host__ inline void res_finish(ResMap& R) {   // call after Sq/fan/S are set
   R.dSq = make_fdiv(R.Sq); R.dfan = make_fdiv(R.fan); R.dS = make_fdiv(R.S);
 }
 
+#define PS_WPLANES_MAX 8         // weights one WPlaneScope can hold
 #define PS_GEMM_KIDX_MAX 2048   // reduction rows of ONE split a row-list weight gradient can map (LDS ints)
 
 struct GemmProblem {
@@ -317,6 +318,9 @@ struct GemmProblem {
                                         // stores its own partial matrix, a second launch adds them up in split order)
   int no_deep;                          // never pick the 128-deep-slab form (133 KB of LDS per workgroup): for small products that
                                         // run BESIDE other launches, where that footprint starves them of CUs
+  // filled by the launcher (gemm.hip, WPlaneScope): the B segments as pre-split bf16 plane matrices [3][N][kseg] (hi / mid / lo,
+  // reduction index contiguous whatever tb says), or null — gemm_x3w_kernel reads B from them
+  const uint16_t* bpl[3];
 };
 
 struct GemmGroup {
@@ -328,6 +332,8 @@ struct GemmGroup {
   // problem i owns [flat0[i], flat0[i+1]): split-major, then row tile, then column tile; each problem keeps its own ksplit
   int flat;
   int flat0[4], flat_tm[3], flat_tiles[3];
+  // weight-gradient launches whose caller sized ksplit for 128x128 tiles: take gemm_x3d_kernel (tem.hip, run_wgrads)
+  int prefer_x3d;
   // diagnostics (PS_GEMM_STAMP=1 + ps_debug_set_stamp_buffer, tools/gemm_stamps.py): the waves of one mid-grid workgroup of the
   // bf16x3 kernel record s_memtime at their phase boundaries, 32 slots per wave
   unsigned long long* stamp;
@@ -350,5 +356,17 @@ __device__ __forceinline__ void fork_signal(uint32_t* sig, uint32_t val) {
 // PS_DETERMINISTIC=1 / ps_set_deterministic(1): bitwise run-to-run reproducible TEM training steps — one stream,
 // weight gradients through per-split partials + an ordered sum, table scatters by sole-owner waves walking the tasks in order.
 bool ps_deterministic();
-// deterministic mode's library-owned scratch: per device and slot (0: split reductions, 1: score backward), grow-only
+// library-owned scratch: per device and slot (0: deterministic split reductions, 1: deterministic score backward, 2: the weight
+// planes of WPlaneScope), grow-only
 float* ps_det_scratch(int slot, size_t floats, hipStream_t st);
+// For its lifetime the listed fp32 weight matrices ([rows][cols], nn.Linear layout, row stride = cols) exist as bf16x3 plane
+// images in both orientations — split ONCE per entry-point call by one small launch on `st` — and ps_launch_gemm routes
+// products whose B operand is one of them (ta == 0, whole 32-deep slabs) to gemm_x3w_kernel, which no longer splits B at all
+// (and reads the transposed orientation for tb == 1: the dX products stop paying the row-contiguous loader).  Not nestable;
+// thread-local; nothing outlives the scope, so a weight the optimizer has moved is never multiplied through stale planes.
+bool gemm_x3w_on();
+struct WPlaneScope {
+  WPlaneScope(hipStream_t st, const float* const* w, const int* rows, const int* cols, int n);
+  ~WPlaneScope();
+  bool on;
+};

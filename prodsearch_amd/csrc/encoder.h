@@ -18,7 +18,8 @@ struct Ws {
   int64_t word_blk, item_blk, ticket;   // folded scoring (ScoreArgs): word / item loss partials, arrival counter
   int64_t wsplit;           // bf16x3 planes of the last layer's wo / w1 / w2 (WSplit), 0: not allocated
   int64_t denc, dy2, do2, da1, dln1, dy1, do_, dctx, dq, dkv, dxn, dx, dqpre, dqmean;
-  int64_t lnpart;           // PS_MAX_COLFOLD x [256][3][d] parked LN-backward column sums
+  int64_t lnpart;           // PS_MAX_COLFOLD x [lnrows][3][d] parked LN-backward column sums
+  int lnrows;               // parked rows per entry: 256 (the LayerNorm backward's row groups) or one per 32-row workgroup of the fused backward, whichever is more
   int64_t gcpart;           // [4 * row tiles][3][F] parked column sums of the FF2 dX GEMM (b1 gradient)
   int64_t abpart;           // per layer [n_in][3][d] parked attention bias gradients {bq, bk, bv} (sq1 backward)
   int64_t vrows, vcount;    // int32 [B*S] valid-row list of x and its length (EmbedArgs::vrows), TEM only

@@ -31,6 +31,7 @@
 // transformer 15 % (one workgroup per CU).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -985,6 +986,237 @@ __global__ __launch_bounds__(256, 2) void gemm_x3d_kernel(const GemmGroup g) {
   }
 }
 
+// ====================================================================== bf16x3 products against PRE-SPLIT weights (round 4)
+// In the products of a layer's forward and input gradients the B operand is a WEIGHT: a few hundred KB that every one of the
+// launch's hundreds of workgroups used to split again, slab by slab (and, for the dX products, fetch through the row-contiguous
+// loader with its strided 4 / 8-byte accesses).  WPlaneScope splits each weight once per entry-point call into bf16 plane
+// matrices [3][N][K] in BOTH orientations; this kernel then
+//   * brings B's planes global -> LDS by global_load_lds_dwordx4 ([row][32 k] bf16 images, 16-byte chunks XOR-swizzled by
+//     (row >> 2) & 3 on the source address: the read pattern of gemm_x3_kernel, SQ_LDS_BANK_CONFLICT 0) and feeds them to the
+//     MFMAs as they are: no VALU, no LDS store;
+//   * brings A (the activation, fp32) in as gemm_x3d_kernel does and splits its fragments in registers — but the four waves
+//     are stacked 4 x 1 over the 128-row tile (wave tile 32 x 128), so every A fragment is split by exactly ONE wave: a quarter
+//     of gemm_x3d_kernel's split work per MFMA, an eighth of gemm_x3_kernel's per element (which re-split A for every 64-wide
+//     column tile);
+//   * tile 128 x 128, 32-deep slabs, two LDS stages of 16 KB (A) + 24 KB (B planes), one barrier per slab, two workgroups per CU.
+// K-concatenated B operands (the K/V dX product: [dK | dV] against [Wk ; Wv]) pick the segment per slab (kseg % 32 == 0).
+#define X3W_STAGE (X3D_T * X3D_BK * 4 + 3 * X3D_T * X3D_BK * 2)      // 16 KB + 24 KB
+static bool x3_on();
+
+template <int FULL, int IDX>
+__global__ __launch_bounds__(256, 2) void gemm_x3w_kernel(const GemmGroup g) {
+  fork_signal(g.sig, g.sigval);
+  constexpr int MAIN_BYTES = 2 * X3W_STAGE;
+  constexpr int EPI_BYTES = FULL ? 4 * 64 * LDT * 4 : 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+
+  const int prob = blockIdx.z;
+  const GemmProblem& P = g.p[prob];
+  const bool listed = IDX && P.ridx != nullptr;                 // block-uniform
+  const int nlist = listed ? *P.rcount : 0;
+  const int M = listed ? nlist : P.M, N = P.N, K = P.K;
+  int tm, tn;                                                    // XCD-aware tile mapping as in gemm_f32_kernel
+  {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int L = blockIdx.y * nx + blockIdx.x;
+    const int grp = L / (8 * nx), r = L - grp * 8 * nx;
+    const int rows_here = min(8, ny - grp * 8);
+    tm = grp * 8 + r % rows_here;
+    tn = r / rows_here;
+  }
+  const int m0 = tm * X3D_T, n0 = tn * X3D_T;
+  if (m0 >= M || n0 >= N) return;                               // block-uniform
+  const int nsl = K / X3D_BK;                                    // (K % 32 == 0: the launcher checked)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- per-thread sources of the slab loads.  A: 16 instructions of 8 rows x 128 B, wave w issues 4 w .. 4 w + 3.
+  const float* pa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 32 * wave + 8 * j + (lane >> 3);
+    int row = min(m0 + r, M - 1);
+    if (listed) row = P.ridx[row];
+    pa[j] = P.A + (size_t)row * P.lda + 4 * ((lane & 7) ^ ((r >> 1) & 7));
+  }
+  // B planes: 24 instructions of 16 rows x 64 B (3 planes x 8 row blocks), wave w issues 6 w .. 6 w + 5
+  const int kseg = P.kseg;
+  size_t pboff[6];                                               // element offset inside a segment's plane set, slab 0
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int q = 6 * wave + j, pl = q >> 3, rb = q & 7;
+    const int r = 16 * rb + (lane >> 2);
+    const int row = min(n0 + r, N - 1);
+    pboff[j] = ((size_t)pl * N + row) * kseg + 8 * ((lane & 3) ^ ((r >> 2) & 3));
+  }
+  auto issue = [&](int it) __attribute__((always_inline)) {
+    unsigned char* const stage = smem + (it & 1) * X3W_STAGE;
+    const int k0 = it * X3D_BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa[j] + k0), (lds_ptr_t)(stage + (4 * wave + j) * 1024), 16, 0, 0);
+    const int sg = k0 >= kseg ? (k0 >= 2 * kseg ? 2 : 1) : 0;   // block-uniform
+    const uint16_t* const bp = (sg == 0 ? P.bpl[0] : (sg == 1 ? P.bpl[1] : P.bpl[2])) + (k0 - sg * kseg);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bp + pboff[j]), (lds_ptr_t)(stage + X3D_T * X3D_BK * 4 + (6 * wave + j) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4];                                                 // column block j = 2 ni + wn of the tile, rows 32 wave ..
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int swz = (l31 >> 1) & 7, bsw = (l31 >> 2) & 3;
+  issue(0);
+  for (int it = 0; it < nsl; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* const sa = smem + (it & 1) * X3W_STAGE;
+    const unsigned char* const sb = sa + X3D_T * X3D_BK * 4;
+    float fa[2][8];
+    bf16x8 b[2][4][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      x3d_frag<0>(sa, 32 * wave + l31, s, h, swz, fa[s]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          b[s][j][p] = *reinterpret_cast<const bf16x8*>(sb + p * (X3D_T * 64) + (32 * j + l31) * 64 + (((2 * s + h) ^ bsw) << 4));
+    }
+    if (it + 1 < nsl) issue(it + 1);                             // block-uniform; flies under the products below
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3];
+      x3d_split8(fa[s], a);
+#define X3W_TERM(pa_, pb_)                                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa_], b[s][j][pb_], acc[j], 0, 0, 0);
+      X3W_TERM(0, 2) X3W_TERM(2, 0) X3W_TERM(1, 1) X3W_TERM(0, 1) X3W_TERM(1, 0) X3W_TERM(0, 0)
+#undef X3W_TERM
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue: this wave holds block (wm, wn) = (wave & 1, j & 1) of
+  // the 64x64 quadrants (mi, ni) = (wave >> 1, j >> 1) — the layout the shared epilogues expect
+  const int mi = wave >> 1, wm = wave & 1;
+  if (!FULL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (m0 + 64 * mi < M && n0 + 64 * (j >> 1) < N)
+        epi_plain<0, IDX>(P, acc[j], m0 + 64 * mi, n0 + 64 * (j >> 1), 0, M, N, listed, wm, j & 1, l31, h);
+    return;
+  }
+  __syncthreads();                                               // the last slab's fragments have left LDS in every wave
+  float (*Ct)[64][LDT] = reinterpret_cast<float (*)[64][LDT]>(smem);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) epi_stage(Ct[mi * 2 + (j >> 1)], acc[j], wm, j & 1, l31, h);
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int mq = m0 + 64 * (q >> 1), nq = n0 + 64 * (q & 1);
+    if (mq < M && nq < N) epi_full<0, IDX>(P, Ct[q], mq, nq, 2 * tm + (q >> 1), 0, M, N, listed, tid);
+  }
+}
+
+// ---- the weight planes
+struct WPlaneJob { const float* w; int rows, cols; uint16_t* nrm; uint16_t* trn; int first_block; };
+struct WPlaneJobs { WPlaneJob j[PS_WPLANES_MAX]; int n; };
+// one thread per 8-element chunk of an output plane row: first the rows x cols / 8 chunks of the normal orientation, then the
+// cols x rows / 8 chunks of the transposed one (strided reads of a matrix that lives in L2)
+__global__ __launch_bounds__(256) void wplanes_kernel(const WPlaneJobs J) {
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < PS_WPLANES_MAX; ++i)
+    if (i < J.n && (int)blockIdx.x >= J.j[i].first_block) ji = i;
+  const WPlaneJob& jb = J.j[ji];
+  const int rows = jb.rows, cols = jb.cols;
+  const int64_t c = (int64_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  const int64_t n_nrm = (int64_t)rows * (cols >> 3), n_trn = (int64_t)cols * (rows >> 3);
+  if (c >= n_nrm + n_trn) return;
+  float v[8];
+  uint16_t* dst;
+  size_t pstride = (size_t)rows * cols;
+  if (c < n_nrm) {
+    const int r = (int)(c / (cols >> 3)), kc = (int)(c - (int64_t)r * (cols >> 3));
+    const float4 v0 = *reinterpret_cast<const float4*>(jb.w + (size_t)r * cols + 8 * kc);
+    const float4 v1 = *reinterpret_cast<const float4*>(jb.w + (size_t)r * cols + 8 * kc + 4);
+    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    dst = jb.nrm + (size_t)r * cols + 8 * kc;
+  } else {
+    const int64_t t = c - n_nrm;
+    const int cc = (int)(t / (rows >> 3)), rc = (int)(t - (int64_t)cc * (rows >> 3));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = jb.w[(size_t)(8 * rc + j) * cols + cc];
+    dst = jb.trn + (size_t)cc * rows + 8 * rc;
+  }
+  bf16x8 pl[3];
+  x3d_split8(v, pl);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * pstride) = pl[p];
+}
+
+struct WPlaneEntry { const float* w; int rows, cols; const uint16_t* nrm; const uint16_t* trn; };
+static thread_local WPlaneEntry g_wplanes[PS_WPLANES_MAX];
+static thread_local int g_wplanes_n = 0;
+
+WPlaneScope::WPlaneScope(hipStream_t st, const float* const* w, const int* rows, const int* cols, int n) : on(false) {
+  g_wplanes_n = 0;
+  if (!gemm_x3w_on() || n <= 0) return;
+  WPlaneJobs J;
+  memset(&J, 0, sizeof(J));
+  size_t elems = 0;
+  int blocks = 0, k = 0;
+  for (int i = 0; i < n && k < PS_WPLANES_MAX; ++i) {
+    if (!w[i] || rows[i] % 32 || cols[i] % 32 || ((uintptr_t)w[i] & 15)) continue;
+    bool dup = false;
+    for (int q = 0; q < k; ++q) dup = dup || J.j[q].w == w[i];
+    if (dup) continue;
+    J.j[k].w = w[i]; J.j[k].rows = rows[i]; J.j[k].cols = cols[i]; J.j[k].first_block = blocks;
+    blocks += ps_cdiv((int64_t)2 * rows[i] * (cols[i] >> 3), 256);
+    elems += (size_t)rows[i] * cols[i];
+    ++k;
+  }
+  if (!k) return;
+  uint16_t* base = reinterpret_cast<uint16_t*>(ps_det_scratch(2, (elems * 2 * 3 * 2 + 3) / 4 + 64, st));
+  if (!base) return;                                             // stream capture or out of memory: the products split B themselves
+  size_t off = 0;
+  for (int i = 0; i < k; ++i) {
+    const size_t e = (size_t)J.j[i].rows * J.j[i].cols;
+    J.j[i].nrm = base + off; off += 3 * e;
+    J.j[i].trn = base + off; off += 3 * e;
+    g_wplanes[i] = WPlaneEntry{J.j[i].w, J.j[i].rows, J.j[i].cols, J.j[i].nrm, J.j[i].trn};
+  }
+  J.n = k;
+  hipLaunchKernelGGL(wplanes_kernel, dim3(blocks), dim3(256), 0, st, J);
+  if (hipGetLastError() != hipSuccess) return;
+  g_wplanes_n = k;
+  on = true;
+}
+WPlaneScope::~WPlaneScope() { g_wplanes_n = 0; }
+
+// B segments of `p` as plane matrices [3][N][kseg]; false: not (all) registered, or a shape the kernel does not take
+static bool wplanes_for(GemmProblem& p) {
+  if (g_wplanes_n == 0 || p.ta || p.K % X3D_BK || p.kseg % X3D_BK || ((uintptr_t)p.A & 15) || p.lda % 4) return false;
+  const int nseg = ps_cdiv(p.K, p.kseg), ks = nseg > 1 ? p.kseg : p.K;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const uint16_t* found = nullptr;
+    for (int i = 0; i < g_wplanes_n; ++i) {
+      const WPlaneEntry& e = g_wplanes[i];
+      if (e.w != p.Bseg[sg]) continue;
+      if (!p.tb && e.rows == p.N && e.cols == ks && p.ldb == e.cols) found = e.nrm;       // B[n][k] = W[n][k]
+      if (p.tb && e.cols == p.N && e.rows == ks && p.ldb == e.cols) found = e.trn;        // B[k][n] = W[k][n]: planes of W^T
+    }
+    if (!found) return false;
+    p.bpl[sg] = found;
+  }
+  return true;
+}
+
 static bool needs_full(const GemmProblem& p) {
   return p.act != ACT_NONE || p.drop.thr != 0u || p.res.mode != RES_NONE || p.aux_out || p.out2 || p.colsum;
 }
@@ -1038,7 +1270,7 @@ static void launch(int ta, int tb, dim3 grid, hipStream_t stream, const GemmGrou
 // CU, 1.53 vs 1.41 ms per step), the weight gradients take 64x64 with the split counts tem.hip picks.
 static int g_x3_mode = -2, g_x3_force = -1;           // -2: not read yet
 extern "C" int ps_gemm_x3_config(int mode, int force_shape) {   // tests / experiments: mode 0|1, force_shape -1 (rule) | 0 | 1 | 2
-  PS_REQUIRE((mode == 0 || mode == 1) && force_shape >= -1 && force_shape <= 3, "gemm x3 config %d %d", mode, force_shape);
+  PS_REQUIRE((mode == 0 || mode == 1) && force_shape >= -1 && force_shape <= 4, "gemm x3 config %d %d", mode, force_shape);
   g_x3_mode = mode; g_x3_force = force_shape;
   return PS_OK;
 }
@@ -1051,7 +1283,7 @@ static int x3_shape(const GemmGroup& g, int maxM, int maxN) {
   x3_on();
   static const int t22 = ps_diag_int("PS_GEMM_X3_T22", 4096), t21 = ps_diag_int("PS_GEMM_X3_T21", 384), t11 = ps_diag_int("PS_GEMM_X3_T11", 512);
   if (!g_x3_mode) return -1;
-  if (g_x3_force >= 0) return g_x3_force > 3 ? 3 : g_x3_force;
+  if (g_x3_force >= 0 && g_x3_force != 4) return g_x3_force > 3 ? 3 : g_x3_force;   // (4: pre-split weights where registered — the caller's business —, the rule elsewhere)
   const int z = g.n * g.p[0].ksplit;
   int kmin = g.p[0].K;
   for (int i = 1; i < g.n; ++i) kmin = g.p[i].K < kmin ? g.p[i].K : kmin;
@@ -1153,6 +1385,10 @@ static bool try_x3(int ta, int tb, bool full, bool listed, int shape, int maxM, 
   return true;
 }
 
+// the pre-split-weight form is OFF unless asked for (ps_gemm_x3_config(1, 4) / PS_GEMM_X3_SHAPE=4): measured on MI355X it ties
+// the 128x64 kernel on the d = 256 step's products (profiles/r04_gemm_notes.md) — kept as a tested alternative, not the default
+bool gemm_x3w_on() { x3_on(); return g_x3_mode != 0 && g_x3_force == 4; }
+static int x3w_min_rows() { static const int v = ps_diag_int("PS_GEMM_X3W_MIN_ROWS", 4096); return v; }
 static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
 int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   GemmGroup g = g0;
@@ -1225,6 +1461,28 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
       PS_REQUIRE(p.tb == 1 && per * 32 <= KIDX_MAX, "gemm: row-list weight gradient: %d rows per split > %d", per * 32, KIDX_MAX);
     }
   }
+  // products against pre-split weights (WPlaneScope): every member's B found, enough rows to be worth a 128-row tile
+  if (gemm_x3w_on() && !g.p[0].ta && g.p[0].ksplit == 1 && maxM >= x3w_min_rows()) {
+    GemmGroup gw = g;
+    bool all = true;
+    for (int i = 0; i < gw.n; ++i) all = all && wplanes_for(gw.p[i]);
+    const dim3 wgrid(ps_cdiv(maxN, X3D_T), ps_cdiv(maxM, X3D_T), gw.n);
+    if (all && wgrid.y <= 65535) {
+      for (int i = 0; i < gw.n; ++i)
+        if (ps_cdiv(gw.p[i].K, gw.p[i].kseg) == 1) gw.p[i].kseg = gw.p[i].K;      // one segment: its planes are [3][N][K]
+      if (full && listed) hipLaunchKernelGGL((gemm_x3w_kernel<1, 1>), wgrid, dim3(256), 0, stream, gw);
+      else if (full) hipLaunchKernelGGL((gemm_x3w_kernel<1, 0>), wgrid, dim3(256), 0, stream, gw);
+      else if (listed) hipLaunchKernelGGL((gemm_x3w_kernel<0, 1>), wgrid, dim3(256), 0, stream, gw);
+      else hipLaunchKernelGGL((gemm_x3w_kernel<0, 0>), wgrid, dim3(256), 0, stream, gw);
+      PS_LAUNCH_CHECK();
+      return PS_OK;
+    }
+  }
+  if (g.prefer_x3d && x3_on() && (g_x3_force < 0 || g_x3_force == 4) &&
+      try_x3d(g.p[0].ta, g.p[0].tb, full, listed, maxM, maxN, g.n * g.p[0].ksplit, stream, g)) {
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
   const int x3 = x3_shape(g, maxM, maxN);
   if (x3 >= 0 && try_x3(g.p[0].ta, g.p[0].tb, full, listed, x3, maxM, maxN, g.n * g.p[0].ksplit, stream, g)) {
     PS_LAUNCH_CHECK();
@@ -1262,9 +1520,25 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
   return PS_OK;
 }
 
+static int gemm_f32_impl(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* Cm, int ldc,
+                         int M, int N, int K, const float* bias, float alpha, int accumulate, ps_stream_t stream);
 extern "C" int ps_gemm_f32(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* Cm, int ldc,
                            int M, int N, int K, const float* bias, float alpha, int accumulate,
                            ps_stream_t stream) {
+  return gemm_f32_impl(A, lda, ta, Bm, ldb, tb, Cm, ldc, M, N, K, bias, alpha, accumulate, stream);
+}
+// the same product with B declared a WEIGHT ([N][K] for tb == 0, [K][N] for tb == 1, dense rows): split once into bf16 planes
+// for the duration of the call (WPlaneScope), multiplied by gemm_x3w_kernel where that kernel applies — the path the
+// training step's forward and dX products of a d >= 256 model take; tests and tools/gemm_x3_bench.py
+extern "C" int ps_gemm_f32_weight(const float* A, int lda, const float* W, int tb, float* Cm, int ldc, int M, int N, int K,
+                                  const float* bias, float alpha, ps_stream_t stream) {
+  const float* ws[1] = {W};
+  const int rows[1] = {tb ? K : N}, cols[1] = {tb ? N : K};
+  WPlaneScope scope((hipStream_t)stream, ws, rows, cols, 1);
+  return gemm_f32_impl(A, lda, 0, W, tb ? N : K, tb, Cm, ldc, M, N, K, bias, alpha, 0, stream);
+}
+static int gemm_f32_impl(const float* A, int lda, int ta, const float* Bm, int ldb, int tb, float* Cm, int ldc,
+                         int M, int N, int K, const float* bias, float alpha, int accumulate, ps_stream_t stream) {
   GemmGroup g = {};
   g.n = 1;
   GemmProblem& p = g.p[0];

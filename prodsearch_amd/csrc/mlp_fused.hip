@@ -444,8 +444,10 @@ int64_t mlp_x3_floats(int d, int F) {      // forward + backward fragment stream
 }
 bool mlp_fwd_can_fold_score(int M, int F, int d) {
   static const bool fold_on = ps_env_int("PS_NO_FOLD_SCORE", 0) == 0;
-  return fold_on && d == MD && mlp_x3_enabled(F) && M > 0 &&
-         ps_cdiv(M, MBM) <= 256;               // one workgroup per CU, all resident: the ticket hand-off's measured regime
+  // (round 3 stopped at 256 workgroups — all resident — and B >= 391 at K = 20 silently fell off the folded path.  Nothing in
+  // the hand-off needs residency: every workgroup ADDS its fixed-point partial and its arrival into one 64-bit word and
+  // leaves; whichever add returns count == grid - 1 finishes — no workgroup waits for another.  The arrival count has 16 bits.)
+  return fold_on && d == MD && mlp_x3_enabled(F) && M > 0 && ps_cdiv(M, MBM) <= 65535;
 }
 bool mlp_fused_serves(int d, int F) { return d == MD && mlp_x3_enabled(F); }
 
@@ -461,7 +463,7 @@ static int set_lds_attr(K kernel, bool& done) {
 int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   PS_REQUIRE(mlp_x3_enabled(a.F) && a.M > 0, "fused mlp: F=%d M=%d (F must be 256, 512 or 1024)", a.F, a.M);
   PS_REQUIRE(a.x3.on && a.x3.fwd_wo && a.x3.fwd_ff, "fused mlp: the weight fragment streams are missing (WSplit)");
-  PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs <= 256 workgroups");
+  PS_REQUIRE(!a.fold_score || mlp_fwd_can_fold_score(a.M, a.F, MD), "fused mlp: folded scoring needs <= 65535 workgroups");
   KTimeScope kt("mlp_fwd", st);
   MlpFwdArgs as = a;
   as.stamp = g_mlp_stamp;

@@ -862,25 +862,25 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
   const int t0 = grp * SCORE_U;
   Task tk[SCORE_U];
   float4 r[SCORE_U][CH], v[SCORE_U][CH];
+  bool live[SCORE_U];
+  // A row group past the end repeats the LAST task (same addresses, its result dropped) instead of skipping its loads: a
+  // load under a per-lane test is a branch of its own, and at the join the compiler waits for everything in flight
+  //  — the vector (known from the task number alone) was then requested only after the index had come back.
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
-    int t = t0 + u;
-    if (t < ntask) tk[u] = score_task(a, t);
-    else { tk[u].row = nullptr; tk[u].vec = nullptr; tk[u].bias = 0.f; tk[u].out = nullptr; tk[u].term = nullptr; tk[u].tw = 0.f; tk[u].lw = 0.f; }
+    live[u] = t0 + u < ntask;
+    tk[u] = score_task(a, min(t0 + u, ntask - 1));
   }
   float cps = 0.f, cil = 0.f;
   const int wl = lpr == 32 ? 31 : (lpr == 16 ? 15 : 0);
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u)
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      r[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      v[u][k] = r[u][k];
-      if (tk[u].row) {
-        r[u][k] = *reinterpret_cast<const float4*>(tk[u].row + 4 * (c + lpr * k));
-        v[u][k] = *reinterpret_cast<const float4*>(tk[u].vec + 4 * (c + lpr * k));
-      }
-    }
+    for (int k = 0; k < CH; ++k) v[u][k] = *reinterpret_cast<const float4*>(tk[u].vec + 4 * (c + lpr * k));
+#pragma unroll
+  for (int u = 0; u < SCORE_U; ++u)
+#pragma unroll
+    for (int k = 0; k < CH; ++k) r[u][k] = *reinterpret_cast<const float4*>(tk[u].row + 4 * (c + lpr * k));
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
     float s = 0.f;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
     for (int k = 0; k < CH; ++k)
       s += r[u][k].x * v[u][k].x + r[u][k].y * v[u][k].y + r[u][k].z * v[u][k].z + r[u][k].w * v[u][k].w;
     s = lpr == 32 ? half_sum_last(s) : (lpr == 16 ? row16_sum_last(s) : group_sum(s, lpr));
-    if (c == wl && tk[u].out) {
+    if (c == wl && live[u]) {
       const float sc = s + tk[u].bias;
       *tk[u].out = sc;
       if (tk[u].term) {
@@ -920,7 +920,9 @@ static int score_wide_ch(const ScoreArgs& a, int ntask) {
   int ch;
   if (env >= 0) ch = env;
   else {
-    const bool huge = (size_t)ntask * a.d * 4 >= ((size_t)256 << 20);
+    // 8 lanes per row from 128 MB of rows per launch (round 3: 256 MB): with index sets that really come from HBM the B = 8192
+    // launch of the C5 shape runs 97.5 us against 103.4 (0.69 against 0.65 of the HBM peak); at B = 1024 the two tie (15.2 / 15.3)
+    const bool huge = (size_t)ntask * a.d * 4 >= ((size_t)128 << 20);
     ch = nch / (huge ? 8 : 16);
     if (ch > 8) ch = 8;
   }

@@ -187,7 +187,8 @@ int make_ws(const PsTemDesc& D, Ws& w) {
   }
   w.dqpre = take(cur, (int64_t)B * d);
   w.dqmean = take(cur, (int64_t)B * d);
-  w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * 256 * 3 * d);
+  w.lnrows = (int)((maxM2 + 31) / 32 > 256 ? (maxM2 + 31) / 32 : 256);
+  w.lnpart = take(cur, (int64_t)PS_MAX_COLFOLD * w.lnrows * 3 * d);
   w.stage = take(cur, 4 + 2 * ((int64_t)B * (D.Q + D.L + 1 + D.W + D.K + D.W * D.K) + 8));   // int64 = 2 floats
   w.gcpart = take(cur, (int64_t)4 * ((maxM2 + 31) / 32 + 1) * 3 * (tem && NL > 0 ? D.F : 0));   // >= mlp_bwd_b1_rows()
   w.abpart = take(cur, (int64_t)NL * (NL > 0 ? w.layer[NL - 1].n_in : 0) * 3 * d);
@@ -234,6 +235,23 @@ WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const W
   s.fwd_wo = base; s.fwd_ff = base + n_wo; s.bwd_ff = base + n_wo + n_ff; s.bwd_wo = base + n_wo + 2 * n_ff;
   s.on = 1;
   return s;
+}
+
+// The encoder weights a WPlaneScope (common.h) should hold for this call: the last layer's six linears when its products are
+// big enough for the pre-split-weight kernel (>= 4096 replica rows) and are not taken by the fused d = 128 kernels.
+int wplane_list(const PsTemDesc& D, const PsTemTensors& P, const Ws& w, const float** ws_, int* rows, int* cols) {
+  const int NL = D.model == PS_MODEL_TEM ? D.n_layers : 0;
+  if (NL < 1 || D.d < 256 || D.d % 32 || D.F % 32) return 0;
+  int n = 0;
+  for (int i = NL - 1; i >= 0 && n + 6 <= PS_WPLANES_MAX; --i) {
+    const LayerWs& l = w.layer[i];
+    if ((int64_t)l.M2 < 4096 && (int64_t)l.n_in * w.S < 4096) continue;
+    const PsLayerTensors& L = P.layer[i];
+    const float* ptr[6] = {L.wk, L.wv, L.wq, L.wo, L.w1, L.w2};
+    const int r[6] = {D.d, D.d, D.d, D.d, D.F, D.d}, c[6] = {D.d, D.d, D.d, D.d, D.d, D.F};
+    for (int k = 0; k < 6; ++k) { ws_[n] = ptr[k]; rows[n] = r[k]; cols[n] = c[k]; ++n; }
+  }
+  return n;
 }
 
 // ----------------------------------------------------------------- GEMM helpers
@@ -362,6 +380,17 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
     rows = ps[i].K > rows ? ps[i].K : rows;
   }
   int ks = pick_ksplit(tiles, rows);
+  // Big weight gradients (the d = 256 step's W2 / W1: 16 tiles of 128 x 128 over 21,504 reduction rows) take the direct-to-LDS
+  // bf16x3 kernel with 128x128 tiles and ~512 workgroups: 104-109 us against 129-131 for the 64x64 tiles at ANY split count
+  // (MI355X, profiles/r04_gemm_wgrad_ksplit.txt) — half the operand bytes per flop through LDS, a quarter of the atomic tiles'
+  // row segments.  Few tiles (Wo: 4) or few rows (C2: 8,064) cannot fill the chip that way and keep the 64x64 form.
+  {
+    int t128 = 0;
+    for (int i = 0; i < n; ++i) t128 += ps_cdiv(ps[i].M, 128) * ps_cdiv(ps[i].N, 128);
+    const int by_rows = ps_cdiv(rows, 512), by_fill = 512 / (t128 > 0 ? t128 : 1);
+    const int ks3 = by_rows < by_fill ? by_rows : by_fill;
+    if (plain && gemm_x3_on() && !ps_deterministic() && t128 * ks3 >= 384 && rows % 32 == 0) { ks = ks3; g.prefer_x3d = 1; }
+  }
   for (int i = 0; i < n; ++i)
     if (ps[i].ridx) {   // a row-list problem maps one split's reduction rows through LDS: at most PS_GEMM_KIDX_MAX of them
       const int need = ps_cdiv(ps_cdiv(ps[i].K, 32) * 32, PS_GEMM_KIDX_MAX - 32);
@@ -549,11 +578,11 @@ static bool stream_capturing(hipStream_t st) {
   return cs != hipStreamCaptureStatusNone;
 }
 float* ps_det_scratch(int slot, size_t floats, hipStream_t st) {
-  static float* buf[PS_MAX_DEVICES][2];
-  static size_t cap[PS_MAX_DEVICES][2];
+  static float* buf[PS_MAX_DEVICES][3];
+  static size_t cap[PS_MAX_DEVICES][3];
   static std::mutex mu;
   int dev = 0;
-  if (slot < 0 || slot > 1) return nullptr;
+  if (slot < 0 || slot > 2) return nullptr;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PS_MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lock(mu);
   if (cap[dev][slot] < floats) {
@@ -827,6 +856,9 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   PS_REQUIRE(e.qw && (!tem || e.ui), "forward: null batch indices");
   PS_REQUIRE(!tem || !D.use_pos_emb || P.pe, "forward: null positional table");
   if (tem && rows_list_ok(D)) { e.vrows = reinterpret_cast<int32_t*>(ws + w.vrows); e.vcount = reinterpret_cast<int32_t*>(ws + w.vcount); }
+  const float* wp_w[PS_WPLANES_MAX]; int wp_r[PS_WPLANES_MAX], wp_c[PS_WPLANES_MAX];
+  const int wp_n = wplane_list(D, P, w, wp_w, wp_r, wp_c);
+  WPlaneScope wplanes(st, wp_w, wp_r, wp_c, wp_n);             // the big linears multiply against pre-split weight planes (gemm.hip)
   if (samp) {
     e.samp_prob = samp->prob; e.samp_alias = samp->alias; e.samp_items = samp->items; e.samp_words = samp->words;
     e.samp_nitem = D.B * D.K; e.samp_nword = D.B * D.W * D.K; e.samp_step = (uint32_t)D.step;
@@ -987,7 +1019,7 @@ extern "C" int ps_tem_encode(const PsTemDesc* desc, const PsTemTensors* params, 
 static void park_colsums(LnBwdArgs& a, float* ws, const Ws& w, ColFoldList* fold) {
   if (!fold || fold->n >= PS_MAX_COLFOLD) return;
   ColFold& f = fold->e[fold->n];
-  a.partial = ws + w.lnpart + (size_t)fold->n * 256 * 3 * a.d;
+  a.partial = ws + w.lnpart + (size_t)fold->n * w.lnrows * 3 * a.d;
   f.partial = a.partial; f.nblk = ln_bwd_blocks(a.rows); f.d = a.d;
   f.dst[0] = a.dgamma; f.dst[1] = a.dbeta; f.dst[2] = a.colsum;
   ++fold->n;
@@ -1026,13 +1058,13 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
   f.dy = ws + w.denc; f.lddy = d; f.stats = ws + w.fin_stats; f.g = P.final_ln_g; f.d = d;
   f.dgamma = G.final_ln_g; f.dbeta = G.final_ln_b;
   // The last layer's whole per-replica backward (final LN, FFN, FF LN, Wo) as one kernel (mlp_fused.hip) when the
-  // forward took the fused form too; needs parked column sums (fold) and one parked row per workgroup (<= 256).
+  // forward took the fused form too; needs parked column sums (fold) and one parked row per workgroup (Ws::lnrows of them).
   side_set_light((int64_t)B * S * d <= ((int64_t)2 << 20));   // C2: 1.03 M elements of x; review transformer 10 M; C5 5.5 M
   static const bool bwd_fuse_on = ps_env_int("PS_NO_FUSE_BWD", 0) == 0;
   const int bwd_fuse_min = fuse_bwd_min_slot();
   const bool fuse_last = NL > 0 && fold && bwd_fuse_on && ps_fusion_enabled() && w.layer[NL - 1].Sq == 1 &&
                          mlp_fused_serves(d, F) && w.wsplit && w.layer[NL - 1].M2 == w.Mf && w.Mf >= bwd_fuse_min &&
-                         mlp_bwd_fused_blocks(w.Mf) <= 256 && fold->n + 3 <= PS_MAX_COLFOLD;
+                         mlp_bwd_fused_blocks(w.Mf) <= w.lnrows && fold->n + 3 <= PS_MAX_COLFOLD;
   if (score_on_side && !(fuse_last && w.R > 1)) {
     // not the fused form: d enc is needed first, so the score backward is cut in two — its d enc half leads the main
     // stream, its table scatter (the expensive half: 127 us of scattered atomics at C5) goes to the side stream
@@ -1099,12 +1131,12 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       const int nwg = mlp_bwd_fused_blocks(M2);
       {   // parked column sums: {final LN gamma, beta, b2}, {b1}, {FF LN gamma, beta, bo}
         ColFold& c0 = fold->e[fold->n];
-        m.part_f = ws + w.lnpart + (size_t)fold->n * 256 * 3 * d;
+        m.part_f = ws + w.lnpart + (size_t)fold->n * w.lnrows * 3 * d;
         c0.partial = m.part_f; c0.nblk = nwg; c0.d = d;
         c0.dst[0] = G.final_ln_g; c0.dst[1] = G.final_ln_b; c0.dst[2] = Lg.b2;
         ++fold->n;
         ColFold& c1 = fold->e[fold->n];
-        m.part_1 = ws + w.lnpart + (size_t)fold->n * 256 * 3 * d;
+        m.part_1 = ws + w.lnpart + (size_t)fold->n * w.lnrows * 3 * d;
         c1.partial = m.part_1; c1.nblk = nwg; c1.d = d;
         c1.dst[0] = Lg.ff_ln_g; c1.dst[1] = Lg.ff_ln_b; c1.dst[2] = Lg.bo;
         ++fold->n;
@@ -1359,6 +1391,9 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
   const bool score_deferred = tem && NL > 0 && w.R > 1 && score_side_on;
   if (!score_deferred) TRY(launch_score_bwd(s, st));
 
+  const float* wp_w[PS_WPLANES_MAX]; int wp_r[PS_WPLANES_MAX], wp_c[PS_WPLANES_MAX];
+  const int wp_n = wplane_list(D, P, w, wp_w, wp_r, wp_c);
+  WPlaneScope wplanes(st, wp_w, wp_r, wp_c, wp_n);             // the dX products read the TRANSPOSED weight planes (gemm.hip)
   ColFoldList fold;
   fold.n = 0;
   const float* dqe = ws + w.denc;   // grad wrt query_emb rows (QEM: enc IS query_emb)

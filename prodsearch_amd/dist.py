@@ -372,7 +372,15 @@ class ShardedAdamExchange(object):
         each, batched (ncclSend / ncclRecv pairs: on a fully connected xGMI node every pair has its own direct link) straight
         from the slice into its place — no staging copy (round 3 expanded the slice W times for all_to_all_single: a 27 MB
         torch copy per step at C2).  When ``shard`` IS the rank's slice of ``full`` (the step path) nothing is copied at all."""
-        if mode == 'a2a':
+        if mode == 'a2a' and shard.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo rehearsals of the N-rank path on GPU tensors (tests/test_gpu_dp.py): its send / recv read device memory from
+            # the host WITHOUT waiting for the stream (observed: replicas diverged at world 4), its collectives do wait — so
+            # the slice goes through all_to_all_single from a W-fold staging copy there, as in round 3
+            if getattr(self, '_a2a_send', None) is None:
+                self._a2a_send = torch.empty(self.world, shard.numel(), device=shard.device, dtype=torch.float32)
+            self._a2a_send.copy_(shard.unsqueeze(0).expand_as(self._a2a_send))
+            dist.all_to_all_single(full, self._a2a_send.view(-1), group=self.group)
+        elif mode == 'a2a':
             W, r, n = self.world, self.rank, shard.numel()
             mine = full[r * n:(r + 1) * n]
             if mine.data_ptr() != shard.data_ptr():

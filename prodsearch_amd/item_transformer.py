@@ -565,6 +565,16 @@ class ItemTransformerRanker(nn.Module):
 
     def _run_forward(self, batch, neg_items=None, neg_words=None):
         lib = _lib.load()
+        if self._lazy_exact():
+            # catch_up_rows() (below) advances the touched rows' "steps applied" to T + 1 on the promise that optim.step() T + 1
+            # follows: a second training forward before that step would leave the first one's rows one replay short of the dense
+            # optimizer — refused here, before anything of this forward has happened (the first forward stays backward-able)
+            opt = self.__dict__.get('_lazy_optim')
+            opt = opt() if opt is not None else None
+            if opt is not None and opt._lazy_awaiting_step:
+                raise RuntimeError("lazy_exact_adam: a second training forward without an optimizer step in between (the rows of "
+                                   "the first were already advanced to the coming step); call optim.step() after every "
+                                   "training forward, or model.eval() for forwards that do not train")
         ps, _ = self._structs()
         plan = self._plan_for(batch, eval_mode=False)
         self.__dict__['_last_plan'] = plan
@@ -620,6 +630,7 @@ class ItemTransformerRanker(nn.Module):
             self._coalesce_touched(plan)
             plan.coalesced_at = self._fwd_step
             opt.catch_up_rows()
+            opt._lazy_awaiting_step = True
             plan.staged = False
             _lib.check(lib.ps_tem_forward(plan.desc, ps, plan.batch, plan.ws.data_ptr(), loss3.data_ptr(),
                                           self._loss_acc.data_ptr(), self._stream()), 'ps_tem_forward')

@@ -49,6 +49,7 @@ class Optimizer(object):
         self.lazy_exact = False              # args.lazy_exact_adam: row-sparse machinery, the DENSE optimizer's results (catch_up_rows)
         self._lazy_last = {}                 # id(table parameter) -> int32 [n_rows]: optimizer steps applied to each row
         self._lazy_base = 0                  # value a new entry of _lazy_last starts from (the step of a loaded checkpoint)
+        self._lazy_awaiting_step = False     # a training forward has advanced its rows to the coming step (a second one is refused)
 
     def set_parameters(self, params):
         """``set_parameters`` (optimizers.py:165-187): every parameter that requires grad."""
@@ -191,6 +192,7 @@ class Optimizer(object):
         lib = _lib.load()
         plan = None if self._sharded is not None else (self._plan if self._plan_ok() else self._build_plan())
         self._step += 1
+        self._lazy_awaiting_step = False
         if self.decay_method == "noam":      # host mirror of the in-kernel schedule (optimizers.py:214-219)
             self.learning_rate = self.original_lr * min(self._step ** (-0.5),
                                                         self._step * self.warmup_steps ** (-1.5))

@@ -72,6 +72,12 @@ class ShardedItemTable(object):
         self.bad = torch.zeros(1, device=dev, dtype=i32)
         self._remap_out = {}
         self.pending = False             # a backward's gradient buffer waits to be pushed to the owners
+        # the overflow / dropped-index status word reaches the host ONE lookup late without a synchronisation: every lookup
+        # queues an asynchronous 4-byte copy into pinned memory, the next lookup reads what the previous one left (its copy
+        # finished a whole step ago) — round 3 only looked where the trainer read the loss, up to steps_per_checkpoint steps
+        # of silently wrong embeddings later
+        self._bad_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
+        self._bad_evt = None
 
     def attach(self, param):
         """Use ``param`` (``[slots + 1, d]``, the model's ``product_emb.weight``) as the receive buffer."""
@@ -145,6 +151,7 @@ class ShardedItemTable(object):
         if self.pending:
             raise RuntimeError("ShardedItemTable.lookup: the last backward's gradient still sits in the receive buffer (slots are "
                                "per lookup): call optimizer.step() before the next forward / encode / test")
+        self._poll_flag()
         total = sum(t.numel() for t in index_tensors)
         if total > self.cap and self.cap < self.n_rows:
             raise RuntimeError("ShardedItemTable.lookup: %d indices but the table was built for %d per step "
@@ -168,7 +175,26 @@ class ShardedItemTable(object):
                 o = self._remap_out[(k, t.numel())] = torch.empty(t.numel(), device=self.device, dtype=torch.int64)
             self._k_remap(t, o)
             out.append(o.view(t.shape))
+        self._post_flag()
         return out
+
+    def _post_flag(self):
+        if self._bad_host is not None:
+            self._bad_host.copy_(self.bad, non_blocking=True)
+            self._bad_evt = torch.cuda.Event()
+            self._bad_evt.record(torch.cuda.current_stream(self.device))
+
+    def _poll_flag(self):
+        """Raise if the PREVIOUS lookup overflowed a request or dropped an index (no stall: its status copy is a step old)."""
+        if self._bad_evt is None:
+            return
+        self._bad_evt.synchronize()
+        self._bad_evt = None
+        flag = int(self._bad_host[0])
+        if flag:
+            self.bad.zero_()
+            raise RuntimeError("sharded item table (previous lookup): " + ("an index was not in the step's row list" if flag == 1 else
+                               "a request to one owner overflowed its capacity of %d rows (skewed ids: raise the headroom)" % self.capp))
 
     def push_grads(self, grad_buf):
         """Route the receive buffer's gradient rows (``[slots + 1, d]``) to their owners and merge them into ``self.grad``;

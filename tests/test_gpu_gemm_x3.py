@@ -108,3 +108,38 @@ def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore, shape):
     print("denormal low plane: error / sum|ab|  bf16x3 %.3g  fp32 MFMA %.3g" % (e[1], e[0]))
     assert e[0] < 6e-7
     assert e[1] < 6e-7, e
+
+
+@pytest.mark.parametrize('M,N,K,tb', [(21504, 256, 256, 0), (21504, 1024, 256, 0), (21504, 256, 1024, 0), (21504, 256, 1024, 1),
+                                      (21504, 1024, 256, 1), (8064, 128, 512, 1), (4100, 160, 96, 0), (5001, 96, 224, 1)])
+def test_products_against_pre_split_weights_match_fp64(x3_restore, M, N, K, tb):
+    """gemm_x3w_kernel (csrc/gemm.hip): the weight operand split ONCE into bf16 planes (both orientations), the activation split
+    on its fragments in registers — the forward / input-gradient products of the d = 256 step (models/neural.py:30-33, 86-96).
+    Same bound against fp64 as the fp32 MFMA, ragged row and column tails included; and really another kernel than ps_gemm_f32's."""
+    from prodsearch_amd import _lib
+    lib = x3_restore
+    lib.ps_gemm_x3_config(1, 4)
+    gen = torch.Generator().manual_seed(M + 3 * N + 7 * K + tb)
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(K, N, generator=gen) * 0.1           # logical [K][N]
+    bias = torch.randn(N, generator=gen)
+    Wd = (W.contiguous() if tb else W.t().contiguous()).cuda()
+    Ad, bd = A.cuda(), bias.cuda()
+    C = torch.zeros(M, N, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ps_gemm_f32_weight(Ad.data_ptr(), K, Wd.data_ptr(), tb, C.data_ptr(), N, M, N, K, bd.data_ptr(), 0.5, st),
+               'ps_gemm_f32_weight')
+    lib.ps_gemm_x3_config(1, -1)
+    C1 = torch.zeros(M, N, device='cuda')
+    _lib.check(lib.ps_gemm_f32(Ad.data_ptr(), K, 0, Wd.data_ptr(), N if tb else K, tb, C1.data_ptr(), N, M, N, K,
+                               bd.data_ptr(), 0.5, 0, st), 'ps_gemm_f32')
+    torch.cuda.synchronize()
+    rows = slice(0, M, 7)
+    ref = (A[rows].double() @ W.double() + bias.double()) * 0.5
+    mag = A[rows].double().abs() @ W.double().abs() + bias.double().abs()
+    e = float(((C.cpu()[rows].double() - ref).abs() / mag).max())
+    e1 = float(((C1.cpu()[rows].double() - ref).abs() / mag).max())
+    assert e < 6e-7 and e1 < 6e-7, (e, e1)
+    assert float((C - C1).abs().max()) < 1e-4 * float(C1.abs().max())
+    if M >= 8064:
+        assert not torch.equal(C, C1)          # (another kernel, another summation order)

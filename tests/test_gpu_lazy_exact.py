@@ -102,3 +102,22 @@ def test_the_plain_row_sparse_rule_is_a_different_optimizer():
     assert diff > 1e-4
     small = [k for k in pd if pd[k].numel() < 100000 and pd[k].dtype.is_floating_point]
     assert small
+
+
+def test_a_second_training_forward_without_a_step_is_refused():
+    """catch_up_rows() advances the touched rows' step counters at FORWARD time on the promise that optim.step() follows; two
+    training forwards before one step would leave the first forward's rows one replay short of the dense optimizer."""
+    from prodsearch_amd import ItemTransformerRanker, build_optim, readme_tem_args, synth
+    a = readme_tem_args(dropout=0.0, lr=0.002, batch_size=B, neg_per_pos=K, lazy_exact_adam=True)
+    wd = synth.make_word_dists(V)
+    m = ItemTransformerRanker(a, 'cuda', V, P_, None, word_dists=wd)
+    optim = build_optim(a, m, None)
+    m.train()
+    batch = synth.make_tem_batch(1, B, P_, V, Q=6, L=L, W=1, word_dists=wd).to('cuda')
+    loss = m(batch)
+    with pytest.raises(RuntimeError, match='second training forward'):
+        m(batch)
+    m.zero_grad()
+    loss.backward()
+    optim.step()
+    m(batch)                                   # after the step the next training forward is fine

@@ -55,6 +55,7 @@ def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
     (130, 3, 12, 5, 1, 96, 8, 0.1, 0.1),     # ragged batch (not a multiple of any tile), d not a power of two, dropout
     (2, 5, 20, 8, 3, 128, 8, 0.0, 0.1),
     (50, 20, 9, 4, 1, 128, 8, 0.2, 0.1),     # 1,050 replica rows: the fused per-replica kernels with a partial last tile
+    (400, 20, 9, 4, 1, 128, 8, 0.2, 0.1),    # 8,400 replica rows = 263 workgroups: past the 256 round 3 stopped the fused / folded forms at
     # the attention forms (attn_sq1.hip): replicas inside a wave (d = 128, 8 heads, 4..24 replicas, <= 32 positions) ...
     (6, 23, 29, 4, 1, 128, 8, 0.2, 0.1),     # 30 positions (8 key steps), 24 replicas (chunks of 6)
     (9, 3, 31, 4, 1, 128, 8, 0.1, 0.1),      # 32 positions, 4 replicas (one per wave)

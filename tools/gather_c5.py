@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--w', type=int, default=1, help='pv_window_size (0: item tasks only)')
+    ap.add_argument('--sets', type=int, default=8, help='index sets the launches rotate through (1: the same rows every launch = Infinity-Cache hits)')
     a = ap.parse_args()
     lib = _lib.load()
     d, B, K, W, P, V = 256, a.batch, 20, a.w, a.rows, a.vocab
@@ -47,19 +48,22 @@ def main():
     params = _lib.PsTemTensors()
     params.product_emb, params.word_emb, params.word_bias = table.data_ptr(), words.data_ptr(), wbias.data_ptr()
     mk = lambda hi, *shape: torch.randint(0, hi, shape, device=dev, dtype=torch.int64, generator=gen)
-    target, negs, pw, nw = mk(P, B), mk(P, B, K), mk(V - 1, B, max(W, 1)), mk(V - 1, B, max(W, 1) * K)
-    bt = _lib.PsTemBatch()
-    bt.target_prod_idxs, bt.neg_item_idxs = target.data_ptr(), negs.data_ptr()
-    bt.pos_iword_idxs, bt.neg_word_idxs = pw.data_ptr(), nw.data_ptr()
+    sets = []
+    for _ in range(max(1, a.sets)):
+        idx = (mk(P, B), mk(P, B, K), mk(V - 1, B, max(W, 1)), mk(V - 1, B, max(W, 1) * K))
+        bt = _lib.PsTemBatch()
+        bt.target_prod_idxs, bt.neg_item_idxs = idx[0].data_ptr(), idx[1].data_ptr()
+        bt.pos_iword_idxs, bt.neg_word_idxs = idx[2].data_ptr(), idx[3].data_ptr()
+        sets.append((idx, bt))
     st = torch.cuda.current_stream()
-    call = lambda: lib.ps_gather_score(desc, params, bt, ws.data_ptr(), st.cuda_stream)
-    for _ in range(5):
-        _lib.check(call(), 'ps_gather_score')
+    call = lambda i=0: lib.ps_gather_score(desc, params, sets[i % len(sets)][1], ws.data_ptr(), st.cuda_stream)
+    for i in range(8):
+        _lib.check(call(i), 'ps_gather_score')
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record(st)
-    for _ in range(a.iters):
-        call()
+    for i in range(a.iters):
+        call(i)
     e1.record(st)
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / a.iters
@@ -67,7 +71,7 @@ def main():
     rows = B * (1 + K) * (1 + W)
     nbytes = rows * (4 * d + 8) + (B * R + B) * 4 * d + rows * 4
     print(json.dumps({"workload": "gather+score launch, C5 shape: d=256, %d-row item table (%.1f GB), B=%d, K=%d, R=%d"
-                      % (P, (P + 1) * d * 4 / 1e9, B, K, R), "us_per_launch": t * 1e6, "bytes_per_launch": nbytes,
+                      % (P, (P + 1) * d * 4 / 1e9, B, K, R), "index_sets": len(sets), "env": {k: v for k, v in os.environ.items() if k.startswith('PS_SCORE')}, "us_per_launch": t * 1e6, "bytes_per_launch": nbytes,
                       "achieved_GBps": nbytes / t / 1e9, "frac_of_8TBps": nbytes / t / 8e12}))
 
 

@@ -54,4 +54,21 @@ if __name__ == '__main__':
         for shp in (0, 1, 2, 3):
             t, e = one(M, N, K, ta, tb, acc, 1, shp)
             line += " x3[%d] %7.1f us %6.1f TF err %.1e |" % (shp, t, 2.0 * M * N * K / t / 1e6, e)
+        if not ta and N % 32 == 0 and K % 32 == 0:      # the same product against pre-split weight planes (gemm_x3w_kernel)
+            lib.ps_gemm_x3_config(1, 4)
+            A = torch.randn(M, K, device='cuda')
+            W = torch.randn((K, N) if tb else (N, K), device='cuda') * 0.1
+            C = torch.zeros(M, N, device='cuda')
+            wargs = (A.data_ptr(), K, W.data_ptr(), tb, C.data_ptr(), N, M, N, K, None, 1.0, st)
+            for _ in range(5):
+                _lib.check(lib.ps_gemm_f32_weight(*wargs), 'gemm_w')
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                lib.ps_gemm_f32_weight(*wargs)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / 50
+            line += " x3w %7.1f us %6.1f TF (incl. the plane split launch) |" % (t, 2.0 * M * N * K / t / 1e6)
         print(line, flush=True)
