@@ -201,6 +201,8 @@ int launch_rows_scatter_det(const int32_t* keys, int ntask, const float* src, in
                             const float* scale = nullptr, const int32_t* rowidx = nullptr);   // task t: scale[t] * row rowidx[t] of src
 
 // dqpre = dqe * (1 - qe^2), dfb += colsum(dqpre)
+// out[b][c] = sum_j src[(b * fan + j) * ld + c]: the replicas' fan-in into one row per sequence (row-list dX product, tem.hip)
+int launch_fanin_sum(const float* src, int ld, int n_in, int fan, int d, float* out, hipStream_t st);
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
                     hipStream_t st);
 

@@ -1702,6 +1702,35 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* dqe, int ldd
   for (int c = threadIdx.x; c < d; c += 256) atomicAdd(&dfb[c], csum[c]);
 }
 
+// The residual path  out = dropout(context) + inputs  feeds every replica's d y1 back into its sequence's ONE query row:
+// d x[b, qpos] += sum_j d y1[b * fan + j].  As the dX product's RES_FANIN epilogue that walk (21 rows per query row at C5) forced
+// the dense form of the product over all B * S positions; summed here first (22 MB read at C5, one float4 per thread and replica,
+// all of a thread's loads in flight together) the product runs over the VALID positions only, as at d = 128.
+__global__ __launch_bounds__(256) void fanin_sum_kernel(const float* __restrict__ src, int ld, int n_in, int fan, int d4,
+                                                        float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_in * d4) return;
+  const int b = idx / d4, c = idx - b * d4;
+  const float4* p = reinterpret_cast<const float4*>(src + (size_t)b * fan * ld) + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int j = 0;
+  for (; j + 8 <= fan; j += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u) * (ld >> 2)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; j < fan; ++j) { const float4 v = p[(size_t)j * (ld >> 2)]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  reinterpret_cast<float4*>(out)[idx] = s;
+}
+int launch_fanin_sum(const float* src, int ld, int n_in, int fan, int d, float* out, hipStream_t st) {
+  PS_REQUIRE(src && out && n_in > 0 && fan > 0 && d % 4 == 0 && ld % 4 == 0, "fanin_sum: bad argument");
+  hipLaunchKernelGGL(fanin_sum_kernel, dim3(ps_cdiv((int64_t)n_in * (d / 4), 256)), dim3(256), 0, st, src, ld, n_in, fan, d / 4, out);
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 int launch_tanh_bwd(const float* dqe, int lddqe, const float* qe, float* dqpre, float* dfb, int rows, int d,
                     hipStream_t st) {
   hipLaunchKernelGGL(tanh_bwd_kernel, dim3(ps_cdiv(rows, 8)), dim3(256), (size_t)d * sizeof(float), st, dqe, lddqe,

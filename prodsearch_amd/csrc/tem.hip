@@ -37,8 +37,11 @@ extern "C" const char* ps_version(void) { return "prodsearch_hip 0.1 (gfx950, fp
 // operands — six bf16 MFMAs per product step, fp32 accumulation, the fp32 MFMA's accuracy
 bool gemm_x3_on();
 extern "C" const char* ps_arith_info(void) {
-  return gemm_x3_on() ? "f32 (fp32 MFMA and VALU; wide products, the fused per-replica kernels and grouped weight gradients as exact "
-                        "bf16x3 products: 3-way bf16 split of both fp32 operands, 6 bf16 MFMAs per step, fp32 accumulation)"
+  // (the SPLIT is exact — hi + mid + lo carry all 24 mantissa bits; the PRODUCT keeps six of the nine cross terms and drops those
+  // below 2^-24 of the leading one: fp32-GRADE, 1.1e-7 of sum |a b| against fp64, the fp32 MFMA's own 1.13e-7 — not "exact")
+  return gemm_x3_on() ? "f32 (fp32 MFMA and VALU; wide products, the fused per-replica kernels and grouped weight gradients as fp32-grade "
+                        "bf16x3 products: exact 3-way bf16 split of both fp32 operands, 6 of the 9 cross products as bf16 MFMAs per step, "
+                        "fp32 accumulation)"
                       : "f32 (fp32 MFMA and VALU)";
 }
 
@@ -1260,8 +1263,11 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
       static const bool rows_on0 = ps_env_int("PS_NO_ROWLIST", 0) == 0;
       const bool listed0 = rows_on0 && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
-      if (wf) TRY(launch_attn_bwd_wf(a, reinterpret_cast<const uint32_t*>(ws + l.amask), listed0 && (q_folded || l.fan == 1), st));
-      else if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1), st));
+      // round 4: where dQ.Wq is NOT folded (d != 128: the C5 shard) the replicas' fan-in is summed by a launch of its own
+      // (launch_fanin_sum, below) so that the dX product can still run over the row list: 133 -> ~50 us at C5
+      const bool presum = listed0 && !q_folded && l.fan > 1 && l.Sq == 1 && !qall && i == 0 && (d % 4) == 0;
+      if (wf) TRY(launch_attn_bwd_wf(a, reinterpret_cast<const uint32_t*>(ws + l.amask), listed0 && (q_folded || l.fan == 1 || presum), st));
+      else if (w1) TRY(launch_attn_bwd_w1(a, listed0 && (q_folded || l.fan == 1 || presum), st));
       else TRY(sq1 ? launch_attn_bwd_sq1(a, st) : launch_attn_bwd(a, st));
       // weight gradients of Wo, Wk, Wv, Wq: one fork right behind the attention backward, off the dX chain
       GemmProblem wg3[3];
@@ -1315,10 +1321,15 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
           x.res.extra = ws + w.dln1; x.res.extra2 = (w1 && !(wf && attn_bwd_wf_two_partials(a))) ? nullptr : ws + w.dln1 + (size_t)l.n_in * d; x.res.extra_ld = d; x.res.ptr = nullptr;
         }
         else if (q_via_res) { x.res.extra = dxq; x.res.extra_ld = d; }
+        if (presum && listed && q_via_res) {   // fan-in summed up front: one row per sequence beside the dQ.Wq row, nothing to walk
+          float* fsum = ws + w.dln1;          // (free: the FF LayerNorm backward has consumed d ln1)
+          TRY(launch_fanin_sum(ws + w.dy1, d, l.n_in, l.fan, d, fsum, st));
+          x.res.ptr = nullptr; x.res.extra = dxq; x.res.extra2 = fsum; x.res.extra_ld = d;
+        }
       }
       // (the dX product over the row list only when its fan-in residual is already folded: walking 21 replica rows per
       // query row in a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
-      if (listed && (q_folded || l.fan == 1)) { x.ridx = vr; x.rcount = vc; }
+      if (listed && (q_folded || l.fan == 1 || (presum && q_via_res))) { x.ridx = vr; x.rcount = vc; }
       TRY(run1(x, st));
       if (wg3_main) {
         static const bool wg3_last = ps_diag_int("PS_WG3_LAST", 1) != 0;

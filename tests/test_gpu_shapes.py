@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('d,F,B,K,dropout', [(256, 1024, 24, 6, 0.0), (512, 1024, 9, 4, 0.0), (256, 1024, 16, 5, 0.1),
+                                             (256, 1024, 70, 20, 0.1),   # 1,470 replica rows at d = 256: the replicas' fan-in summed by its own launch, the K/V dX product over the row list (round 4)
                                              (512, 1024, 300, 3, 0.0)])   # 6,300 K/V rows, few splits: row-list weight gradients remap their split count
 def test_wide_embeddings_match_oracle(d, F, B, K, dropout):
     from oracle import tem as otem, philox

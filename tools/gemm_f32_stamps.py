@@ -4,6 +4,7 @@
     python tools/gemm_f32_stamps.py 4      the grouped FF / Wo weight gradients (bf16x3 kernel: use tools/gemm_stamps.py's phase names)   (on the GPU box)"""
 import argparse, ctypes, os, sys
 which = sys.argv[1] if len(sys.argv) > 1 else '2'
+os.environ['PS_DIAG_LIB'] = '1'      # stamps exist in the diagnostic build only (python -m prodsearch_amd.build --diag)
 os.environ['PS_GEMM_STAMP'] = which
 if len(sys.argv) > 2:
     os.environ['PS_NO_SIDE'] = sys.argv[2]

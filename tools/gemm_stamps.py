@@ -1,6 +1,7 @@
 """Diagnostic: phase timeline of one mid-grid workgroup of the bf16x3 GEMM kernel (s_memtime per wave; PS_GEMM_STAMP=1).
     PS_GEMM_STAMP=1 python tools/gemm_stamps.py M N K ta tb shape        (on the GPU box)"""
 import ctypes, os, sys
+os.environ['PS_DIAG_LIB'] = '1'      # stamps exist in the diagnostic build only (python -m prodsearch_amd.build --diag)
 os.environ['PS_GEMM_STAMP'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

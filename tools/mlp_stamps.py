@@ -1,6 +1,7 @@
 """Diagnostic: phase timeline of the fused per-replica forward (mlp_fwd_t_kernel), workgroup 0, all 8 waves (s_memtime).
     python tools/mlp_stamps.py        (on the GPU box)"""
 import ctypes, os, sys
+os.environ['PS_DIAG_LIB'] = '1'      # stamps exist in the diagnostic build only (python -m prodsearch_amd.build --diag)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from prodsearch_amd import ItemTransformerRanker, readme_tem_args, synth, _lib

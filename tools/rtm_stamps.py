@@ -1,6 +1,7 @@
 """Diagnostic: phase timeline of one workgroup of the review transformer's forward gather (rtm_embed4_kernel; s_memtime per wave).
     PS_RTM_STAMP=1 python tools/rtm_stamps.py        (on the GPU box)"""
 import argparse, ctypes, os, sys
+os.environ['PS_DIAG_LIB'] = '1'      # stamps exist in the diagnostic build only (python -m prodsearch_amd.build --diag)
 os.environ['PS_RTM_STAMP'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,6 +2,7 @@
     python tools/rtm_wg_times.py        (on the GPU box; PS_RTM_STAMP=1 PS_RTM_DIAG=64 are set here)
 s_memtime per workgroup (wave 0) + its XCC id; times are compared inside one XCC only."""
 import argparse, ctypes, os, sys
+os.environ['PS_DIAG_LIB'] = '1'      # stamps exist in the diagnostic build only (python -m prodsearch_amd.build --diag)
 os.environ['PS_RTM_STAMP'] = '1'
 os.environ['PS_RTM_DIAG'] = '64'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
