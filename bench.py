@@ -60,6 +60,12 @@ TEM_CFG = {
     'c5': dict(P=50_000_000, B=1024, K=20, L=20, Q=8, W=1, D=256, FF=1024, row_sparse=True, config_index=4),
 }
 C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)      # BASELINE configs[3]
+# HBM traffic of ONE gather+score launch at B=1024, d=256 from the committed counter passes (PMC cannot run inside this process)
+GATHER_TRAFFIC = 70.3e6
+GATHER_TRAFFIC_SOURCE = ("committed PMC passes profiles/r04_gather_score_c5_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                         "tools/gather_c5.py --rows 8000000 --batch 1024, 8 rotating index sets): FETCH_SIZE 34.9 MB x2 (gfx950 16-B/lane streaming-read "
+                         "correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE 0.42 MB = 70.3 MB per launch against 67.6 MB algorithmic (1.04x: nothing is "
+                         "re-read; rounds 2-3 with ONE index set: 62.8 MB, part of the rows out of the Infinity Cache)")
 PREWARM_TOTAL = 100                                        # untimed steps in front of the timed region, the W warm-up steps included
 ALSO_C5_ITEMS = 50_000_000                                 # the c5 line inside the default run: the STATED table of configs[4] (205 GB resident)
 GATHER_LEG_ITEMS = 8_000_000                               # the stand-alone gather+score leg: an 8.2 GB table is 32x the Infinity Cache already
@@ -149,9 +155,8 @@ class TemWorkload(object):
                                "frac_of_bf16x3_equivalent_peak": None})
         return dict(tag='gather_score', bound='hbm', work=gather_bytes, peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
-                    extra={"traffic": 63.0e6 if (B, D) == (1024, 256) else None,
-                           "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f; round 3 repeat: profiles/r03_gather_score_c5_pmc.txt, 31.2 MB x2 + 0.4 MB): FETCH_SIZE "
-                                             "31.2 MB x2 + WRITE_SIZE 0.4 MB per launch at B=1024, d=256" if (B, D) == (1024, 256) else None})
+                    extra={"traffic": GATHER_TRAFFIC if (B, D) == (1024, 256) else None,
+                           "traffic_source": GATHER_TRAFFIC_SOURCE if (B, D) == (1024, 256) else None})
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_tem(self.ns, self.c, n_steps)
@@ -527,9 +532,7 @@ def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": res[0]["achieved"], "frac": res[0]["frac"],
             "kernel": "score_fwd_wide_kernel<1,4> alone (embedding gather + score), C5 shape: d=256, %d-row item table "
                       "(%.1f GB), K=20, W=1, R=21; 8 rotating index sets" % (rows, (rows + 1) * d * 4 / 1e9),
-            "by_batch": res, "traffic": 63.0e6,
-            "traffic_source": "committed PMC passes profiles/r02_gather_score_c5_pmc.txt (commit ed4b86f; round 3 repeat: profiles/r03_gather_score_c5_pmc.txt, 31.2 MB x2 + 0.4 MB): FETCH_SIZE 31.2 MB x2 "
-                              "+ WRITE_SIZE 0.4 MB per launch at B=1024 against 67.6 MB algorithmic",
+            "by_batch": res, "traffic": GATHER_TRAFFIC, "traffic_source": GATHER_TRAFFIC_SOURCE,
             "timing": "%d launches per batch size, back to back on their stream between one HIP event pair (us_per_launch); and "
                       "one event pair around every launch (ps_ktimer; us_per_launch_event_pairs, which includes the pairs' own packets)" % iters}
 

@@ -124,3 +124,18 @@ def test_fused_backward_partial_tiles(B, K, L, Q, W, zero_hist):
     finally:
         _lib.load().ps_set_fuse_bwd_min(old)
 
+
+
+def test_pre_split_weight_products_inside_the_step():
+    """``ps_gemm_x3_config(1, 4)``: the d = 256 step's forward / input-gradient products multiply against weight planes split once
+    per entry-point call (WPlaneScope + gemm_x3w_kernel, csrc/gemm.hip) — exercised where the kernel really runs (>= 4,096 replica
+    rows: B = 200, K = 20) against the replicated oracle: loss and every gradient, K-concatenated [dK | dV] product and the
+    transposed planes of the dX products included (models/neural.py:30-33, 86-96, 192-231)."""
+    from prodsearch_amd import _lib
+    lib = _lib.load()
+    lib.ps_gemm_x3_config(1, 4)
+    try:
+        test_wide_embeddings_match_oracle(256, 1024, 200, 20, 0.1)
+    finally:
+        lib.ps_gemm_x3_config(0 if __import__('os').environ.get('PS_GEMM_X3') == '0' else 1,
+                              int(__import__('os').environ.get('PS_GEMM_X3_SHAPE', '-1')))
