@@ -115,7 +115,7 @@ def test_operands_whose_low_plane_is_a_bf16_denormal(x3_restore, shape):
 def test_products_against_pre_split_weights_match_fp64(x3_restore, M, N, K, tb):
     """gemm_x3w_kernel (csrc/gemm.hip): the weight operand split ONCE into bf16 planes (both orientations), the activation split
     on its fragments in registers — the forward / input-gradient products of the d = 256 step (models/neural.py:30-33, 86-96).
-    Same bound against fp64 as the fp32 MFMA, ragged row and column tails included; and really another kernel than ps_gemm_f32's."""
+    Same bound against fp64 as the fp32 MFMA, ragged row and column tails included."""
     from prodsearch_amd import _lib
     lib = x3_restore
     lib.ps_gemm_x3_config(1, 4)
@@ -140,6 +140,6 @@ def test_products_against_pre_split_weights_match_fp64(x3_restore, M, N, K, tb):
     e = float(((C.cpu()[rows].double() - ref).abs() / mag).max())
     e1 = float(((C1.cpu()[rows].double() - ref).abs() / mag).max())
     assert e < 6e-7 and e1 < 6e-7, (e, e1)
+    # (the two kernels issue the same six MFMAs per step in the same order over the same k sequence: their results may be — and at
+    # these shapes are — bitwise equal; what differs is who splits the operands, and when)
     assert float((C - C1).abs().max()) < 1e-4 * float(C1.abs().max())
-    if M >= 8064:
-        assert not torch.equal(C, C1)          # (another kernel, another summation order)
