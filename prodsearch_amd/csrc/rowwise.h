@@ -38,6 +38,7 @@ struct ScoreArgs {
   // negative words drawn inside the launch that consumes them (the sampling workgroups of the same launch have not
   // necessarily run yet): same Philox stream and alias table as sample_kernel, so the values equal neg_words[]
   const float* samp_prob; const int32_t* samp_alias; uint32_t samp_step, samp_k0, samp_k1; int samp_inline;
+  unsigned long long* stamp;     // diagnostic build: per-workgroup s_memrealtime stamps of the gather+score launch (tools/gather_wg_times.py)
 };
 #define PS_WORD_TASKS_PER_WG 16
 inline void score_finish(ScoreArgs& a) {

@@ -853,13 +853,28 @@ __device__ inline float row16_sum_last(float v) {   // sum over rows of 16 lanes
 #undef PS_DPP_ADD
   return v;
 }
+// (scalar registers capped at 80: 256-thread workgroups are admitted 8 per CU up to 80 SGPRs, 7 at 82-96 — MI355X_MICROARCH.md,
+// residency; the kernel asked for 85 — and this launch lives on workgroups in flight: profiles/r04_gather_score_wg_times.txt)
 template <int SCORE_U, int CH>
-__global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, int ntask, int lpr) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void score_fwd_wide_kernel(const ScoreArgs a, int ntask, int lpr) {
   const int tid = threadIdx.x;
   const int gpb = 256 / lpr;
   const int grp = blockIdx.x * gpb + tid / lpr;
   const int c = tid % lpr;
   const int t0 = grp * SCORE_U;
+#if PS_DIAG_ON      // [4 * workgroup + {0 start, 1 indices known, 2 rows arrived, 3 end}]: the 100 MHz counter all CUs share
+#define GS_STAMP(slot)                                                                                    \
+  do {                                                                                                    \
+    if (a.stamp && threadIdx.x == 0) {                                                                    \
+      unsigned long long t_;                                                                              \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      a.stamp[4 * (size_t)blockIdx.x + (slot)] = t_;                                                      \
+    }                                                                                                     \
+  } while (0)
+#else
+#define GS_STAMP(slot) do { } while (0)
+#endif
+  GS_STAMP(0);
   Task tk[SCORE_U];
   float4 r[SCORE_U][CH], v[SCORE_U][CH];
   bool live[SCORE_U];
@@ -873,6 +888,10 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
   }
   float cps = 0.f, cil = 0.f;
   const int wl = lpr == 32 ? 31 : (lpr == 16 ? 15 : 0);
+#if PS_DIAG_ON
+  if (a.stamp) { asm volatile("" ::"v"(tk[0].row)); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+  GS_STAMP(1);
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u)
 #pragma unroll
@@ -881,6 +900,10 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
   for (int u = 0; u < SCORE_U; ++u)
 #pragma unroll
     for (int k = 0; k < CH; ++k) r[u][k] = *reinterpret_cast<const float4*>(tk[u].row + 4 * (c + lpr * k));
+#if PS_DIAG_ON
+  if (a.stamp) { asm volatile("" ::"v"(r[0][0].x), "v"(v[0][0].x)); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+  GS_STAMP(2);
 #pragma unroll
   for (int u = 0; u < SCORE_U; ++u) {
     float s = 0.f;
@@ -898,6 +921,7 @@ __global__ __launch_bounds__(256) void score_fwd_wide_kernel(const ScoreArgs a, 
       }
     }
   }
+  GS_STAMP(3);
   if (!a.loss_blk || a.C > 0) return;
   __shared__ float rps[64], ril[64];
   if (c == wl) { rps[tid / lpr] = cps; ril[tid / lpr] = cil; }
@@ -951,6 +975,11 @@ int score_fwd_blocks(const ScoreArgs& a) {
 int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   PS_REQUIRE(a.d % 4 == 0, "score: d %% 4");
   KTimeScope kt("gather_score", st);
+#if PS_DIAG_ON
+  a.stamp = ps_diag_int("PS_SCORE_STAMP", 0) ? ps_debug_stamp_ptr() : nullptr;
+#else
+  a.stamp = nullptr;
+#endif
   int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
   if (const int ch = score_wide_ch(a, ntask)) {
     const int wl = a.d / 4 / ch, wu = score_wide_u();
