@@ -1315,7 +1315,8 @@ static void launch_x3(int shape, dim3 grid, hipStream_t stream, const GemmGroup&
 static bool x3_flat_d(const GemmGroup& g) {
   x3_on();
   (void)g;
-  return g_x3_force == 3;
+  static const int diag = ps_diag_int("PS_X3_FLAT_D", 0);
+  return g_x3_force == 3 || diag != 0;
 }
 // the direct-to-LDS form (gemm_x3d_kernel) takes single-segment operands and whole 32-deep slabs (a listed weight gradient pads
 // its reduction list itself)
