@@ -358,7 +358,10 @@ print(json.dumps({'graphs': int(_lib.load().ps_graph_replay_enabled()), 'losses'
         assert r.returncode == 0, r.stderr[-2000:]
         out[flag] = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['0']['graphs'] == 0 and out['1']['graphs'] == 1
-    assert out['0']['losses'][0] == out['1']['losses'][0]            # same parameters, same kernels: identical bits
+    # same parameters, same encoder kernels; the loss itself is summed by the fused forward's epilogue in the eager step and by the
+    # stand-alone gather+score + loss launches in the step API (forward_body never folds): two association orders of the same
+    # terms — equal to an fp32 ulp or two, and bitwise only by luck (it was, until round 4's GELU form moved the last bits)
+    assert abs(out['0']['losses'][0] - out['1']['losses'][0]) <= 4e-7 * abs(out['0']['losses'][0])
     for a, b in zip(out['0']['losses'][:3], out['1']['losses'][:3]):  # later steps see atomically-summed table grads
         assert abs(a - b) <= 1e-5 * abs(a)
     for k in out['0']['sum']:
