@@ -213,7 +213,10 @@ int ps_build_alias_host(const double* dist_host, int64_t n, float* prob_host, in
 /* optim.step()                             -- Optimizer.step (models/optimizers.py:205-243):
  * clip_grad_norm_(max_grad_norm) over all listed grads, then dense Adam(eps) with
  * bias correction, optional L2 (weight_decay) and noam schedule.  The tensor
- * table lives on the device (ps_adam_plan_bytes / ps_adam_plan_write_host).
+ * table lives on the device (ps_adam_plan_bytes / ps_adam_plan_write_host); its
+ * tail is device scratch the two launches of a step hand the gradients' non-zero
+ * mask through (the update does not re-read 16-byte groups of zeros), so a plan
+ * serves ONE optimizer step at a time and must be writable.
  * state[0] (device, int64) holds the step count and is incremented by the call;
  * (float*)(state+2) is scratch for n_chunks partial sums. */
 typedef struct PsAdamHyper {

@@ -7,7 +7,8 @@
 //   2. update: every block re-reduces partial[] in a fixed order (bitwise reproducible
 //      norm), derives clip coefficient + bias corrections, then streams p,g,m,v once
 //      (16-byte lanes when the four pointers are aligned).  Pure HBM streaming: 7 dwords
-//      of traffic per parameter (read p,g,m,v; write p,m,v).
+//      of traffic per parameter (read p,g,m,v; write p,m,v) — 6 where the sum-of-squares pass saw
+//      only zeros in a lane's 16 bytes of gradient (AdamPlanHeader::off_mask): untouched table rows.
 #include "optim_core.h"
 #include <string.h>
 
@@ -17,7 +18,7 @@ extern "C" int64_t ps_adam_plan_bytes(int32_t n, const int64_t* numel) {
   int64_t chunks = 0;
   for (int i = 0; i < n; ++i) chunks += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
   return align16(sizeof(AdamPlanHeader)) + align16((int64_t)sizeof(AdamChunkRec) * chunks) + 4 * align16(8 * (int64_t)n) +
-         align16(8 * (int64_t)n) + align16(4 * (int64_t)(n + 1)) + align16(4 * chunks);
+         align16(8 * (int64_t)n) + align16(4 * (int64_t)(n + 1)) + align16(4 * chunks) + 8 * (int64_t)ADAM_MASK_WORDS * chunks;
 }
 
 extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const* g, float* const* m,
@@ -35,7 +36,8 @@ extern "C" int ps_adam_plan_write_host(int32_t n, float* const* p, float* const*
   h.off_v = off; off += align16(8 * (int64_t)n);
   h.off_numel = off; off += align16(8 * (int64_t)n);
   h.off_chunk0 = off; off += align16(4 * (int64_t)(n + 1));
-  h.off_chunk_tensor = off;
+  h.off_chunk_tensor = off; off += align16(4 * total_chunks);
+  h.off_mask = off;                   // device scratch: never read before the sum-of-squares pass of a step has written it
   int32_t* chunk0 = (int32_t*)(base + h.off_chunk0);
   int32_t* chunk_tensor = (int32_t*)(base + h.off_chunk_tensor);
   int64_t chunks = 0;

@@ -10,7 +10,12 @@ struct AdamPlanHeader {
   int32_t n_chunks;
   int64_t off_p, off_g, off_m, off_v, off_numel, off_chunk0;   // byte offsets inside the plan
   int64_t off_chunk_tensor;           // int32[n_chunks]: the tensor each chunk belongs to
+  int64_t off_mask;                   // uint64[n_chunks][ADAM_MASK_WORDS]: which 16-byte groups of the chunk hold a non-zero gradient
 };
+// Written by the sum-of-squares pass (which reads every gradient anyway), read by the update pass of the SAME step: a lane whose
+// four gradients were all zero does not load them again (70 % of the table rows of a C2 step: a quarter of the update's reads).
+// Word [wave * 4 + i] = the ballot of wave `wave` in iteration i of the chunk loop.  DEVICE scratch inside the plan buffer.
+#define ADAM_MASK_WORDS (ADAM_CHUNK / 4 / 64)
 // One record per chunk, at a FIXED offset behind the header: a block reads its four pointers (already advanced to the chunk)
 // and its element count with ONE dependent load — header -> tensor index -> pointer / numel / first chunk -> data was a
 // chain of four, and with every block of the launch resident at once that chain is most of the sum-of-squares kernel.
@@ -34,7 +39,10 @@ __device__ inline float block_sum_256(float v, float* sh) {
 }
 
 
-// Sum of (g*grad_scale)^2 over one ADAM_CHUNK of the plan (block-wide result).
+__device__ inline unsigned long long* adam_chunk_mask(const char* plan, int chunk) {
+  return (unsigned long long*)(const_cast<char*>(plan) + ((const AdamPlanHeader*)plan)->off_mask) + (int64_t)chunk * ADAM_MASK_WORDS;
+}
+// Sum of (g*grad_scale)^2 over one ADAM_CHUNK of the plan (block-wide result); leaves the chunk's non-zero mask for the update.
 __device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad_scale, float* sh) {
   const AdamChunkRec rec = adam_chunk_recs(plan)[chunk];
   const float* g = rec.g;                              // (advanced to the chunk)
@@ -42,9 +50,12 @@ __device__ inline float adam_sumsq_chunk(const char* plan, int chunk, float grad
   float s = 0.f;
   if ((((uintptr_t)g) & 15) == 0 && end - beg == ADAM_CHUNK) {
     const float4* g4 = (const float4*)(g + beg);
+    unsigned long long* mask = adam_chunk_mask(plan, chunk) + (threadIdx.x >> 6) * (ADAM_CHUNK / 4 / 256);
 #pragma unroll
     for (int i = 0; i < ADAM_CHUNK / 4 / 256; ++i) {
       float4 x = g4[threadIdx.x + 256 * i];
+      const unsigned long long nz = __ballot(x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f);   // NaN counts as non-zero
+      if ((threadIdx.x & 63) == 0) mask[i] = nz;
       x.x *= grad_scale; x.y *= grad_scale; x.z *= grad_scale; x.w *= grad_scale;
       s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
     }
@@ -102,13 +113,18 @@ __device__ inline void adam_update_chunk(const char* plan, int chunk, const Adam
   if (vec) {
     float4* p4 = (float4*)(p + beg); float4* g4 = (float4*)(g + beg);
     float4* m4 = (float4*)(m + beg); float4* v4 = (float4*)(v + beg);
+    const unsigned long long* mask = adam_chunk_mask(plan, chunk) + (threadIdx.x >> 6) * (ADAM_CHUNK / 4 / 256);
+    const int lane = threadIdx.x & 63;
 #pragma unroll 2
     for (int i = 0; i < ADAM_CHUNK / 4 / 256; ++i) {
       const int k = threadIdx.x + 256 * i;
-      float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+      const bool nz = (mask[i] >> lane) & 1;        // what the sum-of-squares pass of this step saw in these 16 bytes
+      float4 pp = p4[k], mm = m4[k], vv = v4[k];
+      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nz) gg = g4[k];
       // PsAdamHyper::zero_grads: the step's memset rides here — and only where there is something to clear (70 % of the
       // table rows of a C2 step hold no gradient)
-      if (a.zero_g && (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f)) g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.zero_g && nz) g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       adam_elem(a, pp.x, gg.x, mm.x, vv.x); adam_elem(a, pp.y, gg.y, mm.y, vv.y);
       adam_elem(a, pp.z, gg.z, mm.z, vv.z); adam_elem(a, pp.w, gg.w, mm.w, vv.w);
       p4[k] = pp; m4[k] = mm; v4[k] = vv;
