@@ -25,6 +25,8 @@ events, and
   roofline     — the workload's dominant kernel: algorithmic flops / bytes per launch ÷ its average IN-STEP duration,
                  measured live with one HIP event pair around every launch of it, on the stream it is launched on, over a
                  second pass of --steps steps (ps_ktimer_arm / ps_ktimer_read, include/prodsearch_hip.h)
+  roofline_longest_kernel — c2: the same for the step's LONGEST kernel by rocprofv3 duration, the grouped W2 / W1 / Wo weight
+                 gradients on the side stream (the fused forward of `roofline` is the longest on the critical path)
   cpu_baseline — the oracle (op-for-op CPU restatement; for c2 incl. the B*(K+1) replicated encoder) timed on this box's
                  host cores on a bounded sample: pools of 8, 32 and all hardware threads (rank 0, N=1)
 and, in the default c2 run at N=1 (bounded to about a minute; --no-also skips them):
@@ -157,6 +159,22 @@ class TemWorkload(object):
                     kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
                     extra={"traffic": GATHER_TRAFFIC if (B, D) == (1024, 256) else None,
                            "traffic_source": GATHER_TRAFFIC_SOURCE if (B, D) == (1024, 256) else None})
+
+    def roofline_longest_spec(self):
+        """c2 only: by rocprofv3's durations the step's LONGEST kernel is not the fused forward but the grouped W2 / W1 / Wo
+        weight gradients (one flat-group launch of gemm_x3_kernel<1,1,0,1,1,0,1>, 640 workgroups of 64x64 tiles, fp32 atomics
+        into 0.59 MB of dW): the same 2*d*d + 4*d*F flops per replica row.  It runs on the side stream underneath the score
+        scatter, attention backward, K/V dX product and history scatter of the main stream, so its in-step duration is that
+        of a kernel sharing the chip four ways; reported beside `roofline` so that the line does not flatter the step."""
+        c = self.c
+        R = next(iter(self.model._plans.values())).layout.R
+        if not (c['D'] == 128 and R > 1):
+            return None
+        rows = c['B'] * R
+        return dict(tag='wgrad_group', work=rows * (2 * c['D'] * c['D'] + 4 * c['D'] * c['FF']),
+                    kernel="grouped W2 / W1 / Wo weight gradients (gemm_x3_kernel<1,1,0,1,1,0,1>, flat group): %d reduction rows, "
+                           "dW[%d x %d] + dW[%d x %d] + dW[%d x %d]; side stream, concurrent with the main stream's backward tail"
+                           % (rows, c['D'], c['FF'], c['FF'], c['D'], c['D'], c['D']))
 
     def cpu_baseline(self, n_steps):
         return cpu_baseline_tem(self.ns, self.c, n_steps)
@@ -454,6 +472,20 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                                 "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
                                 "timing": "HIP event pair around every in-step launch, on the launch stream, over a second "
                                           "pass of %d steps (ps_ktimer)" % steps}, **extra)
+        spec2 = wl.roofline_longest_spec() if hasattr(wl, 'roofline_longest_spec') else None
+        if spec2:        # (2b) the longest kernel of the step when that is not the one the critical path is made of
+            _lib.check(lib.ps_ktimer_arm(spec2['tag'].encode(), steps), 'ps_ktimer_arm')
+            for i in range(steps):
+                step(i)
+            _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
+            if cnt.value > 0:
+                ach2 = spec2['work'] / (avg.value * 1e-6) / 1e12
+                out["roofline_longest_kernel"] = {
+                    "bound": "mfma", "achieved": ach2, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach2 / MFMA_F32_PEAK_TFLOPS, "frac_of_bf16x3_equivalent_peak": ach2 / (MFMA_BF16_PEAK_TFLOPS / 6.0),
+                    "kernel": spec2['kernel'], "flops_per_launch": spec2['work'], "us_per_launch": avg.value,
+                    "us_per_launch_min": mn.value, "launches_timed": cnt.value,
+                    "timing": "HIP event pair around every in-step launch, on the SIDE stream it runs on (ps_ktimer)"}
         if world == 1 and cpu_steps > 0 and name == 'c4':
             out["cpu_baseline"] = wl.cpu_baseline(cpu_steps)
         elif world == 1 and cpu_steps > 0 and name == 'c2':

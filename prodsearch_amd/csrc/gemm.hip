@@ -1433,19 +1433,23 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     static const int flat_x3 = ps_diag_int("PS_GEMM_X3_FLAT", 1);
     const bool x3 = flat_x3 && x3_on();
     const bool x3d = x3 && x3_flat_d(g) && x3d_takes(g);
-    const int T = x3d ? X3D_T : BM;
+    static const int flat_shape = ps_diag_int("PS_X3_FLAT_SHAPE", 0);      // 1: 128x64, 2: 128x128 tiles of gemm_x3_kernel
+    const int fs = (x3 && !x3d) ? flat_shape : 0;
+    const int TM = x3d ? X3D_T : (fs >= 1 ? 128 : BM), TN = x3d ? X3D_T : (fs == 2 ? 128 : BM);
     GemmGroup f = g;
     int total = 0;
     for (int i = 0; i < 3; ++i) {
       f.flat0[i] = total;
       if (i >= g.n) { f.flat_tm[i] = 1; f.flat_tiles[i] = 1; continue; }
-      f.flat_tm[i] = ps_cdiv(g.p[i].M, T);
-      f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, T);
+      f.flat_tm[i] = ps_cdiv(g.p[i].M, TM);
+      f.flat_tiles[i] = f.flat_tm[i] * ps_cdiv(g.p[i].N, TN);
       total += f.flat_tiles[i] * g.p[i].ksplit;
     }
     f.flat0[3] = total;
     for (int i = g.n; i < 3; ++i) f.flat0[i] = total + 1;      // never selected
     if (x3d) hipLaunchKernelGGL((gemm_x3d_kernel<1, 1, 0, 0>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3 && fs == 2) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 2, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3 && fs == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else if (x3) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
     PS_LAUNCH_CHECK();

@@ -375,6 +375,7 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
     }
     g.flat = 1;
     if (ps_deterministic()) return run_wgrads_det(g, st);
+    KTimeScope kt("wgrad_group", st);
     return ps_launch_gemm(g, st);
   }
   int tiles = 0, rows = 0;
