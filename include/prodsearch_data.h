@@ -70,6 +70,34 @@ int ps_collate_test(const PsCorpusView* corpus, const PsCollateArgs* args,
                     int64_t* out_query_words, int64_t* out_target, int64_t* out_u_items, int64_t* out_candi,
                     int32_t* out_hist_len, int32_t* out_lmax);
 
+/* The epoch loop `for batch_data in dataloader` (trainer.py:64-66) with the collate on a NATIVE producer thread: the batches
+ * of `order` (n_ids dataset rows in sampler order, cut into batches of B; the last one short unless drop_last) are built one
+ * after another by ps_collate_train — the generator is consumed in exactly the sequential order, so seeded runs stay the
+ * reference's — into a ring of `depth` caller-owned slots (pinned host buffers; u_items with row stride uprev_review_limit),
+ * at most `depth` batches ahead of the consumer.  corpus, args' values, rng, samples, order and the slots' buffers must stay
+ * alive until ps_epoch_stop.  A consumer that stops early leaves the generator up to `depth` batches further than the
+ * sequential loop would have.
+ *   ps_epoch_next    blocks until the next batch is ready; returns its slot (>= 0) with *out_B rows and *out_lmax = the
+ *                    longest history (util.pad's width); -1 after the last batch; -2 on a collate error (ps_data_last_error).
+ *   ps_epoch_release the consumer has finished reading the slot (its H2D copies have completed): it may be overwritten.
+ *   ps_epoch_stop    stops and joins the thread, frees the handle (any time). */
+typedef struct PsTrainSlot {
+  int64_t* query_words;  /* [B,Q]     */
+  int64_t* target;       /* [B]       */
+  int64_t* u_items;      /* [B,limit] */
+  int64_t* pos_words;    /* [B,W]     */
+  int64_t* query_idx;    /* [B] or NULL */
+  int64_t* user_idx;     /* [B] or NULL */
+  int32_t* hist_len;     /* [B]       */
+} PsTrainSlot;
+void* ps_epoch_start(const PsCorpusView* corpus, const PsCollateArgs* args, void* rng,
+                     const int64_t* sample_words, const int64_t* sample_review, int64_t n_samples, int32_t W,
+                     const int64_t* order, int64_t n_ids, int32_t B, int32_t drop_last,
+                     const PsTrainSlot* slots, int32_t depth /* 2..64 */);
+int ps_epoch_next(void* epoch, int32_t* out_B, int32_t* out_lmax);
+int ps_epoch_release(void* epoch, int32_t slot);
+void ps_epoch_stop(void* epoch);
+
 /* ItemPVDataset.collect_train_samples (data/item_pv_dataset.py:73-93): for every train review, in review_info order,
  * random.shuffle its words IN PLACE (the shuffled order persists into later epochs, as there), keep word w when
  * rand[entry] <= sub_rate[w] (entry advances only on kept words, :84-88), and cut the kept stream — which runs across

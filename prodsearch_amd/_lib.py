@@ -210,6 +210,10 @@ class PsCollateArgs(C.Structure):
                 ('prod_pad', C.c_int64)]
 
 
+class PsTrainSlot(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('query_words', 'target', 'u_items', 'pos_words', 'query_idx', 'user_idx', 'hist_len')]
+
+
 class PsRtmCorpusView(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('n_reviews', 'n_users', 'n_products', 'n_queries')] + \
                [(n, C.c_void_p) for n in ('review_u_p', 'u_seq_ptr', 'u_seq', 'i_seq_ptr', 'i_seq', 'ut_seq_ptr', 'ut_seq',
@@ -244,6 +248,11 @@ DATA_SYMBOLS = {
                                    C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32] + [C.c_void_p] * 8),
     'ps_collate_test': (C.c_int, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6),
+    'ps_epoch_start': (C.c_void_p, [C.POINTER(PsCorpusView), C.POINTER(PsCollateArgs), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    'ps_epoch_next': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'ps_epoch_release': (C.c_int, [C.c_void_p, C.c_int32]),
+    'ps_epoch_stop': (None, [C.c_void_p]),
     'ps_rng_shuffle': (None, [C.c_void_p, C.c_void_p, C.c_int64]),
     'ps_collect_train_samples': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

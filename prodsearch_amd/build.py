@@ -27,7 +27,7 @@ def build_data(force=False, verbose=False):
     if not force and os.path.exists(DATA_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(DATA_LIB) for p in deps):
         return DATA_LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-o', DATA_LIB] + \
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-o', DATA_LIB] + \
           [os.path.join(CSRC, s) for s in DATA_SOURCES]
     if verbose:
         print(' '.join(cmd), file=sys.stderr)

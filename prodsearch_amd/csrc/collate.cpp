@@ -583,3 +583,119 @@ extern "C" int ps_rtm_pv_windows(void* np_rng, int64_t* words, uint8_t* masks, i
   }
   return 0;
 }
+
+// ----------------------------------------------------------------------------- epoch producer (native prefetch thread)
+// `for batch in dataloader` (trainer.py:64-66) with the collate OFF the consumer's thread: one std::thread builds the epoch's
+// train batches one after another — so the generator is consumed in exactly the sequential order and seeded runs stay the
+// reference's — into a ring of caller-owned (pinned) slots, while the consumer ships and trains on earlier ones.  No Python in
+// the producer: a Python producer thread shares the interpreter lock with the step's launch code and made the fed step SLOWER
+// (0.338 against 0.320 ms; the GPU step is 0.236).
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+struct PsEpoch {
+  const PsCorpusView* c; PsCollateArgs a; void* rng;
+  const int64_t* sample_words; const int64_t* sample_review; int64_t n_samples; int32_t W;
+  const int64_t* order; int64_t n_ids; int32_t B; int64_t n_batches;
+  std::vector<PsTrainSlot> slots;
+  std::vector<int> state;                 // 0 free, 1 ready, 2 held by the consumer
+  std::vector<int32_t> slot_B, slot_lmax;
+  int64_t produced = 0, consumed = 0;     // batch counters: batch k lives in slot k % depth
+  bool stop = false, failed = false;
+  char err[512] = "";
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread th;
+};
+
+static void epoch_work(PsEpoch* e) {
+  const int depth = (int)e->slots.size();
+  for (int64_t k = 0; k < e->n_batches; ++k) {
+    const int s = (int)(k % depth);
+    {
+      std::unique_lock<std::mutex> lk(e->mu);
+      e->cv.wait(lk, [&] { return e->stop || e->state[s] == 0; });
+      if (e->stop) return;
+    }
+    const int64_t beg = k * e->B;
+    const int32_t nb = (int32_t)((e->n_ids - beg) < e->B ? (e->n_ids - beg) : e->B);
+    const PsTrainSlot& o = e->slots[s];
+    int32_t lmax = 0;
+    const int rc = ps_collate_train(e->c, &e->a, e->rng, e->sample_words, e->sample_review, e->n_samples, e->W, e->order + beg, nb,
+                                    o.query_words, o.target, o.u_items, o.pos_words, o.query_idx, o.user_idx, o.hist_len, &lmax);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (rc) {
+      e->failed = true;
+      snprintf(e->err, sizeof(e->err), "%s", g_err);           // this thread's message -> the handle
+      e->cv.notify_all();
+      return;
+    }
+    e->slot_B[s] = nb; e->slot_lmax[s] = lmax;
+    e->state[s] = 1;
+    e->produced = k + 1;
+    e->cv.notify_all();
+  }
+}
+
+extern "C" void* ps_epoch_start(const PsCorpusView* c, const PsCollateArgs* a, void* rng, const int64_t* sample_words,
+                                const int64_t* sample_review, int64_t n_samples, int32_t W, const int64_t* order, int64_t n_ids,
+                                int32_t B, int32_t drop_last, const PsTrainSlot* slots, int32_t depth) {
+  if (!c || !a || !rng || !sample_words || !sample_review || !order || !slots || B < 1 || W < 1 || n_ids < 0 || depth < 2 || depth > 64) {
+    fail("epoch_start: bad argument (B %d, depth %d, n_ids %lld)", B, depth, (long long)n_ids);
+    return nullptr;
+  }
+  for (int i = 0; i < depth; ++i)
+    if (!slots[i].query_words || !slots[i].target || !slots[i].u_items || !slots[i].pos_words || !slots[i].hist_len) {
+      fail("epoch_start: slot %d has a null buffer", i);
+      return nullptr;
+    }
+  PsEpoch* e = new PsEpoch();
+  e->c = c; e->a = *a; e->rng = rng;
+  e->sample_words = sample_words; e->sample_review = sample_review; e->n_samples = n_samples; e->W = W;
+  e->order = order; e->n_ids = n_ids; e->B = B;
+  e->n_batches = drop_last ? n_ids / B : (n_ids + B - 1) / B;
+  e->slots.assign(slots, slots + depth);
+  e->state.assign(depth, 0); e->slot_B.assign(depth, 0); e->slot_lmax.assign(depth, 0);
+  e->th = std::thread(epoch_work, e);
+  return e;
+}
+
+extern "C" int ps_epoch_next(void* h, int32_t* out_B, int32_t* out_lmax) {
+  PsEpoch* e = (PsEpoch*)h;
+  if (!e || !out_B || !out_lmax) { fail("epoch_next: null argument"); return -2; }
+  std::unique_lock<std::mutex> lk(e->mu);
+  if (e->consumed >= e->n_batches) return -1;
+  const int depth = (int)e->slots.size(), s = (int)(e->consumed % depth);
+  e->cv.wait(lk, [&] { return e->failed || e->state[s] == 1; });
+  if (e->state[s] != 1) {                                       // the producer stopped on an error before this batch
+    snprintf(g_err, sizeof(g_err), "%s", e->err);
+    return -2;
+  }
+  e->state[s] = 2;
+  e->consumed += 1;
+  *out_B = e->slot_B[s]; *out_lmax = e->slot_lmax[s];
+  return s;
+}
+
+extern "C" int ps_epoch_release(void* h, int32_t slot) {
+  PsEpoch* e = (PsEpoch*)h;
+  if (!e || slot < 0 || slot >= (int)e->slots.size()) return fail("epoch_release: bad slot %d", slot);
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->state[slot] != 2) return fail("epoch_release: slot %d is not held by the consumer", slot);
+  e->state[slot] = 0;
+  e->cv.notify_all();
+  return 0;
+}
+
+extern "C" void ps_epoch_stop(void* h) {
+  PsEpoch* e = (PsEpoch*)h;
+  if (!e) return;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->stop = true;
+    e->cv.notify_all();
+  }
+  if (e->th.joinable()) e->th.join();
+  delete e;
+}

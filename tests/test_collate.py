@@ -178,3 +178,60 @@ def test_native_collate_equals_oracle_on_random_corpora(seed):
                 assert np.array_equal(b.u_item_idxs.numpy(), w), (seed, i)
             if i == 2:
                 break
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_native_producer_thread_matches_reference_batches(case):
+    """prefetch > 0: the epoch's batches come from the native producer thread (ps_epoch_start) — the reference's batches still."""
+    z, over, train_ds, _ = _case(case)
+    dl = ItemPVDataloader(default_args(**over), train_ds, batch_size=int(z['batch_size']), shuffle=bool(z['shuffle']),
+                          seed=int(z['py_seed']), prefetch=2)
+    torch.manual_seed(int(z['torch_seed']))
+    n = 0
+    for b in dl:
+        for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs'):
+            want = z['train%d_%s' % (n, k)]
+            got = getattr(b, k)
+            assert got.dtype == torch.int64 and got.is_contiguous()
+            assert np.array_equal(got.numpy().reshape(want.shape), want), (n, k)
+        n += 1
+        if n == int(z['n_train']):
+            break
+    assert n == int(z['n_train'])
+
+
+@pytest.mark.parametrize('prefetch,drop_last,B', [(1, False, 9), (3, False, 16), (2, True, 16), (5, False, 1000)])
+def test_native_producer_thread_equals_the_sequential_loop_over_whole_epochs(prefetch, drop_last, B):
+    """Two epochs, ragged last batch / drop_last / one batch larger than the dataset: every tensor, the per-row ids and the
+    generator state afterwards equal the sequential loader's; batches handed out earlier are not overwritten by later ones."""
+    train_ds, _ = synth.make_corpus(31, n_users=40, n_products=30, n_queries=12, vocab_size=90, Q=4, W=2, max_reviews_per_user=60)
+    args = default_args(uprev_review_limit=6, fix_train_review=False, pv_window_size=2)
+    seq = ItemPVDataloader(args, train_ds, batch_size=B, shuffle=True, seed=9, drop_last=drop_last)
+    thr = ItemPVDataloader(args, train_ds, batch_size=B, shuffle=True, seed=9, drop_last=drop_last, prefetch=prefetch)
+    assert len(train_ds) % B != 0
+    for epoch in range(2):
+        torch.manual_seed(100 + epoch)
+        want = list(seq)
+        torch.manual_seed(100 + epoch)
+        got = list(thr)                                  # ALL batches kept alive: a slot reused too early would show here
+        assert len(got) == len(want) == (len(train_ds) // B if drop_last else -(-len(train_ds) // B))
+        for w, g in zip(want, got):
+            for k in ('query_word_idxs', 'target_prod_idxs', 'u_item_idxs', 'pos_iword_idxs'):
+                assert torch.equal(getattr(w, k), getattr(g, k)), k
+            assert list(w.query_idxs) == list(g.query_idxs) and list(w.user_idxs) == list(g.user_idxs)
+    lib = _lib.load_data()
+    assert lib.ps_rng_randbelow(seq._rng, 1 << 30) == lib.ps_rng_randbelow(thr._rng, 1 << 30)
+
+
+def test_native_producer_thread_surfaces_collate_errors_and_stops_early():
+    train_ds, _ = synth.make_corpus(32, n_users=30, n_products=20, n_queries=8, vocab_size=70, Q=3, W=1, max_reviews_per_user=20)
+    args = default_args(uprev_review_limit=5, fix_train_review=True)
+    dl = ItemPVDataloader(args, train_ds, batch_size=8, shuffle=False, seed=1, prefetch=2)
+    it = iter(dl)
+    next(it)
+    it.close()                                           # consumer leaves early: the thread is stopped and joined
+    dl.sample_review[20] = 10 ** 9                       # third batch is corrupt
+    it = iter(dl)
+    next(it), next(it)
+    with pytest.raises(RuntimeError, match='review id'):
+        next(it)
