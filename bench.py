@@ -35,6 +35,8 @@ and, in the default c2 run at N=1 (bounded to about a minute; --no-also skips th
                  Infinity Cache), event-timed per launch: the kernel the north star's 70 % target names
   also         — the contract lines of c4 and of the c5 shard (the stated 50 M-row table: 205 GB resident), each with its own
                  roofline object.
+  fed_by_loader — the c2 step with its batches built by the data loader (native collate thread + copy stream) instead of resident
+                 in HBM: wall clock per step, data loading included (informational; `value` is the resident-input figure).
 """
 import argparse
 import ctypes
@@ -611,6 +613,44 @@ def self_launch(a):
     print(lines[0])
 
 
+def fed_step_leg(a, dev, steps=400, warmup=60):
+    """c2 with the batches coming from the data loader instead of sitting in HBM (not the contract's `value`,
+    which wants resident inputs): a synthetic Amazon-shaped corpus (20k users, 336k reviews, the catalogue and vocabulary of
+    configs[1]), `ItemPVDataloader(device, prefetch=3)` — collate on the native producer thread, one H2D copy per batch on a copy
+    stream — and the same module-API step.  The whole loop between two synchronisations, data loading included."""
+    from prodsearch_amd import ItemTransformerRanker, build_optim, readme_tem_args, synth
+    from prodsearch_amd.dataloader import ItemPVDataloader
+    c = TEM_CFG['c2']
+    ns = readme_tem_args(dropout=a.dropout, embedding_size=c['D'], ff_size=c['FF'], batch_size=c['B'], fix_train_review=False)
+    train_ds, _ = synth.make_corpus(7, n_users=20000, n_products=c['P'], n_queries=2000, vocab_size=V_WORDS, Q=c['Q'], W=c['W'],
+                                    max_reviews_per_user=400)
+    torch.manual_seed(1234)
+    model = ItemTransformerRanker(ns, 'cuda', V_WORDS, c['P'], None, word_dists=synth.make_word_dists(V_WORDS))
+    optim = build_optim(ns, model, None)
+    model.train()
+    it = iter(ItemPVDataloader(ns, train_ds, batch_size=c['B'], shuffle=True, seed=1, device=dev, drop_last=True, prefetch=3))
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = model(next(it))
+            model.zero_grad()
+            loss.backward()
+            optim.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    run(warmup)
+    t = run(steps)
+    it.close()
+    del model, optim
+    torch.cuda.empty_cache()
+    return {"ms_per_step": t * 1e3, "tuples_per_s": c['B'] * c['K'] / t, "steps": steps, "warmup": warmup,
+            "what": "the c2 step fed by prodsearch_amd.dataloader.ItemPVDataloader(prefetch=3) from a synthetic corpus of %d train "
+                    "samples (random history subsets of <= %d of up to 400 reviews per user): collate + H2D + step, wall clock"
+                    % (len(train_ds), c['L'])}
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     a = parse()
@@ -636,6 +676,7 @@ def main():
         for name, items in (('c5', ALSO_C5_ITEMS), ('c4', 0)):
             also.append(measure(a, name, rank, world, dev, 200, 30, 0, True, 1 if name == 'c4' else 0, items))
         out["also"] = also
+        out["fed_by_loader"] = fed_step_leg(a, dev)
     if later is not None:
         out["cpu_baseline"] = later()
     if world > 1:
