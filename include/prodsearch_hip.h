@@ -229,6 +229,10 @@ typedef struct PsAdamHyper {
   int32_t warmup_steps;/* --warmup_steps                               */
   float grad_scale;    /* multiplies every grad first (1/world for DP) */
   int32_t zero_grads;  /* dense step: leave every gradient it consumed at 0 (the next zero_grad() is then free) */
+  int32_t method;      /* --optim (optimizers.py:175-187): 0 adam, 1 sgd, 2 adagrad (eps 1e-10; the plan's `m` is the sum of
+                          squares, initialised by the caller with adagrad_accum), 3 adadelta (rho 0.9, eps 1e-6; `m` = square_avg,
+                          `v` = acc_delta).  Same clip, same noam schedule; sgd touches neither `m` nor `v`. */
+  int32_t pad_;
 } PsAdamHyper;
 
 int64_t ps_adam_plan_bytes(int32_t n_tensors, const int64_t* numel_host);

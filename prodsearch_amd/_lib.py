@@ -55,7 +55,8 @@ class PsTemWsLayout(C.Structure):
 class PsAdamHyper(C.Structure):
     _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
                 ('weight_decay', C.c_float), ('max_grad_norm', C.c_float), ('noam', C.c_int32),
-                ('warmup_steps', C.c_int32), ('grad_scale', C.c_float), ('zero_grads', C.c_int32)]
+                ('warmup_steps', C.c_int32), ('grad_scale', C.c_float), ('zero_grads', C.c_int32), ('method', C.c_int32),
+                ('pad_', C.c_int32)]
 
 
 class PsIdxList(C.Structure):

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const char* plan, cons
     if (chunk == 0 && gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
   }
   __syncthreads();
-  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads};
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads, scal[3], hp.method};
   adam_update_chunk(plan, chunk, a);
 }
 
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const char* plan, cons
 extern "C" int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper,
                                     int64_t* state_dev, float* gnorm_out_dev, ps_stream_t stream) {
   PS_REQUIRE(plan_dev && hyper && state_dev && n_chunks > 0, "clip_adam: bad argument");
+  PS_REQUIRE(hyper->method >= 0 && hyper->method <= 3, "clip_adam: unknown method %d", hyper->method);
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)(state_dev + 2);
   const float gs = hyper->grad_scale == 0.f ? 1.f : hyper->grad_scale;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void adam_update_ext_kernel(const char* plan, 
     if (chunk == 0 && gnorm_out) { gnorm_out[0] = norm; gnorm_out[1] = scal[3]; }
   }
   __syncthreads();
-  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads};
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.zero_grads, scal[3], hp.method};
   adam_update_chunk(plan, chunk, a);
 }
 extern "C" int ps_adam_sumsq(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
@@ -156,6 +157,7 @@ extern "C" int ps_adam_sumsq(const void* plan_dev, int32_t n_chunks, const PsAda
 extern "C" int ps_adam_update_ext(const void* plan_dev, int32_t n_chunks, const PsAdamHyper* hyper, int64_t* state_dev,
                                   const float* total_sumsq_dev, float* gnorm_out_dev, ps_stream_t stream) {
   PS_REQUIRE(plan_dev && hyper && state_dev && total_sumsq_dev && n_chunks > 0, "adam_update_ext: bad argument");
+  PS_REQUIRE(hyper->method >= 0 && hyper->method <= 3, "adam_update_ext: unknown method %d", hyper->method);
   PsAdamHyper hp = *hyper;
   if (hp.grad_scale == 0.f) hp.grad_scale = 1.f;
   hipLaunchKernelGGL(adam_update_ext_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const char*)plan_dev, hp,

@@ -87,7 +87,11 @@ __device__ inline void adam_scalars(const PsAdamHyper& hp, float total_sumsq, in
   *norm_out = norm;
 }
 
-struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; int zero_g; };
+struct AdamScal { float gmul, step_size, inv_sbc2, b1, b2, eps, wd; int zero_g; float lr; int method; };
+#define PS_OPT_ADAM 0
+#define PS_OPT_SGD 1
+#define PS_OPT_ADAGRAD 2
+#define PS_OPT_ADADELTA 3
 
 // The rounding sequence is PINNED (no contraction left to the compiler, explicit fused multiply-adds where torch's kernels fuse):
 // this function is inlined into the dense chunk loop, the row-sparse row loop and the lazy replay (optim_rows.hip), and the
@@ -103,9 +107,44 @@ __device__ inline void adam_elem(const AdamScal& a, float& pp, float gg, float& 
   pp = pp - a.step_size * (mm / denom);          // param.addcdiv_(exp_avg, denom, -step_size)
 }
 
+// The reference's other `--optim` methods (optimizers.py:175-183), torch's update rules with its defaults, after the same clip:
+//   sgd       p -= lr (g + wd p)                                                              (torch.optim.SGD, no momentum)
+//   adagrad   s1 += g g;  p -= lr g / (sqrt(s1) + 1e-10)                                      (lr_decay 0; s1 starts at adagrad_accum)
+//   adadelta  s1 = 0.9 s1 + 0.1 g g;  dlt = sqrt(s2 + 1e-6) / sqrt(s1 + 1e-6) g;  s2 = 0.9 s2 + 0.1 dlt dlt;  p -= lr dlt
+// lr = the noam rate of the step when --decay_method noam, else --lr (optimizers.py:231-236 sets the rate only under noam).
+__device__ inline void other_elem(const AdamScal& a, float& pp, float gg, float& s1, float& s2) {
+#pragma clang fp contract(off)
+  gg *= a.gmul;
+  if (a.wd != 0.f) gg = __builtin_fmaf(a.wd, pp, gg);
+  if (a.method == PS_OPT_SGD) {
+    pp = pp - a.lr * gg;
+  } else if (a.method == PS_OPT_ADAGRAD) {
+    s1 = __builtin_fmaf(gg, gg, s1);
+    pp = pp - a.lr * (gg / (sqrtf(s1) + 1e-10f));
+  } else {
+    s1 = s1 * 0.9f + (0.1f * gg) * gg;
+    const float dlt = (sqrtf(s2 + 1e-6f) / sqrtf(s1 + 1e-6f)) * gg;
+    s2 = s2 * 0.9f + (0.1f * dlt) * dlt;
+    pp = pp - a.lr * dlt;
+  }
+}
+__device__ inline void other_update_chunk(const AdamChunkRec& rec, const AdamScal& a) {
+  float* p = rec.p; float* g = rec.g; float* m = rec.m; float* v = rec.v;
+  const bool s1 = a.method != PS_OPT_SGD, s2 = a.method == PS_OPT_ADADELTA;      // which state tensors exist
+  for (int i = threadIdx.x; i < rec.n; i += 256) {
+    float pp = p[i], gg = g[i], a1 = s1 ? m[i] : 0.f, a2 = s2 ? v[i] : 0.f;
+    other_elem(a, pp, gg, a1, a2);
+    p[i] = pp;
+    if (s1) m[i] = a1;
+    if (s2) v[i] = a2;
+    if (a.zero_g && gg != 0.f) g[i] = 0.f;
+  }
+}
+
 // clip + Adam over one ADAM_CHUNK of the plan.
 __device__ inline void adam_update_chunk(const char* plan, int chunk, const AdamScal& a) {
   const AdamChunkRec rec = adam_chunk_recs(plan)[chunk];
+  if (a.method != PS_OPT_ADAM) { other_update_chunk(rec, a); return; }       // block-uniform
   float* p = rec.p; float* g = rec.g; float* m = rec.m; float* v = rec.v;    // (advanced to the chunk)
   const int64_t beg = 0, end = rec.n;
   const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 &&

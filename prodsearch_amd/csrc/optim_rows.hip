@@ -339,7 +339,7 @@ __global__ __launch_bounds__(1024) void rs_finalize_kernel(const PsAdamHyper hp,
 
 __global__ __launch_bounds__(256) void rs_update_kernel(const char* plan, int n_chunks, RowTables T,
                                                         const PsAdamHyper hp, const float* scal) {
-  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0};
+  const AdamScal a = {scal[0], scal[1], scal[2], hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0, scal[3], hp.method};
   const int blk = blockIdx.x;
   if (blk < n_chunks) { adam_update_chunk(plan, blk, a); return; }
   const int k = rs_find(T, blk - n_chunks);
@@ -387,6 +387,7 @@ extern "C" int64_t ps_adam_rowsparse_state_floats(int32_t n_chunks, const PsRowT
 extern "C" int ps_clip_adam_rowsparse(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host,
                                       int32_t n_tables, const PsAdamHyper* hyper, int64_t* state_dev,
                                       float* gnorm_out_dev, ps_stream_t stream) {
+  PS_REQUIRE(hyper && hyper->method == 0, "ps_clip_adam_rowsparse: the row-sparse optimizer is Adam only (method %d)", hyper ? hyper->method : -1);
   PS_REQUIRE(hyper && state_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev), "clip_adam_rowsparse: bad argument");
   RowTables T;
   int rc = rs_pack(tables_host, n_tables, &T);
@@ -445,7 +446,7 @@ __device__ inline void catchup_row(const PsRowTable& tb, int32_t* last, int64_t 
     if (s0 + lane <= T) adam_step_scalars(hp, s0 + lane, &my_ss, &my_is, &my_lr);
     const int nstep = (int)((T - s0 + 1) < 64 ? (T - s0 + 1) : 64);
     for (int i = 0; i < nstep; ++i) {
-      AdamScal a = {1.f, __shfl(my_ss, i, 64), __shfl(my_is, i, 64), hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0};
+      AdamScal a = {1.f, __shfl(my_ss, i, 64), __shfl(my_is, i, 64), hp.beta1, hp.beta2, hp.eps, hp.weight_decay, 0, 0.f, PS_OPT_ADAM};
       bool moving = false;
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
@@ -617,6 +618,7 @@ __global__ void rs_scalars_ext_kernel(const PsAdamHyper hp, const int64_t* state
 extern "C" int ps_rowsparse_sumsq(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
                                   int32_t n_shared, const PsAdamHyper* hyper, int64_t* state_dev, float* sums_dev,
                                   ps_stream_t stream) {
+  PS_REQUIRE(hyper && hyper->method == 0, "ps_rowsparse_sumsq: the row-sparse optimizer is Adam only (method %d)", hyper ? hyper->method : -1);
   PS_REQUIRE(hyper && state_dev && sums_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev) && n_shared >= 0 && n_shared <= n_tables,
              "rowsparse_sumsq: bad argument");
   RowTables T;
@@ -636,6 +638,7 @@ extern "C" int ps_rowsparse_sumsq(const void* plan_dev, int32_t n_chunks, const 
 extern "C" int ps_rowsparse_update_ext(const void* plan_dev, int32_t n_chunks, const PsRowTable* tables_host, int32_t n_tables,
                                        const PsAdamHyper* hyper, int64_t* state_dev, const float* sums_dev,
                                        float* gnorm_out_dev, ps_stream_t stream) {
+  PS_REQUIRE(hyper && hyper->method == 0, "ps_rowsparse_update_ext: the row-sparse optimizer is Adam only (method %d)", hyper ? hyper->method : -1);
   PS_REQUIRE(hyper && state_dev && sums_dev && n_chunks >= 0 && (n_chunks == 0 || plan_dev), "rowsparse_update_ext: bad argument");
   RowTables T;
   int rc = rs_pack(tables_host, n_tables, &T);

@@ -509,8 +509,8 @@ def make_exchange(model, optim=None, group=None, mode=None):
         return SparseGradExchange(model, optim, group)
     mode = mode or os.environ.get('PS_DP_EXCHANGE') or 'sharded'
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if mode == 'sharded' and optim is not None and world > 1:
-        return ShardedAdamExchange(model, optim, group)
+    if mode == 'sharded' and optim is not None and world > 1 and getattr(optim, 'method', 'adam') == 'adam':
+        return ShardedAdamExchange(model, optim, group)          # (the other --optim methods: flat all-reduce, replicated update)
     return GradExchange(lambda: model._grad_flat, optim, group)
 
 

@@ -3,11 +3,14 @@
 Mirrors ``models/optimizers.py:111-243`` (``Optimizer(method, learning_rate,
 max_grad_norm, beta1, beta2, decay_method, warmup_steps, weight_decay)``,
 ``set_parameters(named_params)``, ``step()``, ``learning_rate``, ``_step``) and
-``build_optim`` (``models/ps_model.py:20-51``) for ``method == 'adam'``, the only
-method the hot path uses (``main.py:62``).  ``step()`` is two kernel launches
-(global-norm partials, then clip + Adam over every tensor) through
+``build_optim`` (``models/ps_model.py:20-51``).  ``step()`` is two kernel launches
+(global-norm partials, then clip + update over every tensor) through
 ``ps_clip_adam_dense``; dense semantics identical to ``torch.optim.Adam(eps=1e-9)``
 after ``clip_grad_norm_`` — parameters without a gradient are skipped, as there.
+``method`` 'adam' is the hot path (``main.py:62`` default); 'sgd', 'adagrad' and 'adadelta'
+(``optimizers.py:175-183``: torch's rules with its defaults) run through the same two
+launches (``PsAdamHyper.method``); the row-sparse / row-sharded / lazy-exact extensions are
+Adam only.  'sparseadam' (``optimizers.py:188-193``, undocumented in ``main.py``) is not built.
 """
 import os
 import weakref
@@ -18,12 +21,22 @@ from . import _lib
 
 
 class Optimizer(object):
+    METHODS = {'adam': 0, 'sgd': 1, 'adagrad': 2, 'adadelta': 3}                      # PsAdamHyper.method
+    # state tensor names per parameter in torch.optim's state_dict() (first -> the plan's `m`, second -> its `v`)
+    STATE_KEYS = {'adam': ('exp_avg', 'exp_avg_sq'), 'sgd': (), 'adagrad': ('sum',), 'adadelta': ('square_avg', 'acc_delta')}
+
     def __init__(self, method, learning_rate, max_grad_norm,
                  lr_decay=1, start_decay_steps=None, decay_steps=None,
                  beta1=0.9, beta2=0.999, adagrad_accum=0.0,
                  decay_method=None, warmup_steps=4000, weight_decay=0., row_sparse=False):
-        if method != 'adam':
-            raise NotImplementedError("only method='adam' is on the hot path (main.py:62)")
+        if method not in self.METHODS:
+            if method == 'sparseadam':
+                raise NotImplementedError("method 'sparseadam' (optimizers.py:188-193) is not built; args.row_sparse_adam is the "
+                                          "touched-rows-only Adam of this package")
+            raise RuntimeError("Invalid optim method: " + str(method))               # optimizers.py:194-195
+        if method != 'adam' and row_sparse:
+            raise NotImplementedError("row_sparse_adam / lazy_exact_adam / shard_tables need method='adam'")
+        self.adagrad_accum = adagrad_accum
         self.last_ppl = None
         self.learning_rate = learning_rate
         self.original_lr = learning_rate
@@ -81,7 +94,9 @@ class Optimizer(object):
         sizes = [(p.numel() + 3) // 4 * 4 for p in live]
         total = sum(sizes)
         old = getattr(self, '_state_tensors', None)
-        self._m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # (sgd keeps no state and its kernels touch neither buffer; adagrad's sum starts at adagrad_accum, optimizers.py:178-181)
+        self._m_flat = torch.full((total,), float(self.adagrad_accum) if self.method == 'adagrad' else 0.0, device=dev,
+                                  dtype=torch.float32) if self.method != 'sgd' else torch.zeros(total, device=dev)
         self._v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         ms, vs, o = [], [], 0
         for p, s in zip(live, sizes):
@@ -145,6 +160,7 @@ class Optimizer(object):
         hp.noam = int(self.decay_method == "noam")
         hp.warmup_steps = self.warmup_steps
         hp.grad_scale = self.grad_scale
+        hp.method = self.METHODS[self.method]
         return hp
 
     # ------------------------------------------------------------------ lazy-exact dense Adam (args.lazy_exact_adam)
@@ -303,12 +319,15 @@ class Optimizer(object):
                 state[i] = {'step': torch.tensor(float(self._step)),
                             'exp_avg': torch.cat([shard.gather_full('m'), pad]),
                             'exp_avg_sq': torch.cat([shard.gather_full('v'), pad])}
-            elif id(p) in st:
-                m, v = st[id(p)]
-                state[i] = {'step': torch.tensor(float(self._step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
-        return {'state': state, 'param_groups': [{'lr': self.learning_rate, 'betas': tuple(self.betas),
-                                                  'eps': self.eps, 'weight_decay': self.weight_decay,
-                                                  'params': list(range(len(ref)))}], '_step': self._step}
+            elif id(p) in st and self.method != 'sgd':
+                keys = self.STATE_KEYS[self.method]
+                state[i] = {'step': torch.tensor(float(self._step))}
+                for key, t in zip(keys, st[id(p)]):
+                    state[i][key] = t.clone()
+        group = {'lr': self.learning_rate, 'weight_decay': self.weight_decay, 'params': list(range(len(ref)))}
+        if self.method == 'adam':
+            group.update(betas=tuple(self.betas), eps=self.eps)
+        return {'state': state, 'param_groups': [group], '_step': self._step}
 
     def load_state_dict(self, sd):
         """Restore ``state_dict()``'s (or the reference optimizer's) Adam state.  Indices are positions in the reference's
@@ -332,11 +351,17 @@ class Optimizer(object):
                                            % (int(i), key, tuple(t.shape), want))
                     shard.load_full(t, which)
                 continue
-            for key in ('exp_avg', 'exp_avg_sq'):
+            keys = self.STATE_KEYS[self.method]
+            for key in keys:
+                if key not in s:
+                    raise RuntimeError("optimizer state %d has no '%s': the checkpoint was written by another --optim method"
+                                       % (int(i), key))
                 if tuple(s[key].shape) != tuple(p.shape):
                     raise RuntimeError("optimizer state %d (%s): shape %s does not match its parameter's %s — the checkpoint "
                                        "was written for a different parameter list" % (int(i), key, tuple(s[key].shape), tuple(p.shape)))
-            loaded[id(p)] = (s['exp_avg'].to(p.device), s['exp_avg_sq'].to(p.device))
+            if keys:                             # (the plan's second buffer is unused by adagrad: zeros)
+                first = s[keys[0]].to(p.device)
+                loaded[id(p)] = (first, s[keys[1]].to(p.device) if len(keys) > 1 else torch.zeros_like(first))
         self._state_tensors = loaded
         self._plan = None
         self._lazy_last, self._lazy_base = {}, self._step      # lazy_exact_adam: a checkpoint is written flushed (state_dict)
@@ -347,7 +372,7 @@ class Optimizer(object):
 def build_optim(args, model, checkpoint):
     """``build_optim`` (models/ps_model.py:20-51)."""
     optim = Optimizer(args.optim, args.lr, args.max_grad_norm,
-                      beta1=args.beta1, beta2=args.beta2,
+                      beta1=args.beta1, beta2=args.beta2, adagrad_accum=getattr(args, 'adagrad_accum', 0.0),
                       decay_method=args.decay_method,
                       warmup_steps=args.warmup_steps,
                       weight_decay=args.l2_lambda,

@@ -37,7 +37,7 @@ def test_struct_layout_matches_header_sizes(lib):
     assert C.sizeof(_lib.PsLayerTensors) == 16 * 8
     assert C.sizeof(_lib.PsTemTensors) == 10 * 8 + _lib.PS_MAX_LAYERS * 16 * 8
     assert C.sizeof(_lib.PsTemBatch) == 7 * 8
-    assert C.sizeof(_lib.PsAdamHyper) == 40
+    assert C.sizeof(_lib.PsAdamHyper) == 48
 
 
 @pytest.mark.parametrize('over', [dict(), dict(inter_layers=2, sep_prod_emb=True),
@@ -85,7 +85,10 @@ def test_unsupported_heads_raise():
         with pytest.raises(NotImplementedError):
             ItemTransformerRanker(default_args(**over), 'cpu', 300, 200, None)
     with pytest.raises(NotImplementedError):
-        Optimizer('sgd', 0.1, 5.0)
+        Optimizer('sparseadam', 0.1, 5.0)
+    with pytest.raises(RuntimeError, match='Invalid optim method'):      # optimizers.py:194-195
+        Optimizer('rmsprop', 0.1, 5.0)
+    assert Optimizer('sgd', 0.1, 5.0).method == 'sgd'                     # the reference's other methods: tests/test_gpu_optim_methods.py
 
 
 def test_product_never_imports_oracle():
