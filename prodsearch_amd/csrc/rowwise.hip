@@ -553,6 +553,85 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const LnBwdArgs 
   }
 }
 
+// d == 256, 16-byte-aligned operands, no gathered residual (the d = 256 shard step's two LayerNorm backwards over 21,504 rows: 35 us
+// each in the form above — one row per wave in flight, 12 four-byte loads per lane and row, 128 VGPRs = 16 waves per CU, 48 KB in
+// flight per CU against a latency-bandwidth product of ~64 KB).  Here a lane owns 4 CONSECUTIVE columns: one 16-byte load per operand
+// and row, and TWO rows per wave in flight (the second one clamped, not skipped, at the end of the range).
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_v4_kernel(const LnBwdArgs a) {
+  extern __shared__ float sh[];      // [3][LNB_WAVES][256]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const float invd = 1.f / 256.f;
+  const float4 gv = reinterpret_cast<const float4*>(a.g)[lane];
+  const bool has_res = a.res.mode == RES_DIRECT;
+  DropSpec d2 = a.drop2;
+  d2.step = drop_step(a.drop2); d2.step_ptr = nullptr;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag, ac = ag;
+  for (int row0 = wave; row0 < a.rows; row0 += 2 * nw) {
+    const bool two = row0 + nw < a.rows;                            // wave-uniform
+    const int rw[2] = {row0, two ? row0 + nw : row0};
+    float4 xv[2], dyv[2], rr[2];
+    float2 st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st[u] = reinterpret_cast<const float2*>(a.stats)[rw[u]];
+      xv[u] = *reinterpret_cast<const float4*>(a.x + (size_t)rw[u] * a.ldx + 4 * lane);
+      dyv[u] = *reinterpret_cast<const float4*>(a.dy + (size_t)rw[u] * a.lddy + 4 * lane);
+      rr[u] = has_res ? *reinterpret_cast<const float4*>(a.res.ptr + (size_t)rw[u] * a.res.ld + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      const float mean = st[u].x, rstd = st[u].y;
+      const float xh[4] = {(xv[u].x - mean) * rstd, (xv[u].y - mean) * rstd, (xv[u].z - mean) * rstd, (xv[u].w - mean) * rstd};
+      const float dy[4] = {dyv[u].x, dyv[u].y, dyv[u].z, dyv[u].w};
+      const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+      const float r4[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
+      float dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { dxh[i] = dy[i] * g4[i]; s1 += dxh[i]; s2 += dxh[i] * xh[i]; }
+      s1 = wave_sum(s1) * invd;
+      s2 = wave_sum(s2) * invd;
+      float dx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dx[i] = rstd * (dxh[i] - s1 - xh[i] * s2) + r4[i];
+      *reinterpret_cast<float4*>(a.dx + (size_t)rw[u] * a.lddx + 4 * lane) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+      ag.x += dy[0] * xh[0]; ag.y += dy[1] * xh[1]; ag.z += dy[2] * xh[2]; ag.w += dy[3] * xh[3];
+      ab.x += dy[0]; ab.y += dy[1]; ab.z += dy[2]; ab.w += dy[3];
+      if (a.out2) {
+        float v2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v2[i] = dx[i] * drop_mult(d2, (uint32_t)rw[u], (uint32_t)(4 * lane + i));
+        *reinterpret_cast<float4*>(a.out2 + (size_t)rw[u] * 256 + 4 * lane) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+        ac.x += v2[0]; ac.y += v2[1]; ac.z += v2[2]; ac.w += v2[3];
+      } else {
+        ac.x += dx[0]; ac.y += dx[1]; ac.z += dx[2]; ac.w += dx[3];
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(sh + (0 * LNB_WAVES + wv) * 256 + 4 * lane) = ag;
+  *reinterpret_cast<float4*>(sh + (1 * LNB_WAVES + wv) * 256 + 4 * lane) = ab;
+  *reinterpret_cast<float4*>(sh + (2 * LNB_WAVES + wv) * 256 + 4 * lane) = ac;
+  __syncthreads();
+  for (int t = threadIdx.x; t < 3 * 256; t += blockDim.x) {
+    const int which = t >> 8, col = t & 255;
+    float* dst = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.colsum);
+    if (!dst && !a.partial) continue;
+    float s = 0.f;
+    for (int w = 0; w < LNB_WAVES; ++w) s += sh[(which * LNB_WAVES + w) * 256 + col];
+    if (a.partial) a.partial[((size_t)blockIdx.x * 3 + which) * 256 + col] = s;
+    else atomicAdd(&dst[col], s);
+  }
+}
+static bool ln_bwd_v4_takes(const LnBwdArgs& a) {
+  if (a.d != 256 || (a.res.mode != RES_NONE && a.res.mode != RES_DIRECT)) return false;
+  uintptr_t bits = (uintptr_t)a.x | (uintptr_t)a.dy | (uintptr_t)a.dx | (uintptr_t)a.g | (uintptr_t)a.out2 | (uintptr_t)a.stats;
+  int lds = a.ldx | a.lddy | a.lddx;
+  if (a.res.mode == RES_DIRECT) { bits |= (uintptr_t)a.res.ptr; lds |= a.res.ld; }
+  return (bits & 15) == 0 && (lds & 3) == 0;
+}
+
 int ln_bwd_blocks(int rows) {
   int blocks = ps_cdiv(rows, LNB_WAVES);
   return blocks > 256 ? 256 : blocks;   // rows are grid-strided; bounds the gamma/beta partials
@@ -566,6 +645,11 @@ int launch_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
   const size_t lds = sizeof(float) * 3 * LNB_WAVES * 64 * dp;
   const dim3 blk(64 * LNB_WAVES);
   const bool exact = a.d == 64 * dp;
+  if (ln_bwd_v4_takes(a)) {
+    hipLaunchKernelGGL(ln_bwd_v4_kernel, dim3(blocks), blk, sizeof(float) * 3 * LNB_WAVES * 256, st, a);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+  }
 #define LNB_LAUNCH(DP_)                                                                           \
   do {                                                                                            \
     if (exact) hipLaunchKernelGGL((ln_bwd_kernel<DP_, 1>), dim3(blocks), blk, lds, st, a);         \
