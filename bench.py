@@ -70,6 +70,15 @@ GATHER_TRAFFIC_SOURCE = ("committed PMC passes profiles/r04_gather_score_c5_pmc.
                          "tools/gather_c5.py --rows 8000000 --batch 1024, 8 rotating index sets): FETCH_SIZE 34.9 MB x2 (gfx950 16-B/lane streaming-read "
                          "correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE 0.42 MB = 70.3 MB per launch against 67.6 MB algorithmic (1.04x: nothing is "
                          "re-read; rounds 2-3 with ONE index set: 62.8 MB, part of the rows out of the Infinity Cache)")
+# memory-side bytes per launch of the two C2 roofline kernels from the committed counter passes (profiles/r04_c2_pmc_traffic.txt:
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 20 --warmup 5 --no-extras`; FETCH_SIZE x2 — the
+# gfx950 16-B/lane streaming-read correction, MI355X_MICROARCH.md HBM; both counters sit at the L2's fabric side and include
+# Infinity-Cache hits: at C2 the working set lives in that cache, so these are L2-miss bytes)
+C2_TRAFFIC = {'mlp_fwd': 2 * 7.83e6 + 48.8e6, 'wgrad_group': 2 * 25.9e6 + 12.3e6}
+C2_TRAFFIC_SOURCE = ("committed PMC passes profiles/r04_c2_pmc_traffic.txt (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 fabric side, "
+                     "Infinity-Cache hits included): mlp_fwd 2 x 7.83 + 48.8 MB (a1 + h1 + y1 / ln1 / y2 / enc written once, nothing "
+                     "re-read); grouped weight gradients 2 x 25.9 + 12.3 MB for 49.5 MB of operands + 10.5 MB of fp32 atomics "
+                     "(143 MB before the XCD-aware split placement)")
 PREWARM_TOTAL = 100                                        # untimed steps in front of the timed region, the W warm-up steps included
 ALSO_C5_ITEMS = 50_000_000                                 # the c5 line inside the default run: the STATED table of configs[4] (205 GB resident)
 GATHER_LEG_ITEMS = 8_000_000                               # the stand-alone gather+score leg: an 8.2 GB table is 32x the Infinity Cache already
@@ -467,8 +476,11 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
         extra = dict(spec['extra'])
         if 'frac_of_bf16x3_equivalent_peak' in extra:
             extra['frac_of_bf16x3_equivalent_peak'] = ach / (MFMA_BF16_PEAK_TFLOPS / 6.0)
+        c2_shape = name == 'c2' and (wl.c['B'], wl.c['D'], wl.c['FF']) == (384, 128, 512)
         out["roofline"] = dict({"bound": spec['bound'], "achieved": ach, "peak": spec['peak'], "unit": spec['unit'],
-                                "frac": ach / spec['peak'], "traffic": None, "traffic_source": None,
+                                "frac": ach / spec['peak'],
+                                "traffic": C2_TRAFFIC.get(spec['tag']) if c2_shape else None,
+                                "traffic_source": C2_TRAFFIC_SOURCE if c2_shape and spec['tag'] in C2_TRAFFIC else None,
                                 "kernel": spec['kernel'],
                                 ("flops_per_launch" if spec['bound'] == 'mfma' else "bytes_per_launch"): spec['work'],
                                 "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
@@ -485,6 +497,8 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                 out["roofline_longest_kernel"] = {
                     "bound": "mfma", "achieved": ach2, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach2 / MFMA_F32_PEAK_TFLOPS, "frac_of_bf16x3_equivalent_peak": ach2 / (MFMA_BF16_PEAK_TFLOPS / 6.0),
+                    "traffic": C2_TRAFFIC.get(spec2['tag']) if c2_shape else None,
+                    "traffic_source": C2_TRAFFIC_SOURCE if c2_shape else None,
                     "kernel": spec2['kernel'], "flops_per_launch": spec2['work'], "us_per_launch": avg.value,
                     "us_per_launch_min": mn.value, "launches_timed": cnt.value,
                     "timing": "HIP event pair around every in-step launch, on the SIDE stream it runs on (ps_ktimer)"}

@@ -339,6 +339,10 @@ struct GemmGroup {
   // problem i owns [flat0[i], flat0[i+1]): split-major, then row tile, then column tile; each problem keeps its own ksplit
   int flat;
   int flat0[4], flat_tm[3], flat_tiles[3];
+  // flat_xcd: workgroup L runs on XCD L % 8 (round-robin dispatch); with every flat0[] and ksplit a multiple of 8 the decode puts ALL
+  // tiles of a reduction split on one XCD (split % 8 == L % 8), so the split's operand rows cross the fabric once per XCD instead of
+  // once per tile pair (C2's grouped W2 / W1 / Wo gradients: FETCH_SIZE x2 = 143 MB per launch for 49.5 MB of operands, PMC)
+  int flat_xcd;
   // weight-gradient launches whose caller sized ksplit for 128x128 tiles: take gemm_x3d_kernel (tem.hip, run_wgrads)
   int prefer_x3d;
   // diagnostics (PS_GEMM_STAMP=1 + ps_debug_set_stamp_buffer, tools/gemm_stamps.py): the waves of one mid-grid workgroup of the

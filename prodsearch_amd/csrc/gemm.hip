@@ -293,8 +293,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     const int L = blockIdx.x;
     prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
     const int t = L - g.flat0[prob];
-    split = t / g.flat_tiles[prob];
-    ftile = t - split * g.flat_tiles[prob];
+    if (g.flat_xcd) {
+      const int s8 = t >> 3, grp = s8 / g.flat_tiles[prob];
+      split = (t & 7) + 8 * grp;
+      ftile = s8 - grp * g.flat_tiles[prob];
+    } else {
+      split = t / g.flat_tiles[prob];
+      ftile = t - split * g.flat_tiles[prob];
+    }
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -589,8 +595,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
     const int L = blockIdx.x;
     prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
     const int t = L - g.flat0[prob];
-    split = t / g.flat_tiles[prob];
-    ftile = t - split * g.flat_tiles[prob];
+    if (g.flat_xcd) {
+      const int s8 = t >> 3, grp = s8 / g.flat_tiles[prob];
+      split = (t & 7) + 8 * grp;
+      ftile = s8 - grp * g.flat_tiles[prob];
+    } else {
+      split = t / g.flat_tiles[prob];
+      ftile = t - split * g.flat_tiles[prob];
+    }
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -818,8 +830,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3d_kernel(const GemmGroup g) {
     const int L = blockIdx.x;
     prob = L >= g.flat0[2] ? 2 : (L >= g.flat0[1] ? 1 : 0);
     const int t = L - g.flat0[prob];
-    split = t / g.flat_tiles[prob];
-    ftile = t - split * g.flat_tiles[prob];
+    if (g.flat_xcd) {
+      const int s8 = t >> 3, grp = s8 / g.flat_tiles[prob];
+      split = (t & 7) + 8 * grp;
+      ftile = s8 - grp * g.flat_tiles[prob];
+    } else {
+      split = t / g.flat_tiles[prob];
+      ftile = t - split * g.flat_tiles[prob];
+    }
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -1447,6 +1465,10 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     }
     f.flat0[3] = total;
     for (int i = g.n; i < 3; ++i) f.flat0[i] = total + 1;      // never selected
+    static const int flat_xcd = ps_diag_int("PS_FLAT_XCD", 1);
+    f.flat_xcd = flat_xcd;
+    for (int i = 0; i < g.n; ++i)
+      if (g.p[i].ksplit % 8 != 0 || f.flat0[i] % 8 != 0) f.flat_xcd = 0;
     if (x3d) hipLaunchKernelGGL((gemm_x3d_kernel<1, 1, 0, 0>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else if (x3 && fs == 2) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 2, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else if (x3 && fs == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
