@@ -1450,7 +1450,7 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     // (round 2); 128x128 tiles of the direct-to-LDS form where x3_flat_shape() says so
     static const int flat_x3 = ps_diag_int("PS_GEMM_X3_FLAT", 1);
     const bool x3 = flat_x3 && x3_on();
-    const bool x3d = x3 && x3_flat_d(g) && x3d_takes(g);
+    const bool x3d = x3 && (x3_flat_d(g) || g.prefer_x3d) && x3d_takes(g);
     static const int flat_shape = ps_diag_int("PS_X3_FLAT_SHAPE", 0);      // 1: 128x64, 2: 128x128 tiles of gemm_x3_kernel
     const int fs = (x3 && !x3d) ? flat_shape : 0;
     const int TM = x3d ? X3D_T : (fs >= 1 ? 128 : BM), TN = x3d ? X3D_T : (fs == 2 ? 128 : BM);
@@ -1500,6 +1500,26 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     if (p.ta) {
       const int nslab = ps_cdiv(p.K, 32), per = ps_cdiv(nslab, p.ksplit);
       PS_REQUIRE(p.tb == 1 && per * 32 <= KIDX_MAX, "gemm: row-list weight gradient: %d rows per split > %d", per * 32, KIDX_MAX);
+    }
+  }
+  // Plain split reductions (weight gradients) whose form is a bf16x3 kernel that also has a FLAT (1-D grid) launch go through it: the
+  // flat decode puts all tiles of a reduction split on one XCD (GemmGroup::flat_xcd), where this 3-D grid spreads them over all
+  // eight — the C5 shard's W2 / W1 gradients fetched 2 x 129 = 258 MB per launch for 110 MB of operands, its Wo gradient 2 x 68 = 135
+  // MB for 44 (PMC, profiles/r04_c5_pmc_traffic.txt)
+  {
+    static const int flat_all = ps_diag_int("PS_WGRAD_FLAT_ALL", 1);
+    const int ks = g.p[0].ksplit;
+    bool plain = flat_all && !listed && !full && g.p[0].ta == 1 && g.p[0].tb == 1 && ks >= 8 && ks % 8 == 0 && x3_on();
+    for (int i = 0; i < g.n && plain; ++i)
+      plain = g.p[i].accumulate == 2 || (g.p[i].accumulate == 0 && g.p[i].split_stride > 0);
+    if (plain) {
+      const bool d = g.prefer_x3d && (g_x3_force < 0 || g_x3_force == 4) && x3d_takes(g);
+      if (d || x3_shape(g, maxM, maxN) == 0) {
+        GemmGroup f = g;
+        f.flat = 1;
+        f.prefer_x3d = d ? 1 : 0;
+        return launch_gemm_impl(f, stream);
+      }
     }
   }
   // products against pre-split weights (WPlaneScope): every member's B found, enough rows to be worth a 128-row tile
