@@ -343,6 +343,7 @@ struct GemmGroup {
   // tiles of a reduction split on one XCD (split % 8 == L % 8), so the split's operand rows cross the fabric once per XCD instead of
   // once per tile pair (C2's grouped W2 / W1 / Wo gradients: FETCH_SIZE x2 = 143 MB per launch for 49.5 MB of operands, PMC)
   int flat_xcd;
+  int split_xcd;      // the same placement on the 3-D grid (set by ps_launch_gemm: ta == 1, ksplit a multiple of 8)
   // weight-gradient launches whose caller sized ksplit for 128x128 tiles: take gemm_x3d_kernel (tem.hip, run_wgrads)
   int prefer_x3d;
   // diagnostics (PS_GEMM_STAMP=1 + ps_debug_set_stamp_buffer, tools/gemm_stamps.py): the waves of one mid-grid workgroup of the

@@ -301,6 +301,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       split = t / g.flat_tiles[prob];
       ftile = t - split * g.flat_tiles[prob];
     }
+  } else if (g.split_xcd) {       // 3-D grid of a split reduction: all tiles of a split on one XCD, as GemmGroup::flat_xcd does it
+    const int T = gridDim.x * gridDim.y, ks = g.p[0].ksplit;
+    const int Lz = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // dispatch order
+    prob = Lz / (T * ks);
+    const int t = Lz - prob * T * ks, s8 = t >> 3, grp = s8 / T;
+    split = (t & 7) + 8 * grp;
+    ftile = s8 - grp * T;
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -313,6 +320,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   if (g.flat) {
     tm = ftile % g.flat_tm[prob];
     tn = ftile / g.flat_tm[prob];
+  } else if (g.split_xcd) {
+    tm = ftile % (int)gridDim.y;
+    tn = ftile / (int)gridDim.y;
   } else {
     const int nx = gridDim.x, ny = gridDim.y;
     const int L = blockIdx.y * nx + blockIdx.x;       // dispatch order (x fastest)
@@ -603,6 +613,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
       split = t / g.flat_tiles[prob];
       ftile = t - split * g.flat_tiles[prob];
     }
+  } else if (g.split_xcd) {       // 3-D grid of a split reduction: all tiles of a split on one XCD, as GemmGroup::flat_xcd does it
+    const int T = gridDim.x * gridDim.y, ks = g.p[0].ksplit;
+    const int Lz = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // dispatch order
+    prob = Lz / (T * ks);
+    const int t = Lz - prob * T * ks, s8 = t >> 3, grp = s8 / T;
+    split = (t & 7) + 8 * grp;
+    ftile = s8 - grp * T;
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -615,6 +632,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmGroup g) {
   if (g.flat) {
     tm = ftile % g.flat_tm[prob];
     tn = ftile / g.flat_tm[prob];
+  } else if (g.split_xcd) {
+    tm = ftile % (int)gridDim.y;
+    tn = ftile / (int)gridDim.y;
   } else {
     const int nx = gridDim.x, ny = gridDim.y;
     const int L = blockIdx.y * nx + blockIdx.x;
@@ -838,6 +858,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3d_kernel(const GemmGroup g) {
       split = t / g.flat_tiles[prob];
       ftile = t - split * g.flat_tiles[prob];
     }
+  } else if (g.split_xcd) {       // 3-D grid of a split reduction: all tiles of a split on one XCD, as GemmGroup::flat_xcd does it
+    const int T = gridDim.x * gridDim.y, ks = g.p[0].ksplit;
+    const int Lz = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // dispatch order
+    prob = Lz / (T * ks);
+    const int t = Lz - prob * T * ks, s8 = t >> 3, grp = s8 / T;
+    split = (t & 7) + 8 * grp;
+    ftile = s8 - grp * T;
   } else {
     prob = blockIdx.z / g.p[0].ksplit;
     split = blockIdx.z - prob * g.p[0].ksplit;
@@ -850,6 +877,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3d_kernel(const GemmGroup g) {
   if (g.flat) {
     tm = ftile % g.flat_tm[prob];
     tn = ftile / g.flat_tm[prob];
+  } else if (g.split_xcd) {
+    tm = ftile % (int)gridDim.y;
+    tn = ftile / (int)gridDim.y;
   } else {
     const int nx = gridDim.x, ny = gridDim.y;
     const int L = blockIdx.y * nx + blockIdx.x;
@@ -1426,6 +1456,11 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream);
 int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   GemmGroup g = g0;
   g.sig = nullptr; g.sigval = 0;
+  {   // split reductions on the 3-D grid (row-list weight gradients keep it): splits placed by XCD when their count allows
+    static const int split_xcd = ps_diag_int("PS_SPLIT_XCD", 1);
+    const int ks = g.p[0].ksplit;
+    g.split_xcd = split_xcd && !g.flat && g.p[0].ta == 1 && ks >= 8 && ks % 8 == 0;
+  }
   static const int stamps = ps_diag_int("PS_GEMM_STAMP", 0);
   const bool stamp_this = stamps == 1 || (stamps == 2 && g0.p[0].ridx && g0.p[0].res.mode == RES_FANIN) ||
                           (stamps == 3 && g0.p[0].ridx && !g0.p[0].ta && g0.p[0].res.mode == RES_NONE) ||

@@ -400,6 +400,9 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
       const int need = ps_cdiv(ps_cdiv(ps[i].K, 32) * 32, PS_GEMM_KIDX_MAX - 32);
       if (ks < need) ks = need;
     }
+  // a split count that is a multiple of 8 lets the launch place every split's tiles on one XCD (GemmGroup::split_xcd / flat_xcd)
+  static const int ks_round8 = ps_diag_int("PS_KS_ROUND8", 1);
+  if (ks_round8 && ks > 8 && ks % 8 != 0 && !ps_deterministic()) ks = (ks + 7) / 8 * 8;
   for (int i = 0; i < n; ++i) { g.p[i] = ps[i]; g.p[i].ksplit = ks; }
   if (ps_deterministic() && ks > 1) return run_wgrads_det(g, st);
   return ps_launch_gemm(g, st);
