@@ -1440,6 +1440,8 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
     } else {
       TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
       GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
+      p.no_deep = 1;   // the tail of the main stream, beside the side stream's weight gradients: the 128-deep form's 133 KB of LDS per
+                       // workgroup waits for whole CUs there (50 us for 0.13 GFLOP at the C5 shard, r04_c5_step_timeline.txt)
       TRY(run1(p, st));
       e.dqmean_d = ws + w.dqmean;
       e.fw_dy = ws + w.dqpre;
