@@ -1,6 +1,7 @@
 // common.h — device helpers shared by the gfx950 kernels of libprodsearch_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/prodsearch_hip.h"
 
@@ -45,19 +46,29 @@ static inline int ps_diag_int(const char*, int dflt) { return dflt; }
 #endif
 
 // ------------------------------------------------------------------ kernel timer (measurement only)
-// ps_ktimer_arm("tag", n) makes the launch sites of ONE tagged kernel bracket their launch with a HIP event pair recorded
-// on the launch stream (bench.py's roofline: the kernel's in-step duration, measured live on its own stream);
-// ps_ktimer_read averages the pairs.  Unarmed (the default) the two calls are one pointer compare.
+// ps_ktimer_arm("tag", n) makes the launch site of ONE tagged kernel attach a HIP event pair to that launch
+// (hipExtLaunchKernelGGL start / stop events: the pair reads the DISPATCH's own begin / end timestamps — the duration
+// rocprofv3's kernel trace reports for it, tools/micro/extlaunch.hip: 5.59 us against 5.75 — where a hipEventRecord pair
+// around the launch also reads the two barrier packets, +2.5 us); bench.py's roofline: the kernel's in-step duration, measured
+// live on the stream it is launched on.  ps_ktimer_read averages the pairs.  Unarmed (the default) a scope is one pointer
+// compare and PS_KLAUNCH one flag test.  A scope times the FIRST PS_KLAUNCH inside it, nothing else it brackets.
 const char* ps_ktimer_tag();                       // armed tag or nullptr
-void ps_ktimer_mark(const char* tag, hipStream_t st, int end);
+void ps_ktimer_scope(bool open);
+bool ps_ktimer_take(hipEvent_t* e0, hipEvent_t* e1);   // inside an open scope, once: the launch's event pair
 struct KTimeScope {
-  const char* tag; hipStream_t st; bool on;
-  KTimeScope(const char* t, hipStream_t s) : tag(t), st(s), on(false) {
+  bool on;
+  KTimeScope(const char* t, hipStream_t) : on(false) {
     const char* armed = ps_ktimer_tag();
-    if (armed && __builtin_strcmp(armed, t) == 0) { on = true; ps_ktimer_mark(tag, st, 0); }
+    if (armed && __builtin_strcmp(armed, t) == 0) { on = true; ps_ktimer_scope(true); }
   }
-  ~KTimeScope() { if (on) ps_ktimer_mark(tag, st, 1); }
+  ~KTimeScope() { if (on) ps_ktimer_scope(false); }
 };
+#define PS_KLAUNCH(kernel, grid, block, lds, st, ...)                                                        \
+  do {                                                                                                       \
+    hipEvent_t kt_e0_, kt_e1_;                                                                               \
+    if (ps_ktimer_take(&kt_e0_, &kt_e1_)) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, kt_e0_, kt_e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                       \
+  } while (0)
 
 // ------------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al., SC'11), the generator torch/curand use; 10 rounds.

@@ -1504,10 +1504,10 @@ static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
     f.flat_xcd = flat_xcd;
     for (int i = 0; i < g.n; ++i)
       if (g.p[i].ksplit % 8 != 0 || f.flat0[i] % 8 != 0) f.flat_xcd = 0;
-    if (x3d) hipLaunchKernelGGL((gemm_x3d_kernel<1, 1, 0, 0>), dim3(total, 1, 1), dim3(256), 0, stream, f);
-    else if (x3 && fs == 2) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 2, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
-    else if (x3 && fs == 1) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 2, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
-    else if (x3) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    if (x3d) PS_KLAUNCH((gemm_x3d_kernel<1, 1, 0, 0>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3 && fs == 2) PS_KLAUNCH((gemm_x3_kernel<1, 1, 0, 2, 2, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3 && fs == 1) PS_KLAUNCH((gemm_x3_kernel<1, 1, 0, 2, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
+    else if (x3) PS_KLAUNCH((gemm_x3_kernel<1, 1, 0, 1, 1, 0, 1>), dim3(total, 1, 1), dim3(256), 0, stream, f);
     else launch<0, 32>(1, 1, dim3(total, 1, 1), stream, f);
     PS_LAUNCH_CHECK();
     return PS_OK;

@@ -472,14 +472,14 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
 #ifdef PS_DIAG                                                     // timing experiments (WRONG results): diagnostic build only
   static bool ad1 = false, ad2 = false, ad3 = false;
   static const int diag = ps_diag_int("PS_MLP_DIAG", 0);
-  if (a.F == 512 && diag == 1) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 1>, ad1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 1>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && diag == 2) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 2>, ad2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 2>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && diag == 3) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 3>, ad3)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  if (a.F == 512 && diag == 1) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 1>, ad1)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3, 1>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && diag == 2) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 2>, ad2)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3, 2>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && diag == 3) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3, 3>, ad3)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3, 3>), grid, block, sizeof(MlpTLds), st, as); }
   else
 #endif
-  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); hipLaunchKernelGGL((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); hipLaunchKernelGGL((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
-  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); hipLaunchKernelGGL((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); PS_KLAUNCH((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); PS_KLAUNCH((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

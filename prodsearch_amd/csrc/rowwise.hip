@@ -1069,11 +1069,11 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
     const int wl = a.d / 4 / ch, wu = score_wide_u();
     const int wb = ps_cdiv(ps_cdiv(ntask, wu), 256 / wl);
     a.loss_nblk = wb;
-    if (ch == 8) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 8>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
-    else if (ch == 4 && wu == 1) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
-    else if (ch == 4) hipLaunchKernelGGL((score_fwd_wide_kernel<2, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
-    else if (wu == 1) hipLaunchKernelGGL((score_fwd_wide_kernel<1, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
-    else hipLaunchKernelGGL((score_fwd_wide_kernel<2, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    if (ch == 8) PS_KLAUNCH((score_fwd_wide_kernel<1, 8>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (ch == 4 && wu == 1) PS_KLAUNCH((score_fwd_wide_kernel<1, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (ch == 4) PS_KLAUNCH((score_fwd_wide_kernel<2, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else if (wu == 1) PS_KLAUNCH((score_fwd_wide_kernel<1, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
+    else PS_KLAUNCH((score_fwd_wide_kernel<2, 2>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
     PS_LAUNCH_CHECK();
     return PS_OK;
   }
@@ -1081,8 +1081,8 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
   const int lpr = lpr_for(a.d), U = score_one_chunk_u(a, ntask);
   const int blocks = ps_cdiv(ps_cdiv(ntask, U), 256 / lpr);
   a.loss_nblk = blocks;
-  if (U == 1) hipLaunchKernelGGL((score_fwd_kernel<1>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
-  else hipLaunchKernelGGL((score_fwd_kernel<2>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
+  if (U == 1) PS_KLAUNCH((score_fwd_kernel<1>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
+  else PS_KLAUNCH((score_fwd_kernel<2>), dim3(blocks), dim3(256), 0, st, a, ntask, lpr);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }

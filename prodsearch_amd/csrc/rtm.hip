@@ -1937,11 +1937,11 @@ static int rtm_encode(const PsRtmDesc& D, const PsRtmTensors& P, const PsRtmBatc
         glist = gl; gcount = gc;
         egrid = dim3(nq_wg + ps_cdiv(npos + nneg, 4));
       }
-      if (d == 64) hipLaunchKernelGGL(rtm_embed4_kernel<1>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
-      else if (d == 128) hipLaunchKernelGGL(rtm_embed4_kernel<2>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
-      else hipLaunchKernelGGL(rtm_embed4_kernel<4>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
+      if (d == 64) PS_KLAUNCH(rtm_embed4_kernel<1>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
+      else if (d == 128) PS_KLAUNCH(rtm_embed4_kernel<2>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
+      else PS_KLAUNCH(rtm_embed4_kernel<4>, egrid, dim3(256), 0, st, k, npos, nneg, fR, fK, pads_unread, glist, gcount, nq_wg, e4_diag);
     } else {
-      hipLaunchKernelGGL(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
+      PS_KLAUNCH(rtm_embed_kernel, dim3(ps_cdiv(nslots, 4)), dim3(256), 0, st, k);
     }
   }
   PS_LAUNCH_CHECK();

@@ -49,19 +49,21 @@ extern "C" const char* ps_arith_info(void) {
 #include <vector>
 static struct KTimer {
   char tag[32];
-  bool armed;
+  bool armed, open;
   std::vector<hipEvent_t> e0, e1;
   int n, cap;
-} g_kt = {"", false, {}, {}, 0, 0};
+} g_kt = {"", false, false, {}, {}, 0, 0};
 const char* ps_ktimer_tag() { return g_kt.armed ? g_kt.tag : nullptr; }
-void ps_ktimer_mark(const char* tag, hipStream_t st, int end) {
-  (void)tag;
-  if (!g_kt.armed) return;
-  if (!end) { if (g_kt.n < g_kt.cap) (void)hipEventRecord(g_kt.e0[g_kt.n], st); }
-  else if (g_kt.n < g_kt.cap) { (void)hipEventRecord(g_kt.e1[g_kt.n], st); ++g_kt.n; }
+void ps_ktimer_scope(bool open) { g_kt.open = open && g_kt.armed; }
+bool ps_ktimer_take(hipEvent_t* e0, hipEvent_t* e1) {
+  if (!g_kt.open) return false;
+  g_kt.open = false;                                              // one launch per scope
+  if (g_kt.n >= g_kt.cap) return false;
+  *e0 = g_kt.e0[g_kt.n]; *e1 = g_kt.e1[g_kt.n]; ++g_kt.n;
+  return true;
 }
 extern "C" int ps_ktimer_arm(const char* tag, int32_t max_samples) {
-  g_kt.armed = false;
+  g_kt.armed = false; g_kt.open = false;
   g_kt.n = 0;
   if (!tag || !*tag || max_samples <= 0) return PS_OK;            // disarm
   PS_REQUIRE(strlen(tag) < sizeof(g_kt.tag), "ktimer: tag too long");
@@ -79,7 +81,7 @@ extern "C" int ps_ktimer_arm(const char* tag, int32_t max_samples) {
 // average / min duration (us) of the launches bracketed since ps_ktimer_arm; synchronises the device; disarms
 extern "C" int ps_ktimer_read(double* avg_us, double* min_us, int32_t* count) {
   PS_REQUIRE(avg_us && count, "ktimer: null argument");
-  g_kt.armed = false;
+  g_kt.armed = false; g_kt.open = false;
   PS_CHECK_HIP(hipDeviceSynchronize());
   double sum = 0, mn = 1e30;
   for (int i = 0; i < g_kt.n; ++i) {

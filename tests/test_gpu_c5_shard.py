@@ -162,6 +162,59 @@ def test_c5_shard_dropout_step_is_deterministic_and_moves_only_touched_rows():
     assert res[0][0] == res[1][0]          # forward of step 1: same seed, same Philox step -> identical bits
 
 
+def test_c5_shard_dropout_step_matches_the_replicated_oracle():
+    """The shard step bench.py's `also` line times (BASELINE configs[4] with the reference's default dropout 0.1: B = 1024,
+    K = 20, d = 256, ff = 1024, R = 21 replicas = 21,504 replica rows) against the oracle in the reference's own replicated
+    structure (item_transformer.py:471-494: the encoder on B and on B*K expanded copies) on the compacted table, with the
+    product's Philox masks injected: loss / ps / item loss and the [1024, 21] logits <= 1e-4, the gradient of every tensor
+    <= 5e-4 of its max, touched rows of both tables bit-exact.  Only at this size does the step select the 128x128
+    direct-to-LDS weight gradients (gemm_x3d_kernel, tem.hip `t128 * ks3 >= 384`), fanin_sum_kernel and the row-list K/V dX
+    product; the oracle side is ~1 minute and ~20 GB of host memory."""
+    from oracle import tem as otem, philox
+    a, wd, m, optim, batch, ni, nw = _setup(0.1)
+    sd, b2, ni2, items = _compact(m, batch, ni)
+    U = items.numel()
+    loss = m(batch.to('cuda'), neg_item_idxs=ni.cuda(), neg_word_idxs=nw.cuda())
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(m._plans.values()))
+    assert plan.layout.R == K + 1                                   # the replicas really are computed
+    scores = m.workspace_view(plan, 'item_scores', (B, K + 1)).cpu()
+    Pm = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith('pos_emb.pe')) for k, v in sd.items()}
+    keep = {}
+    drop = philox.PhiloxDropout(0.1, m._seed, m._fwd_step, B, K, a.heads, L + 1, 1, L if a.use_item_pos else 0)
+    oloss, ops, oil = otem.tem_forward(Pm, a, b2, ni2, nw, V, U, training=True, replicate=True, drop=drop, keep=keep)
+    assert rel_err(loss.detach().cpu(), oloss.detach()) < 1e-4
+    assert abs(m.ps_loss - float(ops)) < 1e-4 * abs(float(ops)) and abs(m.item_loss - float(oil)) < 1e-4 * abs(float(oil))
+    ref_scores = torch.cat([keep['pos_scores'].detach()[:, None], keep['neg_scores'].detach()], 1)
+    assert rel_err(scores, ref_scores) < 1e-4
+    grads = otem.grads_of(oloss, Pm, otem.tem_pad_rows(a, V, U))
+    del keep, oloss
+    # the item table: the touched list is the batch's index set, its gradient rows against the compact table's
+    assert torch.equal(m.touched_rows()['product_emb.weight'].cpu(), items)
+    g_items = m.product_emb.weight.grad[items.cuda()].cpu()
+    ref_items = grads['product_emb.weight'][:U]
+    assert rel_err(g_items, ref_items) < 5e-4, rel_err(g_items, ref_items)
+    assert torch.equal(g_items.ne(0).any(1), ref_items.ne(0).any(1))
+    nz = m.product_emb.weight.grad.ne(0).any(1)
+    assert int(nz.sum()) == int(nz[items.cuda()].sum())             # nothing outside the touched rows received a gradient
+    for n, p in m.named_parameters():
+        ref = grads.get(n)
+        if n == 'product_emb.weight':
+            continue
+        assert (p.grad is None) == (ref is None), n
+        if ref is None or n.endswith('linear_keys.bias'):          # (exactly-zero true gradient: rounding noise on both sides)
+            continue
+        got = p.grad.cpu()
+        assert rel_err(got, ref) < 5e-4, (n, rel_err(got, ref))
+        if ref.dim() == 2 and ref.shape[0] > 1024:
+            assert torch.equal(got.ne(0).any(1), ref.ne(0).any(1)), n
+    m.check_index_errors()
+    del m, optim
+    torch.cuda.empty_cache()
+
+
 def test_gather_score_launch_in_its_8_lane_form_matches_a_host_dot_product():
     """B = 8192: 344k tasks x 1 KiB = 352 MB of rows per launch selects the 8-lanes-per-row form of
     score_fwd_wide_kernel (rowwise.hip: `huge`); logits against a host fp32 dot product of the same rows."""
