@@ -163,11 +163,12 @@ class TemWorkload(object):
                                "score + loss folded into its epilogue: %d B of gathered rows and scores"
                                % (B * R, D, D, D, FF, B * (1 + K) * (4 * D + 8 + 4)),
                         extra={"gather_score_bytes_all_tasks": gather_bytes,
-                               "peak_note": "peak = dense fp32 MFMA; products issued as exact bf16x3 (6 bf16 MFMAs per fp32-grade "
-                                            "step) have an equivalent peak of %.0f TFLOP/s" % (MFMA_BF16_PEAK_TFLOPS / 6.0),
+                               "peak_note": "peak = dense fp32 MFMA; products issued as fp32-grade bf16x3 (exact 3-way bf16 split of "
+                                            "both operands, 6 of the 9 cross products as bf16 MFMAs per step) have an equivalent "
+                                            "peak of %.0f TFLOP/s" % (MFMA_BF16_PEAK_TFLOPS / 6.0),
                                "frac_of_bf16x3_equivalent_peak": None})
         return dict(tag='gather_score', bound='hbm', work=gather_bytes, peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
-                    kernel="score_fwd_wide_kernel<1,%d> (embedding gather + score; 16 lanes per %d-B row)" % (D // 64, 4 * D),
+                    kernel="score_fwd_sidx_kernel<%d,16> (embedding gather + score; 16 lanes per %d-B row, indices by scalar loads)" % (D // 64, 4 * D),
                     extra={"traffic": GATHER_TRAFFIC if (B, D) == (1024, 256) else None,
                            "traffic_source": GATHER_TRAFFIC_SOURCE if (B, D) == (1024, 256) else None})
 
@@ -484,8 +485,9 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                                 "kernel": spec['kernel'],
                                 ("flops_per_launch" if spec['bound'] == 'mfma' else "bytes_per_launch"): spec['work'],
                                 "us_per_launch": avg.value, "us_per_launch_min": mn.value, "launches_timed": cnt.value,
-                                "timing": "HIP event pair around every in-step launch, on the launch stream, over a second "
-                                          "pass of %d steps (ps_ktimer)" % steps}, **extra)
+                                "timing": "HIP event pair BOUND to every in-step launch of the kernel (hipExtLaunchKernelGGL start / stop "
+                                          "events: the dispatch's own begin / end, what rocprofv3's kernel trace reports), on "
+                                          "the launch stream, over a second pass of %d steps (ps_ktimer)" % steps}, **extra)
         spec2 = wl.roofline_longest_spec() if hasattr(wl, 'roofline_longest_spec') else None
         if spec2:        # (2b) the longest kernel of the step when that is not the one the critical path is made of
             _lib.check(lib.ps_ktimer_arm(spec2['tag'].encode(), steps), 'ps_ktimer_arm')
@@ -501,7 +503,8 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
                     "traffic_source": C2_TRAFFIC_SOURCE if c2_shape else None,
                     "kernel": spec2['kernel'], "flops_per_launch": spec2['work'], "us_per_launch": avg.value,
                     "us_per_launch_min": mn.value, "launches_timed": cnt.value,
-                    "timing": "HIP event pair around every in-step launch, on the SIDE stream it runs on (ps_ktimer)"}
+                    "timing": "HIP event pair bound to every in-step launch (the dispatch's own begin / end), on the SIDE stream it "
+                              "runs on (ps_ktimer)"}
         if world == 1 and cpu_steps > 0 and name == 'c4':
             out["cpu_baseline"] = wl.cpu_baseline(cpu_steps)
         elif world == 1 and cpu_steps > 0 and name == 'c2':
@@ -515,7 +518,7 @@ def measure(a, name, rank, world, dev, steps, warmup, reps, extras, cpu_steps, i
 
 def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
     """The embedding-gather+score launch alone at the C5 shape (d=256, 1-KiB rows, `rows`-row item table far beyond the
-    Infinity Cache), B=1024 and B=8192.  Every launch is bracketed by a HIP event pair on its stream (ps_ktimer); the
+    Infinity Cache), B=1024 and B=8192.  Every launch carries a HIP event pair bound to its dispatch (ps_ktimer); the
     launches walk 8 different index sets in turn (8 x 67.6 MB at B=1024 > the 256 MB Infinity Cache), so a row read by
     one launch is not served from on-die cache to the next."""
     from prodsearch_amd import _lib
@@ -556,9 +559,8 @@ def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
             _lib.check(lib.ps_gather_score(desc, params, sets[i % 8][1], ws.data_ptr(), st.cuda_stream), 'ps_gather_score')
         avg, mn, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int32(0)
         _lib.check(lib.ps_ktimer_read(ctypes.byref(avg), ctypes.byref(mn), ctypes.byref(cnt)), 'ps_ktimer_read')
-        # the same launches back to back between ONE event pair: an event pair around every launch adds its own packets to
-        # what it brackets (17.5 us where rocprofv3's kernel trace reads 14-15, profiles/r04_gather_score_kernel_stats.csv);
-        # the loop average (kernel + the gap to the next launch) is the duration `achieved` is computed from
+        # the same launches back to back between ONE event pair: launch THROUGHPUT (consecutive launches overlap head and tail),
+        # reported beside the per-launch duration, never as it
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record(st)
@@ -570,19 +572,21 @@ def gather_score_hbm_leg(dev, rows=GATHER_LEG_ITEMS, iters=40):
         R = lay.R
         nrows = B * (1 + K) * (1 + W)
         nbytes = nrows * (4 * d + 8) + (B * R + B) * 4 * d + nrows * 4
-        ach = nbytes / (loop_us * 1e-6) / 1e9
-        res.append({"B": B, "bytes_per_launch": nbytes, "us_per_launch": loop_us, "us_per_launch_event_pairs": avg.value,
-                    "us_per_launch_event_pairs_min": mn.value, "launches_timed": cnt.value, "achieved": ach,
-                    "frac": ach / HBM_PEAK_GBS, "frac_event_pairs": nbytes / (avg.value * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        ach = nbytes / (avg.value * 1e-6) / 1e9
+        res.append({"B": B, "bytes_per_launch": nbytes, "us_per_launch": avg.value, "us_per_launch_min": mn.value,
+                    "launches_timed": cnt.value, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                    "back_to_back_us_per_launch": loop_us, "back_to_back_throughput_frac": nbytes / (loop_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
         del ws, sets
     del table, words
     torch.cuda.empty_cache()
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": res[0]["achieved"], "frac": res[0]["frac"],
-            "kernel": "score_fwd_wide_kernel<1,4> alone (embedding gather + score), C5 shape: d=256, %d-row item table "
+            "kernel": "score_fwd_sidx_kernel<4,16> alone (embedding gather + score, index hop on the scalar path), C5 shape: d=256, %d-row item table "
                       "(%.1f GB), K=20, W=1, R=21; 8 rotating index sets" % (rows, (rows + 1) * d * 4 / 1e9),
             "by_batch": res, "traffic": GATHER_TRAFFIC, "traffic_source": GATHER_TRAFFIC_SOURCE,
-            "timing": "%d launches per batch size, back to back on their stream between one HIP event pair (us_per_launch); and "
-                      "one event pair around every launch (ps_ktimer; us_per_launch_event_pairs, which includes the pairs' own packets)" % iters}
+            "timing": "%d launches per batch size; us_per_launch / achieved / frac: one HIP event pair BOUND to every launch "
+                      "(hipExtLaunchKernelGGL start / stop events = the dispatch's own begin / end, what rocprofv3's kernel trace reports: "
+                      "profiles/r05_gather_score_kernel_stats.csv); back_to_back_*: the same launches between ONE event pair — launch "
+                      "throughput, consecutive launches overlapping head and tail, not a kernel duration" % iters}
 
 
 # ------------------------------------------------------------------------------------------ launching N ranks
@@ -594,9 +598,44 @@ def _free_port():
     return p
 
 
+def _run_ranks(a, backend, extra_env):
+    """One set of child ranks -> (rank exit codes, rank 0's JSON lines, tail of rank 0's stderr)."""
+    import tempfile
+    port = _free_port()
+    procs = []
+    err0 = tempfile.TemporaryFile(mode='w+')
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PS_BENCH_CHILD='1', **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=err0 if r == 0 else None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:                                  # a rank left alone in a collective by a dead peer never returns by itself
+            rcs.append(p.wait(timeout=120 if any(rcs) else None))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    err0.seek(0)
+    err_tail = err0.read()[-2000:]
+    err0.close()
+    sys.stderr.write(err_tail)
+    lines = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    return rcs, lines, err_tail
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no torchrun environment: start the N ranks as child processes of this one — nothing
-    here has touched the GPU (device_count() does not initialise it) — relay rank 0's JSON line and fail loudly otherwise."""
+    here has touched the GPU (device_count() does not initialise it) — relay rank 0's JSON line and fail loudly otherwise.
+
+    The sharded optimizer's peer-to-peer forms (batched send / recv all-gather, all-to-all reduce-scatter, the `_tune` pass that
+    times them: prodsearch_amd/dist.py) cannot be exercised on the one-GPU boxes this code is developed on (RCCL refuses two
+    ranks on one device), so the first multi-GPU run is also their first run on RCCL.  If the first set of ranks fails, ONE fresh
+    set of child processes is started with PS_DP_RS=rccl PS_DP_AG=rccl — the library collectives only (reduce_scatter_tensor /
+    all_gather_into_tensor) — and the line says so (`exchange_fallback`, with rank 0's stderr of the failed attempt).  Nothing
+    is retried inside a process that has initialised the GPU."""
     backend = os.environ.get('PS_DIST_BACKEND') or 'nccl'
     ndev = torch.cuda.device_count()
     if ndev < 1:
@@ -604,27 +643,28 @@ def self_launch(a):
     if ndev < a.gpus and backend != 'gloo':
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU over RCCL needs %d "
                          "(PS_DIST_BACKEND=gloo rehearses the N-rank path on fewer devices)" % (a.gpus, ndev, a.gpus))
-    port = _free_port()
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PS_BENCH_CHILD='1')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    rcs, lines, err_tail = _run_ranks(a, backend, {})
+    fallback = None
+    forced = os.environ.get('PS_DP_RS') == 'rccl' and os.environ.get('PS_DP_AG') == 'rccl'
+    if (any(rcs) or len(lines) != 1) and not forced:
+        sys.stderr.write("bench.py --gpus %d: first attempt failed (rank exit codes %s, %d JSON line(s)); starting a fresh set of ranks "
+                         "with PS_DP_RS=rccl PS_DP_AG=rccl (library collectives only)\n" % (a.gpus, rcs, len(lines)))
+        fallback = {"first_attempt_exit_codes": rcs, "first_attempt_rank0_stderr_tail": err_tail[-800:],
+                    "env": {"PS_DP_RS": "rccl", "PS_DP_AG": "rccl"}}
+        rcs, lines, err_tail = _run_ranks(a, backend, {'PS_DP_RS': 'rccl', 'PS_DP_AG': 'rccl'})
     if any(rcs) or len(lines) != 1:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         sys.stderr.write("bench.py --gpus %d: rank exit codes %s, %d JSON line(s) from rank 0\n" % (a.gpus, rcs, len(lines)))
         raise SystemExit(1)
     d = json.loads(lines[0])
     if d.get('n_gpus') != a.gpus:
         sys.stderr.write("bench.py --gpus %d: rank 0 reported n_gpus=%r\n" % (a.gpus, d.get('n_gpus')))
         raise SystemExit(1)
-    print(lines[0])
+    if fallback is not None:
+        d["exchange_fallback"] = True
+        d["exchange_fallback_detail"] = fallback
+        print(json.dumps(d))
+    else:
+        print(lines[0])
 
 
 def fed_step_leg(a, dev, steps=400, warmup=60):
@@ -682,7 +722,17 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    out = measure(a, a.workload, rank, world, dev, a.steps, a.warmup, a.reps, not a.no_extras, a.cpu_steps, a.items)
+    try:
+        out = measure(a, a.workload, rank, world, dev, a.steps, a.warmup, a.reps, not a.no_extras, a.cpu_steps, a.items)
+    except Exception:
+        if world > 1 and not (os.environ.get('PS_DP_RS') == 'rccl' and os.environ.get('PS_DP_AG') == 'rccl'):
+            # (this process has initialised the GPU: nothing is retried here.  `python bench.py --gpus N` without torchrun does the
+            # retry itself, in fresh child processes: self_launch)
+            sys.stderr.write("bench.py rank %d of %d failed.  If the traceback below ends inside the sharded optimizer's peer-to-peer "
+                             "collectives (prodsearch_amd/dist.py: batch_isend_irecv / all_to_all_single / _tune), rerun with "
+                             "PS_DP_RS=rccl PS_DP_AG=rccl in the environment: reduce_scatter_tensor / all_gather_into_tensor "
+                             "only.\n" % (rank, world))
+        raise
     later = out.pop("_cpu_baseline_later", None)
     if a.workload == 'c2' and world == 1 and not a.no_extras and not a.no_also:
         out["roofline_hbm"] = gather_score_hbm_leg(dev)

@@ -404,10 +404,22 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
   __syncthreads();
   unsigned long long mine = 0ull, old = 0ull;
   const unsigned long long one = 1ull << 48, mask = one - 1ull;
+  // Fixed-point scale: the sum of ALL partials must stay below bit 47 (a carry into bit 48 would corrupt the arrival count: the
+  // last-arriver test would fire early or never).  2^20 up to 256 workgroups, one bit coarser per doubling of the
+  // grid beyond that: a workgroup's partial has 2^19 = 524k of headroom at any grid (16k per replica row — a diverged run).
+  // A partial beyond that, negative, NaN or Inf is handed over as 0 and POISONS the step's loss: a flag in the ticket's
+  // second word, set by a RETURNING atomic whose value the arrival add depends on, so the flag is in place before the
+  // arrival can be counted; the last arriver reads it and reports +inf.
+  int shift = 20;
+  for (unsigned g = 256u; g < gridDim.x && shift > 8; g <<= 1) --shift;
+  const float fscale = (float)(1u << shift);
   if (tid == 0) {
     const float p = ((L.red[0] + L.red[1]) + (L.red[2] + L.red[3])) + ((L.red[4] + L.red[5]) + (L.red[6] + L.red[7]));
     unsigned long long* tk = reinterpret_cast<unsigned long long*>(S.ticket);
-    mine = (unsigned long long)(long long)__float2ll_rn(p * 1048576.f) | one;
+    long long fx = 0;
+    if (p >= 0.f && p < 524288.f) fx = __float2ll_rn(p * fscale);
+    else fx = (long long)(__hip_atomic_fetch_or(tk + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0ull);
+    mine = (unsigned long long)fx | one;
     old = __hip_atomic_fetch_add(tk, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // the stage's stores are issued under the atomic's round trip
@@ -417,7 +429,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     float last = 0.f;
     if ((old >> 48) == gridDim.x - 1u) {
       last = 1.f;
-      L.red[9] = (float)((double)((old & mask) + (mine & mask)) * (1.0 / 1048576.0));
+      const unsigned long long poison =
+          __hip_atomic_load(reinterpret_cast<unsigned long long*>(S.ticket) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.red[9] = poison ? __builtin_inff() : (float)((double)((old & mask) + (mine & mask)) / (double)fscale);
     }
     L.red[8] = last;
   }

@@ -1018,6 +1018,145 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void scor
   }
 }
 
+// ---- The same launch with the index hop on the SCALAR path (round 5).  The per-workgroup stamps of the kernel above
+// (profiles/r04_gather_score_wg_times.txt) put 1.5 us (p90 3.6) of a 5.3 us workgroup life into "indices known": the lanes'
+// index loads are vector-memory requests and queue, in the CU's in-order texture path, behind the 1-KiB row requests of every
+// wave that started earlier.  Here a wave owns 64 / LPR CONSECUTIVE tasks of ONE kind (item tasks first, word tasks from a
+// fresh wave), so what a task needs before its row can be requested is wave-uniform: the decode runs on the scalar ALU and
+// the three indices of every task (item / word id, the row's target item, the window's positive word) arrive together by
+// s_load_dwordx2 through the scalar cache — a path of its own to the L2, not behind the rows; a lane picks its row group's
+// values with v_cndmask.  Item waves request their vectors (encoder rows: known from the task number) before the indices
+// are back.  No load sits behind a per-lane test: tasks past the end of a kind repeat its last task.
+#define PS_SLOAD_I64(dst, ptr) asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(dst) : "s"(ptr) : "memory")
+template <int G> struct SIdx { int64_t a[G], b[G], c[G]; };
+template <int G>
+__device__ inline void sidx_wait(SIdx<G>& x) {                     // ONE wait for all of the wave's scalar loads
+  if constexpr (G == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x.a[0]), "+s"(x.a[1]), "+s"(x.b[0]), "+s"(x.b[1]), "+s"(x.c[0]), "+s"(x.c[1]) :: "memory");
+  else if constexpr (G == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x.a[0]), "+s"(x.a[1]), "+s"(x.a[2]), "+s"(x.a[3]), "+s"(x.b[0]), "+s"(x.b[1]), "+s"(x.b[2]), "+s"(x.b[3]),
+                 "+s"(x.c[0]), "+s"(x.c[1]), "+s"(x.c[2]), "+s"(x.c[3]) :: "memory");
+  else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x.a[0]), "+s"(x.a[1]), "+s"(x.a[2]), "+s"(x.a[3]), "+s"(x.a[4]), "+s"(x.a[5]), "+s"(x.a[6]), "+s"(x.a[7]),
+                 "+s"(x.b[0]), "+s"(x.b[1]), "+s"(x.b[2]), "+s"(x.b[3]), "+s"(x.b[4]), "+s"(x.b[5]), "+s"(x.b[6]), "+s"(x.b[7]) :: "memory");
+    asm volatile("" : "+s"(x.c[0]), "+s"(x.c[1]), "+s"(x.c[2]), "+s"(x.c[3]), "+s"(x.c[4]), "+s"(x.c[5]), "+s"(x.c[6]), "+s"(x.c[7]) :: "memory");
+  }
+}
+template <int CH, int LPR>
+__global__ __launch_bounds__(256) void score_fwd_sidx_kernel(const ScoreArgs a, int ntask) {
+  constexpr int G = 64 / LPR;                                    // tasks per wave
+  constexpr int D = 4 * CH * LPR;                                // = a.d (launch_score_fwd)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, myg = lane / LPR, c = lane % LPR;
+  const int K1 = a.K + 1, nitem = a.B * K1, nword = ntask - nitem;
+  const int niw = (nitem + G - 1) / G, nww = (nword + G - 1) / G;
+  const int wv0 = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool wlive = wv0 < niw + nww;
+  const int wv = wlive ? wv0 : niw + nww - 1;
+  const bool item = wv < niw;                                     // the kind of all tasks of this wave (uniform)
+  const int ncat = item ? nitem : nword;
+  const int u0 = (item ? wv : wv - niw) * G;
+#if PS_DIAG_ON
+  unsigned long long stp[4] = {0, 0, 0, 0};
+#define GSS_STAMP(slot) do { if (a.stamp) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stp[slot])::"memory"); } while (0)
+#else
+#define GSS_STAMP(slot) do { } while (0)
+#endif
+  GSS_STAMP(0);
+  // what a lane knows of its task without memory: (q, j) = (row of the kind's index matrix, column), output slots, term sign
+  const int u_l = min(u0 + myg, ncat - 1);
+  const bool live = wlive && u0 + myg < ncat;
+  const int q_l = fdiv(u_l, a.fK1), j_l = u_l - q_l * K1;
+  const int b_l = item ? q_l : fdiv(u_l, a.fWK1);
+  float* out_l = (item ? a.item_scores : a.word_scores) + u_l;
+  float* term_l = (item ? a.item_terms : a.word_terms) + u_l;
+  const float tw_l = j_l == 0 ? (item ? -(a.pos_weight ? (float)a.K : 1.f) : -1.f) : 1.f;
+  // hop 1 (scalar): index of the task's row, the target item of its batch row, the positive word of its window
+  const int64_t* pFirst = item ? a.target : a.pos_words;          // [*, 1]: column 0 of the kind's index matrix
+  const int64_t* pRest = item ? a.neg_items : a.neg_words;        // [*, K]: columns 1 .. K
+  SIdx<G> x;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int u = min(u0 + g, ncat - 1);
+    const int q = fdiv(u, a.fK1), j = u - q * K1;
+    const int bb = item ? q : fdiv(u, a.fWK1);
+    const int64_t* pa = j == 0 ? pFirst + q : pRest + ((size_t)q * a.K + (j - 1));
+    PS_SLOAD_I64(x.a[g], pa);
+    PS_SLOAD_I64(x.b[g], a.target + bb);
+    PS_SLOAD_I64(x.c[g], pFirst + q);
+  }
+  float4 r[CH], v[CH];
+  if (item) {                                                      // encoder rows: requested under the index hop
+    const float* vec = a.enc + ((size_t)b_l * a.R + (a.R > 1 ? j_l : 0)) * D;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) v[k] = *reinterpret_cast<const float4*>(vec + 4 * (c + LPR * k));
+  }
+  sidx_wait<G>(x);
+  int64_t ia = x.a[0], ib = x.b[0], ic = x.c[0];
+#pragma unroll
+  for (int g = 1; g < G; ++g) {
+    ia = myg == g ? x.a[g] : ia;
+    ib = myg == g ? x.b[g] : ib;
+    ic = myg == g ? x.c[g] : ic;
+  }
+  GSS_STAMP(1);
+  const int64_t idx = clamp_idx(ia, item ? a.P : a.V - 1);
+  if (!item) {
+    const float* vec = a.product_emb + (size_t)clamp_idx(ib, a.P) * D;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) v[k] = *reinterpret_cast<const float4*>(vec + 4 * (c + LPR * k));
+  }
+  const float* row = (item ? a.product_emb : a.word_emb) + (size_t)idx * D;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) r[k] = *reinterpret_cast<const float4*>(row + 4 * (c + LPR * k));
+  // under the rows: the row's bias; the weight of a word task's term in the batch loss (masked mean over the window,
+  // get_vector_mean, item_transformer.py:281: padded slots drop out)
+  const float* pbias = item ? (a.bias_product ? a.product_bias : nullptr) : a.word_bias;
+  const float bias_l = pbias ? pbias[idx] : 0.f;
+  float lw_l = 1.f;
+  if (!item) {
+    int cnt = ic != a.V - 1;
+    if (a.W > 1) {
+      cnt = 0;
+      for (int ww = 0; ww < a.W; ++ww) cnt += a.pos_words[(size_t)b_l * a.W + ww] != a.V - 1;
+    }
+    lw_l = ic != a.V - 1 ? -1.f / (float)cnt : -0.f;
+  }
+#if PS_DIAG_ON
+  if (a.stamp) { asm volatile("" ::"v"(r[0].x), "v"(v[0].x)); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+  GSS_STAMP(2);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) s += r[k].x * v[k].x + r[k].y * v[k].y + r[k].z * v[k].z + r[k].w * v[k].w;
+  s = LPR == 32 ? half_sum_last(s) : (LPR == 16 ? row16_sum_last(s) : group_sum(s, LPR));
+  constexpr int wl = LPR == 32 ? 31 : (LPR == 16 ? 15 : 0);
+  float cps = 0.f, cil = 0.f;
+  if (c == wl && live) {
+    const float sc = s + bias_l;
+    *out_l = sc;
+    const float term = fabsf(tw_l) * softplus_f(tw_l < 0.f ? -sc : sc);
+    *term_l = term;
+    if (lw_l > 0.f) cps += term; else cil -= term * lw_l;
+  }
+  GSS_STAMP(3);
+#if PS_DIAG_ON
+  if (a.stamp && tid == 0)
+    for (int q = 0; q < 4; ++q) a.stamp[4 * (size_t)blockIdx.x + q] = stp[q];
+#endif
+  if (!a.loss_blk) return;
+  constexpr int gpb = 256 / LPR;
+  __shared__ float rps[64], ril[64];
+  if (tid < 64) { rps[tid] = 0.f; ril[tid] = 0.f; }
+  __syncthreads();
+  if (c == wl) { rps[tid / LPR] = cps; ril[tid / LPR] = cil; }
+  __syncthreads();
+  if (tid < 64) {                                                  // a fixed tree: bitwise reproducible
+    const float p = wave_sum(rps[tid]), q = wave_sum(ril[tid]);
+    if (tid == 0) { a.loss_blk[2 * blockIdx.x] = p; a.loss_blk[2 * blockIdx.x + 1] = q; }
+  }
+  (void)gpb;
+}
+
 // wide form: chunks per lane (0 = use the one-chunk kernels above).  Default: 16 lanes per row (d = 128: 2 chunks,
 // 256: 4, 512: 8), 8 lanes per row for launches of >= 256 MB of rows; other widths keep the one-chunk kernels.
 // Measured (MI355X): C5 shape B=1024 22.6 -> 13.6 us (4.99 TB/s), B=8192 167 -> 95.7 us (5.65 TB/s = 0.71 of the HBM
@@ -1050,9 +1189,23 @@ static int score_one_chunk_u(const ScoreArgs& a, int ntask) {
   return (size_t)ntask * a.d * 4 < ((size_t)64 << 20) ? 1 : 2;
 }
 
+// training launches whose draws sit in memory take the index hop on the scalar path (score_fwd_sidx_kernel; PS_SCORE_SIDX=0: the
+// per-lane form): workgroups of the launch, 0 = not that form.  A wave holds 64 / lpr tasks of ONE kind.
+static int score_sidx_blocks(const ScoreArgs& a, int ntask, int ch) {
+  static const bool sidx = ps_env_int("PS_SCORE_SIDX", 1) != 0;
+  const int wl = a.d / 4 / ch;
+  if (!sidx || a.C != 0 || a.samp_inline || score_wide_u() != 1 || (wl != 16 && wl != 8) || ntask <= 0) return 0;
+  if (!((wl == 16 && (ch == 2 || ch == 4 || ch == 8)) || (wl == 8 && (ch == 4 || ch == 8)))) return 0;
+  const int G = 64 / wl, nitem = a.B * (a.K + 1);
+  return ps_cdiv(ps_cdiv(nitem, G) + ps_cdiv(ntask - nitem, G), 4);
+}
+
 int score_fwd_blocks(const ScoreArgs& a) {
   const int ntask = a.C > 0 ? a.B * a.C : a.B * (a.K + 1) * (1 + a.W);
-  if (const int ch = score_wide_ch(a, ntask)) return ps_cdiv(ps_cdiv(ntask, score_wide_u()), 256 / (a.d / 4 / ch));
+  if (const int ch = score_wide_ch(a, ntask)) {
+    if (const int sb = score_sidx_blocks(a, ntask, ch)) return sb;
+    return ps_cdiv(ps_cdiv(ntask, score_wide_u()), 256 / (a.d / 4 / ch));
+  }
   return ps_cdiv(ps_cdiv(ntask, score_one_chunk_u(a, ntask)), 256 / lpr_for(a.d));
 }
 
@@ -1069,6 +1222,17 @@ int launch_score_fwd(ScoreArgs& a, hipStream_t st) {
     const int wl = a.d / 4 / ch, wu = score_wide_u();
     const int wb = ps_cdiv(ps_cdiv(ntask, wu), 256 / wl);
     a.loss_nblk = wb;
+    if (const int sb = score_sidx_blocks(a, ntask, ch)) {
+      a.loss_nblk = sb;
+      bool done = true;
+      if (wl == 16 && ch == 2) PS_KLAUNCH((score_fwd_sidx_kernel<2, 16>), dim3(sb), dim3(256), 0, st, a, ntask);
+      else if (wl == 16 && ch == 4) PS_KLAUNCH((score_fwd_sidx_kernel<4, 16>), dim3(sb), dim3(256), 0, st, a, ntask);
+      else if (wl == 16 && ch == 8) PS_KLAUNCH((score_fwd_sidx_kernel<8, 16>), dim3(sb), dim3(256), 0, st, a, ntask);
+      else if (wl == 8 && ch == 4) PS_KLAUNCH((score_fwd_sidx_kernel<4, 8>), dim3(sb), dim3(256), 0, st, a, ntask);
+      else if (wl == 8 && ch == 8) PS_KLAUNCH((score_fwd_sidx_kernel<8, 8>), dim3(sb), dim3(256), 0, st, a, ntask);
+      else { done = false; a.loss_nblk = wb; }
+      if (done) { PS_LAUNCH_CHECK(); return PS_OK; }
+    }
     if (ch == 8) PS_KLAUNCH((score_fwd_wide_kernel<1, 8>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
     else if (ch == 4 && wu == 1) PS_KLAUNCH((score_fwd_wide_kernel<1, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);
     else if (ch == 4) PS_KLAUNCH((score_fwd_wide_kernel<2, 4>), dim3(wb), dim3(256), 0, st, a, ntask, wl);

@@ -798,11 +798,19 @@ __global__ __launch_bounds__(256) void rtm_score_kernel(const RtmK a, float* out
   __syncthreads();
   if (threadIdx.x == 0) {
     const float mine_f = (wterm[0] + wterm[1]) + (wterm[2] + wterm[3]);           // >= 0: weights and softplus are
-    const unsigned long long mine = (unsigned long long)llrintf(mine_f * 1048576.f) + (1ull << 48);
+    // (a partial that is NaN / Inf / beyond the 48-bit field's share — 2^27 / grid per workgroup — is handed over as 0 and
+    // poisons the loss through the spare word of the cleared group, set by a returning atomic the arrival add depends on:
+    // garbage must not carry into the arrival count)
+    uint32_t* spare = reinterpret_cast<uint32_t*>(ticket) + 3;
+    long long fx = 0;
+    if (mine_f >= 0.f && mine_f * (float)gridDim.x < 134217728.f) fx = (long long)llrintf(mine_f * 1048576.f);
+    else fx = (long long)(__hip_atomic_fetch_or(spare, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0u);
+    const unsigned long long mine = (unsigned long long)fx + (1ull << 48);
     const unsigned long long old = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((old >> 48) == (unsigned long long)gridDim.x - 1ull) {
       const unsigned long long tot = (old + mine) & ((1ull << 48) - 1ull);
-      const float psl = (float)((double)tot * (1.0 / 1048576.0)) / (float)a.B;
+      const bool poison = __hip_atomic_load(spare, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      const float psl = poison ? __builtin_inff() : (float)((double)tot * (1.0 / 1048576.0)) / (float)a.B;
       a.loss3[0] = psl; a.loss3[1] = psl; a.loss3[2] = 0.f;
       a.nvalid[0] = 0.f;
     }

@@ -333,7 +333,15 @@ class ItemPVDataloader(object):
         generator order as the sequential loop; a consumer that stops early leaves the generator up to ``prefetch + 1`` batches
         further than the sequential loop would."""
         import collections
+        import weakref
         lib = self._lib
+        # The producer thread draws from self._rng — with seed=None the process-wide generator the dataset's epoch shuffles use
+        # too — and that generator has no lock: ONE live epoch per loader, and nothing else may draw from the generator while it
+        # runs (a private fork would change the batches: they are the sequential loop's, draw for draw).  ADVICE r4.
+        box = self.__dict__.setdefault('_live_epoch', [None])
+        if box[0] is not None:
+            raise RuntimeError("ItemPVDataloader: an epoch iterator of this loader is still alive (its producer thread owns the "
+                               "random generator): exhaust or close() it before starting another")
         depth = min(max(self.prefetch + 2, 4), 64)
         order = np.ascontiguousarray(sampler_order(len(self.dataset), self.shuffle), dtype=np.int64)
         B, W, Q = int(self.batch_size), self.sample_words.shape[1], self.corpus.view.Q
@@ -355,6 +363,13 @@ class ItemPVDataloader(object):
                                len(order), B, int(self.drop_last), slots, depth)
         if not h:
             raise RuntimeError("ps_epoch_start failed: %s" % lib.ps_data_last_error().decode('utf-8', 'replace'))
+        box[0] = h
+
+        def _stop(box=box, lib=lib, keep=(ring, order, sw, sr, slots, a)):      # the thread writes into `ring`: stop it before
+            if box[0] is not None:                                               # anything it touches can be freed
+                lib.ps_epoch_stop(box[0])
+                box[0] = None
+        fin = weakref.finalize(self, _stop)      # also runs at interpreter exit, where a generator's `finally` may not
 
         def views(flat, n, L):
             ui = flat[o_ui:o_ui + B * lim].view(B, lim)[:n]
@@ -406,4 +421,4 @@ class ItemPVDataloader(object):
         finally:
             for s, ev in held:
                 ev.synchronize()
-            lib.ps_epoch_stop(h)
+            fin()                                 # ps_epoch_stop, once

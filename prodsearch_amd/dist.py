@@ -386,10 +386,12 @@ class ShardedAdamExchange(object):
             if mine.data_ptr() != shard.data_ptr():
                 mine.copy_(shard)
             ops = []
+            # P2POp's peer is a GLOBAL rank; self.rank is the rank inside self.group (they differ on a strict sub-group)
+            peer = (lambda g: g) if self.group is None else (lambda g: dist.get_global_rank(self.group, g))
             for k in range(1, W):                # ring-shifted order: in every round each rank sends to a different peer
                 dst, src = (r + k) % W, (r - k) % W
-                ops.append(dist.P2POp(dist.isend, shard, dst, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, full[src * n:(src + 1) * n], src, group=self.group))
+                ops.append(dist.P2POp(dist.isend, shard, peer(dst), group=self.group))
+                ops.append(dist.P2POp(dist.irecv, full[src * n:(src + 1) * n], peer(src), group=self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         else:
@@ -515,9 +517,12 @@ def make_exchange(model, optim=None, group=None, mode=None):
 
 
 def broadcast_parameters(model, src=0, group=None):
-    """Replicas must start identical (tables and weights replicated)."""
+    """Replicas must start identical (tables and weights replicated).  ``src`` is a rank INSIDE ``group`` (torch's broadcast
+    wants the global one: translated here, so a strict sub-group that does not hold global rank 0 works)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    if group is not None:
+        src = dist.get_global_rank(group, src)
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src, group=group)
 

@@ -392,6 +392,8 @@ def build_optim(args, model, checkpoint):
             and os.environ.get('PS_KEEP_GRADS', '0') in ('', '0'):
         optim.zero_grads_owner = weakref.ref(model)
     if getattr(model, '_shard', None) is not None:
+        if args.optim != 'adam':      # (the constructor's own check only sees its row_sparse ARGUMENT; this path sets the flag afterwards)
+            raise NotImplementedError("shard_tables: the owner-side row-sparse optimizer is Adam only (--optim %s)" % args.optim)
         optim.row_sparse = True
         optim.shard_owner = weakref.ref(model)
     if getattr(args, 'train_from', '') != '' and checkpoint is not None:

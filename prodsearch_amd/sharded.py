@@ -180,7 +180,16 @@ class ShardedItemTable(object):
 
     def _post_flag(self):
         if self._bad_host is not None:
-            self._bad_host.copy_(self.bad, non_blocking=True)
+            src = self.bad
+            if self.world > 1:
+                # the status is per rank but every rank must fail in the SAME lookup (a rank that raised alone would leave the
+                # others blocked in the next all_to_all until the collective's timeout): max over the ranks, on the stream, no sync
+                if getattr(self, '_bad_all', None) is None:
+                    self._bad_all = torch.zeros_like(self.bad)
+                self._bad_all.copy_(self.bad)
+                dist.all_reduce(self._bad_all, op=dist.ReduceOp.MAX, group=self.group)
+                src = self._bad_all
+            self._bad_host.copy_(src, non_blocking=True)
             self._bad_evt = torch.cuda.Event()
             self._bad_evt.record(torch.cuda.current_stream(self.device))
 
@@ -193,8 +202,10 @@ class ShardedItemTable(object):
         flag = int(self._bad_host[0])
         if flag:
             self.bad.zero_()
-            raise RuntimeError("sharded item table (previous lookup): " + ("an index was not in the step's row list" if flag == 1 else
-                               "a request to one owner overflowed its capacity of %d rows (skewed ids: raise the headroom)" % self.capp))
+            raise RuntimeError("sharded item table (previous lookup, on this or another rank — every rank raises here together; that step's "
+                               "forward, backward and update ran with zero rows in place of the missing ones: restore the last checkpoint): "
+                               + ("an index was not in the step's row list" if flag == 1 else
+                                  "a request to one owner overflowed its capacity of %d rows (skewed ids: raise the headroom)" % self.capp))
 
     def push_grads(self, grad_buf):
         """Route the receive buffer's gradient rows (``[slots + 1, d]``) to their owners and merge them into ``self.grad``;

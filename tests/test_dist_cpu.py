@@ -293,6 +293,74 @@ def test_gloo_sharded_adam_protocol(world, forms):                              
         assert r[1] and r[2] and r[3] and r[4] and r[5] == 1.0 / world, r
 
 
+def _subgroup_worker(rank, world, port, q):
+    """the peer-to-peer all-gather names its peers by GLOBAL rank.  World 4, the exchange on the strict sub-group
+    {1, 3} (group rank 0 = global rank 1, group rank 1 = global rank 3): a group-local peer number would send rank 1's slice to
+    global rank 1 (itself) / receive from 0 — a hang or slices in the wrong replicas.  The members must end with bitwise equal
+    parameters that match clip + Adam on the mean of THEIR two gradients; ranks 0 and 2 take no part."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), PS_DP_RS='a2a', PS_DP_AG='a2a')
+    pdist.init_from_env(backend='gloo')
+    members = [1, 3]
+    grp = dist.new_group(ranks=members)                     # collective over the whole world
+    if rank in members:
+        CpuSharded = _cpu_sharded_class()
+
+        class Opt(object):
+            _step, grad_scale, _sharded, _plan = 0, 1.0, None, None
+
+        torch.manual_seed(3)
+        model, opt = _StubModel(), Opt()
+        ref = {n: p.detach().clone() for n, p in model.named_parameters()}
+        ex = CpuSharded(model, opt, group=grp)
+        assert ex.world == 2 and ex.rank == members.index(rank) and ex.ag_mode == 'a2a'
+        refp = [torch.nn.Parameter(ref[n].clone()) for n, _ in model.named_parameters()]
+        ropt = torch.optim.Adam(refp, lr=_Hyper.lr, betas=(0.9, 0.999), eps=1e-9)
+        ok = True
+        for step in range(2):
+            model._structs()
+            grads_all = []
+            for r in members:
+                g = torch.Generator().manual_seed(1000 * step + r)
+                grads_all.append([torch.randn(p.shape, generator=g) * 3.0 for _, p in model.named_parameters()])
+            views = dict((id(a), b) for a, b in model._grad_views)
+            for (_, p), gr in zip(model.named_parameters(), grads_all[members.index(rank)]):
+                views[id(p)].copy_(gr)
+            ex()
+            hp = _Hyper()
+            hp.grad_scale = opt.grad_scale
+            ex.step(hp)
+            for i, q_ in enumerate(refp):
+                q_.grad = sum(ga[i] for ga in grads_all) / len(members)
+            torch.nn.utils.clip_grad_norm_(refp, 5.0)
+            ropt.step()
+            for (n, p), q_ in zip(model.named_parameters(), refp):
+                ok = ok and torch.allclose(p.detach(), q_.detach(), rtol=2e-5, atol=2e-6)
+        flats = [torch.zeros_like(model._param_flat) for _ in members]
+        dist.all_gather(flats, model._param_flat, group=grp)
+        q.put((rank, bool(ok), bool(torch.equal(flats[0], flats[1]))))
+    else:
+        q.put((rank, True, True))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_sharded_adam_on_a_strict_subgroup_of_the_world():
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2], r
+
+
 def _resume_worker(rank, world, port, q):
     """Save / resume under the sharded optimizer: three steps, then the moments and the step count go through
     ``Optimizer.state_dict()`` / ``load_state_dict()`` semantics — ``full_moments()`` -> per-parameter tensors ->

@@ -55,7 +55,7 @@ t = buf.cpu().numpy().reshape(NWG, 4)
 live = t[:, 0] != 0
 t = t[live]
 t0 = t[:, 0].min()
-print("PS_SCORE_CH=%s B=%d: %d workgroups stamped; 1 tick = 10 ns" % (os.environ.get('PS_SCORE_CH', 'default'), B, live.sum()))
+print("PS_SCORE_CH=%s PS_SCORE_SIDX=%s B=%d: %d workgroups stamped; 1 tick = 10 ns" % (os.environ.get("PS_SCORE_CH", "default"), os.environ.get("PS_SCORE_SIDX", "1"), B, live.sum()))
 print("span first start -> last end: %d ticks" % (t[:, 3].max() - t0))
 for name, col in (("start", t[:, 0] - t0), ("idx known", t[:, 1] - t[:, 0]), ("rows arrived", t[:, 2] - t[:, 1]), ("tail", t[:, 3] - t[:, 2]),
                   ("life", t[:, 3] - t[:, 0])):
