@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprodsearch_hip.so')
 DIAG_LIB = os.path.join(LIBDIR, 'libprodsearch_hip_diag.so')      # -DPS_DIAG: tuning knobs, stamps, timing-only variants (tools/)
 SOURCES = ['gemm.hip', 'rowwise.hip', 'attn_sq1.hip', 'mlp_fused.hip', 'optim.hip', 'optim_rows.hip', 'rank.hip', 'tem.hip', 'rtm.hip']
-HEADERS = ['common.h', 'rowwise.h', 'encoder.h', 'optim_core.h', 'graph.h', os.path.join('..', '..', 'include', 'prodsearch_hip.h')]
+HEADERS = ['common.h', 'rowwise.h', 'encoder.h', 'optim_core.h', 'graph.h', 'x3frag.h', os.path.join('..', '..', 'include', 'prodsearch_hip.h')]
 
 
 DATA_LIB = os.path.join(LIBDIR, 'libprodsearch_data.so')

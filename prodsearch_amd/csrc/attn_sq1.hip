@@ -9,6 +9,7 @@
 // Everything is LDS-resident fp32 VALU work (S <= 64, a few KB per sequence); replicas are
 // processed in chunks of JC so that the Philox masks are generated once per element.
 #include "rowwise.h"
+#include "x3frag.h"
 #include <stdlib.h>
 
 #define SQ1_LDS_MAX (128 * 1024)   // dynamic LDS these kernels may request (160 KB per CU on gfx950)
@@ -715,6 +716,217 @@ __global__ __launch_bounds__(256) void attn_fwd_wf_kernel(const AttnArgs a, uint
   }
 }
 
+// ================================================================== K / V / Q projections + replica attention, one launch
+// Round 5: the C2 forward's front end was three latency-bound launches over the same 384 x 21 rows — embed
+// (11 us), the K / V / Q GEMM (13 us: 0.5 GFLOP) and the replica attention above (10 us).  Here a workgroup of 8 waves owns ONE
+// sequence for the last two:
+//   * K / V:  D^T = W . X^T as in the fused per-replica kernels (x3frag.h): the sequence's <= 32 positions are the MFMA's N
+//     dimension (padded positions are zero rows), wave w streams the 8 fragments of feature block w (0-3: linear_keys, 4-7:
+//     linear_values; WSplit::fwd_kv, re-split by the embed launch in front) global -> registers at kernel start and runs 48
+//     bf16 MFMAs (fp32-grade bf16x3).  The tiles go to LDS for the attention and, valid positions only, to kp / vp for the
+//     backward (a lane's 16 consecutive features = one 64-byte run);
+//   * Q (one row): 16 lane groups of 32 lanes dot the query row with 8 coalesced rows of linear_query each (exact fp32);
+//   * attention: attn_fwd_wf_kernel's body with wave = (head group, replica chunk), K / V / q read from LDS.
+// Outputs are exactly those of the three launches it replaces (kp, vp, qp, attn, amask, ctx): the backward is unchanged.
+struct KvqLds {
+  uint16_t Xa[3][X3_ROWS * X3_K];    // x planes [position][k]
+  float Ks[X3_ROWS][132];            // K / V tiles [position][feature], +16 B per row
+  float Vs[X3_ROWS][132];
+  float qs[128];
+  int sp[8][64];
+};
+#if PS_DIAG_ON      // [8 * workgroup + slot]: the 100 MHz counter all CUs share, wave 0's view
+#define KVQ_STAMP(slot)                                                                                  \
+  do {                                                                                                   \
+    if (g.stamp && threadIdx.x == 0) {                                                                   \
+      unsigned long long t_;                                                                             \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      kvq_st[slot] = t_;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+#else
+#define KVQ_STAMP(slot) do { } while (0)
+#endif
+template <int MAXK>
+__global__ __launch_bounds__(512, 2) void kvq_attn_fwd_kernel(const KvqArgs g) {      // <= 128 registers: two workgroups per CU, every sequence resident
+  constexpr int DH = 16, LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 128;
+  extern __shared__ float kvq_lds_raw[];
+  KvqLds& L = *reinterpret_cast<KvqLds*>(kvq_lds_raw);
+  const AttnArgs& a = g.at;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x, S = a.S, HF = a.H;
+#if PS_DIAG_ON
+  unsigned long long kvq_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  KVQ_STAMP(0);
+  DropSpec drop = a.drop;                                              // (the step word lives in device memory: read it with the rest)
+  drop.step = drop_step(a.drop); drop.step_ptr = nullptr;
+  // ---- everything with a global round trip, requested now
+  // (1) the wave's weight fragments: feature block nb = wave & 3 of K (wave < 4) or V
+  const uint16_t* stream = g.kv_stream + (size_t)(wave * 8) * 1536;
+  uint4 wf[4][3];                                                      // a ring of four: steps 4..7 are requested as 0..3 retire
+#pragma unroll
+  for (int t = 0; t < 4; ++t) load_frag(wf[t], stream, t, lane);
+  // (2) x rows -> planes: thread = (position, one 8-element chunk); positions past S are zero rows
+  {
+    const int row = tid >> 4, kc = tid & 15;
+    const float* src = g.x + ((size_t)b * S + (row < S ? row : 0)) * D + 8 * kc;
+    const float4 v0 = f4_ld(src), v1 = f4_ld(src + 4);
+    const bool on = row < S;
+    const float v[8] = {on ? v0.x : 0.f, on ? v0.y : 0.f, on ? v0.z : 0.f, on ? v0.w : 0.f,
+                        on ? v1.x : 0.f, on ? v1.y : 0.f, on ? v1.z : 0.f, on ? v1.w : 0.f};
+    put8(L.Xa, row, 8 * kc, v);
+  }
+  // (3) Q: lane group gq (32 lanes) owns outputs gq + 16 u; lane cq holds 4 elements of the query row and of each weight row
+  const int gq = tid >> 5, cq = tid & 31;
+  const float4 x0 = f4_ld(g.x + (size_t)b * S * D + 4 * cq);
+  float4 wq[8];
+  float bqv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { wq[u] = f4_ld(g.wq + (size_t)(gq + 16 * u) * D + 4 * cq); bqv[u] = g.bq[gq + 16 * u]; }
+  // (4) the sequence's valid positions (every wave keeps its own copy of the list)
+  const unsigned long long vm = w1_valid(a, b, lane, L.sp[wave]);
+  const int Sv = __popcll(vm);
+  const int nb = wave & 3, f0 = 32 * nb + 16 * h;
+  // Q while the planes settle
+  KVQ_STAMP(1);                                                        // valid list known (the first full wait)
+  // (no global load or store under the lane test: each would be a round trip of its own behind a full wait)
+  float qv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) qv[u] = (half_sum_last(f4_dot(wq[u], x0)) + bqv[u]) * a.qscale;
+  if (cq == 31) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) L.qs[gq + 16 * u] = qv[u];
+  }
+  KVQ_STAMP(2);
+  __syncthreads();                                                     // planes + q in LDS
+  KVQ_STAMP(3);
+  if (tid < D) g.qp[(size_t)b * D + tid] = L.qs[tid];
+  // ---- K / V tile of this wave: [32 features x 32 positions] over k = 128
+  {
+    // this lane's 16 bias values (requested under the products)
+    const float* bsrc = (wave < 4 ? g.bk : g.bv) + f0;
+    float4 bias4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias4[q] = f4_ld(bsrc + 4 * q);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      uint4 bq[3];
+      read_b(bq, L.Xa, l31, 16 * t + 8 * h);
+      x3_mma(acc, wf[t & 3], bq);
+      if (t < 4) load_frag(wf[t], stream, t + 4, lane);
+      __builtin_amdgcn_sched_barrier(0);       // keep the refill where it is issued (x3frag.h, load_frag)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[4 * q] += bias4[q].x; acc[4 * q + 1] += bias4[q].y; acc[4 * q + 2] += bias4[q].z; acc[4 * q + 3] += bias4[q].w; }
+    float* tile = (wave < 4 ? &L.Ks[0][0] : &L.Vs[0][0]) + l31 * 132 + f0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f4_st(tile + 4 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+    if ((vm >> l31) & 1ull) {                                          // valid positions only: nothing reads the others
+      float* out = (wave < 4 ? g.kp : g.vp) + ((size_t)b * S + l31) * D + f0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f4_st(out + 4 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+    }
+  }
+  KVQ_STAMP(4);
+  __syncthreads();                                                     // K / V tiles in LDS
+  KVQ_STAMP(5);
+  // ---- attention of position 0: wave = (head group hg, replica chunk ch)
+  const int hg = wave >> 2, ch = wave & 3;
+  const int jper = (a.fan + 3) >> 2, jbeg = ch * jper, jend = min(a.fan, jbeg + jper);
+  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, hd = 4 * hg + hl;
+  const int* sp = L.sp[wave];
+  const float4 q4 = f4_ld(&L.qs[c]);
+  float4 v4[MAXK]; float P[MAXK]; int pk[MAXK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int k = i * KPS + sub;
+    pk[i] = sp[k < Sv ? k : 0];
+    const float4 k4 = f4_ld(&L.Ks[pk[i]][c]);
+    v4[i] = f4_ld(&L.Vs[pk[i]][c]);
+    float dot = f4_dot(q4, k4);
+#pragma unroll
+    for (int o = 1; o < LPH; o <<= 1) dot += __shfl_xor(dot, o, 64);
+    P[i] = k < Sv ? dot : -INFINITY;
+    mx = fmaxf(mx, P[i]);
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float lsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) { P[i] = i * KPS + sub < Sv ? expf(P[i] - mx) : 0.f; lsum += P[i]; }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
+  const float inv = 1.f / lsum;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    P[i] *= inv;
+    if (ch == 0 && i * KPS + sub < Sv && (cl & (LPH - 1)) == 0) a.attn[((size_t)b * HF + hd) * S + pk[i]] = P[i];
+  }
+  if (ch == 0 && lane < S && !((vm >> lane) & 1ull))         // masked positions: weight 0 (lane = position)
+    for (int hh = 0; hh < 4; ++hh) a.attn[((size_t)b * HF + 4 * hg + hh) * S + lane] = 0.f;
+  const int mykey = sp[lane < Sv ? lane : 0];
+  KVQ_STAMP(6);
+  for (int j = jbeg; j < jend; ++j) {
+    const size_t rrow = (size_t)b * a.fan + j;
+    uint32_t keep[4] = {~0u, ~0u, ~0u, ~0u};
+    if (drop.thr) {
+      const Philox4 r = philox4x32_10((uint32_t)mykey, (uint32_t)(rrow * HF + 4 * hg) >> 2, drop.site, drop.step, drop.k0, drop.k1);
+      const bool live = lane < Sv;
+      keep[0] = (uint32_t)__ballot(live && r.x >= drop.thr); keep[1] = (uint32_t)__ballot(live && r.y >= drop.thr);
+      keep[2] = (uint32_t)__ballot(live && r.z >= drop.thr); keep[3] = (uint32_t)__ballot(live && r.w >= drop.thr);
+    }
+    if (lane < 4) g.amask[rrow * HF + 4 * hg + lane] = lane == 0 ? keep[0] : (lane == 1 ? keep[1] : (lane == 2 ? keep[2] : keep[3]));
+    const uint32_t kh = hl == 0 ? keep[0] : (hl == 1 ? keep[1] : (hl == 2 ? keep[2] : keep[3]));
+    float4 ctx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      const int k = i * KPS + sub;
+      const float m = (k < Sv && ((kh >> k) & 1u)) ? drop.scale : 0.f;
+      f4_fma(ctx4, P[i] * (drop.thr ? m : (k < Sv ? 1.f : 0.f)), v4[i]);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) ctx4 = f4_xor_add(ctx4, o);
+    if (sub == 0) f4_st(a.ctx + rrow * D + c, ctx4);
+  }
+  KVQ_STAMP(7);
+#if PS_DIAG_ON
+  if (g.stamp && tid == 0)
+    for (int q = 0; q < 8; ++q) g.stamp[8 * (size_t)blockIdx.x + q] = kvq_st[q];
+#endif
+}
+bool kvq_attn_fits(const AttnArgs& a) {
+  static const bool on = ps_env_int("PS_KVQ_FUSED", 1) != 0;
+  return on && a.Sq == 1 && a.qpos == 0 && a.H == 8 && a.d == 128 && a.dh == 16 && a.S <= 32 && a.fan >= 4 && a.fan <= 24 &&
+         a.seq_div == 1 && !a.valid;
+}
+int launch_kvq_attn_fwd(const KvqArgs& g, hipStream_t st) {
+  PS_REQUIRE(kvq_attn_fits(g.at), "fused K/V/Q + attention: unsupported shape");
+  PS_REQUIRE(g.x && g.kv_stream && g.bk && g.bv && g.wq && g.bq && g.kp && g.vp && g.qp && g.amask && g.at.attn && g.at.ctx && g.at.ui,
+             "fused K/V/Q + attention: null pointer");
+  static bool attr24 = false, attr32 = false;
+#if PS_DIAG_ON
+  KvqArgs gd = g;
+  gd.stamp = ps_diag_int("PS_KVQ_STAMP", 0) ? ps_debug_stamp_ptr() : nullptr;
+  const KvqArgs& gl = gd;
+#else
+  const KvqArgs& gl = g;
+#endif
+  if (g.at.S <= 24) {
+    if (!attr24) { PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kvq_attn_fwd_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(KvqLds))); attr24 = true; }
+    hipLaunchKernelGGL((kvq_attn_fwd_kernel<6>), dim3(g.at.n_in), dim3(512), sizeof(KvqLds), st, gl);
+  } else {
+    if (!attr32) { PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kvq_attn_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(KvqLds))); attr32 = true; }
+    hipLaunchKernelGGL((kvq_attn_fwd_kernel<8>), dim3(g.at.n_in), dim3(512), sizeof(KvqLds), st, gl);
+  }
+  PS_LAUNCH_CHECK();
+  return PS_OK;
+}
+
 // Backward with the replicas of a (sequence, head group) split over the FOUR waves of a workgroup (d = 128, H = 8: two
 // workgroups per sequence).  Each wave repeats the short set-up and sums d V / d P over its 5-6 replicas (their d context
 // rows all requested up front); the partial sums meet in LDS, wave 0 finishes (softmax backward, d K / d V rows, dq) and the
@@ -729,15 +941,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
   // keys of a lane group: i = hf * MAXK + ii, hf < NH (the key range is walked in NH parts so that only MAXK V rows and
   // d V sums are in registers at a time: d = 256 needs 11 keys per group for 21 positions)
   constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 8 * DH, NK = NH * MAXK, NV = 5 * NK, JB = 6;
-  __shared__ int sp[4][64];
-  __shared__ float red[4][NV][64];                            // [wave][value][lane]
-  __shared__ float dqs[HC];
-  __shared__ float part[128];
+  // fused d x (DH == 16 only): the head group's dK | dV rows as bf16x3 B-operand planes [position][128 k].  Only the rows of
+  // valid positions are ever written, the product reads 32: a column of the MFMA's B operand only reaches the same column of
+  // its result, and the columns of other positions are dropped — so the planes have XR = MAXK * KPS rows and reads past them
+  // land in what follows inside this struct.
+  constexpr int XR = DH == 16 ? MAXK * KPS : 1;
+  struct Lds {
+    int sp[4][64];
+    uint16_t Xb[3][XR * X3_K];
+    float red[4][NV][64];                                     // [wave][value][lane]
+    float dqs[HC];
+    float part[128];
+    float part0[128];
+  };
+  static_assert(DH != 16 || sizeof(Lds) >= sizeof(int) * 256 + 3 * 32 * X3_K * 2, "planes: over-reads must stay inside the struct");
+  __shared__ Lds Ls;
+  auto& sp = Ls.sp; auto& red = Ls.red; auto& dqs = Ls.dqs; auto& part = Ls.part;
   const int tid = threadIdx.x, lane = tid & 63, ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = a.S, HF = a.H;
   const int b = (int)blockIdx.x >> 1, hg = (int)blockIdx.x & 1;
   const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
   const bool fold_q = a.wq != nullptr && DH == 16;
+  const bool fuse_dx = DH == 16 && fold_q && a.kvb_stream != nullptr;   // (kernel-uniform)
   const unsigned long long vm = w1_valid(a, b, lane, sp[ch]);
   const int Sv = __popcll(vm);
   const int jper = (a.fan + 3) >> 2, jbeg = ch * jper, jend = min(a.fan, jbeg + jper), nj = max(0, jend - jbeg);   // nj <= JB (fits)
@@ -790,6 +1015,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
 #pragma unroll
     for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
   }
+  // fused d x: wave ch owns the 32 input features 32 ch ..; its first four weight fragments (of eight) are requested now
+  uint4 wfr[4][3];
+  const uint16_t* kvb = nullptr;
+  if constexpr (DH == 16) {
+    if (fuse_dx) {
+      kvb = a.kvb_stream + (size_t)((hg * 4 + ch) * 8) * 1536;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) load_frag(wfr[t], kvb, t, lane);
+    }
+  }
   __syncthreads();
   if (ch == 0) {
     const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
@@ -819,6 +1054,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
         const float4 dk4 = f4_scale(g, q4);
         f4_st(a.dkv + row * a.lddkv + c, dk4);
         f4_st(a.dkv + row * a.lddkv + D + c, dvs);
+        if constexpr (DH == 16) {
+          if (fuse_dx) {     // k index inside the group's product: its 64 dK columns, then its 64 dV columns
+            const int pos = sp[0][k];
+            put4<XR>(Ls.Xb, pos, 4 * cl, dk4);
+            put4<XR>(Ls.Xb, pos, 64 + 4 * cl, dvs);
+          }
+        }
         sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
         sv4.x += dvs.x; sv4.y += dvs.y; sv4.z += dvs.z; sv4.w += dvs.w;
       }
@@ -852,6 +1094,33 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
   }
   if (!fold_q) return;
   __syncthreads();
+  if constexpr (DH == 16) {
+    if (fuse_dx) {
+      // d x^T block = [Wk^T | Wv^T](32 features x 128 k) . (dK | dV)^T (128 k x positions): 48 bf16 MFMAs per wave
+      const int l31 = lane & 31, hh = lane >> 5;
+      f32x16 accx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        uint4 bq[3];
+        read_b_rows<XR>(bq, Ls.Xb, l31, 16 * t + 8 * hh);
+        x3_mma(accx, wfr[t & 3], bq);
+        if (t < 4) load_frag(wfr[t], kvb, t + 4, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // lane (position l31, half hh) holds input features 32 ch + 16 hh + r: one 64-byte run of the position's partial row
+      const int f0 = 32 * ch + 16 * hh;
+      if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ls.part0[f0 + r] = accx[r];                 // the query position's row leaves with the tail
+      } else if (l31 < S && ((vm >> l31) & 1ull)) {
+        float* out = a.dxp[hg] + ((size_t)b * S + l31) * D + f0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f4_st(out + 4 * q, make_float4(accx[4 * q], accx[4 * q + 1], accx[4 * q + 2], accx[4 * q + 3]));
+      }
+    }
+  }
   {
     const int i = tid & 127, half = tid >> 7;
     float acc = 0.f;
@@ -861,7 +1130,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
     for (int k = 0; k < 32; ++k) acc = fmaf(dqs[half * 32 + k], wq[k], acc);
     if (half == 1) part[i] = acc;
     __syncthreads();
-    if (half == 0) a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
+    if (half == 0) {
+      if (fuse_dx) a.dxp[hg][(size_t)b * S * D + i] = (acc + part[i]) + Ls.part0[i];
+      else a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
+    }
   }
 }
 // shapes the replica form is built for (both directions): 8 heads — two four-head groups per sequence — of 16 (d = 128)
@@ -890,6 +1162,7 @@ int launch_attn_fwd_wf(const AttnArgs& a, uint32_t* amask, hipStream_t st) {
 int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unread, hipStream_t st) {
   PS_REQUIRE(attn_wf_fits(a) && amask, "attention bwd(wf): unsupported shape");
   PS_REQUIRE(!a.wq || (a.dxq_part && a.d == 128), "attention bwd(wf): folded dQ.Wq needs d == 128 and its output row buffer");
+  PS_REQUIRE(!a.kvb_stream || (a.wq && a.dxp[0] && a.dxp[1] && a.d == 128), "attention bwd(wf): fused d x needs the folded dQ.Wq form and both partial buffers");
   AttnArgs b = a;
   b.sig = nullptr; b.sigval = 0;
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)

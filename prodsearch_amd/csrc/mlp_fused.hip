@@ -27,6 +27,7 @@
 // Dropout masks of the three sites are the 16-bit column-shared Philox form (common.h): a lane's 8 consecutive features /
 // columns share one call.  Everything the backward needs (y1, ln1, a1, h1, y2, LN statistics) is still written once.
 #include "rowwise.h"
+#include "x3frag.h"
 #include <stdlib.h>
 #ifndef TRY
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
@@ -36,9 +37,6 @@ bool ps_fusion_enabled() {
   static const bool on = ps_env_int("PS_NO_FUSE", 0) == 0;
   return on;
 }
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define MD 128            // model width this kernel is specialised for
 #define MBM 32            // replica rows per workgroup
@@ -57,66 +55,6 @@ struct MlpTLds {
 };
 static_assert(sizeof(MlpTLds) <= 160 * 1024, "fused MLP: LDS budget");
 
-__device__ __forceinline__ int xa_off(int row, int k) { return row * MD + ((((k >> 3) ^ (row & 15)) << 3) | (k & 7)); }
-
-// exact three-way bf16 split of 8 fp32 values -> one 16-byte chunk per plane
-__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[3]) {
-  uint32_t w[3][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    uint16_t hb[2][3];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float x = v[2 * i + e];
-      const __bf16 bh = (__bf16)x;
-      float r = x - (float)bh;
-      const __bf16 bm = (__bf16)r;
-      r -= (float)bm;
-      const __bf16 bl = (__bf16)r;
-      hb[e][0] = __builtin_bit_cast(uint16_t, bh); hb[e][1] = __builtin_bit_cast(uint16_t, bm); hb[e][2] = __builtin_bit_cast(uint16_t, bl);
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) w[p][i] = (uint32_t)hb[0][p] | ((uint32_t)hb[1][p] << 16);
-  }
-#pragma unroll
-  for (int p = 0; p < 3; ++p) pl[p] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
-}
-__device__ __forceinline__ void put8(uint16_t (*planes)[MBM * MD], int row, int k0, const float (&v)[8]) {
-  uint4 pl[3];
-  split8(v, pl);
-  const int off = xa_off(row, k0);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(&planes[p][off]) = pl[p];
-}
-// six bf16 MFMAs = one exact-fp32-grade 32x32x16 product step (small terms first); a = weight planes, b = activation planes
-__device__ __forceinline__ void x3_mma(f32x16& acc, const uint4 (&a)[3], const uint4 (&b)[3]) {
-#define BF(x) __builtin_bit_cast(bf16x8, x)
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[0]), BF(b[2]), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[2]), BF(b[0]), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[1]), BF(b[1]), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[0]), BF(b[1]), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[1]), BF(b[0]), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(a[0]), BF(b[0]), acc, 0, 0, 0);
-#undef BF
-}
-// one product step's weight fragment: three planes of 64 lanes x 16 bytes, contiguous (WSplit, fragment order).
-// The main phase is one fully unrolled basic block; left alone, hipcc's scheduler sinks these refills next to the MFMAs that
-// consume them and waits vmcnt(0..1) in front of every product step — an effective prefetch distance of ONE step whatever PF
-// says (round-3 ISA listing).  Every step therefore ends in a sched_barrier: the refill stays where it is issued, PF steps
-// ahead of its use, and the waits become the counted vmcnt(3 (PF - 1)) they should be.
-__device__ __forceinline__ void load_frag(uint4 (&f)[3], const uint16_t* __restrict__ stream, int step, int lane) {
-  const uint4* q = reinterpret_cast<const uint4*>(stream) + (size_t)step * 192 + lane;
-  f[0] = q[0]; f[1] = q[64]; f[2] = q[128];
-}
-__device__ __forceinline__ void load_frag2(uint4 (&f)[3], const uint16_t* __restrict__ stream, int step, int lane) {   // DIAG
-  const uint4* q = reinterpret_cast<const uint4*>(stream) + (size_t)step * 192 + lane;
-  f[0] = q[0]; f[1] = q[64];
-}
-__device__ __forceinline__ void read_b(uint4 (&b)[3], const uint16_t (*planes)[MBM * MD], int l31, int k0) {
-  const int off = xa_off(l31, k0);
-#pragma unroll
-  for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const uint4*>(&planes[p][off]);
-}
 // sum over the 16 lanes of a DPP row, returned to every lane of the row (rotations: 4 adds)
 __device__ __forceinline__ float row16_sum(float v) {
 #define PS_ROR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
@@ -453,8 +391,8 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
 
 // the fused kernels take F = 256 * {1, 2, 4}; the planes live in the workspace (WSplit), re-split by the embed launch
 bool mlp_x3_enabled(int F) { return ps_fusion_enabled() && (F == 256 || F == 512 || F == 1024); }
-int64_t mlp_x3_floats(int d, int F) {      // forward + backward fragment streams: 2 x 3 planes x (d*d + 2*d*F) bf16
-  return ((int64_t)2 * 3 * ((int64_t)d * d + 2 * (int64_t)d * F) * 2 + 3) / 4 + 16;
+int64_t mlp_x3_floats(int d, int F) {      // forward + backward fragment streams: 2 x 3 planes x (d*d + 2*d*F) bf16,
+  return ((int64_t)2 * 3 * ((int64_t)d * d + 2 * (int64_t)d * F) * 2 + (int64_t)2 * 3 * 2 * d * d * 2 + 3) / 4 + 16;   // + the K / V streams (WSplit::fwd_kv, bwd_kv)
 }
 bool mlp_fwd_can_fold_score(int M, int F, int d) {
   static const bool fold_on = ps_env_int("PS_NO_FOLD_SCORE", 0) == 0;

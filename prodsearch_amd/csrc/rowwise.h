@@ -65,6 +65,14 @@ struct WSplit {
   const float* w[3]; int rows[3], cols[3];     // final_linear [d][d], w_1 [F][d], w_2 [d][F]  (nn.Linear [out][in])
   uint16_t* fwd_wo; uint16_t* fwd_ff; uint16_t* bwd_ff; uint16_t* bwd_wo;
   int on;
+  // round 5: the K / V projection weights of a ONE-layer encoder for the fused projection + attention forward
+  // (kvq_attn_fwd_kernel, attn_sq1.hip):  fwd_kv [8 nb][8 t]  rows 32(nb&3)+phi of linear_keys (nb < 4) / linear_values
+  // (nb >= 4), k = 16t + 8h + e — the fwd_wo layout; null wkv[0]: not produced
+  const float* wkv[2]; uint16_t* fwd_kv;
+  // ... and for the K / V input gradient fused into the replica attention backward (AttnArgs::kvb_stream):
+  //   bwd_kv [2 hg][4 nb][8 t]   rows 32nb+phi of [Wk^T | Wv^T] restricted to head group hg: k = 16t + 8h + e walks the group's
+  //   64 linear_keys rows (t < 4: row 64hg + 16t + 8h + e) then its 64 linear_values rows
+  uint16_t* bwd_kv;
 };
 struct EmbedArgs {
   int B, Q, L, S, d;
@@ -155,6 +163,12 @@ struct AttnArgs {
   // fanin_src[(b*fan + j)*128 + i] (d y1), each head group adding its own 64 columns to its partial row
   const float* fanin_src;
   uint32_t* sig; uint32_t sigval;   // backward launchers: a pending side-stream fork signalled by this launch (common.h, fork_signal)
+  // round 5 (replica backward, d = 128, dQ.Wq folded): the K / V input gradient  d x = dK.Wk + dV.Wv  rides in the same launch.
+  // Each head-group workgroup multiplies ITS 64 dK and 64 dV columns into the matching weight rows (WSplit::bwd_kv, fragment
+  // order, re-split by the forward's embed launch) and writes one PARTIAL row per valid position into dxp[group]; the row of
+  // the query position also takes the group's dQ.Wq + fan-in row (dxq_part is then not written).  The consumer (embed
+  // scatter) adds the two partials.  Replaces the dX GEMM launch of the step's dependent chain.
+  const uint16_t* kvb_stream; float* dxp[2];
 };
 inline void attn_finish(AttnArgs& a) {
   a.fS = make_fdiv(a.S); a.fd = make_fdiv(a.d); a.fdh = make_fdiv(a.dh); a.fd4 = make_fdiv(a.d / 4);
@@ -162,6 +176,20 @@ inline void attn_finish(AttnArgs& a) {
 }
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd(const AttnArgs& a, hipStream_t st);
+// K / V / Q projections of a one-layer encoder + the replica attention of its one consumed position as ONE launch, a workgroup
+// per sequence (round 5; attn_sq1.hip): `at` as for launch_attn_fwd_wf (kp / vp / qp are OUTPUTS here), x = the [n_in, S, 128]
+// encoder input the embed launch wrote, kv_stream = WSplit::fwd_kv of the same embed launch.
+struct KvqArgs {
+  AttnArgs at;
+  const float* x;
+  const uint16_t* kv_stream;
+  const float* bk; const float* bv; const float* wq; const float* bq;
+  float* kp; float* vp; float* qp;
+  uint32_t* amask;
+  unsigned long long* stamp;     // diagnostic build: 8 s_memrealtime stamps per workgroup (tools/kvq_wg_times.py)
+};
+bool kvq_attn_fits(const AttnArgs& a);     // d = 128, 8 heads, <= 32 positions, 4..24 replicas, query position 0
+int launch_kvq_attn_fwd(const KvqArgs& a, hipStream_t st);
 // last-layer form (Sq == 1): one workgroup per sequence, all heads, replicas share K/V in LDS (attn_sq1.hip)
 int launch_attn_fwd_sq1(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd_sq1(const AttnArgs& a, hipStream_t st);
@@ -181,6 +209,7 @@ struct EmbedBwdArgs {
   int tem;
   const int64_t* qw; const int64_t* ui;
   const float* dx;               // [B,S,d] (tem)
+  const float* dx2;              // optional: a second partial of the same shape, added to dx wherever dx is read (AttnArgs::dxp)
   const float* dqmean_d;         // [B,d] grad wrt the post-dropout query mean
   DropSpec drop_fs;
   float* g_hist_tab; float* g_word_emb;
@@ -192,6 +221,7 @@ struct EmbedBwdArgs {
   // row's query words; the f_W workgroups above recompute dqpre on the fly (fw_dy is then unused) and also add up
   // g_fs_b.  Replaces a tanh-backward launch and a [B,d]x[d,d] GEMM launch on the tail of the backward.
   const float* fsb_dqe; int fsb_lddqe; const float* fsb_qe; const float* fsb_w; float* g_fs_b;
+  const float* fsb_dqe2; float fsb_k2;   // filled by the launcher: the second partial of d query_emb (dx2) and its weight (1, or 0 with fsb_dqe2 = fsb_dqe)
   ColFoldList fold;              // parked column sums to add up (n = 0: none)
   float* det_dm;                 // deterministic mode + fused FS backward: [B,d] buffer for the rows' d mean (scattered by the sole-owner pass)
   uint32_t* sig; uint32_t sigval; // a pending side-stream fork signalled by this launch (common.h, fork_signal)

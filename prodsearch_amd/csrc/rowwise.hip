@@ -147,17 +147,25 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     const int d = W.cols[0], F = W.rows[1];
     const int n_wo = d * d / 8, n_ff = 2 * d * F / 8;
     int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;
-    if (q >= 2 * (n_wo + n_ff)) return;
+    const int n_kv = W.wkv[0] ? 2 * d * d / 8 : 0;
+    if (q >= 2 * (n_wo + n_ff) + 2 * n_kv) return;
     uint16_t* dst;
-    int which;                                   // 0 fwd_wo, 1 fwd_ff, 2 bwd_ff, 3 bwd_wo
+    int which;                                   // 0 fwd_wo, 1 fwd_ff, 2 bwd_ff, 3 bwd_wo, 4 fwd_kv
     if (q < n_wo) { which = 0; dst = W.fwd_wo; }
     else if (q < n_wo + n_ff) { which = 1; q -= n_wo; dst = W.fwd_ff; }
     else if (q < n_wo + 2 * n_ff) { which = 2; q -= n_wo + n_ff; dst = W.bwd_ff; }
-    else { which = 3; q -= n_wo + 2 * n_ff; dst = W.bwd_wo; }
+    else if (q < 2 * (n_wo + n_ff)) { which = 3; q -= n_wo + 2 * n_ff; dst = W.bwd_wo; }
+    else if (q < 2 * (n_wo + n_ff) + n_kv) { which = 4; q -= 2 * (n_wo + n_ff); dst = W.fwd_kv; }
+    else { which = 5; q -= 2 * (n_wo + n_ff) + n_kv; dst = W.bwd_kv; }
     const int step = q >> 6, ln = q & 63, l31 = ln & 31, hh = ln >> 5;
     const int phi = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
     const float* src; int stride;                // element e of the chunk = src[e * stride]
     if (which == 0) { const int nb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(32 * nb + phi) * d + 16 * t + 8 * hh; stride = 1; }
+    else if (which == 4) { const int nb = step >> 3, t = step & 7; src = W.wkv[nb >> 2] + (size_t)(32 * (nb & 3) + phi) * d + 16 * t + 8 * hh; stride = 1; }
+    else if (which == 5) {                      // rows = input features (32 nb + phi), k = the head group's 64 K rows then its 64 V rows
+      const int hg = step >> 5, nb = (step >> 3) & 3, t = step & 7;
+      src = W.wkv[t >> 2] + (size_t)(64 * hg + 16 * (t & 3) + 8 * hh) * d + 32 * nb + phi; stride = d;
+    }
     else if (which == 3) { const int kb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(16 * t + 8 * hh) * d + 32 * kb + phi; stride = d; }
     else {
       const int fb = step >> 4, r = step & 15;
@@ -365,7 +373,9 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
     PS_REQUIRE(W.rows[0] == 128 && W.cols[0] == 128 && W.cols[1] == 128 && W.rows[2] == 128 && W.rows[1] == W.cols[2] &&
                W.rows[1] % 256 == 0, "embed: weight split: shapes [%d,%d] [%d,%d] [%d,%d]", W.rows[0], W.cols[0], W.rows[1],
                W.cols[1], W.rows[2], W.cols[2]);
-    b.split_wgs = ps_cdiv(2 * (W.cols[0] * W.cols[0] + 2 * W.cols[0] * W.rows[1]) / 8, 256);   // one thread per 16-byte chunk
+    PS_REQUIRE(!W.wkv[0] || (W.wkv[1] && W.fwd_kv), "embed: weight split: K / V weights without their stream");
+    PS_REQUIRE(!W.wkv[0] || W.bwd_kv, "embed: weight split: K / V weights without their backward stream");
+    b.split_wgs = ps_cdiv(2 * (W.cols[0] * W.cols[0] + 2 * W.cols[0] * W.rows[1]) / 8 + (W.wkv[0] ? 4 * W.cols[0] * W.cols[0] / 8 : 0), 256);   // one thread per 16-byte chunk
   }
   PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
   b.zero_wgs = a.zero_i32 && a.zero_n > 0 ? ps_cdiv(a.zero_n, 1024) : 0;
@@ -1654,6 +1664,14 @@ __device__ __forceinline__ void row_fetch_add(float* dst, const float* src, int 
 #pragma unroll
   for (int k = 0; k < EPL; ++k) atomicAdd(&dst[c + 32 * k], scale == 1.f ? v[k] : v[k] * scale);
 }
+template <int EPL>
+__device__ __forceinline__ void row_fetch_add2(float* dst, const float* src, const float* src2, int c) {   // two partial rows
+  float v[EPL], u[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) { v[k] = src[c + 32 * k]; u[k] = src2[c + 32 * k]; }
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) atomicAdd(&dst[c + 32 * k], v[k] + u[k]);
+}
 // Backward of the history gather (item_transformer.py:466-469) and of the query mean
 // (text_encoder.py:6-16 + FS dropout): dense grads with padding_idx rows untouched.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a, int ntask, int nq, int nfw, int nfold) {
@@ -1678,7 +1696,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     }
     for (int e = tid; e < d; e += 256) {
       const float y = a.fsb_qe[(size_t)b * d + e];
-      dq_s[e] = a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] * (1.f - y * y);
+      dq_s[e] = (a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] + a.fsb_k2 * a.fsb_dqe2[(size_t)b * a.fsb_lddqe + e]) * (1.f - y * y);
     }
     int cnt = 0;
     for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
@@ -1735,7 +1753,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
 #pragma unroll 16
       for (int b = seg; b < a.B; b += 8) {
         const float y = a.fsb_qe[(size_t)b * d + o];
-        const float dy = a.fsb_dqe[(size_t)b * a.fsb_lddqe + o] * (1.f - y * y);
+        const float dy = (a.fsb_dqe[(size_t)b * a.fsb_lddqe + o] + a.fsb_k2 * a.fsb_dqe2[(size_t)b * a.fsb_lddqe + o]) * (1.f - y * y);
         acc = fmaf(dy, a.fw_x[(size_t)b * d + i], acc);
         bacc += dy;
       }
@@ -1799,6 +1817,17 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     if (idx == a.P || idx < 0 || idx > a.P) return;
     const float* src = a.dx + ((size_t)b * a.S + 1 + l) * d;
     float* dst = a.g_hist_tab + (size_t)idx * d;
+    if (a.dx2) {                                  // (kernel-uniform) the row arrives as two partials: AttnArgs::dxp
+      const float* src2 = a.dx2 + ((size_t)b * a.S + 1 + l) * d;
+      switch (epl) {
+        case 1: row_fetch_add2<1>(dst, src, src2, c); break;
+        case 2: row_fetch_add2<2>(dst, src, src2, c); break;
+        case 4: row_fetch_add2<4>(dst, src, src2, c); break;
+        case 8: row_fetch_add2<8>(dst, src, src2, c); break;
+        default: for (int k = 0; k < epl; ++k) atomicAdd(&dst[c + 32 * k], src[c + 32 * k] + src2[c + 32 * k]);
+      }
+      return;
+    }
     // fetch the whole row, then add it: in a `load, add` loop every load waits for the previous group's ATOMIC to be
     // acknowledged (one in-order counter tracks both) — epl dependent round trips per row instead of one
     switch (epl) {
@@ -1942,6 +1971,11 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   EmbedBwdArgs a2 = a;
   if (!det) a2.det_dm = nullptr;
   a2.sig = nullptr; a2.sigval = 0;
+  PS_REQUIRE(!a.dx2 || (!det && (!fsb || a.fsb_dqe == a.dx)), "embed scatter: a second dx partial needs the default path with d query_emb = row 0 of dx");
+  if (fsb) {       // d query_emb as two partials (AttnArgs::dxp): always two reads, the second weighted 0 when there is one buffer
+    a2.fsb_dqe2 = a.dx2 ? a.dx2 : a.fsb_dqe;
+    a2.fsb_k2 = a.dx2 ? 1.f : 0.f;
+  }
   if (nq + nsb + nfw + nfold > 0) {
     side_take_signal(st, &a2.sig, &a2.sigval);        // (every check is behind us: the launch happens)
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(nq + nsb + nfw + nfold), dim3(256), lds, st, a2, ntask, nq, nfw, nfold);

@@ -239,6 +239,11 @@ WSplit make_wsplit(const PsTemDesc& D, const PsTemTensors& P, float* ws, const W
   const size_t n_wo = (size_t)3 * d * d, n_ff = (size_t)3 * 2 * d * F;
   s.fwd_wo = base; s.fwd_ff = base + n_wo; s.bwd_ff = base + n_wo + n_ff; s.bwd_wo = base + n_wo + 2 * n_ff;
   s.on = 1;
+  if (NL == 1 && L.wk && L.wv) {      // one layer: its K / V projections can take the fused projection + attention forward
+    s.wkv[0] = L.wk; s.wkv[1] = L.wv;
+    s.fwd_kv = base + 2 * (n_wo + n_ff);
+    s.bwd_kv = s.fwd_kv + (size_t)3 * 2 * d * d;
+  }
   return s;
 }
 
@@ -741,6 +746,7 @@ bool enc_rowlist_taken(const PsTemDesc& D, const Ws& w, bool rows_listed) {
   return attn_sq1_fits(probe);
 }
 
+static bool g_dx_two_partials = false;      // set by enc_layers_backward for the embed backward that follows it (single-thread contract)
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
                        const Ws& w, hipStream_t st, bool rows_listed, const ScoreArgs* fold_sc) {
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
@@ -759,7 +765,27 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       TRY(launch_ln_fwd(a, st));
     }
     const float* xn = ws + l.xn;
-    {   // K, V, Q projections (neural.py:192-197), Q pre-divided by sqrt(dh) (:206)
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
+    a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = ui; a.valid = valid;
+    a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
+    a.drop = make_drop(D, PS_SITE_ATTN(i));
+    a.qscale = qscale;
+    attn_finish(a);
+    // One layer, replicas, d = 128: projections + attention of the one consumed position in ONE launch, a workgroup per
+    // sequence (kvq_attn_fwd_kernel): the K / V weight fragments were re-split by the embed launch in front (WSplit::fwd_kv)
+    const WSplit kvs = (i == 0 && NL == 1) ? make_wsplit(D, P, ws, w) : WSplit{};
+    const bool kvq_fused = i == 0 && NL == 1 && kvs.on && kvs.fwd_kv && ps_fusion_enabled() && enc_rowlist_taken(D, w, rows_listed) &&
+                           attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a) && kvq_attn_fits(a) && l.amask;
+    if (kvq_fused) {
+      KvqArgs q;
+      memset(&q, 0, sizeof(q));
+      q.at = a; q.x = xn; q.kv_stream = kvs.fwd_kv;
+      q.bk = Lp.bk; q.bv = Lp.bv; q.wq = Lp.wq; q.bq = Lp.bq;
+      q.kp = ws + l.kp; q.vp = ws + l.vp; q.qp = ws + l.qp; q.amask = reinterpret_cast<uint32_t*>(ws + l.amask);
+      TRY(launch_kvq_attn_fwd(q, st));
+    } else {   // K, V, Q projections (neural.py:192-197), Q pre-divided by sqrt(dh) (:206)
       GemmGroup g;
       memset(&g, 0, sizeof(g));
       g.n = 3;
@@ -777,14 +803,8 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
       }
       TRY(ps_launch_gemm(g, st));
     }
-    AttnArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = S; a.Sq = l.Sq; a.d = d; a.dh = d / D.H; a.qpos = w.qpos;
-    a.seq_div = l.n_in / B; a.L = D.L; a.P = D.product_size; a.ui = ui; a.valid = valid;
-    a.kp = ws + l.kp; a.vp = ws + l.vp; a.qp = ws + l.qp; a.attn = ws + l.attn; a.ctx = ws + l.ctx;
-    a.drop = make_drop(D, PS_SITE_ATTN(i));
-    attn_finish(a);
-    if (attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a)) TRY(launch_attn_fwd_wf(a, reinterpret_cast<uint32_t*>(ws + l.amask), st));
+    if (kvq_fused) { }
+    else if (attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a)) TRY(launch_attn_fwd_wf(a, reinterpret_cast<uint32_t*>(ws + l.amask), st));
     else if (attn_sq1_fits(a) && attn_w1_fits(a)) TRY(launch_attn_fwd_w1(a, st));
     else TRY(attn_sq1_fits(a) ? launch_attn_fwd_sq1(a, st) : launch_attn_fwd(a, st));
     const bool fuse = ps_fusion_enabled() && i == NL - 1 && l.Sq == 1 && mlp_fused_serves(d, D.F) && w.wsplit &&
@@ -1266,8 +1286,16 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
                             (w1 ? (!wf || d == 128) && (size_t)(wf ? 2 : 1) * l.n_in <= (size_t)M2
                                 : d == 128 && attn_sq1_split(a) == 2 && (size_t)2 * l.n_in <= (size_t)M2);
       if (q_folded) { a.wq = Lp.wq; a.dxq_part = ws + w.dln1; a.fanin_src = ws + w.dy1; }
-      // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
+      // ... and, one-layer encoder with replicas: so does the K / V input gradient itself (AttnArgs::kvb_stream) — no dX GEMM launch
+      // on the dependent chain; the embed scatter adds the two head groups' partial rows (EmbedBwdArgs::dx2)
       static const bool rows_on0 = ps_env_int("PS_NO_ROWLIST", 0) == 0;
+      static const bool dx_fused_on = ps_env_int("PS_KVDX_FUSED", 1) != 0;
+      const WSplit kvs = (i == 0 && NL == 1) ? make_wsplit(D, P, ws, w) : WSplit{};
+      const bool dx_fused = dx_fused_on && wf && q_folded && i == 0 && NL == 1 && d == 128 && kvs.on && kvs.bwd_kv && !ps_deterministic() &&
+                            rows_on0 && rows_listed && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B && attn_bwd_wf_two_partials(a);
+      if (dx_fused) { a.kvb_stream = kvs.bwd_kv; a.dxp[0] = ws + w.dx; a.dxp[1] = ws + w.dxn; }
+      g_dx_two_partials = dx_fused;
+      // valid rows only (below): the dK / dV rows of padded positions are then never read, and never written
       const bool listed0 = rows_on0 && rows_listed && sq1 && i == 0 && NL == 1 && !qall && w.qpos == 0 && w.vrows != 0 && l.n_in == B;
       // round 4: where dQ.Wq is NOT folded (d != 128: the C5 shard) the replicas' fan-in is summed by a launch of its own
       // (launch_fanin_sum, below) so that the dX product can still run over the row list: 133 -> ~50 us at C5
@@ -1336,7 +1364,7 @@ int enc_layers_backward(const PsTemDesc& D, const PsTemTensors& P, const PsTemTe
       // (the dX product over the row list only when its fan-in residual is already folded: walking 21 replica rows per
       // query row in a third of the workgroups made it slower than the dense form — 144 vs 106 us at C5)
       if (listed && (q_folded || l.fan == 1 || (presum && q_via_res))) { x.ridx = vr; x.rcount = vc; }
-      TRY(run1(x, st));
+      if (!dx_fused) TRY(run1(x, st));
       if (wg3_main) {
         static const bool wg3_last = ps_diag_int("PS_WG3_LAST", 1) != 0;
         if (wg3_last && g_wg3_defer_ok && i == 0) { for (int q = 0; q < 3; ++q) g_wg3_last[q] = wg3[q]; g_wg3_last_n = 3; }
@@ -1430,6 +1458,8 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
   memset(&e, 0, sizeof(e));
   e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size; e.tem = tem;
   e.qw = batch->query_word_idxs; e.ui = batch->u_item_idxs; e.dx = ws + w.dx;
+  if (tem && g_dx_two_partials) e.dx2 = ws + w.dxn;      // the attention backward left d x as two partial rows per position
+  g_dx_two_partials = false;
   e.drop_fs = make_drop(D, PS_SITE_FS);
   e.g_hist_tab = ghist; e.g_word_emb = G.word_emb;
   if (D.query_encoder == PS_QENC_FS) {
