@@ -754,6 +754,10 @@ __global__ __launch_bounds__(512, 2) void kvq_attn_fwd_kernel(const KvqArgs g) {
   KvqLds& L = *reinterpret_cast<KvqLds*>(kvq_lds_raw);
   const AttnArgs& a = g.at;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
+  if ((int)blockIdx.x >= a.n_in) {     // the backward-only weight streams are re-split here, under the sequences' workgroups (KvqArgs::split)
+    wsplit_chunk(g.split, 1, ((int)blockIdx.x - a.n_in) * 512 + tid);
+    return;
+  }
   const int b = blockIdx.x, S = a.S, HF = a.H;
 #if PS_DIAG_ON
   unsigned long long kvq_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -909,6 +913,7 @@ int launch_kvq_attn_fwd(const KvqArgs& g, hipStream_t st) {
   PS_REQUIRE(g.x && g.kv_stream && g.bk && g.bv && g.wq && g.bq && g.kp && g.vp && g.qp && g.amask && g.at.attn && g.at.ctx && g.at.ui,
              "fused K/V/Q + attention: null pointer");
   static bool attr24 = false, attr32 = false;
+  const int riders = g.split.on ? ps_cdiv(wsplit_chunks(g.split, 1), 512) : 0;
 #if PS_DIAG_ON
   KvqArgs gd = g;
   gd.stamp = ps_diag_int("PS_KVQ_STAMP", 0) ? ps_debug_stamp_ptr() : nullptr;
@@ -918,10 +923,10 @@ int launch_kvq_attn_fwd(const KvqArgs& g, hipStream_t st) {
 #endif
   if (g.at.S <= 24) {
     if (!attr24) { PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kvq_attn_fwd_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(KvqLds))); attr24 = true; }
-    hipLaunchKernelGGL((kvq_attn_fwd_kernel<6>), dim3(g.at.n_in), dim3(512), sizeof(KvqLds), st, gl);
+    hipLaunchKernelGGL((kvq_attn_fwd_kernel<6>), dim3(g.at.n_in + riders), dim3(512), sizeof(KvqLds), st, gl);
   } else {
     if (!attr32) { PS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kvq_attn_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(KvqLds))); attr32 = true; }
-    hipLaunchKernelGGL((kvq_attn_fwd_kernel<8>), dim3(g.at.n_in), dim3(512), sizeof(KvqLds), st, gl);
+    hipLaunchKernelGGL((kvq_attn_fwd_kernel<8>), dim3(g.at.n_in + riders), dim3(512), sizeof(KvqLds), st, gl);
   }
   PS_LAUNCH_CHECK();
   return PS_OK;

@@ -74,6 +74,75 @@ struct WSplit {
   //   64 linear_keys rows (t < 4: row 64hg + 16t + 8h + e) then its 64 linear_values rows
   uint16_t* bwd_kv;
 };
+// One thread = one 16-byte fragment chunk (8 reduction elements of one weight row) of one product step, all three planes.
+// The streams form two SETS: 0 = what the forward's later launches read (fwd_wo, fwd_ff, fwd_kv), 1 = what only the backward
+// reads (bwd_ff, bwd_wo, bwd_kv).  Set 0 rides in the embed launch; set 1 rides in the launch behind it when that is the fused
+// projection + attention kernel (KvqArgs::split), else in the embed launch too.
+__host__ __device__ inline int wsplit_chunks(const WSplit& W, int /*set: both sets have the same size*/) {
+  const int d = W.cols[0], F = W.rows[1];
+  return (d * d + 2 * d * F) / 8 + (W.wkv[0] ? 2 * d * d / 8 : 0);
+}
+#if defined(__HIPCC__)
+__device__ inline void wsplit_chunk(const WSplit& W, int set, int q) {
+  const int d = W.cols[0], F = W.rows[1];
+  const int n_wo = d * d / 8, n_ff = 2 * d * F / 8, n_kv = W.wkv[0] ? 2 * d * d / 8 : 0;
+  if (q >= n_wo + n_ff + n_kv) return;
+  uint16_t* dst;
+  int which;                                   // 0 fwd_wo, 1 fwd_ff, 2 bwd_ff, 3 bwd_wo, 4 fwd_kv, 5 bwd_kv
+  if (q < n_wo) { which = set ? 3 : 0; dst = set ? W.bwd_wo : W.fwd_wo; }
+  else if (q < n_wo + n_ff) { which = set ? 2 : 1; q -= n_wo; dst = set ? W.bwd_ff : W.fwd_ff; }
+  else { which = set ? 5 : 4; q -= n_wo + n_ff; dst = set ? W.bwd_kv : W.fwd_kv; }
+  const int step = q >> 6, ln = q & 63, l31 = ln & 31, hh = ln >> 5;
+  const int phi = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  const float* src; int stride;                // element e of the chunk = src[e * stride]
+  if (which == 0) { const int nb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(32 * nb + phi) * d + 16 * t + 8 * hh; stride = 1; }
+  else if (which == 4) { const int nb = step >> 3, t = step & 7; src = W.wkv[nb >> 2] + (size_t)(32 * (nb & 3) + phi) * d + 16 * t + 8 * hh; stride = 1; }
+  else if (which == 5) {                      // rows = input features (32 nb + phi), k = the head group's 64 K rows then its 64 V rows
+    const int hg = step >> 5, nb = (step >> 3) & 3, t = step & 7;
+    src = W.wkv[t >> 2] + (size_t)(64 * hg + 16 * (t & 3) + 8 * hh) * d + 32 * nb + phi; stride = d;
+  }
+  else if (which == 3) { const int kb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(16 * t + 8 * hh) * d + 32 * kb + phi; stride = d; }
+  else {
+    const int fb = step >> 4, r = step & 15;
+    if (r < 8) {
+      if (which == 1) { src = W.w[1] + (size_t)(32 * fb + phi) * d + 16 * r + 8 * hh; stride = 1; }          // W1 rows
+      else { src = W.w[2] + (size_t)(16 * r + 8 * hh) * F + 32 * fb + phi; stride = F; }                    // W2^T rows
+    } else {
+      const int t = (r - 8) >> 2, nb = (r - 8) & 3, kf = 32 * fb + 16 * hh + 8 * t;
+      if (which == 1) { src = W.w[2] + (size_t)(32 * nb + phi) * F + kf; stride = 1; }                      // W2 rows, k = features
+      else { src = W.w[1] + (size_t)kf * d + 32 * nb + phi; stride = d; }                                  // W1^T rows, k = features
+    }
+  }
+  float x[8];
+  if (stride == 1) {
+    const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = src[(size_t)e * stride];
+  }
+  uint32_t wd[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint16_t hb[2][3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float xv = x[2 * i + e];
+      const __bf16 bh = (__bf16)xv;
+      float r = xv - (float)bh;
+      const __bf16 bm = (__bf16)r;
+      r -= (float)bm;
+      const __bf16 bl = (__bf16)r;
+      hb[e][0] = __builtin_bit_cast(uint16_t, bh); hb[e][1] = __builtin_bit_cast(uint16_t, bm); hb[e][2] = __builtin_bit_cast(uint16_t, bl);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) wd[pl][i] = (uint32_t)hb[0][pl] | ((uint32_t)hb[1][pl] << 16);
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+    *reinterpret_cast<uint4*>(dst + ((size_t)(step * 3 + pl) * 64 + ln) * 8) = make_uint4(wd[pl][0], wd[pl][1], wd[pl][2], wd[pl][3]);
+}
+#endif
 struct EmbedArgs {
   int B, Q, L, S, d;
   int64_t P, V;
@@ -102,6 +171,7 @@ struct EmbedArgs {
   // filled by the launcher (grid = B gather + samp_wgs + list_wgs + word_wgs workgroups)
   int fold_words; ScoreArgs sc; int word_wgs, list_wgs;
   WSplit split; int split_wgs;   // optional: re-split the fused kernels' weights (WSplit); split_wgs filled by the launcher
+  int split_fwd_only;            // set 1 of the streams (backward-only) is re-split by the launch behind this one (KvqArgs::split)
   uint32_t* clear_word;          // optional: FOUR words (a 64-bit ticket of a later kernel, a list counter, one spare) set to 0 by the launch
   int32_t* zero_i32; int zero_n, zero_wgs;   // optional: int32 words to clear (the review transformer's word counters); zero_wgs filled by the launcher
 };
@@ -187,6 +257,7 @@ struct KvqArgs {
   float* kp; float* vp; float* qp;
   uint32_t* amask;
   unsigned long long* stamp;     // diagnostic build: 8 s_memrealtime stamps per workgroup (tools/kvq_wg_times.py)
+  WSplit split;                  // optional (on): the backward-only streams are re-split by extra workgroups of this launch
 };
 bool kvq_attn_fits(const AttnArgs& a);     // d = 128, 8 heads, <= 32 positions, 4..24 replicas, query position 0
 int launch_kvq_attn_fwd(const KvqArgs& a, hipStream_t st);

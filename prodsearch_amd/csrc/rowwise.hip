@@ -141,71 +141,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     else for (int j = i; j < a.zero_n; ++j) a.zero_i32[j] = 0;
     return;
   }
-  if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs) {   // weight re-split (EmbedArgs::split)
-    // one thread = one 16-byte fragment chunk (8 reduction elements of one weight row) of one product step, all three planes
-    const WSplit& W = a.split;
-    const int d = W.cols[0], F = W.rows[1];
-    const int n_wo = d * d / 8, n_ff = 2 * d * F / 8;
-    int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;
-    const int n_kv = W.wkv[0] ? 2 * d * d / 8 : 0;
-    if (q >= 2 * (n_wo + n_ff) + 2 * n_kv) return;
-    uint16_t* dst;
-    int which;                                   // 0 fwd_wo, 1 fwd_ff, 2 bwd_ff, 3 bwd_wo, 4 fwd_kv
-    if (q < n_wo) { which = 0; dst = W.fwd_wo; }
-    else if (q < n_wo + n_ff) { which = 1; q -= n_wo; dst = W.fwd_ff; }
-    else if (q < n_wo + 2 * n_ff) { which = 2; q -= n_wo + n_ff; dst = W.bwd_ff; }
-    else if (q < 2 * (n_wo + n_ff)) { which = 3; q -= n_wo + 2 * n_ff; dst = W.bwd_wo; }
-    else if (q < 2 * (n_wo + n_ff) + n_kv) { which = 4; q -= 2 * (n_wo + n_ff); dst = W.fwd_kv; }
-    else { which = 5; q -= 2 * (n_wo + n_ff) + n_kv; dst = W.bwd_kv; }
-    const int step = q >> 6, ln = q & 63, l31 = ln & 31, hh = ln >> 5;
-    const int phi = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
-    const float* src; int stride;                // element e of the chunk = src[e * stride]
-    if (which == 0) { const int nb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(32 * nb + phi) * d + 16 * t + 8 * hh; stride = 1; }
-    else if (which == 4) { const int nb = step >> 3, t = step & 7; src = W.wkv[nb >> 2] + (size_t)(32 * (nb & 3) + phi) * d + 16 * t + 8 * hh; stride = 1; }
-    else if (which == 5) {                      // rows = input features (32 nb + phi), k = the head group's 64 K rows then its 64 V rows
-      const int hg = step >> 5, nb = (step >> 3) & 3, t = step & 7;
-      src = W.wkv[t >> 2] + (size_t)(64 * hg + 16 * (t & 3) + 8 * hh) * d + 32 * nb + phi; stride = d;
-    }
-    else if (which == 3) { const int kb = step >> 3, t = step & 7; src = W.w[0] + (size_t)(16 * t + 8 * hh) * d + 32 * kb + phi; stride = d; }
-    else {
-      const int fb = step >> 4, r = step & 15;
-      if (r < 8) {
-        if (which == 1) { src = W.w[1] + (size_t)(32 * fb + phi) * d + 16 * r + 8 * hh; stride = 1; }          // W1 rows
-        else { src = W.w[2] + (size_t)(16 * r + 8 * hh) * F + 32 * fb + phi; stride = F; }                    // W2^T rows
-      } else {
-        const int t = (r - 8) >> 2, nb = (r - 8) & 3, kf = 32 * fb + 16 * hh + 8 * t;
-        if (which == 1) { src = W.w[2] + (size_t)(32 * nb + phi) * F + kf; stride = 1; }                      // W2 rows, k = features
-        else { src = W.w[1] + (size_t)kf * d + 32 * nb + phi; stride = d; }                                  // W1^T rows, k = features
-      }
-    }
-    float x[8];
-    if (stride == 1) {
-      const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = src[(size_t)e * stride];
-    }
-    uint32_t wd[3][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint16_t hb[2][3];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float xv = x[2 * i + e];
-        const __bf16 bh = (__bf16)xv;
-        float r = xv - (float)bh;
-        const __bf16 bm = (__bf16)r;
-        r -= (float)bm;
-        const __bf16 bl = (__bf16)r;
-        hb[e][0] = __builtin_bit_cast(uint16_t, bh); hb[e][1] = __builtin_bit_cast(uint16_t, bm); hb[e][2] = __builtin_bit_cast(uint16_t, bl);
-      }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wd[pl][i] = (uint32_t)hb[0][pl] | ((uint32_t)hb[1][pl] << 16);
-    }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<uint4*>(dst + ((size_t)(step * 3 + pl) * 64 + ln) * 8) = make_uint4(wd[pl][0], wd[pl][1], wd[pl][2], wd[pl][3]);
+  if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs + a.word_wgs) {   // weight re-split (EmbedArgs::split; rowwise.h, wsplit_chunk)
+    const int q = ((int)blockIdx.x - a.B - a.samp_wgs - a.list_wgs - a.word_wgs) * 256 + (int)threadIdx.x;
+    const int n0 = wsplit_chunks(a.split, 0);
+    if (q < n0) wsplit_chunk(a.split, 0, q);
+    else if (!a.split_fwd_only) wsplit_chunk(a.split, 1, q - n0);
     return;
   }
   if ((int)blockIdx.x >= a.B + a.samp_wgs + a.list_wgs) {       // word tasks of the loss (EmbedArgs::fold_words)
@@ -375,7 +315,7 @@ int launch_embed_fwd(const EmbedArgs& a, hipStream_t st) {
                W.cols[1], W.rows[2], W.cols[2]);
     PS_REQUIRE(!W.wkv[0] || (W.wkv[1] && W.fwd_kv), "embed: weight split: K / V weights without their stream");
     PS_REQUIRE(!W.wkv[0] || W.bwd_kv, "embed: weight split: K / V weights without their backward stream");
-    b.split_wgs = ps_cdiv(2 * (W.cols[0] * W.cols[0] + 2 * W.cols[0] * W.rows[1]) / 8 + (W.wkv[0] ? 4 * W.cols[0] * W.cols[0] / 8 : 0), 256);   // one thread per 16-byte chunk
+    b.split_wgs = ps_cdiv(wsplit_chunks(W, 0) + (a.split_fwd_only ? 0 : wsplit_chunks(W, 1)), 256);   // one thread per 16-byte chunk
   }
   PS_REQUIRE(!a.fold_words || (a.sc.word_blk && a.sc.ticket && a.sc.d <= 512), "embed: folded word tasks need their buffers");
   b.zero_wgs = a.zero_i32 && a.zero_n > 0 ? ps_cdiv(a.zero_n, 1024) : 0;

@@ -747,6 +747,20 @@ bool enc_rowlist_taken(const PsTemDesc& D, const Ws& w, bool rows_listed) {
 }
 
 static bool g_dx_two_partials = false;      // set by enc_layers_backward for the embed backward that follows it (single-thread contract)
+static bool g_split_bwd_deferred = false;   // encode_forward -> enc_layers_forward: the fused projection + attention launch re-splits the backward's streams
+// the predicate of enc_layers_forward's fused projection + attention launch, from what encode_forward knows before the embed launch
+static bool kvq_fwd_will_fuse(const PsTemDesc& D, const PsTemTensors& P, float* ws, const Ws& w, bool rows_listed) {
+  if (D.model != PS_MODEL_TEM || D.n_layers != 1 || !ps_fusion_enabled()) return false;
+  const LayerWs& l = w.layer[0];
+  const WSplit kvs = make_wsplit(D, P, ws, w);
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n_in = l.n_in; a.fan = l.fan; a.H = D.H; a.S = w.S; a.Sq = l.Sq; a.d = D.d; a.dh = D.d / (D.H > 0 ? D.H : 1); a.qpos = w.qpos;
+  a.seq_div = l.n_in / D.B; a.L = D.L; a.P = D.product_size;
+  attn_finish(a);
+  return kvs.on && kvs.fwd_kv && enc_rowlist_taken(D, w, rows_listed) && attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a) &&
+         kvq_attn_fits(a) && l.amask;
+}
 int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t* ui, const float* valid, float* ws,
                        const Ws& w, hipStream_t st, bool rows_listed, const ScoreArgs* fold_sc) {
   const int B = D.B, d = D.d, S = w.S, NL = D.n_layers;
@@ -778,9 +792,12 @@ int enc_layers_forward(const PsTemDesc& D, const PsTemTensors& P, const int64_t*
     const WSplit kvs = (i == 0 && NL == 1) ? make_wsplit(D, P, ws, w) : WSplit{};
     const bool kvq_fused = i == 0 && NL == 1 && kvs.on && kvs.fwd_kv && ps_fusion_enabled() && enc_rowlist_taken(D, w, rows_listed) &&
                            attn_sq1_fits(a) && a.fan > 1 && attn_wf_fits(a) && kvq_attn_fits(a) && l.amask;
+    PS_REQUIRE(kvq_fused || !g_split_bwd_deferred, "forward: the embed launch left the backward's weight streams to a launch that is not coming");
     if (kvq_fused) {
       KvqArgs q;
       memset(&q, 0, sizeof(q));
+      if (g_split_bwd_deferred) q.split = kvs;       // the backward-only streams, left out of the embed launch (encode_forward)
+      g_split_bwd_deferred = false;
       q.at = a; q.x = xn; q.kv_stream = kvs.fwd_kv;
       q.bk = Lp.bk; q.bv = Lp.bv; q.wq = Lp.wq; q.bq = Lp.bq;
       q.kp = ws + l.kp; q.vp = ws + l.vp; q.qp = ws + l.qp; q.amask = reinterpret_cast<uint32_t*>(ws + l.amask);
@@ -900,6 +917,8 @@ static int encode_forward(const PsTemDesc& D, const PsTemTensors& P, const PsTem
   if (fs_fused) { e.fs_w = P.fs_w; e.fs_b = P.fs_b; }
   if (fold_sc) { e.fold_words = 1; e.sc = *fold_sc; }
   e.split = make_wsplit(D, P, ws, w);
+  g_split_bwd_deferred = e.split.on && D.training && kvq_fwd_will_fuse(D, P, ws, w, rows_list_ok(D));
+  e.split_fwd_only = g_split_bwd_deferred ? 1 : 0;
   TRY(launch_embed_fwd(e, st));
   if (e.fs && !fs_fused) {   // FSEncoder: tanh(f_W . mean + b)  (text_encoder.py:39); also writes row 0 of x (+pe[0])
     GemmProblem p = gp(ws + w.qmean, d, 0, P.fs_w, d, 0, ws + w.query_emb, d, B, d, d);
