@@ -7,6 +7,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python3 bench.py --ste
 ( echo "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-extras   (per-launch average, KB as reported; gfx950: x2 for 16-B/lane streaming reads)"
   python tools/pmc_summary.py $O/f
   echo; echo "rocprofv3 --pmc WRITE_SIZE -- same command   (per-launch average, KB)"
-  python tools/pmc_summary.py $O/w ) > gpurun_out/r04_c2_pmc_traffic.txt
+  python tools/pmc_summary.py $O/w ) > gpurun_out/r05_c2_pmc_traffic.txt
 rm -rf $O/f $O/w
-cat gpurun_out/r04_c2_pmc_traffic.txt | cut -c1-100
+cat gpurun_out/r05_c2_pmc_traffic.txt | cut -c1-100

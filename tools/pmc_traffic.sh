@@ -8,5 +8,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w -- python3 bench.py "$@" 
 ( echo "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py $* --steps 12 --warmup 4 --cpu-steps 0 --no-extras   (per-launch average, KB as reported; x2 for 16-B/lane reads)"
   python tools/pmc_summary.py $O/f
   echo; echo "rocprofv3 --pmc WRITE_SIZE -- same command   (per-launch average, KB)"
-  python tools/pmc_summary.py $O/w ) > gpurun_out/r04_${tag}_pmc_traffic.txt
+  python tools/pmc_summary.py $O/w ) > gpurun_out/r05_${tag}_pmc_traffic.txt
 rm -rf $O/f $O/w
