@@ -65,17 +65,17 @@ TEM_CFG = {
 }
 C4 = dict(RC=296000, B=256, K=5, WL=100, U=20, I=30)      # BASELINE configs[3]
 # HBM traffic of ONE gather+score launch at B=1024, d=256 from the committed counter passes (PMC cannot run inside this process)
-GATHER_TRAFFIC = 70.3e6
-GATHER_TRAFFIC_SOURCE = ("committed PMC passes profiles/r04_gather_score_c5_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                         "tools/gather_c5.py --rows 8000000 --batch 1024, 8 rotating index sets): FETCH_SIZE 34.9 MB x2 (gfx950 16-B/lane streaming-read "
-                         "correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE 0.42 MB = 70.3 MB per launch against 67.6 MB algorithmic (1.04x: nothing is "
+GATHER_TRAFFIC = 70.4e6
+GATHER_TRAFFIC_SOURCE = ("committed PMC passes profiles/r05_gather_score_c5_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                         "tools/gather_c5.py --rows 8000000 --batch 1024, 8 rotating index sets): FETCH_SIZE 35.0 MB x2 (gfx950 16-B/lane streaming-read "
+                         "correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE 0.42 MB = 70.4 MB per launch against 67.6 MB algorithmic (1.04x: nothing is "
                          "re-read; rounds 2-3 with ONE index set: 62.8 MB, part of the rows out of the Infinity Cache)")
-# memory-side bytes per launch of the two C2 roofline kernels from the committed counter passes (profiles/r04_c2_pmc_traffic.txt:
+# memory-side bytes per launch of the two C2 roofline kernels from the committed counter passes (profiles/r05_c2_pmc_traffic.txt:
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 20 --warmup 5 --no-extras`; FETCH_SIZE x2 — the
 # gfx950 16-B/lane streaming-read correction, MI355X_MICROARCH.md HBM; both counters sit at the L2's fabric side and include
 # Infinity-Cache hits: at C2 the working set lives in that cache, so these are L2-miss bytes)
 C2_TRAFFIC = {'mlp_fwd': 2 * 7.83e6 + 48.8e6, 'wgrad_group': 2 * 25.9e6 + 12.3e6}
-C2_TRAFFIC_SOURCE = ("committed PMC passes profiles/r04_c2_pmc_traffic.txt (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 fabric side, "
+C2_TRAFFIC_SOURCE = ("committed PMC passes profiles/r05_c2_pmc_traffic.txt (FETCH_SIZE x2 + WRITE_SIZE per launch, L2 fabric side, "
                      "Infinity-Cache hits included): mlp_fwd 2 x 7.83 + 48.8 MB (a1 + h1 + y1 / ln1 / y2 / enc written once, nothing "
                      "re-read); grouped weight gradients 2 x 25.9 + 12.3 MB for 49.5 MB of operands + 10.5 MB of fp32 atomics "
                      "(143 MB before the XCD-aware split placement)")
@@ -259,10 +259,10 @@ class RtmWorkload(object):
             note = "%d review rows + %d B of x" % (slots, out_bytes)
         return dict(tag='rtm_embed', bound='hbm', work=int(nbytes), peak=HBM_PEAK_GBS, unit='GB/s', scale=1e9,
                     kernel="rtm_embed4_kernel (review-vector gather + mean-pool; %s)" % note,
-                    extra={"traffic": 79.5e6 if self.a.encoder == 'pvc' else None,
-                           "traffic_source": "committed PMC passes profiles/r03_rtm_embed_pmc.txt (round 3, the commit that added "
-                                             "it; refreshed on the final round-3 kernel): FETCH_SIZE 34.5 MB x2 + WRITE_SIZE 10.6 MB "
-                                             "per launch (round 2, with the rank atomics in this kernel: 123.3 MB)" if self.a.encoder == 'pvc' else None,
+                    extra={"traffic": 79.3e6 if self.a.encoder == 'pvc' else None,
+                           "traffic_source": "committed PMC passes profiles/r05_c4_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                             "passes over bench.py --workload c4): FETCH_SIZE 34.4 MB x2 + WRITE_SIZE 10.6 MB per launch of "
+                                             "rtm_embed4_kernel (round 2, with the rank atomics in this kernel: 123.3 MB)" if self.a.encoder == 'pvc' else None,
                            "bound_note": "the 59 MB of word rows come from a 16.6 MB table that lives in the L2s / Infinity Cache; "
                                          "what the kernel takes from HBM is the ids and what it writes"})
 
