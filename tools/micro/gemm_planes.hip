@@ -79,6 +79,7 @@ __device__ __forceinline__ void read_frags(i32x4 (&fa)[2][3], i32x4 (&fb)[2][3],
   (void)T;
 }
 
+template <int DIAG>   // timing-only variants (WRONG results): 1 no DMA inside the loop, 2 no MFMAs, 3 no fragment reads
 __global__ __launch_bounds__(NTHR) void gemm_planes_kernel(const uint16_t* Ap, const uint16_t* Bp, float* C, int M, int N, int K, int ntn) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
@@ -116,23 +117,44 @@ __global__ __launch_bounds__(NTHR) void gemm_planes_kernel(const uint16_t* Ap, c
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     const uint32_t so = cur ? STAGE : 0;
-    if (kt + 1 < KT) stage_issue(s, m0, n0, (kt + 1) * BK, smem + (cur ? 0 : STAGE), tid, wave);   // flies under this step's products
+    if (kt + 1 < KT && DIAG != 1) stage_issue(s, m0, n0, (kt + 1) * BK, smem + (cur ? 0 : STAGE), tid, wave);   // flies under this step's products
     i32x4 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
-    read_frags<0>(fa0, fb0, aA[0] + so, aB[0] + so);
-    read_frags<1>(fa1, fb1, aA[1] + so, aB[1] + so);
+    if (DIAG != 3) {
+      read_frags<0>(fa0, fb0, aA[0] + so, aB[0] + so);
+      read_frags<1>(fa1, fb1, aA[1] + so, aB[1] + so);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { asm volatile("" : "=v"(fa0[i][p])); asm volatile("" : "=v"(fb0[i][p])); asm volatile("" : "=v"(fa1[i][p])); asm volatile("" : "=v"(fb1[i][p])); }
+    }
     asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (DIAG != 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) x3(acc[i][j], fa0[i], fb0[j]);
+        for (int j = 0; j < 2; ++j) x3(acc[i][j], fa0[i], fb0[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { asm volatile("" :: "v"(fa0[i][p])); asm volatile("" :: "v"(fb0[i][p])); }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (DIAG != 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) x3(acc[i][j], fa1[i], fb1[j]);
+        for (int j = 0; j < 2; ++j) x3(acc[i][j], fa1[i], fb1[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { asm volatile("" :: "v"(fa1[i][p])); asm volatile("" :: "v"(fb1[i][p])); }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the next stage has landed (this wave's pieces)
@@ -156,7 +178,12 @@ static double now_us(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedT
 int main(int argc, char** argv) {
   struct Shape { int M, N, K; const char* what; };
   const Shape shapes[] = {{21504, 1024, 256, "FF1 of the C5 shard"}, {21504, 256, 1024, "FF2"}, {4096, 4096, 4096, "4096^3"}, {8192, 8192, 1024, "8192 x 8192 x 1024"}};
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  const int diag = argc > 1 ? atoi(argv[1]) : 0;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  if (diag) printf("timing-only variant %d (results are wrong on purpose)\n", diag);
   for (const Shape& sh : shapes) {
     const int M = sh.M, N = sh.N, K = sh.K;
     if (M % BM || N % BN || K % BK) { printf("%s: shape not tileable\n", sh.what); continue; }
@@ -172,7 +199,12 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(split_kernel, dim3((hA.size() + 255) / 256), dim3(256), 0, 0, dA, pA, hA.size());
     hipLaunchKernelGGL(split_kernel, dim3((hB.size() + 255) / 256), dim3(256), 0, 0, dB, pB, hB.size());
     const int ntm = M / BM, ntn = N / BN;
-    auto launch = [&]() { hipLaunchKernelGGL(gemm_planes_kernel, dim3(ntm * ntn), dim3(NTHR), 2 * STAGE, 0, pA, pB, dC, M, N, K, ntn); };
+    auto launch = [&]() {
+      if (diag == 1) hipLaunchKernelGGL(gemm_planes_kernel<1>, dim3(ntm * ntn), dim3(NTHR), 2 * STAGE, 0, pA, pB, dC, M, N, K, ntn);
+      else if (diag == 2) hipLaunchKernelGGL(gemm_planes_kernel<2>, dim3(ntm * ntn), dim3(NTHR), 2 * STAGE, 0, pA, pB, dC, M, N, K, ntn);
+      else if (diag == 3) hipLaunchKernelGGL(gemm_planes_kernel<3>, dim3(ntm * ntn), dim3(NTHR), 2 * STAGE, 0, pA, pB, dC, M, N, K, ntn);
+      else hipLaunchKernelGGL(gemm_planes_kernel<0>, dim3(ntm * ntn), dim3(NTHR), 2 * STAGE, 0, pA, pB, dC, M, N, K, ntn);
+    };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
