@@ -87,7 +87,6 @@ static inline int rtm_eb_waves(int B, int K, int R, int* npos_w, int* nneg_w) {
   return np + nn + ps_cdiv((int64_t)B * (K + 1), EB_QSEQ);
 }
 #define RTM_HIST_G 256          // workgroups (= partitions of the review rows) of the LDS-histogram index
-#define WR_SWEEP_LIM 256        // occurrences of a word above which it leaves the sweeping reduce for the chunked heavy-word workgroups
 #define RTM_HIST_MAXV 38000     // vocabulary sizes whose histogram fits one workgroup's LDS (4 B per word, 160 KB)
 static inline int64_t rtake(int64_t& cur, int64_t n) { int64_t o = cur; cur += (n + 3) & ~(int64_t)3; return o; }
 
@@ -146,7 +145,7 @@ static int rtm_make_ws(const PsRtmDesc& D, bool eval, RtmWs& r, Ws& w, PsTemDesc
   if (!eval && D.review_encoder != PS_RENC_PV) {
     r.wcnt = rtake(cur, D.vocab_size + 1);        // [V] occurrence counts + the segment allocator's running total
     r.woff = rtake(cur, D.vocab_size + 1);
-    r.wcur = rtake(cur, D.vocab_size + 4);        // [V] fill cursors (PS_RTM_HIST=0) / the heavy-word list of the histogram index, + its count
+    r.wcur = rtake(cur, D.vocab_size);
     r.wl = rtake(cur, 2 * (int64_t)r.Bseq * D.R * D.WL);
     r.wrank = rtake(cur, (int64_t)r.Bseq * D.R * D.WL);
     if (D.vocab_size <= RTM_HIST_MAXV) r.hist = rtake(cur, (int64_t)RTM_HIST_G * D.vocab_size);
@@ -1561,7 +1560,7 @@ __global__ __launch_bounds__(NT) void rtm_hist_kernel(const RtmK a) {
 }
 // 64 words x 8 groups of RTM_HIST_G/8 partitions per workgroup: every lane has its group's counts in registers at once
 // (independent loads), the groups meet in LDS, wave 0 allocates the 64 segments (wave prefix + ONE bump of the running total)
-__global__ __launch_bounds__(512) void rtm_hist_scan_kernel(int* hist, int* wcnt, int* woff, int* tot, int V, int* heavy, int* nheavy, int heavy_lim) {
+__global__ __launch_bounds__(512) void rtm_hist_scan_kernel(int* hist, int* wcnt, int* woff, int* tot, int V) {
   __shared__ int l_tot[8][64];
   __shared__ int l_base[64];
   constexpr int PG = RTM_HIST_G / 8;
@@ -1592,8 +1591,6 @@ __global__ __launch_bounds__(512) void rtm_hist_scan_kernel(int* hist, int* wcnt
     base = __shfl(base, 63, 64) + incl - total;
     l_base[lane] = base;
     if (in) { woff[w] = base; wcnt[w] = total; }
-    // words with more occurrences than one wave should walk alone (rtm_wreduce_sweep_kernel): listed for its chunked workgroups
-    if (heavy && in && total > heavy_lim) heavy[atomicAdd(nheavy, 1)] = w;
   }
   __syncthreads();
   const int start = l_base[lane] + before;
@@ -1669,152 +1666,6 @@ __global__ __launch_bounds__(256) void rtm_wreduce_kernel(const RtmK a) {
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     if (lane + 64 * k < d) atomicAdd(&grow[lane + 64 * k], acc[k]);
-  }
-}
-
-// ---- The word-gradient reduce as a SWEEP over the slot space (round 5; d <= 128, LDS-histogram index).
-// rtm_wreduce_kernel above reads one 512-byte slot-gradient row per occurrence — 594 MB per C4 step — at the Infinity Cache's gather
-// rate (8.9 TB/s: the 9.5 MB of valid slot rows do not fit an XCD's 4 MB L2, and a word's ~36 occurrences are spread over all of
-// them).  Here a wave OWNS G consecutive words (it is the only adder of their runs: one atomic row per word instead of one per run of
-// a 64-entry chunk) and walks their occurrences in NR passes over the slot space: pass r takes the entries whose slot lies in the
-// r-th NR-th of [0, nslots).  All waves start together and do the same amount of work, so at any time the whole chip reads slot rows
-// of one or two passes: a window of ~1-2 MB that every XCD's L2 holds, filled once per XCD from the Infinity Cache.  A word's entries
-// (<= 64 per chunk) sit in ONE register, lane = entry; a pass picks its members with a ballot, so the list need not be sorted.
-// Words with more than WR_SWEEP_LIM occurrences (Zipf heads) were listed by rtm_hist_scan_kernel: the workgroups behind the sweeping
-// ones take them, 64-entry chunks strided over a workgroup's waves, one atomic row per wave.
-template <int G, int NR>
-__global__ __launch_bounds__(256) void rtm_wreduce_sweep_kernel(const RtmK a, int nsweep_wg, int nslots, const int* heavy, const int* nheavy) {
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int d = a.d, V = (int)a.V;
-  const int c0 = lane < d ? lane : d - 1, c1 = lane + 64 < d ? lane + 64 : d - 1;
-  if ((int)blockIdx.x >= nsweep_wg) {                                 // ---- heavy words: one per workgroup at a time
-    const int nh = *nheavy;
-    for (int hI = (int)blockIdx.x - nsweep_wg; hI < nh; hI += (int)gridDim.x - nsweep_wg) {
-      const int w = heavy[hI], n = a.wcnt[w], off = a.woff[w];
-      float a0 = 0.f, a1 = 0.f;
-      for (int base = wv * 64; base < n; base += 4 * 64) {
-        const int cnt = min(64, n - base);
-        const int my = a.wl[off + base + (lane < cnt ? lane : 0)].x;
-        for (int i0 = 0; i0 < cnt; i0 += 16) {
-          float r0[16], r1[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int sl = __builtin_amdgcn_readlane(my, (i0 + u) & 63);
-            const float* row = a.gs + (size_t)(i0 + u < cnt ? sl : __builtin_amdgcn_readlane(my, 0)) * d;
-            r0[u] = row[c0]; r1[u] = row[c1];
-          }
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            if (i0 + u < cnt) { a0 += r0[u]; a1 += r1[u]; }
-        }
-      }
-      float* grow = a.g_word_emb + (size_t)w * d;
-      if (lane < d) atomicAdd(&grow[lane], a0);
-      if (lane + 64 < d) atomicAdd(&grow[lane + 64], a1);
-    }
-    return;
-  }
-  const int w0 = ((int)blockIdx.x * 4 + wv) * G;
-  if (w0 >= V) return;
-  int n[G], off[G], nmax = 0;
-#pragma unroll
-  for (int j = 0; j < G; ++j) {
-    const int w = w0 + j < V ? w0 + j : V - 1;
-    const int cnt = a.wcnt[w];
-    n[j] = (w0 + j < V && cnt <= WR_SWEEP_LIM) ? cnt : 0;              // (heavy words: the workgroups above)
-    off[j] = a.woff[w];
-    nmax = max(nmax, n[j]);
-  }
-  float acc[G][2];
-#pragma unroll
-  for (int j = 0; j < G; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; }
-  const int per = (nslots + NR - 1) / NR;
-  for (int c = 0; c < nmax; c += 64) {
-    int e[G];                                                          // lane = entry c + lane of word j: its slot, or -1
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-      const int idx = c + lane < n[j] ? c + lane : (n[j] > 0 ? n[j] - 1 : 0);
-      const int sl = a.wl[off[j] + idx].x;                             // (unconditional: a real entry of the list, or entry 0 of the segment)
-      e[j] = c + lane < n[j] ? sl : -1;
-    }
-    for (int r = 0; r < NR; ++r) {
-      const int lo = r * per, hi = r == NR - 1 ? 0x7fffffff : lo + per;
-      unsigned long long m[G];
-      unsigned long long any = 0ull;
-#pragma unroll
-      for (int j = 0; j < G; ++j) { m[j] = __ballot(e[j] >= lo && e[j] < hi); any |= m[j]; }
-      while (any) {
-        float r0[G][4], r1[G][4];
-        bool on[G][4];
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            on[j][u] = m[j] != 0ull;                                    // wave-uniform
-            const int i = on[j][u] ? __builtin_ctzll(m[j]) : 0;
-            if (on[j][u]) m[j] &= m[j] - 1ull;
-            const int sl = __builtin_amdgcn_readlane(e[j], i);
-            const float* row = a.gs + (size_t)(on[j][u] ? sl : 0) * d;  // (a dead slot repeats row 0: every load unconditional)
-            r0[j][u] = row[c0]; r1[j][u] = row[c1];
-          }
-        any = 0ull;
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          any |= m[j];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (on[j][u]) { acc[j][0] += r0[j][u]; acc[j][1] += r1[j][u]; }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < G; ++j)
-    if (n[j] > 0) {
-      float* grow = a.g_word_emb + (size_t)(w0 + j) * d;
-      if (lane < d) atomicAdd(&grow[lane], acc[j][0]);
-      if (lane + 64 < d) atomicAdd(&grow[lane + 64], acc[j][1]);
-    }
-}
-
-// Experiment (round 5): a wave owns G words, a slot row goes to 32 lanes x 16 bytes — two occurrences per load
-// instruction, 8 per half-wave in flight — and the sums stay float4 until one flush per word.  d == 128 only.
-template <int G>
-__global__ __launch_bounds__(256) void rtm_wreduce_own16_kernel(const RtmK a) {
-  const int lane = threadIdx.x & 63, h = lane >> 5, c4 = lane & 31;
-  const int wv = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const int V = (int)a.V, w0 = wv * G;
-  if (w0 >= V) return;
-#pragma unroll 1
-  for (int j = 0; j < G; ++j) {
-    const int w = w0 + j;
-    if (w >= V) break;
-    const int n = a.wcnt[w], off = a.woff[w];
-    if (n == 0) continue;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < n; c += 64) {
-      const int cnt = min(64, n - c);
-      const int e = a.wl[off + c + (lane < cnt ? lane : 0)].x;
-      for (int i0 = 0; i0 < cnt; i0 += 16) {
-        float4 r[8]; bool live[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int sa = __builtin_amdgcn_readlane(e, (i0 + 2 * u) & 63), sb = __builtin_amdgcn_readlane(e, (i0 + 2 * u + 1) & 63);
-          live[u] = i0 + 2 * u + h < cnt;
-          const int sl = live[u] ? (h ? sb : sa) : __builtin_amdgcn_readlane(e, 0);
-          r[u] = *reinterpret_cast<const float4*>(a.gs + (size_t)sl * 128 + 4 * c4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          acc.x += live[u] ? r[u].x : 0.f; acc.y += live[u] ? r[u].y : 0.f; acc.z += live[u] ? r[u].z : 0.f; acc.w += live[u] ? r[u].w : 0.f;
-        }
-      }
-    }
-    acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64); acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
-    if (h == 0) {
-      float* grow = a.g_word_emb + (size_t)w * 128 + 4 * c4;
-      atomicAdd(&grow[0], acc.x); atomicAdd(&grow[1], acc.y); atomicAdd(&grow[2], acc.z); atomicAdd(&grow[3], acc.w);
-    }
   }
 }
 
@@ -1978,12 +1829,10 @@ static int rtm_build_index_hist(const RtmK& k, const RtmWs& r, int V, hipStream_
   }
   (void)r;
   PS_CHECK_HIP(hipMemsetAsync(k.wcnt + V, 0, sizeof(int), st));       // the allocator's running total
-  PS_CHECK_HIP(hipMemsetAsync(k.wcur + V, 0, sizeof(int), st));       // the heavy-word count (the list itself: k.wcur, free on this path)
   if (k.det) hipLaunchKernelGGL((rtm_hist_kernel<0, 64, 1>), dim3(RTM_HIST_G), dim3(64), (size_t)V * sizeof(int), st, k);
   else hipLaunchKernelGGL((rtm_hist_kernel<0, 1024, 0>), dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 64)), dim3(512), 0, st, k.hist, k.wcnt, k.woff, k.wcnt + V, V, k.wcur, k.wcur + V,
-                     WR_SWEEP_LIM);
+  hipLaunchKernelGGL(rtm_hist_scan_kernel, dim3(ps_cdiv(V, 64)), dim3(512), 0, st, k.hist, k.wcnt, k.woff, k.wcnt + V, V);
   PS_LAUNCH_CHECK();
   hipLaunchKernelGGL((rtm_hist_kernel<1, 1024, 0>), dim3(RTM_HIST_G), dim3(1024), (size_t)V * sizeof(int), st, k);
   PS_LAUNCH_CHECK();
@@ -2379,25 +2228,9 @@ static int rtm_backward_impl(const PsRtmDesc* desc, const PsRtmTensors* params, 
       if (d <= 128) WR_DET_LAUNCH(2); else if (d <= 256) WR_DET_LAUNCH(4); else WR_DET_LAUNCH(8);
 #undef WR_DET_LAUNCH
     } else {
-      // the sweep form (rtm_wreduce_sweep_kernel): needs the per-word segments and the heavy-word list of the LDS-histogram index
-      static const bool sweep_on = ps_env_int("PS_RTM_WR_SWEEP", 1) != 0;
-      if (sweep_on && d <= 128 && rtm_hist_index(D, k, r)) {
-        const int V = (int)D.vocab_size;
-        static const int shape = ps_diag_int("PS_RTM_WR_SHAPE", 0);   // tuning: (words per wave, passes)
-        const int Gw = (shape == 1 || shape == 2) ? 8 : 4;
-        const int nsw = ps_cdiv(ps_cdiv(V, Gw), 4);                  // Gw words per wave, 4 waves per workgroup
-        const dim3 grid(nsw + 256);
-        const int ns = r.Bseq * r.S;
-        if (shape == 1) hipLaunchKernelGGL((rtm_wreduce_sweep_kernel<8, 8>), grid, dim3(256), 0, wst, k, nsw, ns, k.wcur, k.wcur + V);
-        else if (shape == 2) hipLaunchKernelGGL((rtm_wreduce_sweep_kernel<8, 4>), grid, dim3(256), 0, wst, k, nsw, ns, k.wcur, k.wcur + V);
-        else if (shape == 3) hipLaunchKernelGGL((rtm_wreduce_sweep_kernel<4, 4>), grid, dim3(256), 0, wst, k, nsw, ns, k.wcur, k.wcur + V);
-        else if (shape == 4) hipLaunchKernelGGL((rtm_wreduce_sweep_kernel<4, 1>), grid, dim3(256), 0, wst, k, nsw, ns, k.wcur, k.wcur + V);
-        else if (shape == 5 && d == 128) hipLaunchKernelGGL((rtm_wreduce_own16_kernel<4>), dim3(nsw), dim3(256), 0, wst, k);
-        else if (shape == 6 && d == 128) hipLaunchKernelGGL((rtm_wreduce_own16_kernel<1>), dim3(ps_cdiv(V, 4)), dim3(256), 0, wst, k);
-        else hipLaunchKernelGGL((rtm_wreduce_sweep_kernel<4, 16>), grid, dim3(256), 0, wst, k, nsw, ns, k.wcur, k.wcur + V);
-      } else {
-        hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, wst, k);
-      }
+      // (round 5, measured and dropped: a wave OWNING words — one atomic row per word — that walks their occurrences in passes over the
+      // slot space for L2 residency, and 32 lanes x 16 bytes per slot row: 57-100 and 79 us against 55.5, profiles/r05_c4_wreduce_notes.md)
+      hipLaunchKernelGGL(rtm_wreduce_kernel, dim3((unsigned)wr), dim3(256), 0, wst, k);
     }
     PS_LAUNCH_CHECK();
   }
