@@ -599,30 +599,37 @@ def _free_port():
 
 
 def _run_ranks(a, backend, extra_env):
-    """One set of child ranks -> (rank exit codes, rank 0's JSON lines, tail of rank 0's stderr)."""
+    """One set of child ranks -> (rank exit codes, rank 0's JSON lines, tail of rank 0's stderr).  A rank that dies leaves its peers
+    inside a collective that never returns: as soon as one rank has exited non-zero the others are killed."""
     import tempfile
     port = _free_port()
     procs = []
-    err0 = tempfile.TemporaryFile(mode='w+')
+    out0, err0 = tempfile.TemporaryFile(mode='w+'), tempfile.TemporaryFile(mode='w+')
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', PS_BENCH_CHILD='1', **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL,
                                       stderr=err0 if r == 0 else None, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:                                  # a rank left alone in a collective by a dead peer never returns by itself
-            rcs.append(p.wait(timeout=120 if any(rcs) else None))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(p.wait())
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(2.0)                       # (let the failing rank's peers print what they have)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    out0.seek(0)
     err0.seek(0)
-    err_tail = err0.read()[-2000:]
+    out_text, err_tail = out0.read(), err0.read()[-2000:]
+    out0.close()
     err0.close()
     sys.stderr.write(err_tail)
-    lines = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    lines = [ln for ln in out_text.splitlines() if ln.startswith('{')]
     return rcs, lines, err_tail
 
 
@@ -714,6 +721,11 @@ def main():
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return self_launch(a)
     from prodsearch_amd import dist as pdist
+    if os.environ.get('PS_BENCH_TEST_FAIL_P2P') and os.environ.get('PS_BENCH_CHILD') and os.environ.get('RANK') == '1' \
+            and not (os.environ.get('PS_DP_RS') == 'rccl' and os.environ.get('PS_DP_AG') == 'rccl'):
+        # test hook (tests/test_gpu_dp.py): a rank of the FIRST self-launched set dies before it has touched the GPU, as a rank
+        # whose peer-to-peer collectives failed would; the library-collectives set that self_launch starts next must deliver
+        raise SystemExit(3)
     rank, local, world = pdist.init_from_env()
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE %d: refusing to report a line for a different rank count" % (a.gpus, world))

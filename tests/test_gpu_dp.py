@@ -282,6 +282,33 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
 
 
+def test_bench_self_launch_falls_back_to_the_library_collectives_once():
+    """the sharded optimizer's peer-to-peer forms meet RCCL for the first time on the driver's node.  If the first
+    set of self-launched ranks fails, bench.py starts ONE fresh set of child processes with PS_DP_RS=rccl PS_DP_AG=rccl and says
+    so in the line.  Here rank 1 of the first set dies before touching the GPU (PS_BENCH_TEST_FAIL_P2P), rank 0 is left in
+    the rendezvous and must be killed, and the second set (gloo, both ranks on cuda:0) delivers the line."""
+    import json
+    bench = os.path.join(os.path.dirname(HERE), 'bench.py')
+    env = dict(os.environ, PS_DIST_BACKEND='gloo', PS_BENCH_WATCHDOG='300', PS_BENCH_TEST_FAIL_P2P='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'PS_DP_RS', 'PS_DP_AG'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d.get('exchange_fallback') is True
+    assert d['exchange_fallback_detail']['first_attempt_exit_codes'][1] == 3
+    assert d['exchange_fallback_detail']['env'] == {'PS_DP_RS': 'rccl', 'PS_DP_AG': 'rccl'}
+    # with the library collectives pinned from the start there is nothing to fall back to: the failure is final
+    env.update(PS_DP_RS='rccl', PS_DP_AG='rccl')
+    env.pop('PS_BENCH_TEST_FAIL_P2P')
+    p = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '2', '--warmup', '0', '--no-extras'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0 and 'exchange_fallback' not in json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][0])
+
+
 def test_side_stream_sequence_words_restart_before_they_wrap():
     """Forks and joins of the side stream compare 32-bit sequence words with >=; side_fork drains both streams and restarts
     the words long before they wrap.  PS_SIDE_SEQ0 starts them just under that threshold: the same 60 steps must give the

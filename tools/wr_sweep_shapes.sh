@@ -1,3 +1,4 @@
+# (works at commit 882ad03 only: the experimental kernels it switches between were removed again — profiles/r05_c4_wreduce_notes.md)
 # gpurun -- bash tools/wr_sweep_shapes.sh : the sweeping word-gradient reduce of C4 under (words per wave, passes) shapes, diagnostic library
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PS_DIAG_LIB=1
