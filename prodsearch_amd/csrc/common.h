@@ -342,7 +342,7 @@ struct GemmProblem {
 };
 
 struct GemmGroup {
-  GemmProblem p[3];
+  GemmProblem p[4];      // (the flat form below holds at most three)
   int n;
   // a fork of the side stream signalled by THIS launch: its first workgroup stores sigval to *sig as it starts (side_take_signal)
   uint32_t* sig; uint32_t sigval;

@@ -1472,7 +1472,7 @@ int ps_launch_gemm(const GemmGroup& g0, hipStream_t stream) {
   return rc;
 }
 static int launch_gemm_impl(const GemmGroup& g, hipStream_t stream) {
-  PS_REQUIRE(g.n >= 1 && g.n <= 3, "gemm: group size %d", g.n);
+  PS_REQUIRE(g.n >= 1 && g.n <= (g.flat ? 3 : 4), "gemm: group size %d", g.n);
   if (g.flat) {
     for (int i = 0; i < g.n; ++i) {
       int rc = validate(g.p[i]);

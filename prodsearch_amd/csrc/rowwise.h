@@ -293,6 +293,9 @@ struct EmbedBwdArgs {
   // g_fs_b.  Replaces a tanh-backward launch and a [B,d]x[d,d] GEMM launch on the tail of the backward.
   const float* fsb_dqe; int fsb_lddqe; const float* fsb_qe; const float* fsb_w; float* g_fs_b;
   const float* fsb_dqe2; float fsb_k2;   // filled by the launcher: the second partial of d query_emb (dx2) and its weight (1, or 0 with fsb_dqe2 = fsb_dqe)
+  // optional: the row workgroups store dqpre [B,d] here and add the bias gradient themselves (atomics); the f_W weight gradient is then
+  // NOT computed by this launch (the caller runs it as a GEMM over dqpre and fw_x)
+  float* fsb_dqpre_out;
   ColFoldList fold;              // parked column sums to add up (n = 0: none)
   float* det_dm;                 // deterministic mode + fused FS backward: [B,d] buffer for the rows' d mean (scattered by the sole-owner pass)
   uint32_t* sig; uint32_t sigval; // a pending side-stream fork signalled by this launch (common.h, fork_signal)

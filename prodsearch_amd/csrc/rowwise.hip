@@ -1636,7 +1636,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
     }
     for (int e = tid; e < d; e += 256) {
       const float y = a.fsb_qe[(size_t)b * d + e];
-      dq_s[e] = (a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] + a.fsb_k2 * a.fsb_dqe2[(size_t)b * a.fsb_lddqe + e]) * (1.f - y * y);
+      const float v = (a.fsb_dqe[(size_t)b * a.fsb_lddqe + e] + a.fsb_k2 * a.fsb_dqe2[(size_t)b * a.fsb_lddqe + e]) * (1.f - y * y);
+      dq_s[e] = v;
+      if (a.fsb_dqpre_out) {                       // (kernel-uniform) the f_W gradient is a GEMM behind this launch: leave it its operand,
+        a.fsb_dqpre_out[(size_t)b * d + e] = v;    // and add this row's share of the bias gradient (text_encoder.py:38-39)
+        atomicAdd(&a.g_fs_b[e], v);
+      }
     }
     int cnt = 0;
     for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
@@ -1901,12 +1906,15 @@ int launch_embed_scatter(const EmbedBwdArgs& a, hipStream_t st) {
   PS_REQUIRE(!det || a.d <= 32 * BW_MAXE, "embed scatter: deterministic mode supports d <= %d", 32 * BW_MAXE);
   int ntask = (a.tem ? a.B * a.L : 0) + (fsb ? 0 : a.B * a.Q);   // fused: the query words are scattered by the row workgroups
   if (det) ntask = 0;                                            // ... deterministic mode: by the sole-owner pass below
+  static const int parts = ps_diag_int("PS_SCATTER_PARTS", 15);   // timing experiments (WRONG results): 1 FS rows, 2 f_W gradient, 4 folds, 8 scatter tasks
+  if (!(parts & 8)) ntask = 0;
   const int nsb = ps_cdiv(ntask, 8);
-  const int nq = fsb ? a.B : 0;
-  const int nfw = a.g_fs_w ? ps_cdiv(a.d * a.d, 32) : 0;
+  const int nq = fsb && (parts & 1) ? a.B : 0;
+  const int nfw = a.g_fs_w && (parts & 2) && !(fsb && a.fsb_dqpre_out) ? ps_cdiv(a.d * a.d, 32) : 0;
   PS_REQUIRE(!a.g_fs_w || fsb || (a.fw_dy && a.fw_x), "embed scatter: f_W gradient operands missing");
   int nfold = 0;
   for (int k = 0; k < a.fold.n; ++k) nfold += ps_cdiv(3 * a.fold.e[k].d, 32);
+  if (!(parts & 4)) nfold = 0;
   const size_t lds = fsb ? sizeof(float) * (size_t)(256 / (a.d / 4) + 2) * a.d : 0;
   EmbedBwdArgs a2 = a;
   if (!det) a2.det_dm = nullptr;

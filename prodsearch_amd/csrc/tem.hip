@@ -343,7 +343,7 @@ static int run_wgrads_det(GemmGroup& g, hipStream_t st) {
   float* sc = det_scratch(total, st);
   PS_REQUIRE(sc, "deterministic mode: no scratch for the split reduction (allocation failed or stream capture)");
   PS_CHECK_HIP(hipMemsetAsync(sc, 0, total * sizeof(float), st));     // splits without slabs (row lists) leave zeros
-  float* dW[3]; float* part[3];
+  float* dW[4]; float* part[4];
   size_t off = 0;
   for (int i = 0; i < g.n; ++i) {
     GemmProblem& p = g.p[i];
@@ -373,7 +373,7 @@ static int run_wgrads(GemmProblem* ps, int n, hipStream_t st) {
     same = same && ps[i].M == ps[0].M && ps[i].N == ps[0].N && ps[i].K == ps[0].K;
     plain = plain && !ps[i].ridx;
   }
-  if (n > 1 && !same && plain) {
+  if (n > 1 && n <= 3 && !same && plain) {
     // different shapes in one launch: the flat form (GemmGroup::flat) — every problem keeps the split count it would
     // take alone, no idle workgroups for the tiles the smaller members do not have
     for (int i = 0; i < n; ++i) {
@@ -1086,7 +1086,7 @@ extern "C" int ps_set_fuse_bwd_min(int rows) {
 // K/V/Q weight gradients of the first layer that the caller launches on the main stream AFTER its embedding scatter
 // (PS_WG3_LAST, item transformer): the scatter (atomics) then shares the machine with the side stream's W2 / W1 / Wo
 // products, and these follow when those are nearly through, instead of slowing each other down product beside product
-static thread_local GemmProblem g_wg3_last[3];
+static thread_local GemmProblem g_wg3_last[4];
 static thread_local int g_wg3_last_n = 0;
 static thread_local bool g_wg3_defer_ok = false;          // set by a caller that will flush them
 static int flush_wg3_last(hipStream_t st) {
@@ -1473,6 +1473,7 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
   }
 
   // 4. query encoder backward + scatter to the word / history rows
+  bool fw_by_gemm = false;
   EmbedBwdArgs e;
   memset(&e, 0, sizeof(e));
   e.B = B; e.Q = D.Q; e.L = D.L; e.S = S; e.d = d; e.P = D.product_size; e.V = D.vocab_size; e.tem = tem;
@@ -1488,6 +1489,11 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
       // ... and so does the rest of the FS backward: tanh', d mean = dqpre . f_W (per-row mat-vec), bias gradient
       e.fsb_dqe = dqe; e.fsb_lddqe = lddqe; e.fsb_qe = ws + w.query_emb; e.fsb_w = P.fs_w; e.g_fs_b = G.fs_b;
       e.det_dm = ws + w.dqmean;                   // (deterministic mode only: launch_embed_scatter)
+      // round 5: the f_W weight gradient as one more member of the weight-gradient GEMM launched behind this one, instead of 512
+      // extra workgroups of the scatter launch looping over the batch (33 of its 40 us at C2: tools/scatter_parts.sh); the row
+      // workgroups leave dqpre in the workspace for it and add the bias gradient themselves.  PS_FW_BY_GEMM=0: the riders.
+      static const bool fw_gemm_on = ps_env_int("PS_FW_BY_GEMM", 1) != 0;
+      if (fw_gemm_on && !ps_deterministic()) { e.fsb_dqpre_out = ws + w.dqpre; fw_by_gemm = true; }
     } else {
       TRY(launch_tanh_bwd(dqe, lddqe, ws + w.query_emb, ws + w.dqpre, G.fs_b, B, d, st));
       GemmProblem p = gp(ws + w.dqpre, d, 0, P.fs_w, d, 1, ws + w.dqmean, d, B, d, d);   // d mean = dqpre . f_W
@@ -1506,6 +1512,10 @@ static int tem_backward_impl(const PsTemDesc* desc, const PsTemTensors* params, 
   e.fold = fold;
   const int rc_sc = launch_embed_scatter(e, st);
   if (rc_sc != PS_OK) { g_wg3_last_n = 0; return rc_sc; }
+  if (fw_by_gemm) {      // g_fs_w[o][i] += sum_b dqpre[b][o] * qmean[b][i]  (text_encoder.py:38)
+    PS_REQUIRE(g_wg3_last_n <= 3, "backward: deferred weight-gradient group is full");
+    g_wg3_last[g_wg3_last_n++] = gp_wgrad(ws + w.dqpre, d, ws + w.qmean, d, G.fs_w, d, d, B);
+  }
   TRY(flush_wg3_last(st));
   TRY(side_join(st));
   return PS_OK;
