@@ -227,11 +227,15 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// 1 / x as ONE v_rcp_f32 (1 ulp).  `__frcp_rn(x)` and `1.f / x` are the correctly rounded division on this compiler: v_div_scale x2 +
+// v_rcp + 6 fma / mul + v_div_fmas + v_div_fixup = 11 vector instructions (round 5: 36 of them per wave of the fused per-replica
+// kernels, one per GELU, a seventh of the wave's vector instructions).  Every caller below divides 1 by a value in [1, inf].
+__device__ inline float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 // tanh via one v_exp_f32 + one v_rcp_f32: 1 - 2/(e^{2u}+1); saturates correctly at +-inf.
 // |error| <= ~2e-7 absolute, far inside the 1e-4 budget and ~8x fewer instructions than tanhf.
 __device__ inline float tanh_fast(float u) {
   const float e = __expf(2.f * u);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return 1.f - 2.f * rcp_fast(e + 1.f);
 }
 // gelu (models/neural.py:7-8): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  Computed in its logistic form —
 // 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)) — with the constants folded into the exponent of ONE v_exp_f32: 7 vector instructions
@@ -241,7 +245,7 @@ __device__ inline float tanh_fast(float u) {
 #define PS_GELU_B 0.10294324f         /* PS_GELU_A * 0.044715 */
 __device__ inline float gelu_sigmoid2u(float x, float x2) {      // 1 / (1 + exp(-2u)) = 0.5 (1 + tanh u)
   const float e = __builtin_amdgcn_exp2f(-x * fmaf(PS_GELU_B, x2, PS_GELU_A));
-  return __frcp_rn(1.f + e);
+  return rcp_fast(1.f + e);
 }
 __device__ inline float gelu_tanh_f(float x) {
   return x * gelu_sigmoid2u(x, x * x);
@@ -258,7 +262,7 @@ __device__ inline float softplus_f(float x) {      // log(1+exp(x)), stable
 }
 __device__ inline float sigmoid_f(float x) {
   const float e = __expf(-fabsf(x));
-  const float r = __frcp_rn(1.f + e);
+  const float r = rcp_fast(1.f + e);
   return x >= 0.f ? r : e * r;
 }
 
