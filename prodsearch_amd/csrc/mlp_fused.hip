@@ -69,6 +69,53 @@ __device__ __forceinline__ void dump_acc(float* slot, const f32x16& v, int l31, 
   for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// Row-per-lane register tiles <-> global memory through a wave-private LDS tile.  In the products a lane owns 16 consecutive
+// features (64 B) of ONE replica row, so a `global_store_dwordx4` straight from those registers writes 64 separate 16-byte
+// pieces in 32 rows, 2 KB apart — 64 partial-line requests per instruction, and the chain's a1 / h1 stores were a sixth of the
+// forward kernel (tools/mlp_stamps.py, PS_MLP_DIAG=3: 57.0k -> 47.4k cycles without them).  Through the tile an instruction
+// covers 8 rows x one full 128-byte line (8 lanes x 16 B per row).  The tile is the wave's own partial slot, idle during the
+// chain; LDS executes a wave's instructions in order, so no barrier is needed.  Row stride 36 floats: the row-per-lane side is
+// conflict-free, the line-per-8-lanes side pays one extra cycle per instruction.
+#define TLD 36
+__device__ __forceinline__ void tile_put(float* tile, const float (&v)[16], int l31, int h) {
+  float* p = tile + l31 * TLD + 16 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+__device__ __forceinline__ void tile_get(const float* tile, float (&v)[16], int l31, int h) {
+  const float* p = tile + l31 * TLD + 16 * h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+// tile -> rows m0 .. m0+31 of g (row stride ldg floats, the block's 32 features at g): four coalesced instructions
+__device__ __forceinline__ void tile_store(const float* tile, float* g, int ldg, int lane, int rows_left) {
+  const int rr = lane >> 3, cc = 4 * (lane & 7);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + rr;
+    const float4 t = *reinterpret_cast<const float4*>(tile + row * TLD + cc);
+    if (row < rows_left) *reinterpret_cast<float4*>(g + (size_t)row * ldg + cc) = t;
+  }
+}
+// the same rows of g, requested coalesced into registers (tile_load_put places them once they have arrived)
+__device__ __forceinline__ void tile_load(float4 (&t)[4], const float* g, int ldg, int lane, int rows_left) {
+  const int rr = lane >> 3, cc = 4 * (lane & 7);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + rr;
+    t[i] = *reinterpret_cast<const float4*>(g + (size_t)(row < rows_left ? row : 0) * ldg + cc);
+    if (row >= rows_left) t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void tile_load_put(float* tile, const float4 (&t)[4], int lane) {
+  const int rr = lane >> 3, cc = 4 * (lane & 7);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(tile + (8 * i + rr) * TLD + cc) = t[i];
+}
+
 // diagnostic timeline (tools/mlp_stamps.py): wave w of workgroup 0 stores s_memtime into stamp[16 * w + slot]
 static unsigned long long* g_mlp_stamp = nullptr;
 extern "C" void ps_debug_set_stamp_buffer(void* p) { g_mlp_stamp = (unsigned long long*)p; }
@@ -227,7 +274,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
   const int mrow_p = m0 + l31;                                         // this lane's replica row in the products
-  const bool row_ok = mrow_p < M;
   constexpr int NS = 16 * NBW;
 #pragma unroll
   for (int bi = 0; bi < NBW; ++bi) {
@@ -256,14 +302,12 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     MLP_STAMP(6 + 3 * bi);
     // epilogue in registers: bias, GELU, dropout; a1 / h1 leave as one 64-byte run per lane; h1 becomes the next B operand
     float hv[16];
-    float* a1p = a.a1 + (size_t)opaque(mrow_p) * F + f0;
-    float* h1p = a.h1 + (size_t)opaque(mrow_p) * F + f0;
+    float* tile = &L.Ps[wave][0];                                      // the wave's own partial slot: idle until the dumps below
+    {
+      float av[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] += bias[r];
-    if (row_ok && DIAG != 3) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(a1p + 4 * q) = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+      for (int r = 0; r < 16; ++r) { acc1[r] += bias[r]; av[r] = acc1[r]; }
+      if (DIAG != 3) tile_put(tile, av, l31, h);
     }
     Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
     if (a.drop_ff1.thr) {
@@ -276,10 +320,10 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       if (a.drop_ff1.thr) g *= drop_half(a.drop_ff1, r < 8 ? r0 : r1, r & 7);
       hv[r] = g;
     }
-    if (row_ok && DIAG != 3) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(h1p + 4 * q) = make_float4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
+    if (DIAG != 3) {
+      tile_put(tile + MBM * TLD, hv, l31, h);
+      tile_store(tile, a.a1 + (size_t)m0 * F + 32 * fb, F, lane, M - m0);
+      tile_store(tile + MBM * TLD, a.h1 + (size_t)m0 * F + 32 * fb, F, lane, M - m0);
     }
     uint4 hf[2][3];
     {
@@ -403,6 +447,10 @@ bool mlp_fwd_can_fold_score(int M, int F, int d) {
 }
 bool mlp_fused_serves(int d, int F) { return d == MD && mlp_x3_enabled(F); }
 
+static int mlp_pf() {      // weight fragments in flight per wave (F = 512): experiment knob
+  static const int v = ps_env_int("PS_MLP_PF", MLP_PF_DEFAULT);
+  return v;
+}
 template <class K>
 static int set_lds_attr(K kernel, bool& done) {
   if (!done) {
@@ -430,6 +478,9 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   else
 #endif
   if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); PS_KLAUNCH((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && mlp_pf() == 4) { static bool p4 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 4>, p4)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 4>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && mlp_pf() == 5) { static bool p5 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 5>, p5)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, as); }
+  else if (a.F == 512 && mlp_pf() == 6) { static bool p6 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 6>, p6)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 6>), grid, block, sizeof(MlpTLds), st, as); }
   else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
   else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); PS_KLAUNCH((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
   PS_LAUNCH_CHECK();
@@ -589,15 +640,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
 #pragma unroll
   for (int bi = 0; bi < NBW; ++bi) {
     const int fb = wave * NBW + bi, f0 = 32 * fb + 16 * h;
-    float a1v[16];
-    {
-      const float* a1p = a.a1 + (size_t)(row_ok ? mrow_p : 0) * F + f0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = row_ok ? *reinterpret_cast<const float4*>(a1p + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        a1v[4 * q] = v.x; a1v[4 * q + 1] = v.y; a1v[4 * q + 2] = v.z; a1v[4 * q + 3] = v.w;
-      }
-    }
+    float* tile = &L.Ps[wave][0];                                      // the wave's own partial slot (tile_put above): idle in the chain
+    float4 a1g[4];                                                     // a1 of the block, requested coalesced; placed behind the steps
+    tile_load(a1g, a.a1 + (size_t)m0 * F + 32 * fb, F, lane, M - m0);
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
@@ -617,6 +662,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       r0 = drop_call16(a.drop_ff1, (uint32_t)mrow_p, (uint32_t)(f0 >> 3), step_ff1);
       r1 = drop_call16(a.drop_ff1, (uint32_t)mrow_p, (uint32_t)(f0 >> 3) + 1u, step_ff1);
     }
+    float a1v[16];
+    tile_load_put(tile, a1g, lane);
+    tile_get(tile, a1v, l31, h);
     float dv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -624,11 +672,8 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       if (a.drop_ff1.thr) g *= drop_half(a.drop_ff1, r < 8 ? r0 : r1, r & 7);
       dv[r] = row_ok ? g : 0.f;
     }
-    if (row_ok) {
-      float* dp = a.da1 + (size_t)opaque(mrow_p) * F + f0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dp + 4 * q) = make_float4(dv[4 * q], dv[4 * q + 1], dv[4 * q + 2], dv[4 * q + 3]);
-    }
+    tile_put(tile + MBM * TLD, dv, l31, h);
+    tile_store(tile + MBM * TLD, a.da1 + (size_t)m0 * F + 32 * fb, F, lane, M - m0);
     // b1 column sums of this block over the workgroup's 32 rows: DPP scan over the 32 lanes of each half; lanes 31 and 63
     // hold the totals of features f0 .. f0+15 of their half and park them (one row per workgroup: part_b1[wg][slot 0][F])
     {
@@ -731,6 +776,10 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   else if (a.F == 512) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 3>, a2));
   else TRY(set_lds_attr(mlp_bwd_t_kernel<4, 3>, a4));
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
+  if (a.F == 512 && mlp_pf() == 4) { static bool p4 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 4>, p4)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 4>), grid, block, sizeof(MlpTLds), st, b); }
+  else if (a.F == 512 && mlp_pf() == 5) { static bool p5 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 5>, p5)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, b); }
+  else if (a.F == 512 && mlp_pf() == 6) { static bool p6 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 6>, p6)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 6>), grid, block, sizeof(MlpTLds), st, b); }
+  else
   if (a.F == 256) hipLaunchKernelGGL((mlp_bwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, b);
   else if (a.F == 512) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, b);
   else hipLaunchKernelGGL((mlp_bwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, b);
