@@ -41,7 +41,7 @@ bool ps_fusion_enabled() {
 #define MD 128            // model width this kernel is specialised for
 #define MBM 32            // replica rows per workgroup
 #define MT_THREADS 512
-#define MLP_PF_DEFAULT 3
+#define MLP_PF_DEFAULT 3   // weight fragments in flight per wave (round 5: 4 / 5 / 6 measured, no change: profiles/r05_mlp_notes.md)
 #define PLD 132           // row stride (floats) of the partial tiles in LDS: [m][n], 16-byte aligned rows, +16 B per row
 
 // Launder a value through an empty asm: stops LLVM from hoisting per-row store addresses out of unrolled code.
@@ -447,10 +447,6 @@ bool mlp_fwd_can_fold_score(int M, int F, int d) {
 }
 bool mlp_fused_serves(int d, int F) { return d == MD && mlp_x3_enabled(F); }
 
-static int mlp_pf() {      // weight fragments in flight per wave (F = 512): experiment knob
-  static const int v = ps_env_int("PS_MLP_PF", MLP_PF_DEFAULT);
-  return v;
-}
 template <class K>
 static int set_lds_attr(K kernel, bool& done) {
   if (!done) {
@@ -478,9 +474,6 @@ int launch_mlp_fwd_fused(const MlpFwdArgs& a, hipStream_t st) {
   else
 #endif
   if (a.F == 256) { TRY(set_lds_attr(mlp_fwd_t_kernel<1, 3>, a1)); PS_KLAUNCH((mlp_fwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && mlp_pf() == 4) { static bool p4 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 4>, p4)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 4>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && mlp_pf() == 5) { static bool p5 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 5>, p5)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, as); }
-  else if (a.F == 512 && mlp_pf() == 6) { static bool p6 = false; TRY(set_lds_attr(mlp_fwd_t_kernel<2, 6>, p6)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 6>), grid, block, sizeof(MlpTLds), st, as); }
   else if (a.F == 512) { TRY(set_lds_attr(mlp_fwd_t_kernel<2, 3>, a2)); PS_KLAUNCH((mlp_fwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, as); }
   else { TRY(set_lds_attr(mlp_fwd_t_kernel<4, 3>, a4)); PS_KLAUNCH((mlp_fwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, as); }
   PS_LAUNCH_CHECK();
@@ -776,10 +769,6 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   else if (a.F == 512) TRY(set_lds_attr(mlp_bwd_t_kernel<2, 3>, a2));
   else TRY(set_lds_attr(mlp_bwd_t_kernel<4, 3>, a4));
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
-  if (a.F == 512 && mlp_pf() == 4) { static bool p4 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 4>, p4)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 4>), grid, block, sizeof(MlpTLds), st, b); }
-  else if (a.F == 512 && mlp_pf() == 5) { static bool p5 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 5>, p5)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 5>), grid, block, sizeof(MlpTLds), st, b); }
-  else if (a.F == 512 && mlp_pf() == 6) { static bool p6 = false; TRY(set_lds_attr(mlp_bwd_t_kernel<2, 6>, p6)); hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 6>), grid, block, sizeof(MlpTLds), st, b); }
-  else
   if (a.F == 256) hipLaunchKernelGGL((mlp_bwd_t_kernel<1, 3>), grid, block, sizeof(MlpTLds), st, b);
   else if (a.F == 512) hipLaunchKernelGGL((mlp_bwd_t_kernel<2, 3>), grid, block, sizeof(MlpTLds), st, b);
   else hipLaunchKernelGGL((mlp_bwd_t_kernel<4, 3>), grid, block, sizeof(MlpTLds), st, b);
