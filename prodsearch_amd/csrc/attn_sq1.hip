@@ -829,15 +829,21 @@ __global__ __launch_bounds__(512, 2) void kvq_attn_fwd_kernel(const KvqArgs g) {
     float* tile = (wave < 4 ? &L.Ks[0][0] : &L.Vs[0][0]) + l31 * 132 + f0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) f4_st(tile + 4 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
-    if ((vm >> l31) & 1ull) {                                          // valid positions only: nothing reads the others
-      float* out = (wave < 4 ? g.kp : g.vp) + ((size_t)b * S + l31) * D + f0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) f4_st(out + 4 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
-    }
   }
   KVQ_STAMP(4);
   __syncthreads();                                                     // K / V tiles in LDS
   KVQ_STAMP(5);
+  // K / V rows leave from the tiles, a whole 512-byte row per half wave (from the accumulators a lane holds 64 bytes of ONE row:
+  // 64 partial-line pieces per store instruction, profiles/r05_mlp_notes.md); valid positions only: nothing reads the others
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = wave + 8 * it;                                     // (wave-uniform)
+    if (row < S && ((vm >> row) & 1ull)) {
+      const int c4 = 4 * (lane & 31);
+      const float4 v = f4_ld(lane < 32 ? &L.Ks[row][c4] : &L.Vs[row][c4]);
+      f4_st((lane < 32 ? g.kp : g.vp) + ((size_t)b * S + row) * D + c4, v);
+    }
+  }
   // ---- attention of position 0: wave = (head group hg, replica chunk ch)
   const int hg = wave >> 2, ch = wave & 3;
   const int jper = (a.fan + 3) >> 2, jbeg = ch * jper, jend = min(a.fan, jbeg + jper);
@@ -1114,15 +1120,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
         if (t < 4) load_frag(wfr[t], kvb, t + 4, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // lane (position l31, half hh) holds input features 32 ch + 16 hh + r: one 64-byte run of the position's partial row
-      const int f0 = 32 * ch + 16 * hh;
-      if (l31 == 0) {
+      // lane (position l31, half hh) holds input features 32 ch + 16 hh + r: 64 bytes of ONE position's partial row — stored from
+      // there an instruction is 64 partial-line pieces (profiles/r05_mlp_notes.md).  Through the wave's own slice of `red` (dead
+      // since the barrier above; LDS runs a wave's instructions in order) an instruction covers 8 positions x one 128-byte line.
+      float* tile = &Ls.red[ch][0][0];
+      static_assert(NV * 64 >= 32 * 36, "dX tile: the wave's slice of red holds 32 rows of 36 floats");
+      {
+        float* p = tile + l31 * 36 + 16 * hh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Ls.part0[f0 + r] = accx[r];                 // the query position's row leaves with the tail
-      } else if (l31 < S && ((vm >> l31) & 1ull)) {
-        float* out = a.dxp[hg] + ((size_t)b * S + l31) * D + f0;
+        for (int q = 0; q < 4; ++q) f4_st(p + 4 * q, make_float4(accx[4 * q], accx[4 * q + 1], accx[4 * q + 2], accx[4 * q + 3]));
+      }
+      const int rr = lane >> 3, cc = 4 * (lane & 7);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) f4_st(out + 4 * q, make_float4(accx[4 * q], accx[4 * q + 1], accx[4 * q + 2], accx[4 * q + 3]));
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + rr;
+        const float4 t = f4_ld(tile + row * 36 + cc);
+        if (row == 0) f4_st(&Ls.part0[32 * ch + cc], t);                         // the query position's row leaves with the tail
+        else if (row < S && ((vm >> row) & 1ull)) f4_st(a.dxp[hg] + ((size_t)b * S + row) * D + 32 * ch + cc, t);
       }
     }
   }
