@@ -500,6 +500,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
   const int mg = m0 + mrow;
   const bool ok = mg < M;
   const uint32_t step_ctx = drop_step(a.drop_ctx), step_ff1 = drop_step(a.drop_ff1), step_ff2 = drop_step(a.drop_ff2);
+  MLP_STAMP(0);
   float (*Csum)[MBM][MD] = reinterpret_cast<float (*)[MBM][MD]>(&L.Ps[2][0]);   // [3][32 row groups][128] column-sum scratch (slots 2-4)
   static_assert(3 * MBM * MD <= 3 * MBM * PLD, "column-sum scratch must fit three partial slots");
 
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     dy[0] = v0.x; dy[1] = v0.y; dy[2] = v0.z; dy[3] = v0.w; dy[4] = v1.x; dy[5] = v1.y; dy[6] = v1.z; dy[7] = v1.w;
   }
   __syncthreads();                                                     // P: gamma vectors in LDS
+  MLP_STAMP(1);
 
   // LayerNorm backward of this lane's elements:  dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ res);
   // dropped = dx * mask -> Xa planes (+ global out_drop); column sums {dy*xhat, dy, dropped} -> Csum[.][row group][col]
@@ -618,8 +620,10 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     ln_bwd_stage(dyz, x2, st2[0], st2[1], 0, false, zero, a.drop_ff2, step_ff2, dy2r, nullptr, a.do2);
   }
   __syncthreads();                                                     // 1: do2 planes + column sums
+  MLP_STAMP(2);
   park(a.part_f);
   __syncthreads();                                                     // 2: column-sum scratch (partial slots 2-4) free again
+  MLP_STAMP(3);
 
   // ---- per feature block: d h1 -> d a1 (registers) -> d ln1 partial
   f32x16 acc2[4];
@@ -650,6 +654,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
+    MLP_STAMP(4 + 2 * bi);
     Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
     if (a.drop_ff1.thr) {
       r0 = drop_call16(a.drop_ff1, (uint32_t)mrow_p, (uint32_t)(f0 >> 3), step_ff1);
@@ -679,6 +684,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(pb + 4 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
       }
     }
+    MLP_STAMP(5 + 2 * bi);
     uint4 df[2][3];
     {
       const float lo8[8] = {dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7]};
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     }
   }
   // FF LayerNorm inputs and the Wo^T fragments, requested under the dumps and the barrier
+  MLP_STAMP(8);
   float x1[8], st1v[2] = {0.f, 0.f};
   {
     const float* src = a.y1 + (size_t)(ok ? mg : 0) * MD + c8;
@@ -711,6 +718,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) dump_acc(L.Ps[wave], acc2[nb], l31, h, nb);
   __syncthreads();                                                     // 3: the 8 waves' d ln1 partials in Ps[0..7]
+  MLP_STAMP(9);
 
   // ---- FF LayerNorm backward (+ d y2 residual) -> dy1 ; dout = dropout(dy1) -> planes
   float dl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -720,12 +728,14 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     dl[0] += p0.x; dl[1] += p0.y; dl[2] += p0.z; dl[3] += p0.w; dl[4] += p1.x; dl[5] += p1.y; dl[6] += p1.z; dl[7] += p1.w;
   }
   __syncthreads();                                                     // 4: partial slots consumed (the column sums reuse slots 2-4)
+  MLP_STAMP(10);
   {
     float dy1r[8];
     const bool same = a.dout == a.dy1;
     ln_bwd_stage(dl, x1, st1v[0], st1v[1], 1, true, dy2r, a.drop_ctx, step_ctx, dy1r, a.dy1, same ? nullptr : a.dout);
   }
   __syncthreads();                                                     // 5: dout planes + column sums
+  MLP_STAMP(11);
   park(a.part_1);
   // ---- d ctx^T = Wo^T . dout^T : this wave's output block over its reduction half; halves meet in slots 0 / 1
   {
@@ -741,6 +751,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     dump_acc(L.Ps[nh], acc, l31, h, kbo);
   }
   __syncthreads();                                                     // 6: both halves in Ps[0..1]
+  MLP_STAMP(12);
   if (ok) {
     const float* p0 = &L.Ps[0][mrow * PLD + c8];
     const float* p1 = &L.Ps[1][mrow * PLD + c8];
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     *reinterpret_cast<float4*>(q) = make_float4(u0.x + w0.x, u0.y + w0.y, u0.z + w0.z, u0.w + w0.w);
     *reinterpret_cast<float4*>(q + 4) = make_float4(u1.x + w1.x, u1.y + w1.y, u1.z + w1.z, u1.w + w1.w);
   }
+  MLP_STAMP(13);
 }
 
 int mlp_bwd_fused_blocks(int M) { return ps_cdiv(M, MBM); }
@@ -763,6 +775,7 @@ int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st) {
   KTimeScope kt("mlp_bwd", st);
   MlpBwdArgs b = a;
   b.sig = nullptr; b.sigval = 0;
+  b.stamp = g_mlp_stamp ? g_mlp_stamp + 128 : nullptr;
   const dim3 grid(ps_cdiv(a.M, MBM)), block(MT_THREADS);
   static bool a1 = false, a2 = false, a4 = false;
   if (a.F == 256) TRY(set_lds_attr(mlp_bwd_t_kernel<1, 3>, a1));

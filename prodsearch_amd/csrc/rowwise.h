@@ -371,6 +371,7 @@ struct MlpBwdArgs {
   float* part_b1;                                      // [mlp_bwd_b1_rows()][3][F] slot 0: colsum -> b1
   WSplit x3;                                           // bf16x3 fragment streams (the bwd_* ones are read here)
   uint32_t* sig; uint32_t sigval;                      // a pending side-stream fork signalled by this launch (common.h, fork_signal)
+  unsigned long long* stamp;                           // diagnostics: as MlpFwdArgs::stamp (the backward's slots follow the forward's 128)
 };
 int launch_mlp_bwd_fused(const MlpBwdArgs& a, hipStream_t st);
 int mlp_bwd_fused_blocks(int M);
