@@ -289,6 +289,12 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
     uint4 bq[2][3];                                                    // the B operand of step t + 1 is read under step t's MFMAs
     read_b(bq[0], L.Xa, l31, 8 * h);
+    // product steps one wave-priority level above epilogues: the SIMD's other wave is usually in the other kind of phase, and an MFMA
+    // that waits behind its vector instructions leaves the pipe idle (round 5: 29.0 -> 28.5 us forward, the same backward; four
+    // alternating pairs).  And one more level for waves 4-7 in the first feature block, for waves 0-3 in the second: at equal priority
+    // the older wave of a SIMD wins every tie and waves 0-3 reached the chain's end 7-10 k cycles before their partners
+    // (profiles/r05_mlp_stamps.txt); another 0.3 us.
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                      // a1^T block = W1[block rows] . ln1^T
       const int s = 16 * bi + t;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       else if (DIAG != 2) load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     MLP_STAMP(6 + 3 * bi);
     // epilogue in registers: bias, GELU, dropout; a1 / h1 leave as one 64-byte run per lane; h1 becomes the next B operand
     float hv[16];
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       split8(hi8, hf[1]);
     }
     MLP_STAMP(7 + 3 * bi);
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {                                      // y2^T += W2[:, block] . h1^T block   (k step u >> 2, rows 32 (u & 3) ..)
       const int s = 16 * bi + 8 + u;
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   MLP_STAMP(12);
   // folded scoring: the item row this lane's enc elements will be dotted with (requested under the dumps and the barrier)
   float itr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -645,6 +654,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
     uint4 bq[2][3];                                                    // the B operand of step t + 1 is read under step t's MFMAs
     read_b(bq[0], L.Xa, l31, 8 * h);
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {                                      // d h1^T block = W2^T[block rows] . do2^T
       const int s = 16 * bi + t;
@@ -654,6 +664,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       load_frag(ring[s % PF], ff_stream, s + PF < NS ? s + PF : NS - 1, lane);
       __builtin_amdgcn_sched_barrier(0);       // keep the step's order: operand reads, six MFMAs, the refill PF steps ahead (see load_frag)
     }
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     MLP_STAMP(4 + 2 * bi);
     Philox4 r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
     if (a.drop_ff1.thr) {
@@ -685,6 +696,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
       }
     }
     MLP_STAMP(5 + 2 * bi);
+    { if ((wave >= 4) == (bi == 0)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
     uint4 df[2][3];
     {
       const float lo8[8] = {dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6], dv[7]};
@@ -701,6 +713,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_bwd_t_kernel(const MlpBwdAr
     }
   }
   // FF LayerNorm inputs and the Wo^T fragments, requested under the dumps and the barrier
+  __builtin_amdgcn_s_setprio(0);
   MLP_STAMP(8);
   float x1[8], st1v[2] = {0.f, 0.f};
   {
