@@ -947,8 +947,22 @@ int launch_kvq_attn_fwd(const KvqArgs& g, hipStream_t st) {
 // eight waves per sequence in one workgroup: 18 us alone but two rounds of 256-register workgroups, 40 us in the step; the
 // LDS workgroup form: 29 us.)
 template <int DH, int MAXK, int NH>   // DH = 16: d = 128 (C2); DH = 32: d = 256 (C5 shard; its dQ.Wq is a GEMM of its own: no tail)
-__global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread, unsigned long long* stamp) {
   fork_signal(a.sig, a.sigval);
+#if PS_DIAG_ON      // [8 * workgroup + slot]: the 100 MHz counter all CUs share, wave 0's view (tools/attn_bwd_wg_times.py)
+  unsigned long long abw_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ABW_STAMP(slot)                                                                                  \
+  do {                                                                                                   \
+    if (stamp && threadIdx.x == 0) {                                                                     \
+      unsigned long long t_;                                                                             \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+      abw_st[slot] = t_;                                                                                 \
+    }                                                                                                    \
+  } while (0)
+#else
+#define ABW_STAMP(slot) do { } while (0)
+#endif
+  ABW_STAMP(0);
   // keys of a lane group: i = hf * MAXK + ii, hf < NH (the key range is walked in NH parts so that only MAXK V rows and
   // d V sums are in registers at a time: d = 256 needs 11 keys per group for 21 positions)
   constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 8 * DH, NK = NH * MAXK, NV = 5 * NK, JB = 6;
@@ -1018,13 +1032,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
       red[ch][5 * i + 3][lane] = dv4[ii].w; red[ch][5 * i + 4][lane] = dP[ii];
     }
   }
-  // the tail's weights: thread (half, i) owns output column i and 32 of this group's 64 query features; requested now
-  // (the d context rows are consumed), used after the two barriers below
-  float wq[32];
-  if (fold_q) {
+  ABW_STAMP(1);
+  // the tail's fan-in rows (this group's 64 columns of the replicas' d y1 sum): requested now (the d context rows are consumed), all
+  // at once, and in flight ACROSS the two barriers below (raw s_barrier behind an LDS wait: `__syncthreads` would drain them) — as a
+  // loop with a runtime trip count in the tail each of its ~11 loads was a round trip of its own (3.4 of the workgroup's 14.8 us,
+  // tools/attn_bwd_wg_times.py).  Same addition order as before: bitwise the same sums.
+  constexpr int FIN = 12;                                    // fan <= 24: at most 12 replicas per half
+  float fin[FIN];
+  if (fold_q) {                                              // (kernel-uniform)
     const int i = tid & 127, half = tid >> 7;
+    const bool mine = a.fanin_src && (i >> 6) == hg;
+    const float* src = a.fanin_src ? a.fanin_src : a.dctx;   // (any mapped address: the value is dropped)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
+    for (int u = 0; u < FIN; ++u) {
+      const int j = half + 2 * u;
+      fin[u] = src[((size_t)b * a.fan + (j < a.fan ? j : 0)) * D + i];
+    }
+    (void)mine;                                              // (masked where they are used: see the tail)
   }
   // fused d x: wave ch owns the 32 input features 32 ch ..; its first four weight fragments (of eight) are requested now
   uint4 wfr[4][3];
@@ -1036,7 +1060,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
       for (int t = 0; t < 4; ++t) load_frag(wfr[t], kvb, t, lane);
     }
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (what crosses it is in LDS)
+  ABW_STAMP(2);
   if (ch == 0) {
     const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
     float dPs[NK];
@@ -1103,8 +1128,18 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
       }
     }
   }
+  ABW_STAMP(3);
   if (!fold_q) return;
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (dK | dV planes and d q: LDS)
+  ABW_STAMP(4);
+  // the tail's weights: thread (half, i) owns output column i and 32 of this group's 64 query features; requested behind the d x
+  // product's last fragment refill (so that no product step waits for them), used in the tail
+  float wq[32];
+  if (!fuse_dx) {                                            // (no product here: requested now)
+    const int i = tid & 127, half = tid >> 7;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
+  }
   if constexpr (DH == 16) {
     if (fuse_dx) {
       // d x^T block = [Wk^T | Wv^T](32 features x 128 k) . (dK | dV)^T (128 k x positions): 48 bf16 MFMAs per wave
@@ -1119,6 +1154,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
         x3_mma(accx, wfr[t & 3], bq);
         if (t < 4) load_frag(wfr[t], kvb, t + 4, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (t == 3) {
+          const int i = tid & 127, half = tid >> 7;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) wq[k] = a.wq[(size_t)(hg * HC + half * 32 + k) * D + i];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // lane (position l31, half hh) holds input features 32 ch + 16 hh + r: 64 bytes of ONE position's partial row — stored from
       // there an instruction is 64 partial-line pieces (profiles/r05_mlp_notes.md).  Through the wave's own slice of `red` (dead
@@ -1140,11 +1181,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
       }
     }
   }
+  ABW_STAMP(5);
   {
     const int i = tid & 127, half = tid >> 7;
     float acc = 0.f;
-    if (a.fanin_src && (i >> 6) == hg)                       // this group's 64 columns of the replicas' fan-in sum
-      for (int j = half; j < a.fan; j += 2) acc += a.fanin_src[((size_t)b * a.fan + j) * D + i];
+    {   // this group's 64 columns of the replicas' fan-in sum.  Masked by a 0 / 1 WEIGHT in an fma, not by a test: under a test of
+        // its only use hipcc sinks each load beneath it — a branch, a load and a full wait per row.  fma(v, 1, acc) is
+        // acc + v rounded once, fma(v, 0, acc) is acc: bitwise the sums of the guarded loop.
+      const bool mine = a.fanin_src && (i >> 6) == hg;
+#pragma unroll
+      for (int u = 0; u < FIN; ++u) acc = __builtin_fmaf(fin[u], mine && half + 2 * u < a.fan ? 1.f : 0.f, acc);
+    }
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc = fmaf(dqs[half * 32 + k], wq[k], acc);
     if (half == 1) part[i] = acc;
@@ -1154,6 +1201,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
       else a.dxq_part[((size_t)hg * a.n_in + b) * D + i] = acc + part[i];
     }
   }
+  ABW_STAMP(6);
+#if PS_DIAG_ON
+  if (stamp && tid == 0)
+    for (int q = 0; q < 8; ++q) stamp[8 * (size_t)blockIdx.x + q] = abw_st[q];
+#endif
 }
 // shapes the replica form is built for (both directions): 8 heads — two four-head groups per sequence — of 16 (d = 128)
 // or 32 (d = 256, <= 24 positions) columns, keys
@@ -1185,9 +1237,13 @@ int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unrea
   AttnArgs b = a;
   b.sig = nullptr; b.sigval = 0;
   side_take_signal(st, &b.sig, &b.sigval);             // (every check is behind us: the launch happens)
-  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
-  else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
-  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
+  unsigned long long* stamp = nullptr;
+#if PS_DIAG_ON
+  if (ps_diag_int("PS_ABW_STAMP", 0)) stamp = ps_debug_stamp_ptr();
+#endif
+  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
+  else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
+  else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
