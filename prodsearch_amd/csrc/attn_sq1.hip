@@ -1207,6 +1207,168 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_wf4_kernel(const AttnArgs a, 
     for (int q = 0; q < 8; ++q) stamp[8 * (size_t)blockIdx.x + q] = abw_st[q];
 #endif
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same backward with the KEYS split across the workgroup's four waves instead of the replicas (round 5, d = 256 / DH = 32, the
+// C5 shard).  attn_bwd_wf4_kernel gives every wave a quarter of the replicas and ALL keys: the waves' d V / d P partials (5 values x 12
+// keys x 64 lanes each) then meet in 61 KB of LDS and ONE wave finishes the softmax backward.  At d = 256 that footprint lets two
+// workgroups onto a CU alone and none beside the two 64 KB weight-gradient workgroups of the side stream: 47 us stand-alone, 140-150 in
+// the C5 step, on its dependent chain (profiles/r05_c5_step_timeline.txt).  Here wave ch owns keys (4 ii + ch) KPS + sub, ii < NKW, for
+// ALL replicas: its d V / d P sums are complete in registers, the softmax backward and the d K / d V rows of its keys are its own, and
+// what crosses waves is one float per lane (sum of P dP of the lane's head) and three float4 (d q, column sums of d K and d V): 4 KB.
+// Every d context row is read by all four waves (L1 / L2 hits); rows past the fan re-read replica 0 with an all-zero keep word, so
+// no load sits under a test.  Sums run over replicas 0 .. fan-1 in order, then over waves 0 .. 3: deterministic, not the bits of the
+// replica-split form (which adds its four waves' partial sums pairwise).
+// sum over the 8 lanes of a head (DH = 32: 8 lanes x float4), returned to every one of them: three DPP adds (quad_perm xor 1, xor 2,
+// then row_half_mirror — within a quad the values are already equal, so the mirror is the xor-4 exchange) instead of three
+// ds_bpermute round trips per dot product (216 per wave here)
+__device__ __forceinline__ float head8_sum(float v) {
+#define PS_DPP_ADD8(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  PS_DPP_ADD8(0xB1); PS_DPP_ADD8(0x4E); PS_DPP_ADD8(0x141);
+#undef PS_DPP_ADD8
+  return v;
+}
+template <int DH, int NKW>
+__global__ __launch_bounds__(256, 3) void attn_bwd_wk_kernel(const AttnArgs a, const uint32_t* amask, int pads_unread) {
+  fork_signal(a.sig, a.sigval);
+  constexpr int LPR = DH, KPS = 64 / LPR, HC = 4 * DH, LPH = DH / 4, D = 8 * DH, JMAX = 24;
+  static_assert(4 * NKW * KPS >= JMAX, "key slots cover 24 positions");
+  __shared__ int sp[4][64];
+  __shared__ float ths[4][LPR];
+  __shared__ float4 sums[4][3][LPR];
+  const int tid = threadIdx.x, lane = tid & 63, ch = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.S, HF = a.H;
+  const int b = (int)blockIdx.x >> 1, hg = (int)blockIdx.x & 1;
+  const int sub = lane / LPR, cl = lane % LPR, c = hg * HC + 4 * cl, hl = cl / LPH, h = 4 * hg + hl;
+  // ---- requests that do not need the valid list: the first batch of the replicas' d context chunks (four rows; the next batch is
+  // requested when one starts to be consumed, in a ROLLED loop: unrolled, hipcc hoists every batch to the top and the kernel needs
+  // 240 registers — at <= 152 a workgroup fits beside two of the side stream's 180-register weight-gradient workgroups on every SIMD),
+  // the keep words, the query row
+  constexpr int JB = 4;
+  float4 cur[JB];
+  auto dc_load = [&](float4 (&dst)[JB], const int j0) {
+#pragma unroll
+    for (int u = 0; u < JB; ++u) dst[u] = f4_ld(a.dctx + ((size_t)b * a.fan + (j0 + u < a.fan ? j0 + u : 0)) * D + c);
+  };
+  dc_load(cur, 0);
+  const bool masked = a.drop.thr != 0u;
+  // lane l: keep word of (replica l / 4, head l & 3); a second register for replicas 16 .. 23
+  uint32_t mw0, mw1;
+  {
+    const int j0 = lane >> 2, j1 = 16 + (lane >> 2);
+    mw0 = amask[((size_t)b * a.fan + (j0 < a.fan ? j0 : 0)) * HF + 4 * hg + (lane & 3)];
+    mw1 = amask[((size_t)b * a.fan + (j1 < a.fan ? j1 : 0)) * HF + 4 * hg + (lane & 3)];
+    if (!masked) { mw0 = ~0u; mw1 = ~0u; }
+  }
+  const float4 q4 = f4_ld(a.qp + (size_t)b * D + c);
+  const float scale = masked ? a.drop.scale : 1.f;
+  const unsigned long long vm = w1_valid(a, b, lane, sp[ch]);
+  const int Sv = __popcll(vm);
+  // ---- this wave's keys
+  int kk[NKW], pk[NKW]; bool on[NKW];
+  float4 v4[NKW], dv4[NKW]; float P[NKW], dP[NKW];
+#pragma unroll
+  for (int ii = 0; ii < NKW; ++ii) {
+    kk[ii] = (ii * 4 + ch) * KPS + sub;
+    on[ii] = kk[ii] < Sv;
+    const int p = sp[ch][on[ii] ? kk[ii] : 0];
+    pk[ii] = p;
+    v4[ii] = f4_ld(a.vp + ((size_t)b * S + p) * D + c);
+    const float pr = a.attn[((size_t)b * HF + h) * S + p];
+    P[ii] = on[ii] ? pr : 0.f;
+    dv4[ii] = make_float4(0.f, 0.f, 0.f, 0.f); dP[ii] = 0.f;
+  }
+  // ---- all replicas (those past the fan: keep word 0), four at a time, two batches per trip of the rolled loop (ping-pong: a batch
+  // is requested one batch of arithmetic before it is used, and nothing is copied)
+  auto dc_batch = [&](const float4 (&dc)[JB], const int j0) {
+#pragma unroll
+    for (int u = 0; u < JB; ++u) {
+      const int j = j0 + u;
+      uint32_t kh = __shfl(j < 16 ? mw0 : mw1, (j & 15) * 4 + hl, 64);
+      kh = j < a.fan ? kh : 0u;
+#pragma unroll
+      for (int ii = 0; ii < NKW; ++ii) {
+        const float m = ((kh >> kk[ii]) & 1u) ? scale : 0.f;
+        static_assert(LPH == 8, "head8_sum");
+        const float dot = head8_sum(f4_dot(dc[u], v4[ii]));
+        dP[ii] = fmaf(m, dot, dP[ii]);
+        f4_fma(dv4[ii], P[ii] * m, dc[u]);
+      }
+    }
+  };
+  static_assert(JMAX % (2 * JB) == 0, "two batches per trip");
+#pragma unroll 1
+  for (int j0 = 0; j0 < JMAX; j0 += 2 * JB) {
+    float4 oth[JB];
+    dc_load(oth, j0 + JB);
+    __builtin_amdgcn_sched_barrier(0);
+    dc_batch(cur, j0);
+    __builtin_amdgcn_sched_barrier(0);
+    dc_load(cur, j0 + 2 * JB < JMAX ? j0 + 2 * JB : 0);      // (the last trip re-reads batch 0: no load under a test)
+    __builtin_amdgcn_sched_barrier(0);
+    dc_batch(oth, j0 + JB);
+  }
+  // the K rows of this wave's keys (their round trip runs under the exchange below)
+  float4 k4[NKW];
+#pragma unroll
+  for (int ii = 0; ii < NKW; ++ii) k4[ii] = f4_ld(a.kp + ((size_t)b * S + pk[ii]) * D + c);
+  // ---- softmax backward: th = sum over ALL keys of P dP (per head): this wave's keys, its lane groups, then the four waves
+  float thp = 0.f;
+#pragma unroll
+  for (int ii = 0; ii < NKW; ++ii) thp = fmaf(P[ii], dP[ii], thp);
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) thp += __shfl_xor(thp, o, 64);
+  if (sub == 0) ths[ch][cl] = thp;
+  __syncthreads();
+  const float th = (ths[0][cl] + ths[1][cl]) + (ths[2][cl] + ths[3][cl]);
+  float4 dq4 = make_float4(0.f, 0.f, 0.f, 0.f), sk4 = dq4, sv4 = dq4;
+#pragma unroll
+  for (int ii = 0; ii < NKW; ++ii) {
+    const float g = P[ii] * (dP[ii] - th);                   // (0 for a dead key: P = 0)
+    f4_fma(dq4, g, k4[ii]);
+    const float4 dk4 = f4_scale(g, q4);
+    if (on[ii]) {
+      float* o = a.dkv + ((size_t)b * S + pk[ii]) * a.lddkv;
+      f4_st(o + c, dk4);
+      f4_st(o + D + c, dv4[ii]);
+      sk4.x += dk4.x; sk4.y += dk4.y; sk4.z += dk4.z; sk4.w += dk4.w;
+      sv4.x += dv4[ii].x; sv4.y += dv4[ii].y; sv4.z += dv4[ii].z; sv4.w += dv4[ii].w;
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) { dq4 = f4_xor_add(dq4, o); sk4 = f4_xor_add(sk4, o); sv4 = f4_xor_add(sv4, o); }
+  if (sub == 0) { sums[ch][0][cl] = dq4; sums[ch][1][cl] = sk4; sums[ch][2][cl] = sv4; }
+  __syncthreads();
+  if (ch == 0 && sub == 0) {
+    float4 t[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float4 s0 = sums[0][q][cl], s1 = sums[1][q][cl], s2 = sums[2][q][cl], s3 = sums[3][q][cl];
+      t[q] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    }
+    dq4 = f4_scale(a.qscale, t[0]); sk4 = t[1]; sv4 = t[2];
+    f4_st(a.dq + (size_t)b * a.lddq + c, dq4);
+    if (a.bias_part) {                                       // parked: folded by the step's last launch
+      float* bp = a.bias_part + (size_t)b * 3 * D + c;
+      f4_st(bp, dq4); f4_st(bp + D, sk4); f4_st(bp + 2 * D, sv4);
+    } else {
+      const float dqv[4] = {dq4.x, dq4.y, dq4.z, dq4.w}, skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w}, svv[4] = {sv4.x, sv4.y, sv4.z, sv4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&a.dbq[c + e], dqv[e]); atomicAdd(&a.dbk[c + e], skv[e]); atomicAdd(&a.dbv[c + e], svv[e]);
+      }
+    }
+  } else if (ch == 1 && !pads_unread) {                      // masked positions: exact zeros (dense consumers read them)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < S; s0 += KPS) {
+      const int sidx = s0 + sub;
+      if (sidx < S && !((vm >> sidx) & 1ull)) {
+        float* o = a.dkv + ((size_t)b * S + sidx) * a.lddkv;
+        f4_st(o + c, z); f4_st(o + D + c, z);
+      }
+    }
+  }
+}
+
 // shapes the replica form is built for (both directions): 8 heads — two four-head groups per sequence — of 16 (d = 128)
 // or 32 (d = 256, <= 24 positions) columns, keys
 // within the register budget and their keep bits within one word, the replicas of a chunk within the backward's row batch
@@ -1241,7 +1403,9 @@ int launch_attn_bwd_wf(const AttnArgs& a, const uint32_t* amask, bool pads_unrea
 #if PS_DIAG_ON
   if (ps_diag_int("PS_ABW_STAMP", 0)) stamp = ps_debug_stamp_ptr();
 #endif
-  if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
+  static const bool wk_on = ps_env_int("PS_ATTN_WK", 1) != 0;       // d = 256: keys, not replicas, across the waves (0: the replica-split form)
+  if (a.dh == 32 && wk_on && !a.wq) hipLaunchKernelGGL((attn_bwd_wk_kernel<32, 3>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0);
+  else if (a.dh == 32) hipLaunchKernelGGL((attn_bwd_wf4_kernel<32, 6, 2>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
   else if (a.S <= 24) hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 6, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
   else hipLaunchKernelGGL((attn_bwd_wf4_kernel<16, 8, 1>), dim3(a.n_in * 2), dim3(256), 0, st, b, amask, pads_unread ? 1 : 0, stamp);
   PS_LAUNCH_CHECK();
