@@ -1251,6 +1251,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
   const int tid = threadIdx.x, rg = tid >> 5, c = tid & 31;
   const int d = a.d, K1 = a.K + 1;
   const bool split = a.R > 1;
+  GS_STAMP(0);
   const bool item_wg = split && (int)blockIdx.x >= 2 * a.B;
   int b = blockIdx.x, j0 = rg, j1 = K1;
   int wt0 = rg, wstride = SB_RG;                 // word tasks of this workgroup: wt0, wt0 + wstride, ...
@@ -1317,7 +1318,8 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
     }
     __syncthreads();
   }
-  if (item_wg || a.part == 1) return;
+  GS_STAMP(1);
+  if (item_wg || a.part == 1) { GS_STAMP(3); return; }
   // ---- word tasks
 #pragma unroll
   for (int k = 0; k < EPL; ++k) acc[k] = 0.f;
@@ -1351,6 +1353,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
 #pragma unroll
   for (int k = 0; k < EPL; ++k)
     if (EPL < 16 || cok[k]) red[rg * d + col[k]] = acc[k];
+  GS_STAMP(2);
   __syncthreads();
   if (tb != a.P)
     for (int e = tid; e < d; e += 32 * SB_RG) {
@@ -1358,6 +1361,7 @@ __global__ __launch_bounds__(32 * SB_RG) void score_bwd_kernel(const ScoreArgs a
       for (int r = 0; r < SB_RG; ++r) s += red[r * d + e];
       atomicAdd(&a.g_product_emb[(size_t)tb * d + e], s);
     }
+  GS_STAMP(3);
 }
 static void launch_score_bwd_kernel(const ScoreArgs& a, int blocks, hipStream_t st) {
   const size_t lds = (size_t)SB_RG * a.d * sizeof(float);
@@ -1590,7 +1594,13 @@ int launch_score_bwd(const ScoreArgs& a, hipStream_t st) {
     return PS_OK;
   }
   const int item_wgs = a.R > 1 ? ps_cdiv(a.B * (a.K + 1), SB_RG) : 0;
+#if PS_DIAG_ON
+  ScoreArgs as = a;
+  as.stamp = ps_diag_int("PS_SBW_STAMP", 0) ? ps_debug_stamp_ptr() : nullptr;
+  launch_score_bwd_kernel(as, (a.R > 1 ? 2 : 1) * a.B + item_wgs, st);
+#else
   launch_score_bwd_kernel(a, (a.R > 1 ? 2 : 1) * a.B + item_wgs, st);
+#endif
   PS_LAUNCH_CHECK();
   return PS_OK;
 }
