@@ -18,7 +18,8 @@ for a, b in (('bench_kernel_stats.csv', '_bench_kernel_stats.csv'), ('rtm_kernel
              ('det_rtm_step_timeline.txt', '_det_rtm_step_timeline.txt'), ('mlp_stamps.txt', '_mlp_stamps.txt'),
              ('gather_score_kernel_stats.csv', '_gather_score_kernel_stats.csv'),
              ('gather_score_b8192_kernel_stats.csv', '_gather_score_b8192_kernel_stats.csv'),
-             ('gather_score_wg_times.txt', '_gather_score_wg_times.txt'), ('kvq_wg_times.txt', '_kvq_wg_times.txt')):
+             ('gather_score_wg_times.txt', '_gather_score_wg_times.txt'), ('kvq_wg_times.txt', '_kvq_wg_times.txt'),
+             ('attn_bwd_wg_times.txt', '_attn_bwd_wg_times.txt'), ('score_bwd_wg_times.txt', '_score_bwd_wg_times.txt')):
     if os.path.exists(os.path.join(src, a)):
         shutil.copyfile(os.path.join(src, a), os.path.join(dst, rnd + b))
 print(sorted(f for f in os.listdir(dst) if f.startswith(rnd)))

@@ -32,6 +32,9 @@ python tools/gather_c5.py --rows 8000000 --batch 1024 --iters 48 --sets 1 2>/dev
 python tools/gather_wg_times.py --batch 1024 > $O/gather_score_wg_times.txt 2>&1 || true
 PS_SCORE_SIDX=0 python tools/gather_wg_times.py --batch 1024 >> $O/gather_score_wg_times.txt 2>&1 || true
 python tools/kvq_wg_times.py > $O/kvq_wg_times.txt 2>&1 || true
+python tools/attn_bwd_wg_times.py > $O/attn_bwd_wg_times.txt 2>&1 || true
+python tools/score_bwd_wg_times.py > $O/score_bwd_wg_times.txt 2>&1 || true
+python tools/mlp_stamps.py > $O/mlp_stamps.txt 2>&1 || true
 echo "gather done"
 python bench.py --workload c5 --items 8000000 --steps 100 --warmup 10 --cpu-steps 0 > $O/c5_bench.json 2> $O/c5_bench.err || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_prof -- python3 bench.py --workload c5 --items 8000000 --steps 30 --warmup 5 --cpu-steps 0 --no-extras > $O/c5_prof.json 2> $O/c5_prof.err
