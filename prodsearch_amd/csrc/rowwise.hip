@@ -158,8 +158,30 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedArgs a) {
     // scan kernel, no host round trip, nothing added to the gather's own chain
     __shared__ int vred[4];
     const int b = (int)blockIdx.x - a.B - a.samp_wgs, tid = threadIdx.x;
+    // (round 5: eight entries per lane and trip, four 16-byte loads in flight (eight measured the same) — as a loop of one 8-byte load per trip, each waited for,
+    //  the last sequences' workgroups took 30 serial round trips at C2 and 80 at the C5 shard: the longest workgroups of the launch)
     int cntp = 0;
-    for (int i = tid; i < b * a.L; i += 256) cntp += (a.ui[i] != a.P);
+    {
+      const int n = b * a.L;
+      const bool al16 = (reinterpret_cast<uintptr_t>(a.ui) & 15) == 0;
+      if (al16) {
+        const longlong2* u2 = reinterpret_cast<const longlong2*>(a.ui);
+        const int n2 = n >> 1;                                  // pairs; an odd last entry is counted below
+        for (int i = tid; i < n2; i += 4 * 256) {
+          longlong2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int j = i + 256 * u; v[u] = u2[j < n2 ? j : 0]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = i + 256 * u;
+            cntp += (j < n2 && v[u].x != a.P) + (j < n2 && v[u].y != a.P);
+          }
+        }
+        if ((n & 1) && tid == 0) cntp += (a.ui[n - 1] != a.P);
+      } else {
+        for (int i = tid; i < n; i += 256) cntp += (a.ui[i] != a.P);
+      }
+    }
     const bool mine = tid < a.L && a.ui[(size_t)b * a.L + tid] != a.P;       // L <= 64 (validated): wave 0 holds the row
     const unsigned long long vm = __ballot(mine);
     cntp = (int)wave_sum((float)cntp);                        // < 2^24: exact in fp32

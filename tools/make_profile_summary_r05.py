@@ -43,7 +43,10 @@ event pair BOUND to the launch (`hipExtLaunchKernelGGL` start / stop events = th
 kernel trace reports; `tools/micro/extlaunch.hip`: 5.59 us against 5.75 us, where a `hipEventRecord` pair around the launch read 8.22).
 The round's other notes: `r05_gemm_notes.md` (the GEMM, closed), `r05_gather_sidx.txt` + `r05_gather_score_wg_times.txt` (the index hop
 on the scalar path), `r05_kvq_wg_times.txt` (the fused projection + attention forward), `r05_front_end_ab.txt` (the two C2 fusions, same
-box, alternating), `r05_env_matrix.txt`.
+box, alternating), `r05_mlp_notes.md` + `r05_mlp_stamps_before.txt` / `r05_mlp_stamps.txt` + `r05_c2_pmc_l2.txt` (the fused per-replica
+kernels: what their stores cost, why their chain is L2-bound, five experiments that did not move it), `r05_attn_bwd_wg_times.txt` /
+`r05_score_bwd_wg_times.txt` (per-workgroup phases of the replica attention backward and of the score backward in the step),
+`r05_c4_wreduce_notes.md`, `r05_env_matrix.txt`.
 
 ## C2 — `python bench.py` (BASELINE configs[1]: item_transformer d=128, bs 384, 20 negatives, dropout 0.1)
 
@@ -77,7 +80,8 @@ Timeline `r05_rtm_step_timeline.txt` (%s); kernel statistics (`r05_rtm_kernel_st
 
 bench line (`r05_c5_bench.json`): **%.0f tuples/s, %.3f ms/step** (round 4: 1.25-1.30; the 50 M-row table in the default run's `also`:
 %.3f); roofline object: the gather+score launch inside the step (`score_fwd_sidx_kernel<4,16>`), %.0f GB/s = %.3f of peak (round 4: 0.41
-between event pairs, 0.47 by rocprofv3).  The step itself did not move: it is GEMM time (`r05_gemm_notes.md`).  Timeline
+between event pairs, 0.47 by rocprofv3).  The step is GEMM time (`r05_gemm_notes.md`); what moved it this round is the key-split replica
+attention backward (`attn_bwd_wk_kernel<32,3>`: 30 us alone for 46.5, 114 in the step for 147; 1.247 -> 1.226 ms on one box).  Timeline
 `r05_c5_step_timeline.txt` (%s); kernel statistics (`r05_c5_kernel_stats.csv`):
 
 %s
