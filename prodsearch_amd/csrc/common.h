@@ -187,6 +187,38 @@ __host__ inline FDiv make_fdiv(int d) {
 }
 __device__ inline int fdiv(int n, const FDiv& f) { return f.d == 1 ? n : (int)__umulhi((uint32_t)n, f.m); }
 
+// ------------------------------------------------------------------ strided sums of a global array
+// p[first] + p[first + stride] + ... (index < n), added in that order: what `for (i = first; i < n; i += stride) s += p[i]` computes —
+// but that loop is one load and one full wait per trip (hipcc neither unrolls a runtime trip count nor overlaps the trips' loads), i.e. a
+// round trip of its own for every element a lane adds (round 5: 30 serial round trips in the embed launch's list workgroups, 24 in
+// rtm_rowlist_kernel, 7 at the head of every workgroup of the dense Adam update, 8 in the fused forward's last arriver).  Here U
+// loads are in flight per trip, unconditional from a clamped index; an element past the end enters with weight 0 through an fma
+// (fma(v, 1, s) is s + v rounded once: bitwise the same sums; under `if (j < n) s += v` hipcc sinks the load beneath the test, 5f).
+template <int U>
+__device__ __forceinline__ float strided_sum_f32(const float* __restrict__ p, int n, int first, int stride) {
+  float s = 0.f;
+  for (int i = first; i < n; i += U * stride) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int j = i + u * stride; v[u] = p[j < n ? j : 0]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s = __builtin_fmaf(v[u], i + u * stride < n ? 1.f : 0.f, s);
+  }
+  return s;
+}
+template <int U>
+__device__ __forceinline__ int strided_sum_i32(const int* __restrict__ p, int n, int first, int stride) {
+  int s = 0;
+  for (int i = first; i < n; i += U * stride) {
+    int v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int j = i + u * stride; v[u] = p[j < n ? j : 0]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u] * (i + u * stride < n ? 1 : 0);
+  }
+  return s;
+}
+
 // ------------------------------------------------------------------ wave helpers
 // Sum over the 64 lanes, returned to every lane.  DPP adds, not ds_bpermute shuffles: an inclusive scan inside each
 // row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then row_bcast:15 /

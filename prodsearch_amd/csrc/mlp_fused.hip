@@ -431,7 +431,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void mlp_fwd_t_kernel(const MlpFwdAr
   if (L.red[8] == 0.f) return;
   if (wave == 0) {      // last arriver: add the word tasks' partials in a fixed order => bitwise reproducible
     float il = 0.f;
-    for (int i = lane; i < S.word_nblk; i += 64) il += S.word_blk[i];
+    il = strided_sum_f32<8>(S.word_blk, S.word_nblk, lane, 64);      // (eight loads in flight: this wave ends the launch)
     il = wave_sum(il);
     if (lane == 0) {
       const float ps = L.red[9] / (float)S.B;

@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const char* plan, cons
   const AdamPlanHeader* h = (const AdamPlanHeader*)plan;
   const int chunk = blockIdx.x;
   // fixed-order reduction of the partial sums: identical in every block
-  float s = 0.f;
-  for (int i = threadIdx.x; i < h->n_chunks; i += 256) s += partial[i];
+  const float s = strided_sum_f32<8>(partial, h->n_chunks, threadIdx.x, 256);    // (in front of every block's stream: eight loads in flight)
   const float total = block_sum_256(s, sh);
   if (threadIdx.x == 0) {
     float norm;
@@ -124,8 +123,7 @@ extern "C" int ps_clip_adam_dense(const void* plan_dev, int32_t n_chunks, const 
 // ps_adam_update_ext applies clip + Adam with that external total.
 __global__ __launch_bounds__(256) void adam_total_kernel(const float* partial, int n_chunks, float* out) {
   __shared__ float sh[4];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n_chunks; i += 256) s += partial[i];
+  const float s = strided_sum_f32<8>(partial, n_chunks, threadIdx.x, 256);
   const float total = block_sum_256(s, sh);
   if (threadIdx.x == 0) out[0] = total;
 }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void co_emit_kernel(unsigned long long* bitmap
   __shared__ int base_sh;
   // rows emitted by earlier blocks
   int part = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blocksum[i];
+  part = strided_sum_i32<4>(blocksum, (int)blockIdx.x, threadIdx.x, 256);
   sh[threadIdx.x] = part;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -323,8 +323,7 @@ __global__ __launch_bounds__(1024) void rs_finalize_kernel(const PsAdamHyper hp,
                                                            const float* partial, int n_partial, float* scal,
                                                            float* gnorm_out) {
   __shared__ float sh[16];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n_partial; i += 1024) s += partial[i];
+  float s = strided_sum_f32<8>(partial, n_partial, threadIdx.x, 1024);       // (one block ends the clip norm: eight loads in flight per trip)
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -598,9 +597,8 @@ extern "C" int ps_shard_remap(const int64_t* idx_dev, int64_t n, int64_t pad_in,
 //                            dense plan and the touched rows of every table; touched gradient rows come back zeroed
 __global__ __launch_bounds__(1024) void rs_two_sums_kernel(const float* partial, int n_common, int n_all, float* sums) {
   __shared__ float sh[2][16];
-  float s0 = 0.f, s1 = 0.f;
-  for (int i = threadIdx.x; i < n_common; i += 1024) s0 += partial[i];
-  for (int i = n_common + threadIdx.x; i < n_all; i += 1024) s1 += partial[i];
+  float s0 = strided_sum_f32<8>(partial, n_common, threadIdx.x, 1024);
+  float s1 = strided_sum_f32<8>(partial + n_common, n_all - n_common, threadIdx.x, 1024);
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
   __syncthreads();

@@ -218,8 +218,7 @@ __global__ __launch_bounds__(256) void rtm_rowlist_kernel(const RtmK a) {
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nseq = a.B * a.J;
   if (n >= nseq) return;
-  int prev = 0;
-  for (int i = lane; i < n; i += 64) prev += a.seqcnt[i];
+  int prev = strided_sum_i32<8>(a.seqcnt, n, lane, 64);      // (up to 24 elements per lane: as a plain loop, 24 serial round trips)
   prev = (int)wave_sum((float)prev);                         // < 2^24: exact in fp32
   const bool okl = lane < a.S && a.valid[(size_t)n * a.S + lane] != 0.f;
   const unsigned long long vm = __ballot(okl);
