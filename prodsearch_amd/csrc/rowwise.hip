@@ -1234,7 +1234,18 @@ __global__ __launch_bounds__(256) void loss_kernel(const ScoreArgs a) {
   float aps = 0.f, ail = 0.f;
   const int n2 = a.loss_nblk >> 1;                                         // two workgroups' {ps, il} per 16 bytes
   const float4* p4 = reinterpret_cast<const float4*>(a.loss_blk);          // workspace regions are 16-byte aligned
-  for (int t = tid; t < n2; t += 256) { const float4 v = p4[t]; aps += v.x + v.z; ail += v.y + v.w; }
+  // (eight loads in flight per trip; an entry past the end enters with weight 0 through an fma — the same sums in the same order,
+  //  common.h strided_sum_f32: as one load per trip this single block, which the whole chip waits for, took 6 serial round trips at C5)
+  for (int t = tid; t < n2; t += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = t + 256 * u; v[u] = p4[j < n2 ? j : 0]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float w = t + 256 * u < n2 ? 1.f : 0.f;
+      aps = __builtin_fmaf(v[u].x + v[u].z, w, aps); ail = __builtin_fmaf(v[u].y + v[u].w, w, ail);
+    }
+  }
   if (tid == 0 && (a.loss_nblk & 1)) { aps += a.loss_blk[2 * (a.loss_nblk - 1)]; ail += a.loss_blk[2 * a.loss_nblk - 1]; }
   aps = wave_sum(aps); ail = wave_sum(ail);
   if ((tid & 63) == 0) { sps[tid >> 6] = aps; sil[tid >> 6] = ail; }
@@ -2012,7 +2023,17 @@ __global__ __launch_bounds__(256) void fanin_sum_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
-  for (; j < fan; ++j) { const float4 v = p[(size_t)j * (ld >> 2)]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  if (j < fan) {      // the last fan % 8 rows: one more batch of eight (rows past the fan re-read the last one with weight 0 — fma(v, 1, s)
+                      // is s + v: the same sums; as a loop of one load per trip they were up to 7 more serial round trips, 5 at fan = 21)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(j + u < fan ? j + u : fan - 1) * (ld >> 2)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float w = j + u < fan ? 1.f : 0.f;
+      s.x = __builtin_fmaf(v[u].x, w, s.x); s.y = __builtin_fmaf(v[u].y, w, s.y); s.z = __builtin_fmaf(v[u].z, w, s.z); s.w = __builtin_fmaf(v[u].w, w, s.w);
+    }
+  }
   reinterpret_cast<float4*>(out)[idx] = s;
 }
 int launch_fanin_sum(const float* src, int ld, int n_in, int fan, int d, float* out, hipStream_t st) {
