@@ -1687,7 +1687,13 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const EmbedBwdArgs a
       }
     }
     int cnt = 0;
-    for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+    if (a.Q <= 64) {      // one load per lane and a ballot (as a loop: Q loads, each waited for — DESIGN.md 5f, loops)
+      const int ql = tid & 63;
+      const int64_t qm = a.qw[(size_t)b * a.Q + (ql < a.Q ? ql : 0)];
+      cnt = __popcll(__ballot(ql < a.Q && qm != a.V - 1));
+    } else {
+      for (int q = 0; q < a.Q; ++q) cnt += (a.qw[(size_t)b * a.Q + q] != a.V - 1);
+    }
     __syncthreads();
     if (pre) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
